@@ -1,0 +1,210 @@
+/*
+ * rscm_gpu.h -- C ABI of the MI355X (gfx950) ensemble runner for RSCM's two-layer hot path.
+ *
+ * This is the drop-in boundary: every entry point is `extern "C"`, takes plain pointers and
+ * sizes (no torch / C++ types), returns an int status (0 = ok) and never unwinds across the
+ * ABI.  It is what a Rust `impl ModelRunner for GpuRunner` / `impl Component` shim, or the
+ * Python front-end (ctypes), binds -- see INTEGRATION.md for the reference-side stubs.
+ *
+ * Reference interfaces replaced (file:line under the reference tree):
+ *   - Model::run / step / step_model / step_model_component
+ *         crates/rscm-core/src/model/runtime.rs:368-527             -> rscm_ens_run*
+ *   - ModelBuilder::build collection initialisation (initial values at index 0,
+ *     exogenous series on the model axis)
+ *         crates/rscm-core/src/model/builder.rs:735-830             -> rscm_ens_set_initial,
+ *                                                                      rscm_ens_set_forcing
+ *   - VariableSource index rule (Exogenous/OwnState -> n, UpstreamOutput -> n+1)
+ *         crates/rscm-core/src/state/windows.rs:229-234             -> `source` argument
+ *   - TwoLayer::solve + IVP RHS   crates/rscm-two-layer/src/component.rs:159-251
+ *   - CarbonCycle::solve          crates/rscm-components/src/components/carbon_cycle.rs:102-159
+ *   - CO2ERF::solve               crates/rscm-components/src/components/co2_erf.rs:57-80
+ *   - scalar Sum aggregate        crates/rscm-core/src/schema.rs:760-773,886-901
+ *   - RK4 driver + end-time check crates/rscm-core/src/ivp/mod.rs:73-102,245-253
+ *   - ModelRunner::run_batch      crates/rscm-calibrate/src/model_runner.rs:38-85,215-267
+ *         (order-preserving, per-member failure)                    -> rscm_ens_set_params*,
+ *                                                                      rscm_ens_run, rscm_ens_status
+ *   - extract_outputs             crates/rscm-calibrate/src/model_runner.rs:161-212
+ *                                                                   -> rscm_ens_get_series
+ *   - GaussianLikelihood          crates/rscm-calibrate/src/likelihood.rs:167-250
+ *                                                                   -> rscm_ens_loglik
+ *   - ParameterSet::sample_lhs    crates/rscm-calibrate/src/parameter_set.rs:207-233
+ *                                                                   -> rscm_ens_sample_lhs
+ *
+ * Data layout (device, HBM): structure-of-arrays, member index fastest.
+ *   params   [P][N]      f64
+ *   series   [V][T][N]   f64   (index 0 of a state variable holds its initial value; outputs of
+ *                               step n are written at index n+1, runtime.rs:480; never-written
+ *                               entries are NaN, builder.rs:772-780)
+ *   forcing  [S][T]      f64   shared scenarios, staged in LDS by the kernels
+ *
+ * Threading: a handle is not thread-safe; use one handle per device per thread
+ * (the reference calls run_batch from one thread at a time, sampler/ensemble.rs:145).
+ * Ownership: the caller owns every input buffer (copied/uploaded before the call returns);
+ * the library owns device buffers until rscm_ens_destroy.
+ */
+#ifndef RSCM_GPU_H
+#define RSCM_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSCM_GPU_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define RSCM_API __attribute__((visibility("default")))
+#else
+#define RSCM_API
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define RSCM_OK 0
+#define RSCM_ERR_INVALID 1   /* bad argument / size (cf. model_runner.rs:225-231)               */
+#define RSCM_ERR_STATE 2     /* call order / time index (cf. runtime.rs:516 assert)               */
+#define RSCM_ERR_TIME_AXIS 3 /* RK4 end time misses t_next by >= 5e-3 (ivp/mod.rs:97 panics)   */
+#define RSCM_ERR_DEVICE 4    /* HIP runtime error (text in rscm_gpu_last_error)                 */
+#define RSCM_ERR_NOMEM 5
+
+/* ---- model kinds -------------------------------------------------------------------------- */
+#define RSCM_KIND_TWO_LAYER 0 /* stand-alone TwoLayer with a forcing series                     */
+#define RSCM_KIND_COUPLED 1   /* CarbonCycle -> CO2ERF -> Sum aggregate -> TwoLayer             */
+
+/* variable ids, kind TWO_LAYER (V = 3) */
+#define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
+#define RSCM_TL_VAR_TS 1  /* "Surface Temperature"          (state)                             */
+#define RSCM_TL_VAR_TD 2  /* "Deep Ocean Temperature"       (state)                             */
+
+/* variable ids, kind COUPLED (V = 8) */
+#define RSCM_CP_VAR_EMISSIONS 0 /* "Emissions|CO2|Anthropogenic" (input, [S][T] shared)         */
+#define RSCM_CP_VAR_TS 1
+#define RSCM_CP_VAR_TD 2
+#define RSCM_CP_VAR_CONC 3       /* "Atmospheric Concentration|CO2"  (state)                    */
+#define RSCM_CP_VAR_CUM_UPTAKE 4 /* "Cumulative Land Uptake"         (state)                    */
+#define RSCM_CP_VAR_CUM_EMIS 5   /* "Cumulative Emissions|CO2"       (state)                    */
+#define RSCM_CP_VAR_ERF_CO2 6    /* "Effective Radiative Forcing|CO2" (output)                  */
+#define RSCM_CP_VAR_ERF 7        /* "Effective Radiative Forcing"     (aggregate output)        */
+
+/* parameter rows.  TWO_LAYER: P = 6, TwoLayerParameters field order (component.rs:38-90):
+ *   lambda0, a, efficacy, eta, heat_capacity_surface, heat_capacity_deep
+ * COUPLED: P = 10: the six above, then tau, conc_pi, alpha_temperature (carbon_cycle.rs:24-34),
+ *   erf_2xco2 (co2_erf.rs:18-25; CO2ERF.conc_pi == conc_pi as in docs/notebooks/coupled_model.py) */
+#define RSCM_TL_NPARAMS 6
+#define RSCM_CP_NPARAMS 10
+
+/* VariableSource of the shared input as seen by its consumer (state/mod.rs:156-170) */
+#define RSCM_SRC_EXOGENOUS 0 /* read index n   */
+#define RSCM_SRC_UPSTREAM 1  /* read index n+1 */
+
+/* solver components for rscm_ens_set_step_size */
+#define RSCM_COMP_TWO_LAYER 0    /* reference hard-codes 0.1 (component.rs:240)                 */
+#define RSCM_COMP_CARBON_CYCLE 1 /* SolverOptions.step_size, default 0.1 (carbon_cycle.rs:83)   */
+
+/* arithmetic modes */
+#define RSCM_MODE_EXACT 0 /* op-for-op the reference's f64 expression order, no FMA contraction:
+                             bit-identical to the CPU oracle for the two-layer kind            */
+#define RSCM_MODE_FAST 1  /* FMA + reciprocal heat capacities; |rel diff| <= 1e-11 on bounded
+                             trajectories (tests/test_gpu_parity.py states the tolerance)      */
+
+typedef struct rscm_ens rscm_ens;
+
+/* ---- library ------------------------------------------------------------------------------ */
+RSCM_API int rscm_gpu_abi_version(void);
+/* Thread-local text of the last error raised by any call on this thread ("" if none). */
+RSCM_API const char* rscm_gpu_last_error(void);
+RSCM_API int rscm_gpu_device_count(int32_t* out);
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* time_bounds has n_times+1 entries (TimeAxis.bounds, timeseries.rs:66-77) and must increase
+ * strictly; step n integrates over [bounds[n], bounds[n+1]]. */
+RSCM_API int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
+                    int32_t device_id, rscm_ens** out);
+RSCM_API int rscm_ens_destroy(rscm_ens* h);
+
+RSCM_API int rscm_ens_n_params(const rscm_ens* h, int32_t* out);
+RSCM_API int rscm_ens_n_vars(const rscm_ens* h, int32_t* out);
+RSCM_API int rscm_ens_n_members(const rscm_ens* h, int64_t* out);
+RSCM_API int rscm_ens_n_times(const rscm_ens* h, int32_t* out);
+
+/* ---- configuration ------------------------------------------------------------------------ */
+RSCM_API int rscm_ens_set_mode(rscm_ens* h, int32_t mode);
+RSCM_API int rscm_ens_set_step_size(rscm_ens* h, int32_t component, double step);
+/* [P][N] structure-of-arrays. */
+RSCM_API int rscm_ens_set_params(rscm_ens* h, const double* soa);
+/* [N][P] row-major, the shape ModelRunner::run_batch receives (&[Vec<f64>]). */
+RSCM_API int rscm_ens_set_params_aos(rscm_ens* h, const double* aos);
+/* Shared input series already on the model axis: series[n_scen][n_times];
+ * scenario_of_member[N] or NULL (all members use scenario 0). */
+RSCM_API int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const double* series,
+                         const int32_t* scenario_of_member, int32_t source);
+/* Initial value(s) at time index 0 of a state variable: n_values == 1 (broadcast) or N.
+ * Also rewinds the time index to 0. */
+RSCM_API int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int64_t n_values);
+/* Use an existing hipStream_t (as void*) for all launches and copies; NULL = own stream. */
+RSCM_API int rscm_ens_set_stream(rscm_ens* h, void* hip_stream);
+
+/* ---- stepping (Model::step / run) --------------------------------------------------------- */
+/* Execute steps n = step_begin .. step_end-1 (0 <= step_begin <= step_end <= n_times-1).
+ * step_begin must equal the current time index (Model::step advances it by one).
+ * Fails with RSCM_ERR_TIME_AXIS, before launching anything, if for the configured RK4 step
+ * sizes any model step's end time would be missed by >= 5e-3 (ivp/mod.rs:90-102; the reference
+ * panics inside solve()), and with RSCM_ERR_STATE if parameters, the shared input or a state's
+ * initial value are missing (builder.rs:704-717 MissingInitialValue).
+ * rscm_ens_run returns after the work has completed; rscm_ens_run_async only enqueues. */
+RSCM_API int rscm_ens_run(rscm_ens* h, int32_t step_begin, int32_t step_end);
+RSCM_API int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end);
+RSCM_API int rscm_ens_sync(rscm_ens* h);
+RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
+/* Rewind to time index 0 keeping parameters, forcing and initial values (outputs are
+ * overwritten by the next run). */
+RSCM_API int rscm_ens_rewind(rscm_ens* h);
+/* Device time of the most recent rscm_ens_run* launch sequence, from HIP events recorded on
+ * the launch stream (valid after a sync). */
+RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);
+
+/* ---- outputs ------------------------------------------------------------------------------ */
+/* Copy series[var][t][m] for t in {t_begin, t_begin+t_stride, ...} < t_end and
+ * m in [m_begin, m_end) into out, laid out [n_t][m_end-m_begin]. */
+RSCM_API int rscm_ens_get_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end,
+                        int32_t t_stride, int64_t m_begin, int64_t m_end, double* out);
+/* Device pointer of series[var] ([T][N] contiguous) for zero-copy consumers. */
+RSCM_API int rscm_ens_series_devptr(rscm_ens* h, int32_t var_id, void** out);
+RSCM_API int rscm_ens_params_devptr(rscm_ens* h, void** out);
+/* Per-member status after the last run: bit0 = a state variable is non-finite at the current
+ * time index (the reference's failed-member case: NaN/Inf -> Err -> -inf log-posterior). */
+RSCM_API int rscm_ens_status(rscm_ens* h, uint8_t* out);
+
+/* Gaussian log-likelihood per member against observations given by (variable id, time index,
+ * value, sigma); observations must be grouped by variable.  Non-finite model value -> -inf.
+ * out is a host buffer [N]. */
+RSCM_API int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                    const double* obs_value, const double* obs_sigma, int32_t normalize,
+                    double* out);
+/* Ensemble summary of one variable at one time index over finite members:
+ * out[0]=count_finite, out[1]=sum, out[2]=min, out[3]=max (wavefront + block reductions). */
+RSCM_API int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4]);
+
+/* Copy the parameter matrix back to the host as [P][N] (e.g. after rscm_ens_sample_lhs). */
+RSCM_API int rscm_ens_get_params(rscm_ens* h, double* out_soa);
+
+/* ---- device-side Latin hypercube ---------------------------------------------------------- */
+/* Fill params[j][i] = low[j] + u * (high[j] - low[j]) with one sample per stratum and dimension:
+ * u = (perm_j(g) + U_j(g)) / n_total, g = member_offset + i, perm_j a keyed bijection of
+ * [0, n_total).  Counter-based, so ranks that own disjoint member blocks of one global
+ * ensemble generate their rows with no communication. */
+RSCM_API int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const double* high,
+                        int64_t member_offset, int64_t n_total);
+
+/* ---- diagnostics --------------------------------------------------------------------------- */
+/* Element-wise num[i]/den[i] on the device through (a) the compiler's IEEE f64 division and
+ * (b) the hoisted-reciprocal division the kernels use (rk4_device.hpp); used_fast[i] tells
+ * whether (b) took its three-instruction path.  The parity tests require out_ref == out_fast
+ * bit for bit. */
+RSCM_API int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const double* den,
+                          double* out_ref, double* out_fast, uint8_t* used_fast);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSCM_GPU_H */

@@ -1,0 +1,13 @@
+"""rscm_amd -- MI355X (gfx950) ensemble runner for RSCM's two-layer hot path.
+
+The compute path is hand-written HIP behind the C-ABI of ``include/rscm_gpu.h``
+(``rscm_amd/librscm_gpu.so``); this package is the host-side mirror of the reference's Python
+surface for that path.  There is no CPU fallback: without the HIP library every entry point
+raises ``RscmGpuUnavailable``.
+"""
+from ._lib import (KIND_COUPLED, KIND_TWO_LAYER, MODE_EXACT, MODE_FAST, SRC_EXOGENOUS,
+                   SRC_UPSTREAM, RscmGpuError, RscmGpuUnavailable)
+from .ensemble import Ensemble
+
+__all__ = ["Ensemble", "KIND_TWO_LAYER", "KIND_COUPLED", "MODE_EXACT", "MODE_FAST",
+           "SRC_EXOGENOUS", "SRC_UPSTREAM", "RscmGpuError", "RscmGpuUnavailable"]

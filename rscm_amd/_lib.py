@@ -1,0 +1,136 @@
+"""ctypes binding of ``librscm_gpu.so`` -- the C-ABI of include/rscm_gpu.h.
+
+There is no CPU fallback: if the HIP library is missing or fails to load this module raises
+``RscmGpuUnavailable`` and every product entry point fails loudly.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C rscm_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librscm_gpu.so")
+
+OK, ERR_INVALID, ERR_STATE, ERR_TIME_AXIS, ERR_DEVICE, ERR_NOMEM = range(6)
+KIND_TWO_LAYER, KIND_COUPLED = 0, 1
+SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
+COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
+MODE_EXACT, MODE_FAST = 0, 1
+
+TL_VARS = {"Effective Radiative Forcing": 0, "Surface Temperature": 1, "Deep Ocean Temperature": 2}
+CP_VARS = {"Emissions|CO2|Anthropogenic": 0, "Surface Temperature": 1, "Deep Ocean Temperature": 2,
+           "Atmospheric Concentration|CO2": 3, "Cumulative Land Uptake": 4,
+           "Cumulative Emissions|CO2": 5, "Effective Radiative Forcing|CO2": 6,
+           "Effective Radiative Forcing": 7}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+_h = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/rscm_gpu.h declares
+SIGNATURES = {
+    "rscm_gpu_abi_version": (C.c_int, []),
+    "rscm_gpu_last_error": (C.c_char_p, []),
+    "rscm_gpu_device_count": (C.c_int, [_ip]),
+    "rscm_ens_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.POINTER(_h)]),
+    "rscm_ens_destroy": (C.c_int, [_h]),
+    "rscm_ens_n_params": (C.c_int, [_h, _ip]),
+    "rscm_ens_n_vars": (C.c_int, [_h, _ip]),
+    "rscm_ens_n_members": (C.c_int, [_h, C.POINTER(C.c_int64)]),
+    "rscm_ens_n_times": (C.c_int, [_h, _ip]),
+    "rscm_ens_set_mode": (C.c_int, [_h, C.c_int32]),
+    "rscm_ens_set_step_size": (C.c_int, [_h, C.c_int32, C.c_double]),
+    "rscm_ens_set_params": (C.c_int, [_h, _dp]),
+    "rscm_ens_set_params_aos": (C.c_int, [_h, _dp]),
+    "rscm_ens_set_forcing": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, _ip, C.c_int32]),
+    "rscm_ens_set_initial": (C.c_int, [_h, C.c_int32, _dp, C.c_int64]),
+    "rscm_ens_set_stream": (C.c_int, [_h, C.c_void_p]),
+    "rscm_ens_run": (C.c_int, [_h, C.c_int32, C.c_int32]),
+    "rscm_ens_run_async": (C.c_int, [_h, C.c_int32, C.c_int32]),
+    "rscm_ens_sync": (C.c_int, [_h]),
+    "rscm_ens_time_index": (C.c_int, [_h, _ip]),
+    "rscm_ens_rewind": (C.c_int, [_h]),
+    "rscm_ens_last_run_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
+    "rscm_ens_get_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                      C.c_int64, _dp]),
+    "rscm_ens_series_devptr": (C.c_int, [_h, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rscm_ens_params_devptr": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
+    "rscm_ens_status": (C.c_int, [_h, _bp]),
+    "rscm_ens_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
+    "rscm_ens_summary": (C.c_int, [_h, C.c_int32, C.c_int32, _dp]),
+    "rscm_ens_get_params": (C.c_int, [_h, _dp]),
+    "rscm_ens_sample_lhs": (C.c_int, [_h, C.c_uint64, _dp, _dp, C.c_int64, C.c_int64]),
+    "rscm_gpu_selftest_div": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, _dp, _dp, _bp]),
+}
+
+
+class RscmGpuUnavailable(RuntimeError):
+    """The HIP extension is missing or cannot be loaded.  There is no CPU fallback."""
+
+
+class RscmGpuError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"rscm_gpu error {code}: {text}")
+        self.code = code
+
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every declared symbol (no device call is made)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RscmGpuUnavailable(
+            f"{LIB_PATH} not found: build the HIP extension first (make -C rscm_amd/csrc). "
+            "rscm_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RscmGpuUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library diverge
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rscm_gpu_abi_version() != 1:
+        raise RscmGpuUnavailable("ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise RscmGpuError(rc, load().rscm_gpu_last_error().decode())
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    rc = load().rscm_gpu_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_ip)
+
+
+def bptr(a: np.ndarray):
+    assert a.dtype == np.uint8 and a.flags.c_contiguous
+    return a.ctypes.data_as(_bp)

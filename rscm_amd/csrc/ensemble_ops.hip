@@ -1,0 +1,278 @@
+// Ensemble-side device operations around the stepper kernels (gfx950):
+//   * Gaussian log-likelihood per member    crates/rscm-calibrate/src/likelihood.rs:186-250
+//   * ensemble summaries (count/sum/min/max) with wavefront (64-lane) shuffle reductions
+//   * counter-based Latin hypercube          crates/rscm-calibrate/src/parameter_set.rs:207-233
+//   * fills / row broadcast for collection initialisation (builder.rs:772-780)
+//   * the division self-test behind rscm_gpu_selftest_div
+#include "rk4_device.hpp"
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(double* p, int64_t n, double v)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void broadcast_row_kernel(double* row, int64_t n,
+                                                               const double* src, int64_t n_src)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        row[i] = src[n_src == 1 ? 0 : i];
+}
+
+// ---- Gaussian log-likelihood ----------------------------------------------------------------
+// per observation: residual = obs - model; chi = (residual*residual)/(sigma*sigma); l = -0.5*chi;
+// normalised: l -= 0.5*ln(2*pi); l -= ln(sigma).  Per-variable partial sums, then their total
+// (likelihood.rs:206-226, 238-248).  A non-finite model value is a member failure -> -inf
+// (likelihood.rs:216-221, sampler/ensemble.rs:163-172).
+__global__ __launch_bounds__(kBlock) void loglik_kernel(LoglikArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const double ln_2pi = 1.8378770664093453;  // ln(2*pi) rounded to f64
+    double total = 0.0, partial = 0.0;
+    bool bad = false;
+    for (int32_t j = 0; j < a.n_obs; ++j) {
+        if (j > 0 && a.obs_group[j] != a.obs_group[j - 1]) {
+            total += partial;
+            partial = 0.0;
+        }
+        const double m = a.obs_series[j][i];
+        if (!is_finite(m)) {
+            bad = true;
+            break;
+        }
+        const double sigma = a.obs_sigma[j];
+        const double residual = a.obs_value[j] - m;
+        const double chi = (residual * residual) / (sigma * sigma);
+        double l = -0.5 * chi;
+        if (a.normalize) {
+            l -= 0.5 * ln_2pi;
+            l -= log(sigma);
+        }
+        partial += l;
+    }
+    total += partial;
+    a.out[i] = bad ? -__builtin_inf() : total;
+}
+
+// ---- summaries: count/sum/min/max over finite members ---------------------------------------
+struct Stat4 {
+    double cnt, sum, mn, mx;
+};
+
+__device__ __forceinline__ Stat4 stat_merge(Stat4 x, Stat4 y)
+{
+    return {x.cnt + y.cnt, x.sum + y.sum, fmin(x.mn, y.mn), fmax(x.mx, y.mx)};
+}
+
+__device__ __forceinline__ Stat4 wave_reduce(Stat4 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Stat4 o = {__shfl_down(v.cnt, off, 64), __shfl_down(v.sum, off, 64),
+                   __shfl_down(v.mn, off, 64), __shfl_down(v.mx, off, 64)};
+        v = stat_merge(v, o);
+    }
+    return v;
+}
+
+__device__ __forceinline__ Stat4 block_reduce(Stat4 v)
+{
+    __shared__ Stat4 wave_part[kBlock / 64];
+    v = wave_reduce(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_part[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) v = stat_merge(v, wave_part[w]);
+    }
+    return v;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(kBlock) void summary_partial_kernel(const double* row, int64_t n,
+                                                                 double* partial)
+{
+    Stat4 v = {0.0, 0.0, __builtin_inf(), -__builtin_inf()};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double x = row[i];
+        if (is_finite(x)) v = stat_merge(v, {1.0, x, x, x});
+    }
+    v = block_reduce(v);
+    if (threadIdx.x == 0) {
+        partial[4 * blockIdx.x + 0] = v.cnt;
+        partial[4 * blockIdx.x + 1] = v.sum;
+        partial[4 * blockIdx.x + 2] = v.mn;
+        partial[4 * blockIdx.x + 3] = v.mx;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void summary_final_kernel(const double* partial,
+                                                               int32_t n_blocks, double* out)
+{
+    Stat4 v = {0.0, 0.0, __builtin_inf(), -__builtin_inf()};
+    for (int32_t b = threadIdx.x; b < n_blocks; b += kBlock)
+        v = stat_merge(v, {partial[4 * b], partial[4 * b + 1], partial[4 * b + 2], partial[4 * b + 3]});
+    v = block_reduce(v);
+    if (threadIdx.x == 0) {
+        out[0] = v.cnt;
+        out[1] = v.sum;
+        out[2] = v.mn;
+        out[3] = v.mx;
+    }
+}
+
+// ---- counter-based Latin hypercube ----------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011) keyed by (seed, dimension), counter = global member id.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// Keyed bijection of [0, n): 4-round Feistel network on the next even-bit power-of-two domain,
+// cycle-walked back into range (expected < 4 walks).  Replaces the serial Fisher-Yates shuffle
+// of parameter_set.rs:224-226 with something every member can evaluate independently.
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t x, uint64_t n, uint32_t half_bits,
+                                                 uint32_t k0, uint32_t k1)
+{
+    const uint64_t mask = (1ull << half_bits) - 1ull;
+    do {
+        uint64_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+        for (uint32_t round = 0; round < 4; ++round) {
+            uint32_t c[4] = {(uint32_t)r, (uint32_t)(r >> 32), round, 0x5EEDu};
+            philox4x32_10(c, k0, k1);
+            const uint64_t f = (((uint64_t)c[1] << 32) | c[0]) & mask;
+            const uint64_t nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        x = (l << half_bits) | r;
+    } while (x >= n);
+    return x;
+}
+
+__global__ __launch_bounds__(kBlock) void lhs_kernel(double* params, int32_t n_params,
+                                                     int64_t n_local, uint64_t seed,
+                                                     const double* low, const double* high,
+                                                     int64_t member_offset, int64_t n_total,
+                                                     uint32_t half_bits)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_local) return;
+    const uint64_t g = (uint64_t)(member_offset + i);
+    const double interval_size = 1.0 / (double)n_total;  // parameter_set.rs:216
+    for (int32_t j = 0; j < n_params; ++j) {
+        const uint32_t k0 = (uint32_t)seed ^ (0x9E3779B9u * (uint32_t)(j + 1));
+        const uint32_t k1 = (uint32_t)(seed >> 32) + (uint32_t)j;
+        const uint64_t stratum = feistel_perm(g, (uint64_t)n_total, half_bits, k0, k1);
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), 0xA5A5u, (uint32_t)j};
+        philox4x32_10(c, k0, ~k1);
+        // 53-bit uniform in [0,1), like rand's Standard f64 (rng.gen::<f64>())
+        const uint64_t bits53 = (((uint64_t)c[1] << 32) | c[0]) >> 11;
+        const double u01 = (double)bits53 * (1.0 / 9007199254740992.0);
+        // interval_start + U*interval_size (parameter_set.rs:217-218), then the inverse CDF of a
+        // bounded constant-pdf prior, low + u*(high-low) (:331-334)
+        const double u = (double)stratum * interval_size + u01 * interval_size;
+        params[(size_t)j * n_local + i] = low[j] + u * (high[j] - low[j]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void divtest_kernel(const double* num, const double* den,
+                                                         double* out_ref, double* out_fast,
+                                                         uint8_t* used_fast, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double a = num[i], b = den[i];
+    out_ref[i] = a / b;
+    const ConstDiv c = make_const_div(b);
+    out_fast[i] = div_const(a, c);
+    used_fast[i] = const_div_fast_ok(a, c) ? 1 : 0;
+}
+
+inline unsigned grid_for(int64_t n, int64_t cap = 2048)
+{
+    int64_t b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,
+                                hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(broadcast_row_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, row, n, src, n_src);
+    return hipGetLastError();
+}
+
+hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s)
+{
+    if (a.n_members <= 0) return hipSuccess;
+    hipLaunchKernelGGL(loglik_kernel, dim3((unsigned)((a.n_members + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+int32_t summary_blocks(int64_t n) { return (int32_t)grid_for(n, 1024); }
+
+hipError_t launch_summary(const double* row, int64_t n, double* partial, int32_t n_blocks,
+                          double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(summary_partial_kernel, dim3(n_blocks), dim3(kBlock), 0, s, row, n, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(summary_final_kernel, dim3(1), dim3(kBlock), 0, s, partial, n_blocks, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_lhs(double* params, int32_t n_params, int64_t n_local, uint64_t seed,
+                      const double* low, const double* high, int64_t member_offset,
+                      int64_t n_total, hipStream_t s)
+{
+    if (n_local <= 0) return hipSuccess;
+    uint32_t bits = 2;
+    while ((1ull << bits) < (uint64_t)n_total) ++bits;
+    if (bits & 1u) ++bits;  // balanced Feistel halves
+    hipLaunchKernelGGL(lhs_kernel, dim3((unsigned)((n_local + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, s, params, n_params, n_local, seed, low, high, member_offset, n_total,
+                       bits / 2);
+    return hipGetLastError();
+}
+
+hipError_t launch_divtest(const double* num, const double* den, double* out_ref, double* out_fast,
+                          uint8_t* used_fast, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(divtest_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       s, num, den, out_ref, out_fast, used_fast, n);
+    return hipGetLastError();
+}
+
+}  // namespace rscm

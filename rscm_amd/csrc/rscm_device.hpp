@@ -1,0 +1,79 @@
+// Internal launch interface between the C-ABI layer (rscm_gpu.cpp) and the gfx950 kernels.
+// Not part of the public boundary (that is include/rscm_gpu.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rscm {
+
+constexpr int kBlock = 256;                  // 4 wavefronts of 64: one per SIMD of a CU
+constexpr int kMaxStaticLds = 64 * 1024;     // above this the launcher raises the dynamic limit
+constexpr int kMaxLds = 160 * 1024;          // CDNA4: 160 KiB per CU
+
+// Stand-alone two-layer run over steps [step_begin, step_end).
+struct TwoLayerArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t n_scen;
+    int32_t src_off;         // 0: Exogenous -> F[n]; 1: UpstreamOutput -> F[n+1]
+    int32_t lds_forcing;     // 1: forcing slice staged in LDS, 0: read through L2
+    const double* params;    // [6][N]
+    const double* forcing;   // [S][T]
+    const int32_t* scen;     // [N] or nullptr
+    const int32_t* nsub;     // [T-1] RK4 sub-steps of step n = ceil((b[n+1]-b[n])/h)
+    double h;                // RK4 step (reference: 0.1)
+    double* ts;              // [T][N]
+    double* td;              // [T][N]
+    uint8_t* status;         // [N]
+};
+
+// Coupled chain CarbonCycle -> CO2ERF -> Sum -> TwoLayer over steps [step_begin, step_end).
+struct CoupledArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t n_scen;
+    int32_t lds_forcing;
+    const double* params;     // [10][N]
+    const double* emissions;  // [S][T]
+    const int32_t* scen;
+    const int32_t* nsub_tl;   // [T-1]
+    const int32_t* nsub_cc;   // [T-1]
+    double h_tl, h_cc;
+    double* ts; double* td; double* conc; double* cum_uptake; double* cum_emis;
+    double* erf_co2; double* erf_total;   // each [T][N]
+    uint8_t* status;
+};
+
+struct LoglikArgs {
+    int64_t n_members;
+    int32_t n_obs;
+    int32_t normalize;
+    const double* const* obs_series;  // [n_obs] device pointers to the [N] row of (var, tidx)
+    const int32_t* obs_group;         // [n_obs] variable id, for the per-variable partial sums
+    const double* obs_value;
+    const double* obs_sigma;
+    double* out;                      // [N]
+};
+
+hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
+hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
+hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
+hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
+hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,
+                                hipStream_t s);
+// partial[4*n_blocks] then reduced into out[4] = {count_finite, sum, min, max}
+hipError_t launch_summary(const double* row, int64_t n, double* partial, int32_t n_blocks,
+                          double* out, hipStream_t s);
+int32_t summary_blocks(int64_t n);
+hipError_t launch_lhs(double* params, int32_t n_params, int64_t n_local, uint64_t seed,
+                      const double* low, const double* high, int64_t member_offset,
+                      int64_t n_total, hipStream_t s);
+// out[i] = a[i] / b[i] through (1) the compiler's IEEE division and (2) the hoisted-reciprocal
+// path used by the kernels, for the parity test of the latter.
+hipError_t launch_divtest(const double* num, const double* den, double* out_ref,
+                          double* out_fast, uint8_t* used_fast, int64_t n, hipStream_t s);
+
+}  // namespace rscm

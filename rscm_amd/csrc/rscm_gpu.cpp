@@ -1,0 +1,699 @@
+// C-ABI layer of the MI355X ensemble runner: handle management, validation mirroring the
+// reference's error behaviour, host<->device plumbing.  All arithmetic of the hot path lives in
+// the .hip kernels; nothing here computes model values on the host.
+#include "../../include/rscm_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rscm_device.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,      \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                    \
+    } while (0)
+
+#define GUARD_BEGIN try {
+#define GUARD_END                                                                          \
+    }                                                                                      \
+    catch (const std::bad_alloc&) { return fail(RSCM_ERR_NOMEM, "host allocation failed"); } \
+    catch (...) { return fail(RSCM_ERR_INVALID, "unexpected C++ exception"); }
+
+constexpr double kTThreshold = 5e-3;  // crates/rscm-core/src/ivp/mod.rs:73
+
+// ode_solvers Rk4::integrate: n = ceil((t1 - t0)/h) steps of t += h; the caller
+// (get_last_step, ivp/mod.rs:90-102) asserts more than one stored point and
+// |t_last - t1| < 5e-3.
+bool rk4_schedule(const std::vector<double>& bounds, double h, std::vector<int32_t>& nsub,
+                  int32_t* bad_step)
+{
+    const size_t K = bounds.size() - 2;  // T-1 steps
+    nsub.assign(K, 0);
+    for (size_t n = 0; n < K; ++n) {
+        const double t0 = bounds[n], t1 = bounds[n + 1];
+        const double m = std::ceil((t1 - t0) / h);
+        if (!(m >= 1.0) || m > 1e7) {
+            *bad_step = (int32_t)n;
+            return false;
+        }
+        double t = t0;
+        for (int32_t s = 0; s < (int32_t)m; ++s) t = t + h;
+        if (!(std::fabs(t - t1) < kTThreshold)) {
+            *bad_step = (int32_t)n;
+            return false;
+        }
+        nsub[n] = (int32_t)m;
+    }
+    return true;
+}
+
+}  // namespace
+
+struct rscm_ens {
+    int32_t kind = 0;
+    int64_t N = 0;
+    int32_t T = 0;
+    int32_t device = 0;
+    int32_t P = 0, V = 0;
+    int32_t mode = RSCM_MODE_EXACT;
+    std::vector<double> bounds;
+    double h_tl = 0.1, h_cc = 0.1;
+    bool schedule_dirty = true;
+    std::vector<int32_t> nsub_tl, nsub_cc;
+    int32_t* d_nsub_tl = nullptr;
+    int32_t* d_nsub_cc = nullptr;
+
+    double* d_params = nullptr;  // [P][N]
+    double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
+    double* d_forcing = nullptr; // [S][T]
+    int32_t* d_scen = nullptr;   // [N] or null
+    int32_t n_scen = 0;
+    int32_t source = RSCM_SRC_EXOGENOUS;
+    uint8_t* d_status = nullptr;
+
+    double* d_partial = nullptr;  // summary scratch
+    double* d_out4 = nullptr;
+    double* d_loglik = nullptr;   // [N]
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+
+    int32_t time_index = 0;
+    bool params_set = false, forcing_set = false;
+    std::vector<uint8_t> initial_set;  // per variable id
+
+    double* series(int32_t var) const { return d_series + (size_t)(var - 1) * (size_t)T * (size_t)N; }
+    bool is_state(int32_t var) const
+    {
+        if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
+        return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
+    }
+};
+
+namespace {
+
+int set_device(const rscm_ens* h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    return RSCM_OK;
+}
+
+int refresh_schedule(rscm_ens* h)
+{
+    if (!h->schedule_dirty) return RSCM_OK;
+    int32_t bad = -1;
+    if (!rk4_schedule(h->bounds, h->h_tl, h->nsub_tl, &bad))
+        return fail(RSCM_ERR_TIME_AXIS,
+                    "TwoLayer RK4 step %.17g does not land on the end of model step %d "
+                    "([%.17g, %.17g]) within 5e-3 (the reference panics in get_last_step)",
+                    h->h_tl, bad, h->bounds[bad], h->bounds[bad + 1]);
+    HIPCHK(hipMemcpyAsync(h->d_nsub_tl, h->nsub_tl.data(), h->nsub_tl.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice, h->stream));
+    if (h->kind == RSCM_KIND_COUPLED) {
+        if (!rk4_schedule(h->bounds, h->h_cc, h->nsub_cc, &bad))
+            return fail(RSCM_ERR_TIME_AXIS,
+                        "CarbonCycle RK4 step %.17g does not land on the end of model step %d "
+                        "within 5e-3 (the reference panics in get_last_step)", h->h_cc, bad);
+        HIPCHK(hipMemcpyAsync(h->d_nsub_cc, h->nsub_cc.data(), h->nsub_cc.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));  // host vectors may be rebuilt afterwards
+    h->schedule_dirty = false;
+    return RSCM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rscm_gpu_abi_version(void) { return RSCM_GPU_ABI_VERSION; }
+
+const char* rscm_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int rscm_gpu_device_count(int32_t* out)
+{
+    GUARD_BEGIN
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        return fail(RSCM_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out = n;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
+                    int32_t device_id, rscm_ens** out)
+{
+    GUARD_BEGIN
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED)
+        return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
+    if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
+    if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
+    if (!time_bounds) return fail(RSCM_ERR_INVALID, "time_bounds is NULL");
+    for (int32_t i = 0; i < n_times; ++i)
+        if (!(time_bounds[i + 1] > time_bounds[i]))  // timeseries.rs:47-52 assert!(is_monotonic)
+            return fail(RSCM_ERR_INVALID, "time_bounds must be strictly increasing (index %d)", i);
+    if ((uint64_t)n_members > (uint64_t)std::numeric_limits<int32_t>::max() * 256ull)
+        return fail(RSCM_ERR_INVALID, "n_members too large for one launch grid");
+
+    rscm_ens* h = new rscm_ens();
+    h->kind = kind;
+    h->N = n_members;
+    h->T = n_times;
+    h->device = device_id;
+    h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : RSCM_CP_NPARAMS;
+    h->V = kind == RSCM_KIND_TWO_LAYER ? 3 : 8;
+    h->bounds.assign(time_bounds, time_bounds + n_times + 1);
+    h->initial_set.assign(h->V, 0);
+
+    auto cleanup = [&](int rc) {
+        rscm_ens_destroy(h);
+        return rc;
+    };
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(RSCM_ERR_DEVICE, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    }
+#define CK(expr)                                                                              \
+    do {                                                                                      \
+        hipError_t e2_ = (expr);                                                              \
+        if (e2_ != hipSuccess)                                                                \
+            return cleanup(fail(e2_ == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, \
+                                "%s failed: %s", #expr, hipGetErrorString(e2_)));             \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    CK(hipEventCreate(&h->ev0));
+    CK(hipEventCreate(&h->ev1));
+    const size_t series_elems = (size_t)(h->V - 1) * (size_t)h->T * (size_t)h->N;
+    CK(hipMalloc(&h->d_params, (size_t)h->P * h->N * sizeof(double)));
+    CK(hipMalloc(&h->d_series, series_elems * sizeof(double)));
+    CK(hipMalloc(&h->d_status, (size_t)h->N));
+    CK(hipMalloc(&h->d_nsub_tl, (size_t)(h->T - 1) * sizeof(int32_t)));
+    CK(hipMalloc(&h->d_nsub_cc, (size_t)(h->T - 1) * sizeof(int32_t)));
+    CK(hipMalloc(&h->d_partial, 4 * 1024 * sizeof(double)));
+    CK(hipMalloc(&h->d_out4, 4 * sizeof(double)));
+    CK(hipMemsetAsync(h->d_status, 0, (size_t)h->N, h->stream));
+    // never-written entries are NaN (builder.rs:772-780)
+    CK(rscm::launch_fill(h->d_series, (int64_t)series_elems, std::numeric_limits<double>::quiet_NaN(),
+                         h->stream));
+    CK(hipStreamSynchronize(h->stream));
+#undef CK
+    *out = h;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_destroy(rscm_ens* h)
+{
+    if (!h) return RSCM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_params);
+    (void)hipFree(h->d_series);
+    (void)hipFree(h->d_forcing);
+    (void)hipFree(h->d_scen);
+    (void)hipFree(h->d_status);
+    (void)hipFree(h->d_nsub_tl);
+    (void)hipFree(h->d_nsub_cc);
+    (void)hipFree(h->d_partial);
+    (void)hipFree(h->d_out4);
+    (void)hipFree(h->d_loglik);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RSCM_OK;
+}
+
+#define NEED(h) \
+    if (!(h)) return fail(RSCM_ERR_INVALID, "handle is NULL")
+
+int rscm_ens_n_params(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->P; return RSCM_OK; }
+int rscm_ens_n_vars(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->V; return RSCM_OK; }
+int rscm_ens_n_members(const rscm_ens* h, int64_t* out) { NEED(h); *out = h->N; return RSCM_OK; }
+int rscm_ens_n_times(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->T; return RSCM_OK; }
+int rscm_ens_time_index(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->time_index; return RSCM_OK; }
+
+int rscm_ens_set_mode(rscm_ens* h, int32_t mode)
+{
+    NEED(h);
+    if (mode != RSCM_MODE_EXACT && mode != RSCM_MODE_FAST) return fail(RSCM_ERR_INVALID, "unknown mode %d", mode);
+    h->mode = mode;
+    return RSCM_OK;
+}
+
+int rscm_ens_set_step_size(rscm_ens* h, int32_t component, double step)
+{
+    NEED(h);
+    if (!(step > 0.0) || !std::isfinite(step)) return fail(RSCM_ERR_INVALID, "step must be positive and finite");
+    if (component == RSCM_COMP_TWO_LAYER)
+        h->h_tl = step;
+    else if (component == RSCM_COMP_CARBON_CYCLE && h->kind == RSCM_KIND_COUPLED)
+        h->h_cc = step;
+    else
+        return fail(RSCM_ERR_INVALID, "component %d not part of this model kind", component);
+    h->schedule_dirty = true;
+    return RSCM_OK;
+}
+
+int rscm_ens_set_stream(rscm_ens* h, void* hip_stream)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream) {
+        HIPCHK(hipStreamDestroy(h->stream));
+        h->own_stream = false;
+    }
+    if (hip_stream) {
+        h->stream = (hipStream_t)hip_stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_set_params(rscm_ens* h, const double* soa)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!soa) return fail(RSCM_ERR_INVALID, "params is NULL");
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_params, soa, (size_t)h->P * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->params_set = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_set_params_aos(rscm_ens* h, const double* aos)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!aos) return fail(RSCM_ERR_INVALID, "params is NULL");
+    std::vector<double> soa((size_t)h->P * h->N);
+    for (int64_t i = 0; i < h->N; ++i)
+        for (int32_t j = 0; j < h->P; ++j) soa[(size_t)j * h->N + i] = aos[(size_t)i * h->P + j];
+    return rscm_ens_set_params(h, soa.data());
+    GUARD_END
+}
+
+int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const double* series,
+                         const int32_t* scenario_of_member, int32_t source)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id != 0) return fail(RSCM_ERR_INVALID, "variable %d is not the shared input of this kind", var_id);
+    if (n_scen < 1 || !series) return fail(RSCM_ERR_INVALID, "need n_scen >= 1 and a series pointer");
+    if (source != RSCM_SRC_EXOGENOUS && source != RSCM_SRC_UPSTREAM) return fail(RSCM_ERR_INVALID, "unknown source %d", source);
+    if (h->kind == RSCM_KIND_COUPLED && source != RSCM_SRC_EXOGENOUS)
+        return fail(RSCM_ERR_INVALID, "emissions of the coupled chain are exogenous (no component produces them)");
+    if (scenario_of_member)
+        for (int64_t i = 0; i < h->N; ++i)
+            if (scenario_of_member[i] < 0 || scenario_of_member[i] >= n_scen)
+                return fail(RSCM_ERR_INVALID, "scenario_of_member[%lld] = %d out of range [0, %d)", (long long)i,
+                            scenario_of_member[i], n_scen);
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_scen != h->n_scen || !h->d_forcing) {
+        HIPCHK(hipFree(h->d_forcing));
+        h->d_forcing = nullptr;
+        HIPCHK(hipMalloc(&h->d_forcing, (size_t)n_scen * h->T * sizeof(double)));
+    }
+    HIPCHK(hipMemcpyAsync(h->d_forcing, series, (size_t)n_scen * h->T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (scenario_of_member) {
+        if (!h->d_scen) HIPCHK(hipMalloc(&h->d_scen, (size_t)h->N * sizeof(int32_t)));
+        HIPCHK(hipMemcpyAsync(h->d_scen, scenario_of_member, (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    } else if (h->d_scen) {
+        HIPCHK(hipFree(h->d_scen));
+        h->d_scen = nullptr;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_scen = n_scen;
+    h->source = source;
+    h->forcing_set = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int64_t n_values)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
+    if (!values || (n_values != 1 && n_values != h->N))
+        return fail(RSCM_ERR_INVALID, "initial values: need 1 or n_members values, got %lld", (long long)n_values);
+    if (int rc = set_device(h)) return rc;
+    if (n_values == 1)
+        HIPCHK(rscm::launch_fill(h->series(var_id), h->N, values[0], h->stream));
+    else
+        HIPCHK(hipMemcpyAsync(h->series(var_id), values, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->initial_set[var_id] = 1;
+    h->time_index = 0;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_rewind(rscm_ens* h)
+{
+    NEED(h);
+    h->time_index = 0;
+    return RSCM_OK;
+}
+
+int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (step_begin < 0 || step_end > h->T - 1 || step_begin > step_end)
+        return fail(RSCM_ERR_STATE, "steps [%d, %d) outside [0, %d] (Model::step asserts time_index < len-1)",
+                    step_begin, step_end, h->T - 1);
+    if (step_begin != h->time_index)
+        return fail(RSCM_ERR_STATE, "step_begin %d != current time index %d", step_begin, h->time_index);
+    if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
+    if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
+    for (int32_t v = 1; v < h->V; ++v)
+        if (h->is_state(v) && !h->initial_set[v])  // builder.rs:704-717 MissingInitialValue
+            return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
+    if (int rc = set_device(h)) return rc;
+    if (int rc = refresh_schedule(h)) return rc;
+
+    const int32_t len = step_end - step_begin;
+    const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (h->kind == RSCM_KIND_TWO_LAYER) {
+        rscm::TwoLayerArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.n_scen = h->n_scen;
+        a.src_off = h->source == RSCM_SRC_UPSTREAM ? 1 : 0;
+        a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
+        a.params = h->d_params;
+        a.forcing = h->d_forcing;
+        a.scen = h->d_scen;
+        a.nsub = h->d_nsub_tl;
+        a.h = h->h_tl;
+        a.ts = h->series(RSCM_TL_VAR_TS);
+        a.td = h->series(RSCM_TL_VAR_TD);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
+    } else {
+        rscm::CoupledArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.n_scen = h->n_scen;
+        a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
+        a.params = h->d_params;
+        a.emissions = h->d_forcing;
+        a.scen = h->d_scen;
+        a.nsub_tl = h->d_nsub_tl;
+        a.nsub_cc = h->d_nsub_cc;
+        a.h_tl = h->h_tl;
+        a.h_cc = h->h_cc;
+        a.ts = h->series(RSCM_CP_VAR_TS);
+        a.td = h->series(RSCM_CP_VAR_TD);
+        a.conc = h->series(RSCM_CP_VAR_CONC);
+        a.cum_uptake = h->series(RSCM_CP_VAR_CUM_UPTAKE);
+        a.cum_emis = h->series(RSCM_CP_VAR_CUM_EMIS);
+        a.erf_co2 = h->series(RSCM_CP_VAR_ERF_CO2);
+        a.erf_total = h->series(RSCM_CP_VAR_ERF);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_coupled(a, h->mode, h->stream));
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    h->time_index = step_end;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_sync(rscm_ens* h)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_run(rscm_ens* h, int32_t step_begin, int32_t step_end)
+{
+    if (int rc = rscm_ens_run_async(h, step_begin, step_end)) return rc;
+    return rscm_ens_sync(h);
+}
+
+int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out_ms) return fail(RSCM_ERR_INVALID, "out_ms is NULL");
+    if (!h->timed) return fail(RSCM_ERR_STATE, "no run has been launched yet");
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_get_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end, int32_t t_stride,
+                        int64_t m_begin, int64_t m_end, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
+    if (t_begin < 0 || t_end > h->T || t_begin > t_end || t_stride < 1)
+        return fail(RSCM_ERR_INVALID, "bad time range [%d, %d) stride %d", t_begin, t_end, t_stride);
+    if (m_begin < 0 || m_end > h->N || m_begin > m_end || !out)
+        return fail(RSCM_ERR_INVALID, "bad member range [%lld, %lld)", (long long)m_begin, (long long)m_end);
+    const int64_t width = m_end - m_begin;
+    if (width == 0 || t_begin == t_end) return RSCM_OK;
+    if (int rc = set_device(h)) return rc;
+    // rows beyond the current time index were never computed by this model instance: NaN
+    int64_t n_rows = 0, n_valid = 0;
+    for (int32_t t = t_begin; t < t_end; t += t_stride) {
+        ++n_rows;
+        if (t <= h->time_index) ++n_valid;
+    }
+    if (n_valid > 0)
+        HIPCHK(hipMemcpy2DAsync(out, (size_t)width * sizeof(double),
+                                h->series(var_id) + (size_t)t_begin * h->N + m_begin,
+                                (size_t)h->N * sizeof(double) * (size_t)t_stride, (size_t)width * sizeof(double),
+                                (size_t)n_valid, hipMemcpyDeviceToHost, h->stream));
+    for (int64_t r = n_valid; r < n_rows; ++r)
+        for (int64_t m = 0; m < width; ++m) out[r * width + m] = std::numeric_limits<double>::quiet_NaN();
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_series_devptr(rscm_ens* h, int32_t var_id, void** out)
+{
+    NEED(h);
+    if (!out || var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
+    *out = h->series(var_id);
+    return RSCM_OK;
+}
+
+int rscm_ens_params_devptr(rscm_ens* h, void** out)
+{
+    NEED(h);
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    *out = h->d_params;
+    h->params_set = true;  // the caller fills it on the device
+    return RSCM_OK;
+}
+
+int rscm_ens_status(rscm_ens* h, uint8_t* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipMemcpyAsync(out, h->d_status, (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                    const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (n_obs < 0 || !out || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
+        return fail(RSCM_ERR_INVALID, "bad observation arrays");
+    bool uncomputed = false;
+    for (int32_t j = 0; j < n_obs; ++j) {
+        if (obs_var[j] < 1 || obs_var[j] >= h->V) return fail(RSCM_ERR_INVALID, "observation %d: variable %d has no stored series", j, obs_var[j]);
+        if (obs_tidx[j] < 0 || obs_tidx[j] >= h->T) return fail(RSCM_ERR_INVALID, "observation %d: time index %d out of range", j, obs_tidx[j]);
+        if (obs_tidx[j] > h->time_index) uncomputed = true;  // NaN there -> skipped by extract_outputs -> missing time -> Err
+        if (j > 0 && obs_var[j] != obs_var[j - 1])
+            for (int32_t k = 0; k < j; ++k)
+                if (obs_var[k] == obs_var[j])
+                    return fail(RSCM_ERR_INVALID, "observations must be grouped by variable");
+    }
+    if (uncomputed) {
+        for (int64_t i = 0; i < h->N; ++i) out[i] = -std::numeric_limits<double>::infinity();
+        return RSCM_OK;
+    }
+    if (int rc = set_device(h)) return rc;
+    if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+    std::vector<const double*> ptrs(n_obs);
+    for (int32_t j = 0; j < n_obs; ++j) ptrs[j] = h->series(obs_var[j]) + (size_t)obs_tidx[j] * h->N;
+    void* d_blob = nullptr;
+    const size_t sz_ptr = (size_t)n_obs * sizeof(double*), sz_i = (size_t)n_obs * sizeof(int32_t),
+                 sz_d = (size_t)n_obs * sizeof(double);
+    const size_t off_val = sz_ptr, off_sig = off_val + sz_d, off_grp = off_sig + sz_d;
+    std::vector<unsigned char> blob(off_grp + sz_i + 8);
+    if (n_obs > 0) {
+        memcpy(blob.data(), ptrs.data(), sz_ptr);
+        memcpy(blob.data() + off_val, obs_value, sz_d);
+        memcpy(blob.data() + off_sig, obs_sigma, sz_d);
+        memcpy(blob.data() + off_grp, obs_var, sz_i);
+    }
+    HIPCHK(hipMalloc(&d_blob, blob.size()));
+    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, h->stream);
+    rscm::LoglikArgs a{};
+    a.n_members = h->N;
+    a.n_obs = n_obs;
+    a.normalize = normalize ? 1 : 0;
+    a.obs_series = (const double* const*)d_blob;
+    a.obs_value = (const double*)((char*)d_blob + off_val);
+    a.obs_sigma = (const double*)((char*)d_blob + off_sig);
+    a.obs_group = (const int32_t*)((char*)d_blob + off_grp);
+    a.out = h->d_loglik;
+    if (e == hipSuccess) e = rscm::launch_loglik(a, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_blob);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "loglik: %s", hipGetErrorString(e));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4])
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id < 1 || var_id >= h->V || tidx < 0 || tidx >= h->T || !out)
+        return fail(RSCM_ERR_INVALID, "bad variable/time index");
+    if (tidx > h->time_index) {
+        out[0] = 0.0; out[1] = 0.0;
+        out[2] = std::numeric_limits<double>::infinity();
+        out[3] = -std::numeric_limits<double>::infinity();
+        return RSCM_OK;
+    }
+    if (int rc = set_device(h)) return rc;
+    const int32_t nb = rscm::summary_blocks(h->N);
+    HIPCHK(rscm::launch_summary(h->series(var_id) + (size_t)tidx * h->N, h->N, h->d_partial, nb, h->d_out4, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->d_out4, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const double* high,
+                        int64_t member_offset, int64_t n_total)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!low || !high) return fail(RSCM_ERR_INVALID, "low/high is NULL");
+    if (member_offset < 0 || n_total < 1 || member_offset + h->N > n_total)
+        return fail(RSCM_ERR_INVALID, "member block [%lld, %lld) outside the global ensemble of %lld",
+                    (long long)member_offset, (long long)(member_offset + h->N), (long long)n_total);
+    if (int rc = set_device(h)) return rc;
+    double* d_lh = nullptr;
+    HIPCHK(hipMalloc(&d_lh, 2 * (size_t)h->P * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_lh, low, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lh + h->P, high, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = rscm::launch_lhs(h->d_params, h->P, h->N, seed, d_lh, d_lh + h->P, member_offset, n_total, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_lh);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "sample_lhs: %s", hipGetErrorString(e));
+    h->params_set = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_get_params(rscm_ens* h, double* out_soa)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out_soa) return fail(RSCM_ERR_INVALID, "out is NULL");
+    if (int rc = set_device(h)) return rc;
+    HIPCHK(hipMemcpyAsync(out_soa, h->d_params, (size_t)h->P * h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const double* den,
+                          double* out_ref, double* out_fast, uint8_t* used_fast)
+{
+    GUARD_BEGIN
+    if (n < 0 || !num || !den || !out_ref || !out_fast || !used_fast) return fail(RSCM_ERR_INVALID, "bad arguments");
+    if (n == 0) return RSCM_OK;
+    HIPCHK(hipSetDevice(device_id));
+    double* d = nullptr;
+    uint8_t* du = nullptr;
+    HIPCHK(hipMalloc(&d, 4 * (size_t)n * sizeof(double)));
+    hipError_t e = hipMalloc(&du, (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(d, num, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, den, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rscm::launch_divtest(d, d + n, d + 2 * n, d + 3 * n, du, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_ref, d + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_fast, d + 3 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(used_fast, du, (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    (void)hipFree(du);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "selftest_div: %s", hipGetErrorString(e));
+    return RSCM_OK;
+    GUARD_END
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// Two-layer energy-balance ensemble kernel for gfx950 (MI355X).
+//
+// One thread per ensemble member; the model's whole time loop, the RK4 sub-steps and the
+// TwoLayer right-hand side are fused in that thread, so per member-year the only HBM traffic is
+// the two 8-byte state stores (16 B) that the reference's stepper also produces
+// (crates/rscm-core/src/model/runtime.rs:480 writes outputs at index n+1).
+//
+// What it replaces, per step n (reference file:line):
+//   Model::step_model_component      crates/rscm-core/src/model/runtime.rs:368-497
+//   TwoLayer::solve                  crates/rscm-two-layer/src/component.rs:223-251
+//   IVPBuilder::to_rk4 + Rk4 (10 sub-steps of h = 0.1 for an annual step)
+//                                    crates/rscm-core/src/ivp/mod.rs:245-253
+//   TwoLayer::calculate_dy_dt        crates/rscm-two-layer/src/component.rs:159-189
+// The third integrand (heat content, component.rs:186-187) is integrated from 0 and dropped by
+// the reference (:236,245-248); it cannot influence Ts/Td and is not computed here.
+//
+// Layout: params [6][N], state series [T][N] (member fastest => a wavefront stores 512
+// contiguous bytes per variable per year), shared forcing [S][T] staged once per workgroup in
+// LDS (751 x 8 B = 6 KB per scenario) and read as a broadcast (one scenario) or a per-lane
+// gather (scenario_of_member).  No inter-workgroup communication, so the blockIdx -> XCD
+// round-robin needs no remap: every workgroup streams its own column block and re-reads only
+// the (L2-resident) forcing.
+#include "rk4_device.hpp"
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+struct TLConst {
+    double lambda0, a, eff_eta, eta;
+    ConstDiv cs, cd;
+};
+
+// EXACT: the reference's expression order, every product and sum rounded separately.
+//   temperature_difference = ts - td
+//   lambda_eff = lambda0 - a*ts
+//   heat_exchange_surface = efficacy*eta*temperature_difference      ((efficacy*eta) first)
+//   dts = (erf - lambda_eff*ts - heat_exchange_surface) / heat_capacity_surface
+//   dtd = (eta*temperature_difference) / heat_capacity_deep
+__device__ __forceinline__ void rhs_exact(const TLConst& p, double erf, double ts, double td,
+                                          double& dts, double& dtd)
+{
+    const double diff = ts - td;
+    const double lambda_eff = p.lambda0 - p.a * ts;
+    const double hx_s = p.eff_eta * diff;
+    dts = div_const(erf - lambda_eff * ts - hx_s, p.cs);
+    dtd = div_const(p.eta * diff, p.cd);
+}
+
+struct TLFast {
+    double l0, a, ee, ed;  // lambda0/Cs, a/Cs, efficacy*eta/Cs, eta/Cd
+};
+
+// FAST: same algebra with the heat capacities folded into the coefficients and FMAs.
+__device__ __forceinline__ void rhs_fast(const TLFast& p, double erf_cs, double ts, double td,
+                                         double& dts, double& dtd)
+{
+    const double diff = ts - td;
+    const double lam = __builtin_fma(-p.a, ts, p.l0);
+    const double t = __builtin_fma(-lam, ts, erf_cs);
+    dts = __builtin_fma(-p.ee, diff, t);
+    dtd = p.ed * diff;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
+{
+    extern __shared__ double lds_forcing[];
+    const int32_t len = a.step_end - a.step_begin;
+    if (a.lds_forcing) {
+        const int32_t total = a.n_scen * len;
+        for (int32_t idx = threadIdx.x; idx < total; idx += kBlock) {
+            const int32_t s = idx / len, k = idx - s * len;
+            lds_forcing[idx] = a.forcing[(size_t)s * a.n_times + a.step_begin + a.src_off + k];
+        }
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+
+    const double lambda0 = a.params[0 * N + i];
+    const double pa = a.params[1 * N + i];
+    const double efficacy = a.params[2 * N + i];
+    const double eta = a.params[3 * N + i];
+    const double cs = a.params[4 * N + i];
+    const double cd = a.params[5 * N + i];
+    const int32_t scen = a.scen ? a.scen[i] : 0;
+    const double* fglob = a.forcing + (size_t)scen * a.n_times + a.src_off;
+    const int32_t fl0 = scen * len - a.step_begin;  // lds_forcing[fl0 + n], n >= step_begin
+
+    double ts = a.ts[(size_t)a.step_begin * N + i];
+    double td = a.td[(size_t)a.step_begin * N + i];
+
+    const double h = a.h;
+    const double half_step = h / 2.0;
+    const double sixth = h / 6.0;
+
+    if constexpr (MODE == 0) {
+        TLConst p;
+        p.lambda0 = lambda0;
+        p.a = pa;
+        p.eff_eta = efficacy * eta;
+        p.eta = eta;
+        p.cs = make_const_div(cs);
+        p.cd = make_const_div(cd);
+        for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+            const double erf = a.lds_forcing ? lds_forcing[fl0 + n] : fglob[n];
+            const int32_t m = a.nsub[n];
+            for (int32_t s = 0; s < m; ++s) {
+                double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
+                rhs_exact(p, erf, ts, td, k1s, k1d);
+                rhs_exact(p, erf, ts + k1s * half_step, td + k1d * half_step, k2s, k2d);
+                rhs_exact(p, erf, ts + k2s * half_step, td + k2d * half_step, k3s, k3d);
+                rhs_exact(p, erf, ts + k3s * h, td + k3d * h, k4s, k4d);
+                ts = rk4_combine(ts, k1s, k2s, k3s, k4s, sixth);
+                td = rk4_combine(td, k1d, k2d, k3d, k4d, sixth);
+            }
+            a.ts[(size_t)(n + 1) * N + i] = ts;
+            a.td[(size_t)(n + 1) * N + i] = td;
+        }
+    } else {
+        const double inv_cs = 1.0 / cs;
+        TLFast p;
+        p.l0 = lambda0 * inv_cs;
+        p.a = pa * inv_cs;
+        p.ee = efficacy * eta * inv_cs;
+        p.ed = eta / cd;
+        const double third = h / 3.0;
+        for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+            const double erf = (a.lds_forcing ? lds_forcing[fl0 + n] : fglob[n]) * inv_cs;
+            const int32_t m = a.nsub[n];
+            for (int32_t s = 0; s < m; ++s) {
+                double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
+                rhs_fast(p, erf, ts, td, k1s, k1d);
+                rhs_fast(p, erf, __builtin_fma(k1s, half_step, ts), __builtin_fma(k1d, half_step, td),
+                         k2s, k2d);
+                rhs_fast(p, erf, __builtin_fma(k2s, half_step, ts), __builtin_fma(k2d, half_step, td),
+                         k3s, k3d);
+                rhs_fast(p, erf, __builtin_fma(k3s, h, ts), __builtin_fma(k3d, h, td), k4s, k4d);
+                // y + h/6*(k1+k4) + h/3*(k2+k3)
+                ts = __builtin_fma(k2s + k3s, third, __builtin_fma(k1s + k4s, sixth, ts));
+                td = __builtin_fma(k2d + k3d, third, __builtin_fma(k1d + k4d, sixth, td));
+            }
+            a.ts[(size_t)(n + 1) * N + i] = ts;
+            a.td[(size_t)(n + 1) * N + i] = td;
+        }
+    }
+    a.status[i] = (is_finite(ts) && is_finite(td)) ? 0 : 1;
+}
+
+}  // namespace
+
+hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s)
+{
+    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    const size_t lds = a.lds_forcing ? (size_t)a.n_scen * (a.step_end - a.step_begin) * sizeof(double) : 0;
+    const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
+    auto kern = mode == 0 ? two_layer_kernel<0> : two_layer_kernel<1>;
+    if (lds > (size_t)kMaxStaticLds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace rscm

@@ -1,0 +1,191 @@
+"""``Ensemble``: one device-resident batch of model instances behind the C-ABI.
+
+This is the host-side object the reference-shaped front-ends (``rscm_amd.core.Model``,
+``rscm_amd.calibrate.ModelRunner``) drive.  It owns one ``rscm_ens`` handle = one GPU; all
+arithmetic happens in the HIP kernels.  Semantics follow the reference's stepper
+(crates/rscm-core/src/model/runtime.rs:504-527): ``step()`` solves the current step and writes
+index ``time_index + 1``; ``run()`` steps to the end of the axis.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Ensemble:
+    def __init__(self, kind: int, n_members: int, time_bounds: Sequence[float], device: int = 0):
+        self._lib = L.load()
+        b = L.f64(time_bounds)
+        if b.ndim != 1 or len(b) < 3:
+            raise ValueError("time_bounds needs at least 3 entries (2 time points)")
+        self.kind = kind
+        self.n_members = int(n_members)
+        self.n_times = len(b) - 1
+        self.bounds = b
+        self.device = device
+        self.var_ids: Dict[str, int] = dict(L.TL_VARS if kind == L.KIND_TWO_LAYER else L.CP_VARS)
+        self.n_params = 6 if kind == L.KIND_TWO_LAYER else 10
+        h = C.c_void_p()
+        L.check(self._lib.rscm_ens_create(kind, self.n_members, self.n_times, L.dptr(b), device,
+                                          C.byref(h)))
+        self._h = h
+
+    # -- lifecycle --------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.rscm_ens_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _var(self, var) -> int:
+        return self.var_ids[var] if isinstance(var, str) else int(var)
+
+    # -- configuration ----------------------------------------------------------------------
+    def set_mode(self, mode: int) -> None:
+        L.check(self._lib.rscm_ens_set_mode(self._h, mode))
+
+    def set_step_size(self, component: int, step: float) -> None:
+        L.check(self._lib.rscm_ens_set_step_size(self._h, component, float(step)))
+
+    def set_params(self, soa) -> None:
+        p = L.f64(soa)
+        if p.shape != (self.n_params, self.n_members):
+            raise ValueError(f"params must be [{self.n_params}][{self.n_members}], got {p.shape}")
+        L.check(self._lib.rscm_ens_set_params(self._h, L.dptr(p)))
+
+    def set_params_aos(self, aos) -> None:
+        p = L.f64(aos)
+        if p.shape != (self.n_members, self.n_params):
+            # mirrors model_runner.rs:225-231 "Expected {} parameters, got {}"
+            raise ValueError(f"Expected {self.n_params} parameters per member "
+                             f"([{self.n_members}][{self.n_params}]), got {p.shape}")
+        L.check(self._lib.rscm_ens_set_params_aos(self._h, L.dptr(p)))
+
+    def set_forcing(self, series, scenario_of_member=None, source: int = L.SRC_EXOGENOUS,
+                    var=0) -> None:
+        s = np.atleast_2d(L.f64(series))
+        if s.shape[1] != self.n_times:
+            raise ValueError(f"forcing must have {self.n_times} time points, got {s.shape[1]}")
+        sc = None
+        if scenario_of_member is not None:
+            sc = np.ascontiguousarray(scenario_of_member, dtype=np.int32)
+            if sc.shape != (self.n_members,):
+                raise ValueError("scenario_of_member must have one entry per member")
+        L.check(self._lib.rscm_ens_set_forcing(self._h, self._var(var), s.shape[0], L.dptr(s),
+                                               L.iptr(sc), source))
+
+    def set_initial(self, var, values) -> None:
+        v = np.atleast_1d(L.f64(values))
+        L.check(self._lib.rscm_ens_set_initial(self._h, self._var(var), L.dptr(v), v.size))
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        L.check(self._lib.rscm_ens_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def sample_lhs(self, seed: int, low, high, member_offset: int = 0,
+                   n_total: Optional[int] = None) -> None:
+        lo, hi = L.f64(low), L.f64(high)
+        if lo.shape != (self.n_params,) or hi.shape != (self.n_params,):
+            raise ValueError("low/high need one entry per parameter")
+        n_total = self.n_members if n_total is None else n_total
+        L.check(self._lib.rscm_ens_sample_lhs(self._h, C.c_uint64(seed), L.dptr(lo), L.dptr(hi),
+                                              member_offset, n_total))
+
+    def get_params(self) -> np.ndarray:
+        out = np.empty((self.n_params, self.n_members))
+        L.check(self._lib.rscm_ens_get_params(self._h, L.dptr(out)))
+        return out
+
+    # -- stepping ---------------------------------------------------------------------------
+    @property
+    def time_index(self) -> int:
+        n = C.c_int32()
+        L.check(self._lib.rscm_ens_time_index(self._h, C.byref(n)))
+        return n.value
+
+    def step(self) -> None:
+        n = self.time_index
+        L.check(self._lib.rscm_ens_run(self._h, n, n + 1))
+
+    def run(self, step_end: Optional[int] = None, *, sync: bool = True) -> None:
+        end = self.n_times - 1 if step_end is None else step_end
+        fn = self._lib.rscm_ens_run if sync else self._lib.rscm_ens_run_async
+        L.check(fn(self._h, self.time_index, end))
+
+    def sync(self) -> None:
+        L.check(self._lib.rscm_ens_sync(self._h))
+
+    def rewind(self) -> None:
+        L.check(self._lib.rscm_ens_rewind(self._h))
+
+    def finished(self) -> bool:
+        return self.time_index == self.n_times - 1
+
+    def last_run_ms(self) -> float:
+        ms = C.c_float()
+        L.check(self._lib.rscm_ens_last_run_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # -- outputs ----------------------------------------------------------------------------
+    def get_series(self, var, t_begin: int = 0, t_end: Optional[int] = None, t_stride: int = 1,
+                   m_begin: int = 0, m_end: Optional[int] = None) -> np.ndarray:
+        t_end = self.n_times if t_end is None else t_end
+        m_end = self.n_members if m_end is None else m_end
+        nt = len(range(t_begin, t_end, t_stride))
+        out = np.empty((nt, m_end - m_begin))
+        L.check(self._lib.rscm_ens_get_series(self._h, self._var(var), t_begin, t_end, t_stride,
+                                              m_begin, m_end, L.dptr(out)))
+        return out
+
+    def series_devptr(self, var) -> int:
+        p = C.c_void_p()
+        L.check(self._lib.rscm_ens_series_devptr(self._h, self._var(var), C.byref(p)))
+        return p.value
+
+    def status(self) -> np.ndarray:
+        out = np.empty(self.n_members, dtype=np.uint8)
+        L.check(self._lib.rscm_ens_status(self._h, L.bptr(out)))
+        return out
+
+    def loglik(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize: bool = False) -> np.ndarray:
+        ov = np.ascontiguousarray([self._var(v) for v in np.atleast_1d(obs_var)], dtype=np.int32)
+        ot = np.ascontiguousarray(obs_tidx, dtype=np.int32)
+        val, sig = L.f64(obs_value), L.f64(obs_sigma)
+        if not (len(ov) == len(ot) == len(val) == len(sig)):
+            raise ValueError("observation arrays differ in length")
+        out = np.empty(self.n_members)
+        L.check(self._lib.rscm_ens_loglik(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
+                                          L.dptr(sig), int(normalize), L.dptr(out)))
+        return out
+
+    def summary(self, var, tidx: int) -> Dict[str, float]:
+        out = np.empty(4)
+        L.check(self._lib.rscm_ens_summary(self._h, self._var(var), tidx, L.dptr(out)))
+        cnt = out[0]
+        return {"count": int(cnt), "mean": out[1] / cnt if cnt else float("nan"),
+                "min": out[2], "max": out[3]}
+
+
+def selftest_div(num, den, device: int = 0):
+    """(ref, fast, used_fast) of num/den on the device; see rscm_gpu_selftest_div."""
+    lib = L.load()
+    a, b = L.f64(num).ravel(), L.f64(den).ravel()
+    ref, fast = np.empty_like(a), np.empty_like(a)
+    used = np.empty(a.size, dtype=np.uint8)
+    L.check(lib.rscm_gpu_selftest_div(device, a.size, L.dptr(a), L.dptr(b), L.dptr(ref),
+                                      L.dptr(fast), L.bptr(used)))
+    return ref, fast, used

@@ -1,0 +1,43 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/rscm_gpu.h declares, and
+the ctypes table binds exactly that set.  No compute call is made (no GPU here)."""
+import os
+import re
+
+from rscm_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rscm_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"RSCM_API\s+[\w\s\*]+?\b(rscm_\w+)\s*\(", text))
+
+
+def test_header_and_binding_table_agree():
+    decl = _declared()
+    assert len(decl) >= 30
+    assert decl == set(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()  # binds each symbol; AttributeError if one is missing
+    for name in _declared():
+        assert hasattr(lib, name)
+    assert lib.rscm_gpu_abi_version() == 1
+    assert lib.rscm_gpu_last_error() is not None
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under rscm_amd/ or include/ may import, link
+    or load it."""
+    for top in ("rscm_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            if "build" in dirpath.split(os.sep):
+                continue
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                    src = open(os.path.join(dirpath, f)).read()
+                    for needle in ("import oracle", "from oracle", "librscm_oracle", "rscm_oracle",
+                                   "oracle/"):
+                        assert needle not in src, f"{top}/{f} references {needle!r}"

@@ -1,0 +1,449 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.
+
+Parity bars (stated here, as the task requires):
+  * two-layer kind, RSCM_MODE_EXACT: BIT-EXACT vs the oracle (same f64 expression order, no FMA
+    contraction, IEEE division), including non-finite members.
+  * two-layer kind, RSCM_MODE_FAST: |gpu - oracle| <= 1e-11 * max(1, |oracle|) on members whose
+    trajectory stays bounded (|Ts| < 100 K); runaway members are compared by status only.
+  * coupled kind: exp/log come from the device math library (<= 1 ulp from glibc), so
+    |gpu - oracle| <= 1e-11 * max(1, |oracle|) on bounded members, either mode.
+  * integer/index work (time indexing, scenario selection, status flags, LHS strata): exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import (CC_RANGES, SEED, TL_RANGES, assert_bit_equal, axis_values,
+                           coupled_params, emissions_syn, f_syn, two_layer_params)
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FAST_RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rscm_amd
+    from rscm_amd import _lib
+    _lib.load()  # fails loudly when the HIP extension is missing
+    assert _lib.device_count() >= 1, "no HIP device visible"
+    return rscm_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import cbind
+    return cbind
+
+
+def _tl_gpu(ra, t, P, F, ts0, td0, *, scen=None, source=0, mode=0, h=None, chunks=None):
+    b = np.append(t, t[-1] + (t[-1] - t[-2]))
+    with ra.Ensemble(ra.KIND_TWO_LAYER, P.shape[1], b) as e:
+        e.set_mode(mode)
+        if h is not None:
+            e.set_step_size(0, h)
+        e.set_params(P)
+        e.set_forcing(F, scen, source)
+        e.set_initial("Surface Temperature", ts0)
+        e.set_initial("Deep Ocean Temperature", td0)
+        if chunks:
+            for c in chunks:
+                e.run(c)
+        e.run()
+        assert e.finished()
+        return (e.get_series("Surface Temperature"), e.get_series("Deep Ocean Temperature"),
+                e.status())
+
+
+def _close(a, b, rtol):
+    return np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))
+
+
+# ------------------------------------------------------------------------------ division
+def test_hoisted_reciprocal_division_is_ieee(ra):
+    from rscm_amd.ensemble import selftest_div
+    rng = np.random.default_rng(7)
+    n = 1 << 21
+    num = rng.standard_normal(n) * np.exp(rng.uniform(-40, 40, n))
+    den = rng.uniform(0.5, 300.0, n) * rng.choice([-1.0, 1.0], n)
+    # edge cases: zeros, denormals, huge, inf, nan, divisors outside the window
+    edge_n = np.array([0.0, -0.0, 5e-324, 1e-310, 1e-300, 2.0 ** -767, 2.0 ** -768, 2.0 ** 511,
+                       2.0 ** 512, 1e300, 1.7e308, np.inf, -np.inf, np.nan, 1.0, 3.0])
+    edge_d = np.array([8.0, 100.0, 1e-200, 1e200, 0.0, -0.0, np.inf, np.nan, 5e-324, 2.0 ** 128,
+                       2.0 ** 129, 2.0 ** -128, 2.0 ** -129, 3.0, 2.13, 1.0])
+    en, ed = np.meshgrid(edge_n, edge_d)
+    num = np.concatenate([num, en.ravel()])
+    den = np.concatenate([den, ed.ravel()])
+    # wide-exponent numerators against typical heat capacities
+    wide = np.ldexp(rng.uniform(1, 2, 1 << 16), rng.integers(-1074, 1023, 1 << 16))
+    num = np.concatenate([num, wide])
+    den = np.concatenate([den, rng.uniform(5.0, 200.0, wide.size)])
+    ref, fast, used = selftest_div(num, den)
+    assert_bit_equal(fast, ref, "hoisted-reciprocal division vs compiler division")
+    with np.errstate(all="ignore"):
+        assert_bit_equal(ref, num / den, "device division vs host IEEE division")
+    assert used[: n].mean() > 0.99  # the fast path is the one being exercised
+    assert used[n: n + en.size].mean() < 0.5
+
+
+# ------------------------------------------------------------------------------ two-layer exact
+@pytest.mark.parametrize("n_members", [1, 63, 257, 1000])
+@pytest.mark.parametrize("source", [0, 1])
+def test_two_layer_exact_bitwise_vs_oracle(ra, orc, n_members, source):
+    t = axis_values()
+    P = two_layer_params(n_members, seed=SEED + n_members)
+    F = f_syn(t)
+    want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.0, 0.0, source=source, threads=8)
+    ts, td, st = _tl_gpu(ra, t, P, F, 0.0, 0.0, source=source)
+    assert_bit_equal(ts, want[0], "Ts")
+    assert_bit_equal(td, want[1], "Td")
+    bad = ~(np.isfinite(want[0][-1]) & np.isfinite(want[1][-1]))
+    assert (st.astype(bool) == bad).all()
+
+
+def test_two_layer_golden_fixture(ra):
+    g = np.load(os.path.join(GOLDEN, "two_layer_golden.npz"))
+    for source in (0, 1):
+        ts, td, _ = _tl_gpu(ra, g["time_values"], g["params"], g["forcing"], g["ts0"], g["td0"],
+                            scen=g["scen"], source=source)
+        assert_bit_equal(ts, g[f"ts_src{source}"], f"golden Ts src{source}")
+        assert_bit_equal(td, g[f"td_src{source}"], f"golden Td src{source}")
+
+
+def test_two_layer_scenarios_and_member_initials(ra, orc):
+    t = axis_values(1750, 2100)  # config 1 axis: 351 points
+    n = 513
+    rng = np.random.default_rng(3)
+    P = two_layer_params(n)
+    F = np.stack([f_syn(t) * s for s in (1.0, 0.5, -0.25, 2.0, 0.0)])
+    scen = rng.integers(0, 5, n).astype(np.int32)
+    ts0, td0 = rng.normal(0, 0.5, n), rng.normal(0, 0.2, n)
+    want = orc.two_layer_run(orc.bounds_from_values(t), P, F, ts0, td0, scen=scen, threads=8)
+    ts, td, _ = _tl_gpu(ra, t, P, F, ts0, td0, scen=scen)
+    assert_bit_equal(ts, want[0])
+    assert_bit_equal(td, want[1])
+
+
+def test_two_layer_many_scenarios_bypass_lds(ra, orc):
+    """S*T*8 B beyond the LDS budget: forcing is read through L2 instead; same bits."""
+    t = axis_values()
+    n, S = 300, 40  # 40 * 750 * 8 = 240 KB > 160 KB
+    rng = np.random.default_rng(5)
+    P = two_layer_params(n)
+    F = np.stack([f_syn(t) * rng.uniform(0.2, 1.2) for _ in range(S)])
+    scen = rng.integers(0, S, n).astype(np.int32)
+    want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.0, 0.0, scen=scen, threads=8)
+    ts, td, _ = _tl_gpu(ra, t, P, F, 0.0, 0.0, scen=scen)
+    assert_bit_equal(ts, want[0])
+    assert_bit_equal(td, want[1])
+
+
+def test_two_layer_nonfinite_and_extreme_members(ra, orc):
+    """Runaway feedback (a large) overflows to inf/NaN; tiny and huge forcings leave the fast
+    division window; zero forcing keeps exact zeros.  All bit-identical, failures flagged."""
+    t = axis_values(1750, 2000)
+    base = np.array([1.0, 0.0, 1.0, 0.7, 8.0, 100.0])
+    rows = []
+    for a in (0.0, 0.05, 0.3, 1.0, 5.0):
+        p = base.copy()
+        p[1] = a
+        rows.append(p)
+    for cs, cd in ((1e-3, 1e3), (2.0 ** -130, 1.0), (1.0, 2.0 ** 130), (0.0, 100.0), (8.0, np.inf),
+                   (-8.0, 100.0), (np.nan, 100.0)):
+        p = base.copy()
+        p[4], p[5] = cs, cd
+        rows.append(p)
+    P = np.array(rows).T.copy()
+    n = P.shape[1]
+    F = np.stack([f_syn(t), np.zeros_like(t), f_syn(t) * 1e-300, f_syn(t) * 1e250,
+                  f_syn(t) * 5e-324])
+    with np.errstate(all="ignore"):
+        for s in range(F.shape[0]):
+            scen = np.full(n, s, np.int32)
+            want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.0, 0.0, scen=scen)
+            ts, td, st = _tl_gpu(ra, t, P, F, 0.0, 0.0, scen=scen)
+            assert_bit_equal(ts, want[0], f"Ts scenario {s}")
+            assert_bit_equal(td, want[1], f"Td scenario {s}")
+            bad = ~(np.isfinite(want[0][-1]) & np.isfinite(want[1][-1]))
+            assert (st.astype(bool) == bad).all()
+
+
+def test_two_layer_irregular_axis_and_step_size(ra, orc):
+    """Sub-step count ceil((t1-t0)/h) varies per model step; h = 1/120 as in coupled_models.rs."""
+    t = np.concatenate([np.arange(1750.0, 1760.0, 0.5), np.arange(1760.0, 1800.0, 1.0),
+                        np.arange(1800.0, 1900.0, 5.0)])
+    P = two_layer_params(130)
+    F = f_syn(t)
+    for h in (0.1, 1.0 / 120.0, 0.25):
+        want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.1, 0.0, h=h, threads=8)
+        ts, td, _ = _tl_gpu(ra, t, P, F, 0.1, 0.0, h=h)
+        assert_bit_equal(ts, want[0], f"h={h}")
+        assert_bit_equal(td, want[1], f"h={h}")
+
+
+def test_step_and_resume_equal_one_run(ra):
+    t = axis_values(1750, 1850)
+    P, F = two_layer_params(200), f_syn(t)
+    one = _tl_gpu(ra, t, P, F, 0.0, 0.0)
+    chunked = _tl_gpu(ra, t, P, F, 0.0, 0.0, chunks=[1, 2, 37, 38, 99])
+    assert_bit_equal(one[0], chunked[0])
+    assert_bit_equal(one[1], chunked[1])
+    b = np.append(t, t[-1] + 1.0)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 200, b) as e:
+        e.set_params(P)
+        e.set_forcing(F)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.step()
+        e.step()
+        assert e.time_index == 2
+        part = e.get_series(1)
+        assert_bit_equal(part[:3], one[0][:3])
+        assert np.isnan(part[3:]).all()  # not yet computed by this model instance
+        e.run()
+        assert_bit_equal(e.get_series(1), one[0])
+        # strided / member-window extraction
+        sub = e.get_series(2, 10, 90, 7, 13, 101)
+        assert_bit_equal(sub, one[1][10:90:7, 13:101])
+
+
+# ------------------------------------------------------------------------------ two-layer fast
+def test_two_layer_fast_mode_tolerance(ra, orc):
+    t = axis_values()
+    P = two_layer_params(2000)
+    F = f_syn(t)
+    want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.0, 0.0, threads=8)
+    ts, td, st = _tl_gpu(ra, t, P, F, 0.0, 0.0, mode=1)
+    with np.errstate(all="ignore"):
+        bounded = np.nanmax(np.abs(want[0]), axis=0) < 100.0
+    assert bounded.mean() > 0.5
+    assert _close(ts[:, bounded], want[0][:, bounded], FAST_RTOL).all()
+    assert _close(td[:, bounded], want[1][:, bounded], FAST_RTOL).all()
+    failed = ~(np.isfinite(want[0][-1]) & np.isfinite(want[1][-1]))
+    assert (st.astype(bool)[failed]).all()
+
+
+# ------------------------------------------------------------------------------ coupled chain
+def _cp_gpu(ra, t, P, E, init, scen=None, mode=0):
+    b = np.append(t, t[-1] + (t[-1] - t[-2]))
+    with ra.Ensemble(ra.KIND_COUPLED, P.shape[1], b) as e:
+        e.set_mode(mode)
+        e.set_params(P)
+        e.set_forcing(E, scen)
+        for k, v in init.items():
+            e.set_initial(k, v)
+        e.run()
+        return {k: e.get_series(k) for k in e.var_ids if e.var_ids[k] > 0}, e.status()
+
+
+CP_NAMES = {"ts": "Surface Temperature", "td": "Deep Ocean Temperature",
+            "conc": "Atmospheric Concentration|CO2", "cum_uptake": "Cumulative Land Uptake",
+            "cum_emis": "Cumulative Emissions|CO2", "erf_co2": "Effective Radiative Forcing|CO2",
+            "erf_total": "Effective Radiative Forcing"}
+CP_INIT = {"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0,
+           "Atmospheric Concentration|CO2": 278.0, "Cumulative Land Uptake": 0.0,
+           "Cumulative Emissions|CO2": 0.0}
+
+
+def test_coupled_vs_oracle(ra, orc):
+    t = axis_values()
+    P = coupled_params(777)
+    E = emissions_syn(t)
+    want = orc.coupled_run(orc.bounds_from_values(t), P, E,
+                           dict(ts=0.0, td=0.0, conc=278.0, cum_uptake=0.0, cum_emis=0.0),
+                           threads=8)
+    got, st = _cp_gpu(ra, t, P, E, CP_INIT)
+    with np.errstate(all="ignore"):
+        bounded = np.nanmax(np.abs(want["ts"]), axis=0) < 100.0
+    assert bounded.mean() > 0.5
+    for k, name in CP_NAMES.items():
+        g, w = got[name], want[k]
+        # index-0 NaN of pure outputs (no initial value) is part of the contract
+        assert (np.isnan(g[0]) == np.isnan(w[0])).all(), name
+        assert _close(g[1:, bounded], w[1:, bounded], FAST_RTOL).all(), name
+    # cumulative emissions involve no transcendental: bit-exact
+    assert_bit_equal(got["Cumulative Emissions|CO2"], want["cum_emis"])
+
+
+def test_coupled_golden_fixture(ra):
+    g = np.load(os.path.join(GOLDEN, "coupled_golden.npz"))
+    got, _ = _cp_gpu(ra, g["time_values"], g["params"], g["emissions"], CP_INIT)
+    for k, name in CP_NAMES.items():
+        assert _close(got[name][1:], g[k][1:], FAST_RTOL).all(), name
+
+
+# ------------------------------------------------------------------------------ ensemble ops
+def test_loglik_summary_status(ra, orc):
+    t = axis_values(1750, 2100)
+    n = 1500
+    P = two_layer_params(n)
+    F = f_syn(t)
+    b = np.append(t, t[-1] + 1.0)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(F)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run()
+        ts, td = e.get_series(1), e.get_series(2)
+        tidx = np.arange(100, 271, 10, dtype=np.int32)  # 1850..2020 step 10
+        obs = ts[tidx, 0] + 0.05
+        sig = np.full(len(tidx), 0.1)
+        for normalize in (False, True):
+            got = e.loglik(np.ones(len(tidx), int), tidx, obs, sig, normalize)
+            want = orc.gaussian_loglik([ts], np.zeros(len(tidx), np.int32), tidx, obs, sig,
+                                       normalize, threads=4)
+            fin = np.isfinite(want)
+            assert (np.isfinite(got) == fin).all()
+            assert np.allclose(got[fin], want[fin], rtol=1e-13, atol=0)
+            assert (got[~fin] == -np.inf).all()
+        # two variables: per-variable partial sums, then the total
+        ov = np.r_[np.ones(3, int), np.full(2, 2)]
+        ot = np.array([10, 20, 30, 40, 50], np.int32)
+        val = np.r_[ts[[10, 20, 30], 1], td[[40, 50], 1]] + 0.01
+        got = e.loglik(ov, ot, val, np.full(5, 0.2))
+        want = orc.gaussian_loglik([ts, td], (ov - 1).astype(np.int32), ot, val, np.full(5, 0.2))
+        fin = np.isfinite(want)
+        assert np.allclose(got[fin], want[fin], rtol=1e-13, atol=0)
+        s = e.summary(1, 200)
+        row = ts[200]
+        ok = np.isfinite(row)
+        assert s["count"] == ok.sum()
+        assert np.isclose(s["mean"], row[ok].mean(), rtol=1e-12)
+        assert s["min"] == row[ok].min() and s["max"] == row[ok].max()
+        assert (e.status().astype(bool) == ~(np.isfinite(ts[-1]) & np.isfinite(td[-1]))).all()
+
+
+def test_device_lhs_is_a_latin_hypercube(ra):
+    """One sample per stratum per dimension (the property parameter_set.rs:207-233 guarantees),
+    and rank-sharded generation equals single-device generation."""
+    t = axis_values(1750, 1760)
+    b = np.append(t, t[-1] + 1.0)
+    n = 4099
+    lo = np.array([r[0] for r in TL_RANGES])
+    hi = np.array([r[1] for r in TL_RANGES])
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        e.sample_lhs(SEED, lo, hi)
+        P = e.get_params()
+    u = (P - lo[:, None]) / (hi - lo)[:, None]
+    assert ((u >= 0) & (u < 1)).all()
+    strata = np.floor(u * n).astype(np.int64)
+    for j in range(6):
+        assert np.array_equal(np.sort(strata[j]), np.arange(n)), f"dimension {j}"
+    # dimensions are shuffled independently
+    assert abs(np.corrcoef(u[0], u[1])[0, 1]) < 0.06
+    assert not np.array_equal(strata[0], strata[1])
+    # two ranks owning [0, k) and [k, n) reproduce the same global matrix, no communication
+    k = 1500
+    with ra.Ensemble(ra.KIND_TWO_LAYER, k, b) as e0, ra.Ensemble(ra.KIND_TWO_LAYER, n - k, b) as e1:
+        e0.sample_lhs(SEED, lo, hi, 0, n)
+        e1.sample_lhs(SEED, lo, hi, k, n)
+        assert_bit_equal(np.concatenate([e0.get_params(), e1.get_params()], axis=1), P)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        e.sample_lhs(SEED + 1, lo, hi)
+        assert not np.array_equal(e.get_params(), P)
+
+
+# ------------------------------------------------------------------------------ error behaviour
+def test_error_conventions(ra):
+    from rscm_amd import RscmGpuError
+    t = axis_values(1750, 1760)
+    b = np.append(t, t[-1] + 1.0)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 10, b) as e:
+        with pytest.raises(RscmGpuError) as ei:  # nothing configured
+            e.run()
+        assert ei.value.code == 2
+        e.set_params(two_layer_params(10))
+        e.set_forcing(f_syn(t))
+        e.set_initial(1, 0.0)
+        with pytest.raises(RscmGpuError, match="MissingInitialValue"):
+            e.run()
+        e.set_initial(2, 0.0)
+        with pytest.raises(ValueError):
+            e.set_params(np.zeros((5, 10)))
+        with pytest.raises(ValueError, match="Expected 6 parameters"):
+            e.set_params_aos(np.zeros((10, 5)))
+        with pytest.raises(RscmGpuError):  # scenario index out of range
+            e.set_forcing(f_syn(t), np.full(10, 3, np.int32))
+        e.run()
+        with pytest.raises(RscmGpuError) as ei:  # Model::step asserts time_index < len-1
+            e.step()
+        assert ei.value.code == 2
+    # monthly axis with the hard-coded h = 0.1: the reference panics in get_last_step
+    tm = 1750.0 + np.arange(25) / 12.0
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 4, np.append(tm, tm[-1] + 1 / 12.0)) as e:
+        e.set_params(two_layer_params(4))
+        e.set_forcing(np.ones(25))
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        with pytest.raises(RscmGpuError) as ei:
+            e.run()
+        assert ei.value.code == 3
+        e.set_step_size(0, 1.0 / 120.0)
+        e.run()
+        assert e.finished()
+    with pytest.raises(RscmGpuError):
+        ra.Ensemble(ra.KIND_TWO_LAYER, 4, [3.0, 2.0, 1.0])
+
+
+# ------------------------------------------------------------------------------ full size
+@pytest.mark.parametrize("n_members", [100_000, 1_000_000])
+def test_full_size_properties(ra, orc, n_members):
+    """BASELINE.json sizes (1e5 and 1e6 members x 751 points), checked through properties that do
+    not need the oracle on every member:
+      * determinism: two runs give identical bits;
+      * a = 0 members are linear and doubling F is exact in binary64, so Ts(2F) == 2*Ts(F) bitwise;
+      * permutation equivariance: reversing the member order reverses the outputs;
+      * oracle spot check on 512 random members, bit-exact.
+    """
+    t = axis_values()
+    b = np.append(t, t[-1] + 1.0)
+    F = f_syn(t)
+    lo = np.array([r[0] for r in TL_RANGES])
+    hi = np.array([r[1] for r in TL_RANGES])
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n_members, b) as e:
+        e.sample_lhs(SEED, lo, hi)
+        P = e.get_params()
+        e.set_forcing(F)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run()
+        rows = [1, 100, 375, 750]
+        first = {r: e.get_series(1, r, r + 1)[0] for r in rows}
+        last_td = e.get_series(2, 750, 751)[0]
+        rng = np.random.default_rng(11)
+        pick = np.sort(rng.choice(n_members, 512, replace=False))
+        want = orc.two_layer_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), F,
+                                 0.0, 0.0, threads=8)
+        for i, m in enumerate(pick[:64]):
+            got = e.get_series(1, 0, 751, 1, int(m), int(m) + 1)[:, 0]
+            assert_bit_equal(got, want[0][:, i], f"member {m}")
+        for r in rows:
+            assert_bit_equal(first[r][pick], want[0][r], f"row {r}")
+        assert_bit_equal(last_td[pick], want[1][750])
+        # determinism
+        e.rewind()
+        e.run()
+        for r in rows:
+            assert_bit_equal(e.get_series(1, r, r + 1)[0], first[r], "second run")
+        # permutation equivariance
+        e.set_params(np.ascontiguousarray(P[:, ::-1]))
+        e.rewind()
+        e.run()
+        assert_bit_equal(e.get_series(1, 750, 751)[0][::-1], first[750], "reversed members")
+        # exact linearity in F for a = 0
+        P0 = P.copy()
+        P0[1] = 0.0
+        e.set_params(P0)
+        e.rewind()
+        e.run()
+        base = e.get_series(1, 750, 751)[0]
+        e.set_forcing(2.0 * F)
+        e.rewind()
+        e.run()
+        assert_bit_equal(e.get_series(1, 750, 751)[0], 2.0 * base, "Ts(2F) == 2 Ts(F)")
+        assert np.isfinite(base).all()
