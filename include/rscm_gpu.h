@@ -198,9 +198,9 @@ RSCM_API int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, 
 
 /* ---- diagnostics --------------------------------------------------------------------------- */
 /* Element-wise num[i]/den[i] on the device through (a) the compiler's IEEE f64 division and
- * (b) the hoisted-reciprocal division the kernels use (rk4_device.hpp); used_fast[i] tells
- * whether (b) took its three-instruction path.  The parity tests require out_ref == out_fast
- * bit for bit. */
+ * (b) the three-instruction hoisted-reciprocal quotient of rk4_device.hpp with no fallback;
+ * used_fast[i] = 1 where both operands are inside the windows in which the kernels trust (b).
+ * The parity tests require out_ref == out_fast bit for bit wherever used_fast is 1. */
 RSCM_API int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const double* den,
                           double* out_ref, double* out_fast, uint8_t* used_fast);
 

@@ -18,24 +18,39 @@ namespace rscm {
 //     sd = div_scale(d), sn = div_scale(n)
 //     r  = rcp(sd); e = fma(-sd,r,1); r = fma(r,e,r); e = fma(-sd,r,1); r = fma(r,e,r)
 //     q  = sn*r; rem = fma(-sd,q,sn); res = div_fmas(rem,r,q); div_fixup(res,d,n)
-// (11 VALU instructions, v_rcp_f64 at quarter rate).  When div_scale leaves both operands
-// unscaled and div_fixup passes the quotient through -- true whenever the biased exponent of d
-// is in [895,1151] and that of n in [256,1535] -- the result is exactly
+// (11 VALU instructions, 58 cycles per wavefront measured; tools/valu_microbench.hip).
+// v_div_scale_f64 leaves both operands unscaled and v_div_fixup_f64 passes the quotient through
+// when the divisor is normal with a normal reciprocal, exponent(n) - exponent(d) < 768, the
+// quotient is not denormal and the numerator's biased exponent exceeds 53.  All of that holds
+// when
+//     biased exponent of d in [895, 1151]   (|d| in [2^-128, 2^129))      "divisor window"
+//     biased exponent of n in [512, 1535]   (|n| in [2^-511, 2^513))      "numerator window"
+// and then the compiler's sequence is exactly
 //     q = n*r; rem = fma(-d,q,n); res = fma(rem,r,q)
 // with r depending on d alone.  So r is computed once per member (same instruction sequence)
-// and each division costs three instructions; numerators outside the window (zeros, denormals,
-// huge values on the way to overflow, inf, NaN) take the compiler's full division, so results
-// are bit-identical to IEEE division for every input.  tests/test_gpu_parity.py checks this
-// identity on random and edge-case operands through rscm_gpu_selftest_div.
+// and each division costs three instructions.  Numerators outside the window (zeros,
+// denormals, values on their way to overflow, inf, NaN) must take the compiler's division;
+// kernels either branch per division (div_const) or validate a whole model year at once
+// (two_layer.hip).  tests/test_gpu_parity.py checks the identity on random and edge-case
+// operands through rscm_gpu_selftest_div.
 // ---------------------------------------------------------------------------------------------
-struct ConstDiv {
-    double d;       // divisor
-    double r;       // refined reciprocal
-    uint32_t span;  // width of the accepted numerator-exponent window (0: never use the fast path)
-};
 
-constexpr uint32_t kNumExpLo = 256u << 20;          // numerator biased exponent >= 256
-constexpr uint32_t kNumExpSpan = (1536u - 256u) << 20;  // and < 1536
+// tag < 0  <=>  biased exponent of x in [512, 1535]: (hi << 1) moves exponent bit 10 to bit 31
+// and bit 9 to bit 30; adding 2^30 sets bit 31 exactly for the bit pairs 01 and 10.
+__device__ __forceinline__ int32_t window_tag(double x)
+{
+    // One v_lshl_add_u32 on the high dword (0x40000000 is the inline constant 2.0).  Written as
+    // asm because LLVM canonicalises ((hi << 1) + c) into alignbit + and + add (3 instructions).
+    int32_t t;
+    asm("v_lshl_add_u32 %0, %1, 1, 2.0" : "=v"(t) : "v"(__double2hiint(x)));
+    return t;
+}
+
+__device__ __forceinline__ bool divisor_in_window(double d)
+{
+    const uint32_t ed = ((uint32_t)__double2hiint(d) >> 20) & 0x7FFu;
+    return (ed - 895u) <= 256u;
+}
 
 __device__ __forceinline__ double refined_rcp(double d)
 {
@@ -47,27 +62,37 @@ __device__ __forceinline__ double refined_rcp(double d)
     return r;
 }
 
+// The three-instruction quotient; equals n/d bit for bit inside the two windows.
+__device__ __forceinline__ double spec_div(double n, double d, double r)
+{
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
+struct ConstDiv {
+    double d;  // divisor
+    double r;  // refined reciprocal
+    bool ok;   // divisor inside its window
+};
+
 __device__ __forceinline__ ConstDiv make_const_div(double d)
 {
     ConstDiv c;
     c.d = d;
     c.r = refined_rcp(d);
-    const uint32_t ed = ((uint32_t)__double2hiint(d) >> 20) & 0x7FFu;
-    c.span = (ed - 895u) <= 256u ? kNumExpSpan : 0u;
+    c.ok = divisor_in_window(d);
     return c;
 }
 
 __device__ __forceinline__ bool const_div_fast_ok(double n, const ConstDiv& c)
 {
-    const uint32_t en = (uint32_t)__double2hiint(n) & 0x7FF00000u;
-    return (en - kNumExpLo) < c.span;
+    return c.ok && window_tag(n) < 0;
 }
 
+// Branch-per-division form (used where a year cannot cheaply be replayed).
 __device__ __forceinline__ double div_const(double n, const ConstDiv& c)
 {
-    const double q = n * c.r;
-    const double rem = __builtin_fma(-c.d, q, n);
-    double res = __builtin_fma(rem, c.r, q);
+    double res = spec_div(n, c.d, c.r);
     if (__builtin_expect(!const_div_fast_ok(n, c), 0)) res = n / c.d;
     return res;
 }
@@ -81,6 +106,19 @@ __device__ __forceinline__ double rk4_combine(double y, double k1, double k2, do
                                               double sixth)
 {
     return y + (((k1 + k2 * 2.0) + k3 * 2.0) + k4) * sixth;
+}
+
+// Same value while 2*k2 and 2*k3 cannot overflow (doubling is exact, so fusing it into the
+// following addition does not change the rounding).
+__device__ __forceinline__ double rk4_combine_fused2(double y, double k1, double k2, double k3,
+                                                     double k4, double sixth)
+{
+    return y + (__builtin_fma(k3, 2.0, __builtin_fma(k2, 2.0, k1)) + k4) * sixth;
+}
+
+__device__ __forceinline__ int32_t max3_i32(int32_t a, int32_t b, int32_t c)
+{
+    return max(max(a, b), c);  // v_max3_i32
 }
 
 __device__ __forceinline__ bool is_finite(double x)

@@ -20,6 +20,20 @@
 // gather (scenario_of_member).  No inter-workgroup communication, so the blockIdx -> XCD
 // round-robin needs no remap: every workgroup streams its own column block and re-reads only
 // the (L2-resident) forcing.
+//
+// The year loop issues no vector-memory LOAD: forcing comes from LDS (or is prefetched one year
+// ahead on the L2 path) and the sub-step counts through the scalar cache, so no s_waitcnt vmcnt
+// ever waits behind the previous year's stores -- that wait was 31 % of wave time at
+// 1.5 waves/SIMD (profiles/r1_exact_1e5_v1_pmc.txt).
+//
+// EXACT mode, speculative year: the RK4 sub-steps of a year run branch-free with
+//   * n/C as q = n*r; rem = fma(-C,q,n); fma(rem,r,q)   (rk4_device.hpp: identical to IEEE
+//     division when the numerator's biased exponent is in [512,1535] and C's in [895,1151]),
+//   * k1 + k2*2 as fma(k2, 2, k1)                        (identical while 2*k2 cannot overflow),
+// while one integer max3 per right-hand side accumulates whether every numerator stayed inside
+// the window.  If any did not (zeros in the first year, a member overflowing towards inf, ...)
+// the year is recomputed for those lanes from the saved state with the compiler's full IEEE
+// division and unfused doubling.  Either way the stored bits equal the reference's arithmetic.
 #include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
@@ -28,24 +42,52 @@ namespace rscm {
 namespace {
 
 struct TLConst {
-    double lambda0, a, eff_eta, eta;
-    ConstDiv cs, cd;
+    double lambda0, a, eff_eta, eta, cs, cd, rcs, rcd;
 };
 
-// EXACT: the reference's expression order, every product and sum rounded separately.
+// EXACT arithmetic, the reference's expression order, every product and sum rounded separately:
 //   temperature_difference = ts - td
 //   lambda_eff = lambda0 - a*ts
 //   heat_exchange_surface = efficacy*eta*temperature_difference      ((efficacy*eta) first)
 //   dts = (erf - lambda_eff*ts - heat_exchange_surface) / heat_capacity_surface
 //   dtd = (eta*temperature_difference) / heat_capacity_deep
+template <bool SPEC>
 __device__ __forceinline__ void rhs_exact(const TLConst& p, double erf, double ts, double td,
-                                          double& dts, double& dtd)
+                                          double& dts, double& dtd, int32_t& acc)
 {
     const double diff = ts - td;
     const double lambda_eff = p.lambda0 - p.a * ts;
     const double hx_s = p.eff_eta * diff;
-    dts = div_const(erf - lambda_eff * ts - hx_s, p.cs);
-    dtd = div_const(p.eta * diff, p.cd);
+    const double num_s = erf - lambda_eff * ts - hx_s;
+    const double num_d = p.eta * diff;
+    if constexpr (SPEC) {
+        dts = spec_div(num_s, p.cs, p.rcs);
+        dtd = spec_div(num_d, p.cd, p.rcd);
+        acc = max3_i32(acc, window_tag(num_s), window_tag(num_d));
+    } else {
+        dts = num_s / p.cs;
+        dtd = num_d / p.cd;
+    }
+}
+
+template <bool SPEC>
+__device__ __forceinline__ void rk4_step_exact(const TLConst& p, double erf, double h,
+                                               double half_step, double sixth, double& ts,
+                                               double& td, int32_t& acc)
+{
+    double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
+    rhs_exact<SPEC>(p, erf, ts, td, k1s, k1d, acc);
+    rhs_exact<SPEC>(p, erf, ts + k1s * half_step, td + k1d * half_step, k2s, k2d, acc);
+    rhs_exact<SPEC>(p, erf, ts + k2s * half_step, td + k2d * half_step, k3s, k3d, acc);
+    rhs_exact<SPEC>(p, erf, ts + k3s * h, td + k3d * h, k4s, k4d, acc);
+    if constexpr (SPEC) {
+        // (k1 + k2*2) + k3*2: the doubling is exact, so the fused form rounds identically
+        ts = rk4_combine_fused2(ts, k1s, k2s, k3s, k4s, sixth);
+        td = rk4_combine_fused2(td, k1d, k2d, k3d, k4d, sixth);
+    } else {
+        ts = rk4_combine(ts, k1s, k2s, k3s, k4s, sixth);
+        td = rk4_combine(td, k1d, k2d, k3d, k4d, sixth);
+    }
 }
 
 struct TLFast {
@@ -63,12 +105,12 @@ __device__ __forceinline__ void rhs_fast(const TLFast& p, double erf_cs, double 
     dtd = p.ed * diff;
 }
 
-template <int MODE>
+template <int MODE, bool LDS>
 __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
 {
     extern __shared__ double lds_forcing[];
     const int32_t len = a.step_end - a.step_begin;
-    if (a.lds_forcing) {
+    if constexpr (LDS) {
         const int32_t total = a.n_scen * len;
         for (int32_t idx = threadIdx.x; idx < total; idx += kBlock) {
             const int32_t s = idx / len, k = idx - s * len;
@@ -89,13 +131,24 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
     const int32_t scen = a.scen ? a.scen[i] : 0;
     const double* fglob = a.forcing + (size_t)scen * a.n_times + a.src_off;
     const int32_t fl0 = scen * len - a.step_begin;  // lds_forcing[fl0 + n], n >= step_begin
+    auto forcing_at = [&](int32_t n) -> double {
+        if constexpr (LDS) return lds_forcing[fl0 + n];
+        else return fglob[n];
+    };
 
     double ts = a.ts[(size_t)a.step_begin * N + i];
     double td = a.td[(size_t)a.step_begin * N + i];
+    double* out_ts = a.ts + (size_t)(a.step_begin + 1) * N + i;
+    double* out_td = a.td + (size_t)(a.step_begin + 1) * N + i;
 
     const double h = a.h;
     const double half_step = h / 2.0;
     const double sixth = h / 6.0;
+    const int32_t last = a.step_end - 1;
+
+    // next year's forcing and sub-step count are fetched a year ahead of their use
+    double erf_next = forcing_at(a.step_begin);
+    int32_t m_next = a.nsub[a.step_begin];
 
     if constexpr (MODE == 0) {
         TLConst p;
@@ -103,22 +156,35 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
         p.a = pa;
         p.eff_eta = efficacy * eta;
         p.eta = eta;
-        p.cs = make_const_div(cs);
-        p.cd = make_const_div(cd);
+        p.cs = cs;
+        p.cd = cd;
+        const ConstDiv dcs = make_const_div(cs), dcd = make_const_div(cd);
+        p.rcs = dcs.r;
+        p.rcd = dcd.r;
+        // 0 (never "all inside") when a heat capacity is outside the divisor window
+        const int32_t acc0 = (dcs.ok && dcd.ok) ? (int32_t)0x80000000 : 0;
         for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-            const double erf = a.lds_forcing ? lds_forcing[fl0 + n] : fglob[n];
-            const int32_t m = a.nsub[n];
-            for (int32_t s = 0; s < m; ++s) {
-                double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
-                rhs_exact(p, erf, ts, td, k1s, k1d);
-                rhs_exact(p, erf, ts + k1s * half_step, td + k1d * half_step, k2s, k2d);
-                rhs_exact(p, erf, ts + k2s * half_step, td + k2d * half_step, k3s, k3d);
-                rhs_exact(p, erf, ts + k3s * h, td + k3d * h, k4s, k4d);
-                ts = rk4_combine(ts, k1s, k2s, k3s, k4s, sixth);
-                td = rk4_combine(td, k1d, k2d, k3d, k4d, sixth);
+            const double erf = erf_next;
+            const int32_t m = m_next;
+            const int32_t np = n < last ? n + 1 : n;
+            erf_next = forcing_at(np);
+            m_next = a.nsub[np];
+            const double ts0 = ts, td0 = td;
+            int32_t acc = acc0;
+            for (int32_t s = 0; s < m; ++s) rk4_step_exact<true>(p, erf, h, half_step, sixth, ts, td, acc);
+            // A NaN state at the start of the year makes every value of the year NaN on either
+            // path; everything else must have stayed inside the window.
+            const bool settled = (ts0 != ts0) || (td0 != td0);
+            if (__builtin_expect(acc >= 0 && !settled, 0)) {
+                ts = ts0;
+                td = td0;
+                int32_t unused = 0;
+                for (int32_t s = 0; s < m; ++s) rk4_step_exact<false>(p, erf, h, half_step, sixth, ts, td, unused);
             }
-            a.ts[(size_t)(n + 1) * N + i] = ts;
-            a.td[(size_t)(n + 1) * N + i] = td;
+            *out_ts = ts;
+            *out_td = td;
+            out_ts += N;
+            out_td += N;
         }
     } else {
         const double inv_cs = 1.0 / cs;
@@ -129,8 +195,11 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
         p.ed = eta / cd;
         const double third = h / 3.0;
         for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-            const double erf = (a.lds_forcing ? lds_forcing[fl0 + n] : fglob[n]) * inv_cs;
-            const int32_t m = a.nsub[n];
+            const double erf = erf_next * inv_cs;
+            const int32_t m = m_next;
+            const int32_t np = n < last ? n + 1 : n;
+            erf_next = forcing_at(np);
+            m_next = a.nsub[np];
             for (int32_t s = 0; s < m; ++s) {
                 double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
                 rhs_fast(p, erf, ts, td, k1s, k1d);
@@ -143,8 +212,10 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
                 ts = __builtin_fma(k2s + k3s, third, __builtin_fma(k1s + k4s, sixth, ts));
                 td = __builtin_fma(k2d + k3d, third, __builtin_fma(k1d + k4d, sixth, td));
             }
-            a.ts[(size_t)(n + 1) * N + i] = ts;
-            a.td[(size_t)(n + 1) * N + i] = td;
+            *out_ts = ts;
+            *out_td = td;
+            out_ts += N;
+            out_td += N;
         }
     }
     a.status[i] = (is_finite(ts) && is_finite(td)) ? 0 : 1;
@@ -157,7 +228,9 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const size_t lds = a.lds_forcing ? (size_t)a.n_scen * (a.step_end - a.step_begin) * sizeof(double) : 0;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    auto kern = mode == 0 ? two_layer_kernel<0> : two_layer_kernel<1>;
+    void (*kern)(TwoLayerArgs) =
+        mode == 0 ? (a.lds_forcing ? two_layer_kernel<0, true> : two_layer_kernel<0, false>)
+                  : (a.lds_forcing ? two_layer_kernel<1, true> : two_layer_kernel<1, false>);
     if (lds > (size_t)kMaxStaticLds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,42 @@
+"""Profiling driver: a few passes of the two-layer kernel through the C-ABI (no torch), for
+rocprofv3 --kernel-trace --stats and --pmc runs.  Usage:
+    python3 scripts/profile_two_layer.py [members] [mode 0|1] [passes] [kind 0|1]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rscm_amd  # noqa: E402
+
+members = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+passes = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+kind = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+
+t = np.arange(1750, 2501, dtype=np.float64)
+b = np.append(t, 2501.0)
+F = 4.0 * (1.0 - np.exp(-(t - 1750.0) / 120.0)) + 0.3 * np.sin(2 * np.pi * (t - 1750.0) / 11.0)
+lo = np.array([0.8, 0.0, 1.0, 0.5, 5.0, 50.0, 15.0, 278.0, 0.0, 3.7])
+hi = np.array([1.5, 0.1, 1.8, 1.0, 15.0, 200.0, 40.0, 278.0, 0.1, 3.7])
+P = 6 if kind == 0 else 10
+with rscm_amd.Ensemble(kind, members, b) as e:
+    e.set_mode(mode)
+    e.sample_lhs(20260327, lo[:P], hi[:P])
+    if kind == 0:
+        e.set_forcing(F)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+    else:
+        yrs = np.array([1750.0, 1850.0, 1950.0, 2000.0, 2020.0, 2050.0, 2100.0])
+        e.set_forcing(np.interp(t, yrs, [0.0, 0.5, 3.0, 7.0, 10.0, 5.0, 1.0]))
+        for v, x in ((1, 0.0), (2, 0.0), (3, 278.0), (4, 0.0), (5, 0.0)):
+            e.set_initial(v, x)
+    ms = []
+    for _ in range(passes):
+        e.rewind()
+        e.run()
+        ms.append(e.last_run_ms())
+    print(f"kind={kind} members={members} mode={mode} launch ms: " + " ".join(f"{x:.3f}" for x in ms))
+    print(f"member-years/s (best) = {members * 750 / (min(ms) * 1e-3):.4e}")
