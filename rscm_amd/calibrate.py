@@ -1,0 +1,544 @@
+"""Calibration front for the GPU ensemble -- mirror of ``rscm.calibrate`` for the hot path.
+
+The reference evaluates a batch of parameter vectors with ``ModelRunner::run_batch`` (rayon,
+crates/rscm-calibrate/src/model_runner.rs:261-266; the Python runner is sequential under the
+GIL, crates/rscm-calibrate/src/python/model_runner.rs:274-278), then log-prior + Gaussian
+log-likelihood per member (sampler/ensemble.rs:143-177).  Here ``ModelRunner.run_batch`` uploads
+the whole batch as one ``[N][P]`` matrix, steps all members in one kernel launch and either
+extracts ``{variable: {time: value}}`` per member (reference shape) or reduces the likelihood on
+the device (``log_likelihood_batch``), which is what ``EnsembleSampler``/``PointEstimator`` use.
+
+The sampler's proposal/accept bookkeeping is tiny and stays on the host
+(sampler/ensemble.rs:496-547, sampler/moves.rs:16-128), as in the reference.  The reference
+draws from ``thread_rng`` (not reproducible); here every random draw takes a ``numpy`` Generator.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .core import Model, ModelBuilder
+
+
+# ------------------------------------------------------------------------------------ priors
+class Uniform:
+    """crates/rscm-calibrate/src/distribution.rs:114-180."""
+
+    def __init__(self, low: float, high: float):
+        if low >= high:
+            raise ValueError(f"Uniform: low ({low}) must be less than high ({high})")
+        self._low, self._high = float(low), float(high)
+
+    low = property(lambda self: self._low)
+    high = property(lambda self: self._high)
+
+    def sample(self, rng: np.random.Generator) -> float:
+        return self._low + rng.random() * (self._high - self._low)
+
+    def ln_pdf(self, x: float) -> float:
+        if x < self._low or x > self._high:
+            return -math.inf
+        return -math.log(self._high - self._low)
+
+    def bounds(self) -> Optional[Tuple[float, float]]:
+        return self._low, self._high
+
+    def quantile(self, u):
+        return self._low + u * (self._high - self._low)
+
+
+class Normal:
+    """distribution.rs:211-275."""
+
+    def __init__(self, mean: float, std_dev: float):
+        if not std_dev > 0:
+            raise ValueError(f"Normal: std_dev ({std_dev}) must be positive")
+        self.mean, self.std_dev = float(mean), float(std_dev)
+
+    def sample(self, rng):
+        return rng.normal(self.mean, self.std_dev)
+
+    def ln_pdf(self, x):
+        z = (x - self.mean) / self.std_dev
+        return -0.5 * z * z - math.log(self.std_dev) - 0.5 * math.log(2.0 * math.pi)
+
+    def bounds(self):
+        return None
+
+    def quantile(self, u):
+        from scipy.special import ndtri  # exact inverse CDF (the reference approximates it by sampling)
+        return self.mean + self.std_dev * ndtri(u)
+
+
+class ParameterSet:
+    """parameter_set.rs: ordered named priors; ``sample_lhs`` per :207-233."""
+
+    def __init__(self) -> None:
+        self._names: List[str] = []
+        self._dists: List[object] = []
+
+    def add(self, name: str, distribution) -> "ParameterSet":
+        self._names.append(name)
+        self._dists.append(distribution)
+        return self
+
+    def __len__(self) -> int:
+        return len(self._names)
+
+    @property
+    def param_names(self) -> List[str]:
+        return list(self._names)
+
+    def bounds(self) -> Tuple[List[float], List[float]]:
+        lo, hi = [], []
+        for d in self._dists:
+            b = d.bounds()
+            lo.append(b[0] if b else -math.inf)
+            hi.append(b[1] if b else math.inf)
+        return lo, hi
+
+    def sample_random(self, n: int, rng: Optional[np.random.Generator] = None) -> np.ndarray:
+        rng = rng or np.random.default_rng()
+        return np.array([[d.sample(rng) for d in self._dists] for _ in range(n)])
+
+    def sample_lhs(self, n: int, rng: Optional[np.random.Generator] = None) -> np.ndarray:
+        """Host Latin hypercube, ``[n][P]``: per dimension one draw per stratum
+        (``i*(1/n) + U*(1/n)``), shuffled, through the inverse CDF."""
+        rng = rng or np.random.default_rng()
+        out = np.empty((n, len(self)))
+        size = 1.0 / n
+        for j, d in enumerate(self._dists):
+            u = np.arange(n) * size + rng.random(n) * size
+            rng.shuffle(u)
+            out[:, j] = d.quantile(u)
+        return out
+
+    def log_prior(self, params: Sequence[float]) -> float:
+        if len(params) != len(self):
+            raise ValueError(f"Expected {len(self)} parameters, got {len(params)}")
+        return float(sum(d.ln_pdf(x) for d, x in zip(self._dists, params)))
+
+    def log_prior_batch(self, params: np.ndarray) -> np.ndarray:
+        return np.array([self.log_prior(row) for row in params])
+
+
+# ------------------------------------------------------------------------------------ target
+class Observation:
+    def __init__(self, time: float, value: float, uncertainty: float):
+        if not uncertainty > 0:  # target.rs:25-56
+            raise ValueError(f"Observation uncertainty must be positive, got {uncertainty}")
+        self.time, self.value, self.uncertainty = float(time), float(value), float(uncertainty)
+
+
+class VariableTarget:
+    def __init__(self, name: str):
+        self.name = name
+        self.observations: List[Observation] = []
+
+    def add(self, time, value, uncertainty) -> "VariableTarget":
+        self.observations.append(Observation(time, value, uncertainty))
+        return self
+
+
+class Target:
+    """target.rs:80-230."""
+
+    def __init__(self) -> None:
+        self._vars: Dict[str, VariableTarget] = {}
+
+    def add_variable(self, name: str) -> VariableTarget:
+        return self._vars.setdefault(name, VariableTarget(name))
+
+    def add_observation(self, variable: str, time, value, uncertainty) -> "Target":
+        self.add_variable(variable).add(time, value, uncertainty)
+        return self
+
+    def get_variable(self, name: str) -> Optional[VariableTarget]:
+        return self._vars.get(name)
+
+    def variable_names(self) -> List[str]:
+        return list(self._vars)
+
+    def variables(self):
+        return self._vars.items()
+
+    def total_observations(self) -> int:
+        return sum(len(v.observations) for v in self._vars.values())
+
+
+def time_key(t: float) -> str:
+    """likelihood.rs:40-42."""
+    return f"{t:.6f}"
+
+
+class GaussianLikelihood:
+    """likelihood.rs:167-250.  ``ln_likelihood`` is the host form over the reference's
+    ``{variable: {time: value}}`` output; the batch form runs on the device."""
+
+    def __init__(self, normalize: bool = False):
+        self.normalize = bool(normalize)
+
+    def ln_likelihood(self, output: Dict[str, Dict[float, float]], target: Target) -> float:
+        total = 0.0
+        for name, vt in target.variables():
+            if name not in output:
+                raise KeyError(f"Model output missing variable: {name}")
+            keyed = {time_key(t): v for t, v in output[name].items()}
+            ln_l = 0.0
+            for obs in vt.observations:
+                k = time_key(obs.time)
+                if k not in keyed:
+                    raise KeyError(f"Model output missing time {obs.time} for variable {name}")
+                m = keyed[k]
+                if not math.isfinite(m):
+                    raise ValueError(f"Model output contains non-finite value for {name} at time {obs.time}")
+                residual = obs.value - m
+                chi = (residual * residual) / (obs.uncertainty * obs.uncertainty)
+                l = -0.5 * chi
+                if self.normalize:
+                    l -= 0.5 * math.log(2.0 * math.pi)
+                    l -= math.log(obs.uncertainty)
+                ln_l += l
+            total += ln_l
+        return total
+
+
+# ------------------------------------------------------------------------------------ runner
+class ModelRunner:
+    """GPU-batched ``ModelRunner`` (trait: model_runner.rs:38-85).
+
+    ``model`` is a ``ModelBuilder`` describing the shared structure (axis, components, forcing,
+    initial values); ``param_names`` name component parameters (``lambda0`` ... ``erf_2xco2``)
+    that vary per member, in the order of the parameter vectors; every other parameter keeps the
+    value of the builder's components.  One device ensemble is kept per batch size.
+    """
+
+    def __init__(self, model: ModelBuilder, param_names: Sequence[str],
+                 output_variables: Sequence[str], mode: int = L.MODE_EXACT):
+        self._builder = model
+        self._param_names = list(param_names)
+        self._outputs = list(output_variables)
+        self._mode = mode
+        self._models: Dict[int, Model] = {}
+        probe = self._model(1)
+        unknown = [p for p in self._param_names if p not in probe.param_order]
+        if unknown:
+            raise ValueError(f"unknown model parameter(s) {unknown}; known: {list(probe.param_order)}")
+        missing = [v for v in self._outputs if v not in probe.ensemble.var_ids]
+        if missing:
+            raise KeyError(f"Model output missing variable: {missing[0]}")
+        self._rows = [probe.param_order.index(p) for p in self._param_names]
+
+    @property
+    def param_names(self) -> List[str]:
+        return list(self._param_names)
+
+    @property
+    def output_variables(self) -> List[str]:
+        return list(self._outputs)
+
+    def _model(self, n: int) -> Model:
+        if n not in self._models:
+            if len(self._models) >= 4:  # bounded cache of device ensembles
+                self._models.pop(next(iter(self._models))).close()
+            m = self._builder.build(n_members=n)
+            m.ensemble.set_mode(self._mode)
+            self._models[n] = m
+        return self._models[n]
+
+    def _run(self, param_sets: np.ndarray) -> Model:
+        p = np.asarray(param_sets, dtype=np.float64)
+        if p.ndim != 2 or p.shape[1] != len(self._param_names):
+            got = p.shape[1] if p.ndim == 2 else len(p)
+            raise ValueError(f"Expected {len(self._param_names)} parameters, got {got}")  # :225-231
+        m = self._model(p.shape[0])
+        full = np.repeat(m.base_params[:, None], p.shape[0], axis=1)
+        full[self._rows, :] = p.T
+        m.ensemble.set_params(full)
+        m.ensemble.rewind()
+        m.ensemble.run()
+        return m
+
+    def run(self, params: Sequence[float]) -> Dict[str, Dict[float, float]]:
+        return self.run_batch([list(params)])[0]
+
+    def run_batch(self, param_sets) -> List[Dict[str, Dict[float, float]]]:
+        """Order-preserving; per member ``{variable: {time: value}}`` of the non-NaN entries
+        (extract_outputs, model_runner.rs:161-212)."""
+        m = self._run(np.asarray(param_sets, dtype=np.float64))
+        times = m._axis.values()
+        series = {v: m.ensemble.get_series(v) for v in self._outputs}
+        out = []
+        for i in range(m.ensemble.n_members):
+            member = {}
+            for v, s in series.items():
+                col = s[:, i]
+                ok = ~np.isnan(col)
+                member[v] = {float(t): float(x) for t, x in zip(times[ok], col[ok])}
+            out.append(member)
+        return out
+
+    def log_likelihood_batch(self, param_sets, target: Target,
+                             likelihood: GaussianLikelihood) -> np.ndarray:
+        """Device path: run the batch and reduce the Gaussian log-likelihood per member without
+        moving any series to the host.  Failed members (non-finite or never-computed values at an
+        observation time) get ``-inf`` (sampler/ensemble.rs:163-172)."""
+        m = self._run(np.asarray(param_sets, dtype=np.float64))
+        ov, ot, val, sig = [], [], [], []
+        for name, vt in target.variables():
+            if name not in m.ensemble.var_ids or m.ensemble.var_ids[name] == 0:
+                raise KeyError(f"Model output missing variable: {name}")
+            for obs in vt.observations:
+                idx = m._axis.index_of(obs.time)
+                if idx is None:  # "Model output missing time" -> Err -> -inf for every member
+                    return np.full(m.ensemble.n_members, -np.inf)
+                ov.append(name)
+                ot.append(idx)
+                val.append(obs.value)
+                sig.append(obs.uncertainty)
+        return m.ensemble.loglik(ov, ot, val, sig, likelihood.normalize)
+
+    def close(self) -> None:
+        for m in self._models.values():
+            m.close()
+        self._models.clear()
+
+
+# ------------------------------------------------------------------------------------ sampler
+class WalkerInit:
+    """sampler/init.rs:40-98."""
+
+    def __init__(self, kind: str, **kw):
+        self.kind, self.kw = kind, kw
+
+    @staticmethod
+    def from_prior() -> "WalkerInit":
+        return WalkerInit("prior")
+
+    @staticmethod
+    def ball(center: Sequence[float], radius: float) -> "WalkerInit":
+        return WalkerInit("ball", center=np.asarray(center, dtype=float), radius=float(radius))
+
+    @staticmethod
+    def explicit(positions) -> "WalkerInit":
+        return WalkerInit("explicit", positions=np.asarray(positions, dtype=float))
+
+    def initialize(self, n_walkers: int, params: ParameterSet, rng) -> np.ndarray:
+        if self.kind == "prior":
+            return params.sample_random(n_walkers, rng)
+        if self.kind == "ball":
+            c = self.kw["center"]
+            if len(c) != len(params):
+                raise ValueError(f"Ball center length {len(c)} does not match parameter count {len(params)}")
+            return c[None, :] + (rng.random((n_walkers, len(params))) - 0.5) * self.kw["radius"]
+        pos = self.kw["positions"]
+        if pos.shape != (n_walkers, len(params)):
+            raise ValueError(f"Explicit positions have shape {pos.shape}, expected {(n_walkers, len(params))}")
+        return pos.copy()
+
+
+class Chain:
+    """sampler/chain.rs + diagnostics.rs:39-160 (split-chain R-hat)."""
+
+    def __init__(self, param_names: Sequence[str], thin: int):
+        self.param_names = list(param_names)
+        self.thin = max(1, int(thin))
+        self.total_iterations = 0
+        self._samples: List[np.ndarray] = []
+        self._log_probs: List[np.ndarray] = []
+
+    def push(self, positions: np.ndarray, log_probs: np.ndarray) -> bool:
+        self.total_iterations += 1
+        if (self.total_iterations - 1) % self.thin == 0:
+            self._samples.append(positions.copy())
+            self._log_probs.append(log_probs.copy())
+            return True
+        return False
+
+    def __len__(self) -> int:
+        return len(self._samples)
+
+    def flat_samples(self, discard: int = 0) -> np.ndarray:
+        if not self._samples or discard >= len(self):
+            return np.zeros((0, len(self.param_names)))
+        return np.concatenate(self._samples[discard:], axis=0)
+
+    def flat_log_probs(self, discard: int = 0) -> np.ndarray:
+        if not self._samples or discard >= len(self):
+            return np.zeros(0)
+        return np.concatenate(self._log_probs[discard:])
+
+    def to_param_dict(self, discard: int = 0) -> Dict[str, np.ndarray]:
+        flat = self.flat_samples(discard)
+        return {n: flat[:, j] for j, n in enumerate(self.param_names)}
+
+    def r_hat(self, discard: int = 0) -> Dict[str, float]:
+        if not self._samples or discard >= len(self) or len(self) - discard < 4:
+            return {}
+        x = np.stack(self._samples[discard:])  # [keep][walkers][params]
+        n_split = x.shape[0] // 2
+        halves = np.concatenate([x[:n_split], x[n_split:2 * n_split]], axis=1)  # [n_split][2W][P]
+        means = halves.mean(axis=0)
+        var = halves.var(axis=0, ddof=1)
+        w = var.mean(axis=0)
+        b = n_split * ((means - means.mean(axis=0)) ** 2).sum(axis=0) / (halves.shape[1] - 1)
+        var_plus = ((n_split - 1) * w + b) / n_split
+        with np.errstate(all="ignore"):
+            r = np.sqrt(var_plus / w)
+        return {n: float(r[j]) for j, n in enumerate(self.param_names)}
+
+    def is_converged(self, discard: int = 0, threshold: float = 1.1) -> bool:
+        r = self.r_hat(discard)
+        return bool(r) and all(math.isfinite(v) and v < threshold for v in r.values())
+
+
+class EnsembleSampler:
+    """Affine-invariant stretch-move sampler (sampler/ensemble.rs:106-547, sampler/moves.rs)."""
+
+    def __init__(self, params: ParameterSet, runner: ModelRunner, likelihood: GaussianLikelihood,
+                 target: Target, stretch_a: float = 2.0):
+        if stretch_a <= 1.0:
+            raise ValueError(f"Stretch move scale parameter must be > 1.0, got {stretch_a}")
+        self.params, self.runner, self.likelihood, self.target = params, runner, likelihood, target
+        self.a = float(stretch_a)
+        self.default_n_walkers = max(2 * len(params), 32)
+        self.n_accepted = None
+        self.n_proposed = None
+
+    def log_posterior_batch(self, positions: np.ndarray) -> np.ndarray:
+        """log prior + device log-likelihood; anything failing is -inf (ensemble.rs:143-177)."""
+        lp = self.params.log_prior_batch(positions)
+        ll = self.runner.log_likelihood_batch(positions, self.target, self.likelihood)
+        with np.errstate(invalid="ignore"):
+            out = lp + ll
+        out[~np.isfinite(lp) | np.isnan(out)] = -np.inf
+        return out
+
+    def _update_group(self, pos, logp, active, comp, rng):
+        n_active, n_params = len(active), pos.shape[1]
+        z = ((self.a - 1.0) * rng.random(n_active) + 1.0) ** 2 / self.a     # moves.rs:55-59
+        c = pos[comp[rng.integers(0, len(comp), n_active)]]                  # moves.rs:118-121
+        proposals = c + z[:, None] * (pos[active] - c)                        # y = c + z (x - c)
+        new_lp = self.log_posterior_batch(proposals)
+        with np.errstate(all="ignore"):
+            log_ratio = (n_params - 1.0) * np.log(z) + (new_lp - logp[active])
+            prob = np.minimum(np.exp(log_ratio), 1.0)
+        prob[~np.isfinite(new_lp)] = 0.0                                      # moves.rs:84-87
+        accept = rng.random(n_active) < prob
+        self.n_proposed[active] += 1
+        self.n_accepted[active[accept]] += 1
+        pos[active[accept]] = proposals[accept]
+        logp[active[accept]] = new_lp[accept]
+
+    def run(self, n_iterations: int, init: WalkerInit, thin: int = 1,
+            n_walkers: Optional[int] = None, rng: Optional[np.random.Generator] = None,
+            progress: Optional[Callable[[int, float, float], None]] = None) -> Chain:
+        n_walkers = n_walkers or self.default_n_walkers
+        if n_walkers < 2:
+            raise ValueError("Must have at least 2 walkers")
+        if n_walkers % 2:
+            raise ValueError("Number of walkers must be even")
+        rng = rng or np.random.default_rng()
+        pos = init.initialize(n_walkers, self.params, rng)
+        logp = self.log_posterior_batch(pos)
+        self.n_accepted = np.zeros(n_walkers, dtype=np.int64)
+        self.n_proposed = np.zeros(n_walkers, dtype=np.int64)
+        chain = Chain(self.params.param_names, thin)
+        half = n_walkers // 2
+        first, second = np.arange(half), np.arange(half, n_walkers)
+        for it in range(n_iterations):
+            self._update_group(pos, logp, first, second, rng)
+            self._update_group(pos, logp, second, first, rng)
+            chain.push(pos, logp)
+            if progress:
+                progress(it, float(self.n_accepted.sum() / max(1, self.n_proposed.sum())),
+                         float(logp.mean()))
+        return chain
+
+    def acceptance_rate(self) -> float:
+        return float(self.n_accepted.sum() / max(1, self.n_proposed.sum()))
+
+
+# ------------------------------------------------------------------------------------ point estimate
+class Optimizer:
+    def __init__(self, kind: str):
+        self.kind = kind
+
+    @staticmethod
+    def random_search() -> "Optimizer":
+        return Optimizer("random_search")
+
+
+class OptimizationResult:
+    def __init__(self, best_params, best_ll, best_lp, n):
+        self.best_params = list(best_params)
+        self.best_log_likelihood = float(best_ll)
+        self.best_log_posterior = float(best_lp)
+        self.n_evaluations = int(n)
+        self.converged = True  # "Random search always converges" (optimizer.rs:118)
+
+
+class PointEstimator:
+    """point_estimator.rs + optimizer.rs:85-124; the n_samples evaluations are one GPU batch."""
+
+    def __init__(self, params: ParameterSet, runner: ModelRunner, likelihood: GaussianLikelihood,
+                 target: Target):
+        self.params, self.runner, self.likelihood, self.target = params, runner, likelihood, target
+        self._evaluated_params: List[List[float]] = []
+        self._evaluated_ll: List[float] = []
+
+    @property
+    def param_names(self) -> List[str]:
+        return self.params.param_names
+
+    @property
+    def n_params(self) -> int:
+        return len(self.params)
+
+    @property
+    def n_evaluations(self) -> int:
+        return len(self._evaluated_params)
+
+    def evaluated_params(self):
+        return self._evaluated_params
+
+    def evaluated_log_likelihoods(self):
+        return self._evaluated_ll
+
+    def evaluate_batch(self, samples: np.ndarray) -> np.ndarray:
+        lp = self.params.log_prior_batch(samples)
+        ll = self.runner.log_likelihood_batch(samples, self.target, self.likelihood)
+        ll = np.where(np.isfinite(lp), ll, -np.inf)
+        self._evaluated_params += [list(r) for r in samples]
+        self._evaluated_ll += [float(x) for x in ll]
+        with np.errstate(invalid="ignore"):
+            post = lp + ll
+        post[np.isnan(post)] = -np.inf
+        return post
+
+    def best(self):
+        if not self._evaluated_ll:
+            return None
+        i = int(np.argmax(self._evaluated_ll))
+        return self._evaluated_params[i], self._evaluated_ll[i]
+
+    def optimize(self, optimizer: Optimizer, n_samples: int,
+                 rng: Optional[np.random.Generator] = None) -> OptimizationResult:
+        if optimizer.kind != "random_search":
+            raise ValueError(f"unknown optimizer {optimizer.kind}")
+        rng = rng or np.random.default_rng()
+        lo, hi = self.params.bounds()  # optimizer.rs:127-: uniform within the prior bounds
+        lo, hi = np.asarray(lo), np.asarray(hi)
+        if not (np.isfinite(lo).all() and np.isfinite(hi).all()):
+            samples = self.params.sample_random(n_samples, rng)
+        else:
+            samples = lo + rng.random((n_samples, len(lo))) * (hi - lo)
+        start = len(self._evaluated_ll)
+        post = self.evaluate_batch(samples)
+        if not np.isfinite(post).any():
+            raise RuntimeError("Random search found no valid samples")
+        i = int(np.argmax(post))
+        return OptimizationResult(samples[i], self._evaluated_ll[start + i], post[i], n_samples)

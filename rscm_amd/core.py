@@ -1,0 +1,528 @@
+"""Host-side mirror of the reference's Python model-description surface for the hot path.
+
+Same names, argument meaning and error behaviour as ``rscm._lib.core``
+(python/rscm/_lib/core/__init__.pyi:19-175,322-463,563-628; implementations under
+crates/rscm-core/src/python/), so a script that builds a two-layer or coupled model keeps working:
+
+    model = (ModelBuilder().with_time_axis(axis).with_rust_component(two_layer)
+             .with_exogenous_variable("Effective Radiative Forcing", erf)
+             .with_initial_values({...}).build())
+    model.run(); model.timeseries().get_timeseries_by_name("Surface Temperature").values()
+
+``build()`` resolves the component graph exactly as the reference does
+(crates/rscm-core/src/model/builder.rs:418-860: registration-order variable sources, schema
+aggregates, missing-initial-value check, exogenous resampling onto the model axis) and maps the
+result onto one of the fused HIP kernels.  Graphs outside the supported set raise
+``NotImplementedError`` -- there is no generic CPU interpreter and no CPU fallback.
+
+Everything numeric that happens per time step runs on the GPU; the only host arithmetic here is
+the build-time resampling of exogenous series (cold path, crates/rscm-core/src/timeseries.rs:586-609).
+"""
+from __future__ import annotations
+
+import enum
+import math
+from bisect import bisect_left
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .ensemble import Ensemble
+
+NAN = float("nan")
+
+
+# ------------------------------------------------------------------------------------ time axis
+class TimeAxis:
+    """crates/rscm-core/src/timeseries.rs:45-212.  ``bounds`` has ``len()+1`` entries; value ``i``
+    is the start of step ``i``."""
+
+    def __init__(self, bounds: np.ndarray):
+        b = np.ascontiguousarray(bounds, dtype=np.float64)
+        if b.ndim != 1 or not np.all(b[1:] > b[:-1]):
+            raise ValueError("time axis must be strictly increasing")  # assert!(is_monotonic)
+        self._bounds = b
+
+    @staticmethod
+    def from_values(values) -> "TimeAxis":
+        v = np.asarray(values, dtype=np.float64)
+        if len(v) < 2:
+            raise ValueError("from_values needs at least 2 values")
+        step = v[-1] - v[-2]
+        return TimeAxis(np.concatenate([v, [v[-1] + step]]))
+
+    @staticmethod
+    def from_bounds(bounds) -> "TimeAxis":
+        b = np.asarray(bounds, dtype=np.float64)
+        if len(b) < 2:
+            raise ValueError("from_bounds needs at least 2 bounds")
+        return TimeAxis(b)
+
+    def values(self) -> np.ndarray:
+        return self._bounds[:-1].copy()
+
+    def bounds(self) -> np.ndarray:
+        return self._bounds.copy()
+
+    def __len__(self) -> int:
+        return len(self._bounds) - 1
+
+    def at(self, index: int) -> Optional[float]:
+        return float(self._bounds[index]) if 0 <= index < len(self) else None
+
+    def at_bounds(self, index: int) -> Optional[Tuple[float, float]]:
+        if 0 <= index < len(self):
+            return float(self._bounds[index]), float(self._bounds[index + 1])
+        return None
+
+    def contains(self, value: float) -> bool:
+        return bool(np.any(self._bounds[:-1] == value))
+
+    def index_of(self, value: float) -> Optional[int]:
+        hit = np.nonzero(np.abs(self._bounds[:-1] - value) < 1e-10)[0]  # timeseries.rs:204-211
+        return int(hit[0]) if len(hit) else None
+
+
+class InterpolationStrategy(enum.Enum):
+    Linear = enum.auto()
+    Next = enum.auto()
+    Previous = enum.auto()
+
+
+class VariableType(enum.Enum):
+    Exogenous = enum.auto()
+    Endogenous = enum.auto()
+
+
+# ------------------------------------------------------------------------------------ interpolation
+def _find_segment(target: float, tb: np.ndarray, extrapolate: bool) -> Tuple[str, int]:
+    """crates/rscm-core/src/interpolate/strategies/mod.rs:24-81."""
+    idx = bisect_left(tb, target)
+    fwd = idx == len(tb)
+    back = (not fwd) and idx == 0
+    if not fwd and math.isclose(tb[idx], target, rel_tol=1e-9, abs_tol=0.0):  # is_close! defaults
+        return "OnBoundary", idx
+    if (fwd or back) and not extrapolate:
+        where = "start of" if back else "end of"
+        edge = tb[0] if back else tb[-1]
+        raise RuntimeError(f"Extrapolation is not allowed. Target={target} is before the "
+                           f"{where} the interpolation range={edge}")
+    if back:
+        return "ExtrapolateBackward", 0
+    if fwd:
+        return "ExtrapolateForward", len(tb)
+    return "InSegment", idx
+
+
+def interpolate(strategy: InterpolationStrategy, time: np.ndarray, y: np.ndarray, t: float,
+                extrapolate: bool = True) -> float:
+    """One query of Interp1d (strategies/linear_spline.rs:33-96, previous.rs:58-80,
+    next.rs:56-80).  ``time`` is what the caller hands over: ``interpolate_into`` and ``at_time``
+    pass the len(y) time VALUES, so the Linear strategy's "trim the last bound" drops the last
+    value and a query there goes through the forward-extrapolation formula."""
+    n = len(y)
+    if strategy is InterpolationStrategy.Linear:
+        kind, idx = _find_segment(t, time[: len(time) - 1], extrapolate)
+        idx = min(idx, n - 1)
+        if kind == "OnBoundary":
+            return float(y[idx])
+        if kind == "ExtrapolateBackward":
+            t1, y1, t2, y2 = time[0], y[0], time[1], y[1]
+        elif kind == "ExtrapolateForward":
+            if n < 2:
+                raise RuntimeError("linear extrapolation needs two points")
+            t1, y1, t2, y2 = time[n - 2], y[n - 2], time[n - 1], y[n - 1]
+        else:
+            t1, y1, t2, y2 = time[idx - 1], y[idx - 1], time[idx], y[idx]
+        m = (y2 - y1) / (t2 - t1)
+        return float(m * (t - t1) + y1)
+    kind, idx = _find_segment(t, time, extrapolate)
+    if strategy is InterpolationStrategy.Previous:
+        if kind == "OnBoundary":
+            return float(y[idx])
+        if kind == "ExtrapolateBackward":
+            return float(y[0])
+        if kind == "ExtrapolateForward":
+            return float(y[n - 1])
+        return float(y[idx - 1])
+    idx = min(idx, n - 1)  # Next
+    if kind in ("OnBoundary", "InSegment"):
+        return float(y[idx])
+    return float(y[0] if kind == "ExtrapolateBackward" else y[n - 1])
+
+
+# ------------------------------------------------------------------------------------ timeseries
+class Timeseries:
+    """Scalar timeseries (python/rscm/_lib/core/__init__.pyi:37-93).  Python-built strategies
+    extrapolate (crates/rscm-core/src/python/timeseries.rs:62-74)."""
+
+    def __init__(self, values, time_axis: TimeAxis, units: str,
+                 interpolation_strategy: InterpolationStrategy):
+        v = np.array(values, dtype=np.float64).reshape(-1)
+        if len(v) != len(time_axis):
+            raise ValueError(f"values ({len(v)}) and time axis ({len(time_axis)}) differ in length")
+        self._values = v
+        self._axis = time_axis
+        self._units = units
+        self._strategy = interpolation_strategy
+        self._latest = len(v) - 1 if len(v) and not np.isnan(v[-1]) else self._last_valid(v)
+
+    @staticmethod
+    def _last_valid(v: np.ndarray) -> int:
+        ok = np.nonzero(~np.isnan(v))[0]
+        return int(ok[-1]) if len(ok) else 0
+
+    @staticmethod
+    def from_values(values, time) -> "Timeseries":
+        axis = time if isinstance(time, TimeAxis) else TimeAxis.from_values(time)
+        return Timeseries(values, axis, "", InterpolationStrategy.Linear)
+
+    def with_interpolation_strategy(self, interpolation_strategy) -> "Timeseries":
+        self._strategy = interpolation_strategy
+        return self
+
+    def __len__(self) -> int:
+        return len(self._values)
+
+    def set(self, time_index: int, value: float) -> None:
+        self._values[time_index] = value
+        self._latest = max(self._latest, time_index)
+
+    def values(self) -> np.ndarray:
+        return self._values.copy()
+
+    @property
+    def latest(self) -> int:
+        return self._latest
+
+    @property
+    def units(self) -> str:
+        return self._units
+
+    @property
+    def time_axis(self) -> TimeAxis:
+        return self._axis
+
+    @property
+    def interpolation_strategy(self) -> InterpolationStrategy:
+        return self._strategy
+
+    def latest_value(self) -> Optional[float]:
+        return float(self._values[self._latest]) if len(self._values) else None
+
+    def at(self, time_index: int) -> Optional[float]:
+        return float(self._values[time_index]) if 0 <= time_index < len(self) else None
+
+    def at_time(self, time: float) -> float:
+        return interpolate(self._strategy, self._axis.values(), self._values, float(time), True)
+
+    def interpolate_into(self, new_axis: TimeAxis) -> "Timeseries":
+        """crates/rscm-core/src/timeseries.rs:586-609."""
+        tv = self._axis.values()
+        out = np.array([interpolate(self._strategy, tv, self._values, float(t), True)
+                        for t in new_axis.values()])
+        return Timeseries(out, new_axis, self._units, self._strategy)
+
+
+class TimeseriesCollection:
+    """python/rscm/_lib/core/__init__.pyi:119-190; kept sorted by name like the reference's
+    ``Vec<TimeseriesItem>`` (crates/rscm-core/src/timeseries_collection.rs:318-321)."""
+
+    def __init__(self) -> None:
+        self._items: Dict[str, Tuple[Timeseries, VariableType]] = {}
+
+    def add_timeseries(self, name: str, timeseries: Timeseries,
+                       variable_type: VariableType = VariableType.Exogenous) -> None:
+        if name in self._items:
+            raise ValueError(f"timeseries {name!r} already exists")
+        self._items[name] = (timeseries, variable_type)
+
+    def get_timeseries_by_name(self, name: str) -> Optional[Timeseries]:
+        item = self._items.get(name)
+        if item is None:
+            return None
+        ts = item[0]
+        return Timeseries(ts.values(), ts.time_axis, ts.units, ts.interpolation_strategy)
+
+    def variable_type(self, name: str) -> Optional[VariableType]:
+        item = self._items.get(name)
+        return item[1] if item else None
+
+    def names(self) -> List[str]:
+        return sorted(self._items)
+
+    def timeseries(self) -> List[Timeseries]:
+        return [self.get_timeseries_by_name(n) for n in self.names()]
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._items
+
+
+# ------------------------------------------------------------------------------------ schema
+class VariableSchema:
+    """python/rscm/_lib/core/__init__.pyi:322-404 (scalar variables and aggregates)."""
+
+    def __init__(self) -> None:
+        self.variables: Dict[str, str] = {}
+        self.aggregates: Dict[str, Tuple[str, str, List[str], Optional[List[float]]]] = {}
+
+    def add_variable(self, name: str, unit: str, grid_type=None) -> "VariableSchema":
+        self.variables[name] = unit
+        return self
+
+    def add_aggregate(self, name: str, unit: str, operation: str, contributors: Sequence[str],
+                      weights: Optional[Sequence[float]] = None, grid_type=None) -> "VariableSchema":
+        if operation not in ("Sum", "Mean", "Weighted"):
+            raise ValueError(f"unknown aggregate operation {operation!r}")
+        self.aggregates[name] = (unit, operation, list(contributors),
+                                 list(weights) if weights is not None else None)
+        return self
+
+    def contains(self, name: str) -> bool:
+        return name in self.variables or name in self.aggregates
+
+    def validate(self) -> None:
+        for name, (_, _, contributors, _) in self.aggregates.items():
+            for c in contributors:
+                if not self.contains(c):
+                    raise ValueError(f"aggregate {name!r}: contributor {c!r} is not in the schema")
+
+
+# ------------------------------------------------------------------------------------ components
+class Component:
+    """A built Rust component as the reference's ``ModelBuilder.with_rust_component`` sees it:
+    a type name, parameters, and its requirement definitions in macro order (inputs, outputs,
+    states; crates/rscm-macros/src/lib.rs:645-651)."""
+
+    type_name = "Component"
+    definitions: List[Tuple[str, str, str]] = []  # (name, unit, "Input"|"Output"|"State")
+
+    def __init__(self, parameters: Dict[str, float]):
+        self.parameters = dict(parameters)
+
+    def input_names(self) -> List[str]:
+        return [n for n, _, k in self.definitions if k in ("Input", "State")]
+
+    def output_names(self) -> List[str]:
+        return [n for n, _, k in self.definitions if k in ("Output", "State")]
+
+
+class ComponentBuilder:
+    component_cls = Component
+    required: Tuple[str, ...] = ()
+
+    def __init__(self, parameters: Dict[str, float]):
+        self._parameters = dict(parameters)
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        missing = [k for k in cls.required if k not in parameters]
+        if missing:  # pythonize/serde: "missing field `x`" (crates/rscm-core/src/python/component.rs:19-48)
+            raise ValueError(f"missing field `{missing[0]}`")
+        return cls({k: float(parameters[k]) for k in cls.required})
+
+    def build(self):
+        return self.component_cls(self._parameters)
+
+
+# ------------------------------------------------------------------------------------ builder
+SUPPORTED = ("[TwoLayer] with exogenous or upstream 'Effective Radiative Forcing'",
+             "[CarbonCycle, CO2ERF, TwoLayer] + Sum aggregate 'Effective Radiative Forcing' "
+             "over ['Effective Radiative Forcing|CO2'] (registration order as listed)")
+
+TL_PARAM_ORDER = ("lambda0", "a", "efficacy", "eta", "heat_capacity_surface", "heat_capacity_deep")
+CP_PARAM_ORDER = TL_PARAM_ORDER + ("tau", "conc_pi", "alpha_temperature", "erf_2xco2")
+
+
+class ModelBuilder:
+    """python/rscm/_lib/core/__init__.pyi:405-463 -> crates/rscm-core/src/model/builder.rs."""
+
+    def __init__(self) -> None:
+        self._axis: Optional[TimeAxis] = None
+        self._components: List[Component] = []
+        self._initial: Dict[str, float] = {}
+        self._exogenous = TimeseriesCollection()
+        self._schema: Optional[VariableSchema] = None
+        self._device = 0
+
+    def with_time_axis(self, time_axis: TimeAxis) -> "ModelBuilder":
+        self._axis = time_axis
+        return self
+
+    def with_rust_component(self, component: Component) -> "ModelBuilder":
+        self._components.append(component)
+        return self
+
+    with_component = with_rust_component
+
+    def with_py_component(self, component) -> "ModelBuilder":
+        raise NotImplementedError("Python-defined components cannot be fused into a GPU kernel; "
+                                  "supported graphs: " + "; ".join(SUPPORTED))
+
+    def with_initial_values(self, initial_values: Dict[str, float]) -> "ModelBuilder":
+        self._initial.update({k: float(v) for k, v in initial_values.items()})
+        return self
+
+    def with_exogenous_variable(self, name: str, timeseries: Timeseries) -> "ModelBuilder":
+        self._exogenous.add_timeseries(name, timeseries, VariableType.Exogenous)
+        return self
+
+    def with_exogenous_collection(self, collection: TimeseriesCollection) -> "ModelBuilder":
+        for name in collection.names():
+            self._exogenous.add_timeseries(name, collection.get_timeseries_by_name(name),
+                                           VariableType.Exogenous)
+        return self
+
+    def with_schema(self, schema: VariableSchema) -> "ModelBuilder":
+        self._schema = schema
+        return self
+
+    def with_device(self, device: int) -> "ModelBuilder":
+        """Extension: which GPU the model lives on."""
+        self._device = device
+        return self
+
+    # -- graph resolution (builder.rs:448-560) ----------------------------------------------
+    def _resolve(self):
+        if self._axis is None:
+            raise ValueError("no time axis")
+        endogenous: Dict[str, str] = {}
+        sources: Dict[Tuple[str, str], str] = {}
+        exo_names: List[str] = []
+        kinds: Dict[str, str] = {}
+        aggregates = self._schema.aggregates if self._schema else {}
+        if self._schema:
+            self._schema.validate()
+        for comp in self._components:
+            for name, _, kind in comp.definitions:
+                if kind not in ("Input", "State"):
+                    continue
+                if kind == "State":
+                    src = "OwnState"
+                elif name in endogenous or name in aggregates:
+                    src = "UpstreamOutput"
+                else:
+                    src = "Exogenous"
+                sources[(name, comp.type_name)] = src
+                kinds.setdefault(name, kind)
+                if name not in endogenous and name not in aggregates and name not in exo_names:
+                    exo_names.append(name)
+            for name, _, kind in comp.definitions:
+                if kind in ("Output", "State"):
+                    if kind == "State" or name not in kinds:
+                        kinds[name] = kind
+                    endogenous[name] = comp.type_name
+        for name in aggregates:
+            endogenous[name] = f"Aggregator:{name}"
+            kinds[name] = "Output"
+        for name, kind in kinds.items():  # builder.rs:704-717
+            if kind == "State" and name not in self._initial:
+                raise ValueError(f"Missing initial value for state variable '{name}' "
+                                 f"(component {endogenous.get(name, 'unknown')})")
+        return endogenous, sources, exo_names, aggregates
+
+    def _exogenous_on_axis(self, name: str, exo_names: List[str]) -> Optional[np.ndarray]:
+        if name in exo_names and name in self._exogenous:
+            return self._exogenous.get_timeseries_by_name(name).interpolate_into(self._axis).values()
+        return None
+
+    def build(self, n_members: int = 1) -> "Model":
+        endogenous, sources, exo_names, aggregates = self._resolve()
+        types = [c.type_name for c in self._components]
+        erf = "Effective Radiative Forcing"
+        if types == ["TwoLayer"] and not aggregates:
+            kind = L.KIND_TWO_LAYER
+            forcing = self._exogenous_on_axis(erf, exo_names)
+            if forcing is None:  # builder.rs:772-780: NaN series; run() then yields NaN
+                forcing = np.full(len(self._axis), NAN)
+            src = L.SRC_EXOGENOUS
+            params = [self._components[0].parameters[k] for k in TL_PARAM_ORDER]
+            h = {L.COMP_TWO_LAYER: 0.1}
+        elif (types == ["CarbonCycle", "CO2ERF", "TwoLayer"] and list(aggregates) == [erf]
+              and aggregates[erf][1] == "Sum"
+              and aggregates[erf][2] == ["Effective Radiative Forcing|CO2"]):
+            kind = L.KIND_COUPLED
+            cc, ce, tl = self._components
+            if cc.parameters["conc_pi"] != ce.parameters["conc_pi"]:
+                raise NotImplementedError("CarbonCycle.conc_pi != CO2ERF.conc_pi is not supported "
+                                          "by the fused coupled kernel")
+            assert sources[("Surface Temperature", "CarbonCycle")] == "Exogenous"
+            assert sources[(erf, "TwoLayer")] == "UpstreamOutput"
+            forcing = self._exogenous_on_axis("Emissions|CO2|Anthropogenic", exo_names)
+            if forcing is None:
+                forcing = np.full(len(self._axis), NAN)
+            src = L.SRC_EXOGENOUS
+            params = ([tl.parameters[k] for k in TL_PARAM_ORDER] +
+                      [cc.parameters["tau"], cc.parameters["conc_pi"],
+                       cc.parameters["alpha_temperature"], ce.parameters["erf_2xco2"]])
+            h = {L.COMP_TWO_LAYER: 0.1, L.COMP_CARBON_CYCLE: cc.step_size}
+        else:
+            raise NotImplementedError(
+                f"component graph {types} (aggregates {list(aggregates)}) has no fused GPU kernel; "
+                "supported: " + "; ".join(SUPPORTED))
+        ens = Ensemble(kind, n_members, self._axis.bounds(), device=self._device)
+        for comp_id, step in h.items():
+            ens.set_step_size(comp_id, step)
+        ens.set_params(np.repeat(np.array(params, dtype=np.float64)[:, None], n_members, axis=1))
+        ens.set_forcing(forcing, None, src)
+        for name, vid in ens.var_ids.items():
+            if vid > 0 and name in self._initial:
+                ens.set_initial(vid, self._initial[name])
+        param_order = TL_PARAM_ORDER if kind == L.KIND_TWO_LAYER else CP_PARAM_ORDER
+        return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
+                     np.array(params, dtype=np.float64))
+
+
+class Model:
+    """python/rscm/_lib/core/__init__.pyi:563-628 over one device-resident ensemble.  With
+    ``n_members == 1`` it behaves like the reference's ``Model``; with more it is the batch the
+    calibration front drives (all members share the graph, axis, forcing and initial values and
+    differ in parameters)."""
+
+    def __init__(self, ens: Ensemble, axis: TimeAxis, sources, endogenous, forcing, initial,
+                 param_order, base_params):
+        self.ensemble = ens
+        self._axis = axis
+        self._sources = sources
+        self._endogenous = endogenous
+        self._forcing = forcing
+        self._initial = initial
+        self.param_order = tuple(param_order)
+        self.base_params = base_params
+
+    def variable_sources(self) -> Dict[Tuple[str, str], str]:
+        return dict(self._sources)
+
+    def current_time(self) -> float:
+        return self._axis.at(self.ensemble.time_index)
+
+    def current_time_bounds(self) -> Tuple[float, float]:
+        return self._axis.at_bounds(self.ensemble.time_index)
+
+    def step(self) -> None:
+        if not self.ensemble.time_index < len(self._axis) - 1:
+            raise RuntimeError("assertion failed: self.time_index < self.time_axis.len() - 1")
+        self.ensemble.step()
+
+    def run(self) -> None:
+        self.ensemble.run()
+
+    def finished(self) -> bool:
+        return self.ensemble.finished()
+
+    def timeseries(self, member: int = 0) -> TimeseriesCollection:
+        coll = TimeseriesCollection()
+        input_name = [n for n, v in self.ensemble.var_ids.items() if v == 0][0]
+        for name, vid in self.ensemble.var_ids.items():
+            if vid == 0:
+                vals, vt = self._forcing, VariableType.Exogenous
+            else:
+                vals = self.ensemble.get_series(vid, m_begin=member, m_end=member + 1)[:, 0]
+                vt = VariableType.Endogenous
+            coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), vt)
+        del input_name
+        return coll
+
+    def close(self) -> None:
+        self.ensemble.close()

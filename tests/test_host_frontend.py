@@ -1,0 +1,236 @@
+"""CPU tier: host logic of the product front-end (no GPU calls): time axis, interpolation and
+builder graph resolution in rscm_amd.core against the reference's known answers and against the
+oracle's independent restatement; priors, Latin hypercube, host likelihood and chain diagnostics
+in rscm_amd.calibrate; member sharding arithmetic."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import reference_model as rm
+from rscm_amd import calibrate as cal
+from rscm_amd import core
+from rscm_amd.components import CarbonCycleBuilder, CO2ERFBuilder
+from rscm_amd.distributed import shard_bounds
+from rscm_amd.two_layer import TwoLayerBuilder
+
+S = core.InterpolationStrategy
+
+
+def test_time_axis_doctests(known):
+    k = known["time_axis"]
+    ta = core.TimeAxis.from_values(k["from_values"])
+    assert list(ta.at_bounds(2)) == k["at_bounds_2"]
+    assert ta.at(1) == k["at_1"] and ta.at(27) is None
+    assert ta.contains(1.0) and not ta.contains(27.0)
+    assert ta.index_of(2.0) == 1 and ta.index_of(27.0) is None
+    assert len(core.TimeAxis.from_bounds(k["from_bounds"])) == 3
+    with pytest.raises(ValueError):
+        core.TimeAxis.from_values([2020.0, 1.0, 2021.0])
+
+
+def test_interpolation_tables(known):
+    k = known["interp_linear"]
+    t, y = np.array(k["time"]), np.array(k["y"])
+    for q, e in zip(k["targets"], k["expected"]):
+        assert math.isclose(core.interpolate(S.Linear, t, y, q, False), e, rel_tol=1e-9)
+    for q, e in zip(k["extrap_targets"], k["extrap_expected"]):
+        assert math.isclose(core.interpolate(S.Linear, t, y, q, True), e, rel_tol=1e-9)
+    for q in k["noextrap_error_targets"]:
+        with pytest.raises(RuntimeError, match="Extrapolation is not allowed"):
+            core.interpolate(S.Linear, np.array(k["noextrap_time"]), np.array(k["noextrap_y"]), q, False)
+    k = known["interp_previous"]
+    t, y = np.array(k["time"]), np.array(k["y"])
+    for q, e in zip(k["extrap_targets"], k["extrap_expected"]):
+        assert core.interpolate(S.Previous, t, y, q, True) == e
+    k = known["interp1d_next_extrapolate"]
+    assert core.interpolate(S.Next, np.array(k["years"]), np.array(k["data"]), k["query"]) == k["expected"]
+    k = known["timeseries_at_time"]
+    ts = core.Timeseries.from_values(k["custom_data"], k["custom_years"])
+    assert ts.at_time(k["custom_query"]) == k["custom_linear_expected"]
+    ts.with_interpolation_strategy(S.Previous)
+    assert ts.at_time(k["custom_query"]) == k["custom_previous_expected"]
+
+
+def test_product_interpolation_equals_oracle_restatement():
+    rng = np.random.default_rng(0)
+    src = np.sort(rng.uniform(1700, 2200, 40))
+    y = rng.normal(size=40)
+    q = np.concatenate([rng.uniform(1650, 2250, 300), src, src + 1e-12])
+    for strat, name in ((S.Linear, "Linear"), (S.Previous, "Previous"), (S.Next, "Next")):
+        for t in q:
+            a = core.interpolate(strat, src, y, float(t), True)
+            b = rm.interpolate(name, list(src), list(y), float(t), True)
+            assert a == b or (math.isnan(a) and math.isnan(b))
+    axis = core.TimeAxis.from_values(np.arange(1750.0, 1800.0))
+    ts = core.Timeseries(y, core.TimeAxis.from_values(src), "x", S.Linear)
+    got = ts.interpolate_into(axis).values()
+    want = rm.interpolate_into("Linear", rm.TimeAxis.from_values(src), list(y),
+                               rm.TimeAxis.from_values(np.arange(1750.0, 1800.0)))
+    assert list(got) == want
+
+
+def test_previous_resample_golden(known):
+    k = known["stepper_exogenous_previous"]
+    ts = core.Timeseries(k["emissions_values"], core.TimeAxis.from_bounds(k["emissions_bounds"]),
+                         "GtC / yr", S.Previous)
+    got = ts.interpolate_into(core.TimeAxis.from_values(k["time_values"])).values()
+    assert list(got) == k["resampled_emissions"]
+
+
+P_TL = dict(lambda0=1.1, a=0.0, efficacy=1.3, eta=0.7, heat_capacity_surface=8.0,
+            heat_capacity_deep=100.0)
+
+
+def _coupled_builder():
+    schema = core.VariableSchema()
+    for n, u in (("Emissions|CO2|Anthropogenic", "GtC / yr"), ("Surface Temperature", "K"),
+                 ("Atmospheric Concentration|CO2", "ppm"), ("Cumulative Land Uptake", "Gt C"),
+                 ("Cumulative Emissions|CO2", "Gt C"), ("Effective Radiative Forcing|CO2", "W/m^2"),
+                 ("Deep Ocean Temperature", "K")):
+        schema.add_variable(n, u)
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum",
+                         ["Effective Radiative Forcing|CO2"])
+    return (core.ModelBuilder()
+            .with_time_axis(core.TimeAxis.from_values(np.arange(1750.0, 1761.0)))
+            .with_schema(schema)
+            .with_rust_component(CarbonCycleBuilder.from_parameters(
+                dict(tau=25.0, conc_pi=278.0, alpha_temperature=0.1)).build())
+            .with_rust_component(CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build())
+            .with_rust_component(TwoLayerBuilder.from_parameters(P_TL).build()))
+
+
+def test_builder_sources_match_reference_classification():
+    """Registration-order rule of builder.rs:470-482 on the notebook's coupled model, and the
+    same answer from the oracle's independent restatement."""
+    b = _coupled_builder().with_initial_values({
+        "Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0,
+        "Atmospheric Concentration|CO2": 278.0, "Surface Temperature": 0.0,
+        "Deep Ocean Temperature": 0.0})
+    endogenous, sources, exo, aggregates = b._resolve()
+    assert sources[("Surface Temperature", "CarbonCycle")] == "Exogenous"
+    assert sources[("Atmospheric Concentration|CO2", "CarbonCycle")] == "OwnState"
+    assert sources[("Atmospheric Concentration|CO2", "CO2ERF")] == "UpstreamOutput"
+    assert sources[("Effective Radiative Forcing", "TwoLayer")] == "UpstreamOutput"
+    assert sources[("Surface Temperature", "TwoLayer")] == "OwnState"
+    m = rm.ModelBuilder(
+        axis=rm.TimeAxis.from_values(np.arange(1750.0, 1761.0)),
+        components=[rm.CarbonCycle(25.0, 278.0, 0.1), rm.CO2ERF(3.7, 278.0), rm.TwoLayer(*P_TL.values())],
+        aggregates=[("Effective Radiative Forcing", "Sum", ["Effective Radiative Forcing|CO2"])],
+        initial_values={"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0,
+                        "Atmospheric Concentration|CO2": 278.0, "Surface Temperature": 0.0,
+                        "Deep Ocean Temperature": 0.0}).build()
+    for key, src in m.sources.items():
+        if not key[1].startswith("Aggregator"):
+            assert sources[key] == src, key
+    assert "Emissions|CO2|Anthropogenic" in exo
+
+
+def test_builder_errors():
+    with pytest.raises(ValueError, match="Missing initial value"):
+        _coupled_builder()._resolve()
+    with pytest.raises(ValueError, match="missing field `eta`"):
+        TwoLayerBuilder.from_parameters({k: v for k, v in P_TL.items() if k != "eta"})
+    with pytest.raises(NotImplementedError):
+        core.ModelBuilder().with_py_component(object())
+    b = (core.ModelBuilder().with_time_axis(core.TimeAxis.from_values([0.0, 1.0, 2.0]))
+         .with_rust_component(CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build()))
+    with pytest.raises(NotImplementedError, match="no fused GPU kernel"):
+        b.build()
+
+
+def test_priors_and_lhs():
+    ps = cal.ParameterSet().add("x", cal.Uniform(0.0, 2.0)).add("y", cal.Uniform(-1.0, 1.0))
+    assert ps.param_names == ["x", "y"]
+    assert ps.log_prior([1.0, 0.0]) == -math.log(2.0) - math.log(2.0)
+    assert ps.log_prior([3.0, 0.0]) == -math.inf
+    with pytest.raises(ValueError):
+        cal.Uniform(1.0, 1.0)
+    n = 257
+    s = ps.sample_lhs(n, np.random.default_rng(1))
+    assert s.shape == (n, 2)
+    for j, (lo, hi) in enumerate(((0.0, 2.0), (-1.0, 1.0))):
+        strata = np.floor((s[:, j] - lo) / (hi - lo) * n).astype(int)
+        assert np.array_equal(np.sort(strata), np.arange(n))  # parameter_set.rs:207-233
+    nrm = cal.ParameterSet().add("z", cal.Normal(1.0, 2.0))
+    z = nrm.sample_lhs(4001, np.random.default_rng(2))[:, 0]
+    assert abs(z.mean() - 1.0) < 0.01 and abs(z.std() - 2.0) < 0.02
+
+
+def test_host_likelihood_known_values(known):
+    k = known["likelihood"]
+    lik = cal.GaussianLikelihood()
+    t = cal.Target()
+    for tm, v, s in k["perfect"]["obs"]:
+        t.add_observation("Temperature", tm, v, s)
+    out = {"Temperature": {2020.0: 1.2, 2021.0: 1.3}}
+    assert lik.ln_likelihood(out, t) == 0.0
+    t = cal.Target().add_observation("Temperature", 2020.0, 1.0, 0.1)
+    assert abs(lik.ln_likelihood({"Temperature": {2020.0: 1.1}}, t) + 0.5) < 1e-10
+    assert lik.ln_likelihood({"Temperature": {2020.0000001: 1.1}}, t) < 0  # time_key tolerance (:268-275)
+    with pytest.raises(KeyError, match="missing time"):
+        lik.ln_likelihood({"Temperature": {2021.0: 1.1}}, t)
+    with pytest.raises(ValueError, match="non-finite"):
+        lik.ln_likelihood({"Temperature": {2020.0: math.inf}}, t)
+    with pytest.raises(ValueError):
+        cal.Observation(2020.0, 1.0, 0.0)
+
+
+def test_chain_r_hat_and_flat_samples():
+    rng = np.random.default_rng(3)
+    c = cal.Chain(["a", "b"], thin=2)
+    for _ in range(400):
+        c.push(rng.normal(size=(8, 2)), rng.normal(size=8))
+    assert c.total_iterations == 400 and len(c) == 200
+    assert c.flat_samples(50).shape == (150 * 8, 2)
+    assert c.flat_samples(500).shape == (0, 2)
+    r = c.r_hat(0)
+    assert all(0.95 < v < 1.05 for v in r.values())
+    assert c.is_converged()
+    # one walker stuck elsewhere -> not converged
+    d = cal.Chain(["a"], thin=1)
+    for _ in range(100):
+        x = rng.normal(size=(4, 1))
+        x[0] += 50.0
+        d.push(x, np.zeros(4))
+    assert not d.is_converged()
+
+
+def test_stretch_move_z_range():
+    """sampler/moves.rs in-file tests: z in [1/a, a]."""
+    a = 2.0
+    u = np.random.default_rng(4).random(10000)
+    z = ((a - 1.0) * u + 1.0) ** 2 / a
+    assert z.min() >= 1 / a and z.max() <= a
+
+
+def test_shard_bounds_partition():
+    for n, w in ((10, 3), (100000, 8), (7, 8), (0, 2), (1000001, 4)):
+        blocks = [shard_bounds(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0
+        assert sum(c for _, c in blocks) == n
+        for (o0, c0), (o1, _) in zip(blocks, blocks[1:]):
+            assert o0 + c0 == o1
+        counts = [c for _, c in blocks]
+        assert max(counts) - min(counts) <= 1
+
+
+def test_config_loader_layers():
+    """python/rscm/config/loader.py doctest + tests/test_config_two_layer_integration.py shape."""
+    import os
+    from rscm_amd import config as cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert cfg.deep_merge({"a": 1, "nested": {"x": 1, "y": 2}}, {"b": 2, "nested": {"y": 3}}) == \
+        {"a": 1, "b": 2, "nested": {"x": 1, "y": 3}}
+    base = cfg.load_config(os.path.join(root, "configs/two-layer/defaults.toml"))
+    assert base["time"] == {"start": 1750, "end": 2100}
+    assert base["components"]["climate"]["parameters"]["lambda0"] == 1.0
+    merged = cfg.load_config_layers(os.path.join(root, "configs/two-layer/defaults.toml"),
+                                    os.path.join(root, "configs/two-layer/tuning/high-ecs.toml"))
+    p = merged["components"]["climate"]["parameters"]
+    assert p["lambda0"] == 0.7 and p["efficacy"] == 1.3 and p["eta"] == 0.7
+    assert merged["model"]["name"] == "two-layer-high-ecs" and merged["model"]["type"] == "two-layer"
+    b = cfg.two_layer_builder(merged)
+    assert len(b._axis) == 351 and b._axis.at(0) == 1750.0 and b._axis.at(350) == 2100.0
+    with pytest.raises(ValueError, match="Unknown model type"):
+        cfg.build_model({"model": {"type": "nope"}})
