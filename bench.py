@@ -40,17 +40,28 @@ def f_syn(t):
     return 4.0 * (1.0 - np.exp(-(t - 1750.0) / 120.0)) + 0.3 * np.sin(2.0 * np.pi * (t - 1750.0) / 11.0)
 
 
-def make_ensemble(members, device, rank, world, mode, stream=None):
+def make_ensemble(members, device, rank, world, mode, stream=None, coupled=False):
     import rscm_amd
     t = np.arange(T0, T1 + 1, dtype=np.float64)
     bounds = np.append(t, t[-1] + (t[-1] - t[-2]))
-    ens = rscm_amd.Ensemble(rscm_amd.KIND_TWO_LAYER, members, bounds, device=device)
+    kind = rscm_amd.KIND_COUPLED if coupled else rscm_amd.KIND_TWO_LAYER
+    ens = rscm_amd.Ensemble(kind, members, bounds, device=device)
     ens.set_mode(mode)
     if stream is not None:
         ens.set_stream(stream)
     # global Latin hypercube over world*members members; each rank generates its own block
-    ens.sample_lhs(SEED, TL_LOW, TL_HIGH, rank * members, world * members)
-    ens.set_forcing(f_syn(t))
+    if coupled:  # BASELINE configs[2]: + tau in [15,40], alpha_T in [0,0.1]; conc_pi 278, erf_2xco2 3.7
+        lo = np.concatenate([TL_LOW, [15.0, 278.0, 0.0, 3.7]])
+        hi = np.concatenate([TL_HIGH, [40.0, 278.0, 0.1, 3.7]])
+        ens.sample_lhs(SEED, lo, hi, rank * members, world * members)
+        yrs = np.array([1750.0, 1850.0, 1950.0, 2000.0, 2020.0, 2050.0, 2100.0])
+        ens.set_forcing(np.interp(t, yrs, [0.0, 0.5, 3.0, 7.0, 10.0, 5.0, 1.0]))
+        for var, v in (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0),
+                       ("Cumulative Emissions|CO2", 0.0)):
+            ens.set_initial(var, v)
+    else:
+        ens.sample_lhs(SEED, TL_LOW, TL_HIGH, rank * members, world * members)
+        ens.set_forcing(f_syn(t))
     ens.set_initial("Surface Temperature", 0.0)
     ens.set_initial("Deep Ocean Temperature", 0.0)
     return ens
@@ -159,14 +170,17 @@ def main():
 
     extra = {}
     if rank == 0 and world == 1 and not args.no_extra:
-        for label, members, m in (("fast_1e5", args.members, 1), ("exact_1e6", 1_000_000, 0),
-                                  ("fast_1e6", 1_000_000, 1)):
-            e2 = make_ensemble(members, local_rank, 0, 1, m, stream)
-            w2, k2 = timed_passes(e2, max(3, args.steps // 4), 1, torch, dist, 1, tstream)
+        for label, members, m, cp in (("fast_1e5", args.members, 1, False),
+                                      ("exact_1e6", 1_000_000, 0, False),
+                                      ("fast_1e6", 1_000_000, 1, False),
+                                      ("coupled_1e6", 1_000_000, 0, True)):
+            e2 = make_ensemble(members, local_rank, 0, 1, m, stream, coupled=cp)
+            k = max(3, args.steps // 4)
+            w2, k2 = timed_passes(e2, k, 1, torch, dist, 1, tstream)
             e2.close()
-            extra[label] = {"member_years_per_s": members * years * max(3, args.steps // 4) / w2,
-                            "kernel_ms": k2,
-                            "hbm_frac": ALG_BYTES_PER_MEMBER_YEAR * members * years / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            bpy = 56.0 if cp else ALG_BYTES_PER_MEMBER_YEAR
+            extra[label] = {"member_years_per_s": members * years * k / w2, "kernel_ms": k2,
+                            "hbm_frac": bpy * members * years / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
