@@ -141,6 +141,13 @@ RSCM_API int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, c
 /* Initial value(s) at time index 0 of a state variable: n_values == 1 (broadcast) or N.
  * Also rewinds the time index to 0. */
 RSCM_API int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int64_t n_values);
+/* Checkpoint / resume (the reference serialises time_index + the whole collection,
+ * crates/rscm-core/src/model/runtime.rs:270-282): a run can be resumed from
+ * (time index k, row k of every state variable).  rscm_ens_set_state writes row `tidx` of a stored
+ * series (1 value = broadcast, or N values); rscm_ens_set_time_index moves the stepper there. */
+RSCM_API int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* values,
+                                int64_t n_values);
+RSCM_API int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx);
 /* Use an existing hipStream_t (as void*) for all launches and copies; NULL = own stream. */
 RSCM_API int rscm_ens_set_stream(rscm_ens* h, void* hip_stream);
 
@@ -195,6 +202,14 @@ RSCM_API int rscm_ens_get_params(rscm_ens* h, double* out_soa);
  * ensemble generate their rows with no communication. */
 RSCM_API int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const double* high,
                         int64_t member_offset, int64_t n_total);
+
+/* ---- pinned host buffers -------------------------------------------------------------------- */
+/* Page-locked host memory for the buffers handed to rscm_ens_get_series / rscm_ens_set_params:
+ * the copy then runs as one DMA at PCIe rate instead of being staged through pageable memory
+ * (measured 601 MB of Ts: 11 GB/s into a fresh pageable buffer vs the pinned rate quoted in
+ * DESIGN.md section 6). */
+RSCM_API int rscm_gpu_host_alloc(int64_t n_bytes, void** out);
+RSCM_API int rscm_gpu_host_free(void* p);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */
 /* Element-wise num[i]/den[i] on the device through (a) the compiler's IEEE f64 division and

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rscm_ens_set_params_aos": (C.c_int, [_h, _dp]),
     "rscm_ens_set_forcing": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, _ip, C.c_int32]),
     "rscm_ens_set_initial": (C.c_int, [_h, C.c_int32, _dp, C.c_int64]),
+    "rscm_ens_set_state": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.c_int64]),
+    "rscm_ens_set_time_index": (C.c_int, [_h, C.c_int32]),
     "rscm_ens_set_stream": (C.c_int, [_h, C.c_void_p]),
     "rscm_ens_run": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "rscm_ens_run_async": (C.c_int, [_h, C.c_int32, C.c_int32]),
@@ -64,6 +66,8 @@ SIGNATURES = {
     "rscm_ens_summary": (C.c_int, [_h, C.c_int32, C.c_int32, _dp]),
     "rscm_ens_get_params": (C.c_int, [_h, _dp]),
     "rscm_ens_sample_lhs": (C.c_int, [_h, C.c_uint64, _dp, _dp, C.c_int64, C.c_int64]),
+    "rscm_gpu_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "rscm_gpu_host_free": (C.c_int, [C.c_void_p]),
     "rscm_gpu_selftest_div": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, _dp, _dp, _bp]),
 }
 

@@ -394,6 +394,37 @@ int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int6
     GUARD_END
 }
 
+int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* values, int64_t n_values)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
+    if (tidx < 0 || tidx >= h->T) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (!values || (n_values != 1 && n_values != h->N))
+        return fail(RSCM_ERR_INVALID, "state values: need 1 or n_members values, got %lld", (long long)n_values);
+    if (int rc = set_device(h)) return rc;
+    double* row = h->series(var_id) + (size_t)tidx * h->N;
+    if (n_values == 1)
+        HIPCHK(rscm::launch_fill(row, h->N, values[0], h->stream));
+    else
+        HIPCHK(hipMemcpyAsync(row, values, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (tidx == 0) h->initial_set[var_id] = 1;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
+{
+    NEED(h);
+    if (tidx < 0 || tidx > h->T - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (tidx > 0)
+        for (int32_t v = 1; v < h->V; ++v)
+            if (h->is_state(v)) h->initial_set[v] = 1;  // a restored checkpoint carries its own state rows
+    h->time_index = tidx;
+    return RSCM_OK;
+}
+
 int rscm_ens_rewind(rscm_ens* h)
 {
     NEED(h);
@@ -668,6 +699,24 @@ int rscm_ens_get_params(rscm_ens* h, double* out_soa)
     if (int rc = set_device(h)) return rc;
     HIPCHK(hipMemcpyAsync(out_soa, h->d_params, (size_t)h->P * h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_gpu_host_alloc(int64_t n_bytes, void** out)
+{
+    GUARD_BEGIN
+    if (!out || n_bytes <= 0) return fail(RSCM_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, (size_t)n_bytes, hipHostMallocDefault));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_gpu_host_free(void* p)
+{
+    GUARD_BEGIN
+    if (p) HIPCHK(hipHostFree(p));
     return RSCM_OK;
     GUARD_END
 }

@@ -140,13 +140,45 @@ class Ensemble:
         L.check(self._lib.rscm_ens_last_run_ms(self._h, C.byref(ms)))
         return ms.value
 
+    # -- checkpoint / resume ------------------------------------------------------------------
+    def state_vars(self) -> Dict[str, int]:
+        if self.kind == L.KIND_TWO_LAYER:
+            return {k: v for k, v in self.var_ids.items() if v in (1, 2)}
+        return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}
+
+    def checkpoint(self) -> Dict[str, object]:
+        """What is needed to resume: time index, parameters, and row ``time_index`` of every state
+        variable (the reference's JSON checkpoint holds time_index + the whole collection,
+        crates/rscm-core/src/model/runtime.rs:270-282; rows before the index are history)."""
+        k = self.time_index
+        return {"kind": self.kind, "n_members": self.n_members, "bounds": self.bounds.copy(),
+                "time_index": k, "params": self.get_params(),
+                "state": {name: self.get_series(v, k, k + 1)[0] for name, v in self.state_vars().items()}}
+
+    def restore(self, ck: Dict[str, object]) -> None:
+        if (ck["kind"] != self.kind or ck["n_members"] != self.n_members
+                or not np.array_equal(ck["bounds"], self.bounds)):
+            raise ValueError("checkpoint does not match this ensemble (kind, members or time axis)")
+        self.set_params(ck["params"])
+        k = int(ck["time_index"])
+        for name, row in ck["state"].items():
+            v = L.f64(row)
+            L.check(self._lib.rscm_ens_set_state(self._h, self._var(name), k, L.dptr(v), v.size))
+        L.check(self._lib.rscm_ens_set_time_index(self._h, k))
+
     # -- outputs ----------------------------------------------------------------------------
     def get_series(self, var, t_begin: int = 0, t_end: Optional[int] = None, t_stride: int = 1,
-                   m_begin: int = 0, m_end: Optional[int] = None) -> np.ndarray:
+                   m_begin: int = 0, m_end: Optional[int] = None,
+                   out: Optional[np.ndarray] = None) -> np.ndarray:
+        """``[n_t][m_end - m_begin]`` copy of a stored series.  Pass ``out`` (e.g. from
+        ``pinned_empty``) to reuse a buffer; a page-locked one is filled by DMA at PCIe rate."""
         t_end = self.n_times if t_end is None else t_end
         m_end = self.n_members if m_end is None else m_end
         nt = len(range(t_begin, t_end, t_stride))
-        out = np.empty((nt, m_end - m_begin))
+        if out is None:
+            out = np.empty((nt, m_end - m_begin))
+        elif out.shape != (nt, m_end - m_begin) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float64 array of shape {(nt, m_end - m_begin)}")
         L.check(self._lib.rscm_ens_get_series(self._h, self._var(var), t_begin, t_end, t_stride,
                                               m_begin, m_end, L.dptr(out)))
         return out
@@ -178,6 +210,39 @@ class Ensemble:
         cnt = out[0]
         return {"count": int(cnt), "mean": out[1] / cnt if cnt else float("nan"),
                 "min": out[2], "max": out[3]}
+
+
+class _PinnedOwner:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            L.load().rscm_gpu_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """numpy array over page-locked host memory (hipHostMalloc); freed with the array."""
+    lib = L.load()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    L.check(lib.rscm_gpu_host_alloc(max(n, 1), C.byref(p)))
+    owner = _PinnedOwner(p.value)
+    buf = (C.c_char * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    arr = arr.view(_PinnedArray)
+    arr._owner = owner
+    return arr
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray that keeps its page-locked allocation alive."""
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
 
 
 def selftest_div(num, den, device: int = 0):

@@ -470,3 +470,50 @@ def test_full_size_properties(ra, orc, n_members):
         e.run()
         assert_bit_equal(e.get_series(1, 750, 751)[0], 2.0 * base, "Ts(2F) == 2 Ts(F)")
         assert np.isfinite(base).all()
+
+
+def test_checkpoint_restore_resumes_bit_identically(ra):
+    """Aux subsystem: checkpoint/resume (reference: Model::checkpoint / from_checkpoint,
+    crates/rscm-core/src/model/runtime.rs:270-282).  A fresh handle restored from
+    (time index, parameters, state rows) continues to the same bits."""
+    t = axis_values(1750, 1900)
+    b = np.append(t, t[-1] + 1.0)
+    P, F = two_layer_params(300), f_syn(t)
+    full = _tl_gpu(ra, t, P, F, 0.0, 0.0)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 300, b) as e:
+        e.set_params(P)
+        e.set_forcing(F)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run(60)
+        ck = e.checkpoint()
+    assert ck["time_index"] == 60
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 300, b) as e2:
+        e2.set_forcing(F)
+        e2.restore(ck)
+        assert e2.time_index == 60
+        e2.run()
+        assert_bit_equal(e2.get_series(1)[60:], full[0][60:])
+        assert_bit_equal(e2.get_series(2)[60:], full[1][60:])
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 299, b) as e3:
+        with pytest.raises(ValueError, match="does not match"):
+            e3.restore(ck)
+    # coupled kind: five state rows
+    P10 = coupled_params(64)
+    E = emissions_syn(t)
+    with ra.Ensemble(ra.KIND_COUPLED, 64, b) as e:
+        e.set_params(P10)
+        e.set_forcing(E)
+        for k, v in CP_INIT.items():
+            e.set_initial(k, v)
+        e.run()
+        want = {k: e.get_series(k) for k in e.var_ids if e.var_ids[k] > 0}
+        e.rewind()
+        e.run(40)
+        ck = e.checkpoint()
+    with ra.Ensemble(ra.KIND_COUPLED, 64, b) as e2:
+        e2.set_forcing(E)
+        e2.restore(ck)
+        e2.run()
+        for k, w in want.items():
+            assert_bit_equal(e2.get_series(k)[41:], w[41:], k)

@@ -163,3 +163,13 @@ def test_threaded_split_matches_single_thread():
     many = cbind.two_layer_run(b, P, F, 0.0, 0.0, threads=5)
     assert_bit_equal(one[0], many[0])
     assert_bit_equal(one[1], many[1])
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """Sanitizers run on the CPU build only (GPU ASan is unavailable on the pool)."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-C", here, "asan-check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "oracle selftest ok" in r.stdout
