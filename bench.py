@@ -76,6 +76,9 @@ def timed_passes(ens, steps, warmup, torch, dist, world, tstream):
     for _ in range(warmup):
         one_pass(ens)
     ens.sync()
+    if world > 1:  # communicator creation and the first collective stay outside the timed region
+        dist.barrier()
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
@@ -127,8 +130,8 @@ def cpu_baseline(threads, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--members", type=int, default=100_000, help="members per GPU (configs[1]: 1e5)")
     ap.add_argument("--mode", choices=["exact", "fast"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,7 +220,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                # HBM bytes per launch from rocprofv3 PMC passes of this workload
+                # (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/r1_exact_1e5_v2.txt.
+                # The traffic is input-independent (params + forcing in, Ts/Td out).
+                "traffic": 1.2067e9 if (args.members == 100_000 and args.mode == "exact") else None,
                 "kernel": "two_layer_kernel",
                 "kernel_ms": kernel_ms,
                 "note": "algorithmic 16 B/member-year x members x 750 / launch duration; the "
