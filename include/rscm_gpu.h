@@ -120,6 +120,13 @@ RSCM_API int rscm_gpu_device_count(int32_t* out);
  * strictly; step n integrates over [bounds[n], bounds[n+1]]. */
 RSCM_API int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
                     int32_t device_id, rscm_ens** out);
+/* As rscm_ens_create, with flags.  RSCM_FLAG_NO_SERIES (two-layer kind): keep only the initial
+ * row of every state series -- for likelihood-only work through rscm_ens_run_loglik, where no
+ * time series is ever written to HBM (12 GB per 1e6 members otherwise). */
+#define RSCM_FLAG_NO_SERIES 1u
+RSCM_API int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times,
+                                const double* time_bounds, int32_t device_id, uint32_t flags,
+                                rscm_ens** out);
 RSCM_API int rscm_ens_destroy(rscm_ens* h);
 
 RSCM_API int rscm_ens_n_params(const rscm_ens* h, int32_t* out);
@@ -188,6 +195,14 @@ RSCM_API int rscm_ens_status(rscm_ens* h, uint8_t* out);
 RSCM_API int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
                     const double* obs_value, const double* obs_sigma, int32_t normalize,
                     double* out);
+/* Fused Model::run + GaussianLikelihood for the calibration loop (two-layer kind): steps every
+ * member from time index 0 to the end of the axis and accumulates ln L on the fly, writing no
+ * series (the time index stays 0, status is updated).  Same value as rscm_ens_run followed by
+ * rscm_ens_loglik, bit for bit.  Observations grouped by variable with ascending time indices
+ * inside a group. */
+RSCM_API int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var,
+                                 const int32_t* obs_tidx, const double* obs_value,
+                                 const double* obs_sigma, int32_t normalize, double* out);
 /* Ensemble summary of one variable at one time index over finite members:
  * out[0]=count_finite, out[1]=sum, out[2]=min, out[3]=max (wavefront + block reductions). */
 RSCM_API int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4]);

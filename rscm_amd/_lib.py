@@ -19,6 +19,7 @@ KIND_TWO_LAYER, KIND_COUPLED = 0, 1
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
+FLAG_NO_SERIES = 1
 
 TL_VARS = {"Effective Radiative Forcing": 0, "Surface Temperature": 1, "Deep Ocean Temperature": 2}
 CP_VARS = {"Emissions|CO2|Anthropogenic": 0, "Surface Temperature": 1, "Deep Ocean Temperature": 2,
@@ -37,6 +38,8 @@ SIGNATURES = {
     "rscm_gpu_last_error": (C.c_char_p, []),
     "rscm_gpu_device_count": (C.c_int, [_ip]),
     "rscm_ens_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.POINTER(_h)]),
+    "rscm_ens_create_ex": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_uint32,
+                                     C.POINTER(_h)]),
     "rscm_ens_destroy": (C.c_int, [_h]),
     "rscm_ens_n_params": (C.c_int, [_h, _ip]),
     "rscm_ens_n_vars": (C.c_int, [_h, _ip]),
@@ -63,6 +66,7 @@ SIGNATURES = {
     "rscm_ens_params_devptr": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "rscm_ens_status": (C.c_int, [_h, _bp]),
     "rscm_ens_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
+    "rscm_ens_run_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
     "rscm_ens_summary": (C.c_int, [_h, C.c_int32, C.c_int32, _dp]),
     "rscm_ens_get_params": (C.c_int, [_h, _dp]),
     "rscm_ens_sample_lhs": (C.c_int, [_h, C.c_uint64, _dp, _dp, C.c_int64, C.c_int64]),

@@ -223,6 +223,7 @@ class ModelRunner:
         self._outputs = list(output_variables)
         self._mode = mode
         self._models: Dict[int, Model] = {}
+        self._lik_models: Dict[int, Model] = {}
         probe = self._model(1)
         unknown = [p for p in self._param_names if p not in probe.param_order]
         if unknown:
@@ -249,16 +250,32 @@ class ModelRunner:
             self._models[n] = m
         return self._models[n]
 
-    def _run(self, param_sets: np.ndarray) -> Model:
+    def _lik_model(self, n: int) -> Model:
+        """Likelihood-only ensemble: no series buffers (RSCM_FLAG_NO_SERIES)."""
+        if n not in self._lik_models:
+            if len(self._lik_models) >= 4:
+                self._lik_models.pop(next(iter(self._lik_models))).close()
+            m = self._builder.build(n_members=n, store_series=False)
+            m.ensemble.set_mode(self._mode)
+            self._lik_models[n] = m
+        return self._lik_models[n]
+
+    def _load(self, m: Model, param_sets) -> None:
         p = np.asarray(param_sets, dtype=np.float64)
         if p.ndim != 2 or p.shape[1] != len(self._param_names):
             got = p.shape[1] if p.ndim == 2 else len(p)
             raise ValueError(f"Expected {len(self._param_names)} parameters, got {got}")  # :225-231
-        m = self._model(p.shape[0])
         full = np.repeat(m.base_params[:, None], p.shape[0], axis=1)
         full[self._rows, :] = p.T
         m.ensemble.set_params(full)
         m.ensemble.rewind()
+
+    def _run(self, param_sets: np.ndarray) -> Model:
+        p = np.asarray(param_sets, dtype=np.float64)
+        if p.ndim != 2:
+            raise ValueError(f"Expected {len(self._param_names)} parameters, got {len(p)}")
+        m = self._model(p.shape[0])
+        self._load(m, p)
         m.ensemble.run()
         return m
 
@@ -286,25 +303,50 @@ class ModelRunner:
         """Device path: run the batch and reduce the Gaussian log-likelihood per member without
         moving any series to the host.  Failed members (non-finite or never-computed values at an
         observation time) get ``-inf`` (sampler/ensemble.rs:163-172)."""
-        m = self._run(np.asarray(param_sets, dtype=np.float64))
+        p = np.asarray(param_sets, dtype=np.float64)
+        if p.ndim != 2:
+            raise ValueError(f"Expected {len(self._param_names)} parameters, got {len(p)}")
+        probe = self._model(1)
         ov, ot, val, sig = [], [], [], []
+        fused = probe.ensemble.kind == L.KIND_TWO_LAYER
         for name, vt in target.variables():
-            if name not in m.ensemble.var_ids or m.ensemble.var_ids[name] == 0:
+            if name not in probe.ensemble.var_ids or probe.ensemble.var_ids[name] == 0:
                 raise KeyError(f"Model output missing variable: {name}")
+            prev = -1
             for obs in vt.observations:
-                idx = m._axis.index_of(obs.time)
+                idx = probe._axis.index_of(obs.time)
                 if idx is None:  # "Model output missing time" -> Err -> -inf for every member
-                    return np.full(m.ensemble.n_members, -np.inf)
+                    return np.full(p.shape[0], -np.inf)
+                fused = fused and idx >= prev
+                prev = idx
                 ov.append(name)
                 ot.append(idx)
                 val.append(obs.value)
                 sig.append(obs.uncertainty)
-        return m.ensemble.loglik(ov, ot, val, sig, likelihood.normalize)
+        # Multi-GPU: every rank holds the same batch (same seeds => same proposals, nothing to
+        # scatter), evaluates its contiguous block of members and all-gathers 8 B per member.
+        from .distributed import gather_members, is_distributed, shard_bounds
+        n_total = p.shape[0]
+        if is_distributed():
+            import torch.distributed as dist
+            off, cnt = shard_bounds(n_total, dist.get_rank(), dist.get_world_size())
+            p = p[off:off + cnt]
+        if p.shape[0] == 0:
+            local = np.zeros(0)
+        elif fused:  # run + likelihood in one kernel, nothing written to HBM but ln L
+            m = self._lik_model(p.shape[0])
+            self._load(m, p)
+            local = m.ensemble.run_loglik(ov, ot, val, sig, likelihood.normalize)
+        else:
+            m = self._run(p)
+            local = m.ensemble.loglik(ov, ot, val, sig, likelihood.normalize)
+        return gather_members(local, n_total) if is_distributed() else local
 
     def close(self) -> None:
-        for m in self._models.values():
+        for m in list(self._models.values()) + list(self._lik_models.values()):
             m.close()
         self._models.clear()
+        self._lik_models.clear()
 
 
 # ------------------------------------------------------------------------------------ sampler

@@ -427,7 +427,7 @@ class ModelBuilder:
             return self._exogenous.get_timeseries_by_name(name).interpolate_into(self._axis).values()
         return None
 
-    def build(self, n_members: int = 1) -> "Model":
+    def build(self, n_members: int = 1, store_series: bool = True) -> "Model":
         endogenous, sources, exo_names, aggregates = self._resolve()
         types = [c.type_name for c in self._components]
         erf = "Effective Radiative Forcing"
@@ -461,7 +461,10 @@ class ModelBuilder:
             raise NotImplementedError(
                 f"component graph {types} (aggregates {list(aggregates)}) has no fused GPU kernel; "
                 "supported: " + "; ".join(SUPPORTED))
-        ens = Ensemble(kind, n_members, self._axis.bounds(), device=self._device)
+        if not store_series and kind != L.KIND_TWO_LAYER:
+            store_series = True  # likelihood-only handles exist for the two-layer kind
+        ens = Ensemble(kind, n_members, self._axis.bounds(), device=self._device,
+                       store_series=store_series)
         for comp_id, step in h.items():
             ens.set_step_size(comp_id, step)
         ens.set_params(np.repeat(np.array(params, dtype=np.float64)[:, None], n_members, axis=1))

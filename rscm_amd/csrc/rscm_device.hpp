@@ -27,6 +27,16 @@ struct TwoLayerArgs {
     double* ts;              // [T][N]
     double* td;              // [T][N]
     uint8_t* status;         // [N]
+    // Fused likelihood (launch_two_layer_loglik): no series rows beyond step_begin are written;
+    // observations merged over both variables and sorted by time index.
+    int32_t n_obs;
+    int32_t normalize;
+    int32_t first_is_deep;        // which variable's group comes first in the caller's order
+    const int32_t* obs_tidx;      // [n_obs] ascending
+    const int32_t* obs_is_deep;   // [n_obs] 0: Surface Temperature, 1: Deep Ocean Temperature
+    const double* obs_value;
+    const double* obs_sigma;
+    double* loglik;               // [N]
 };
 
 // Coupled chain CarbonCycle -> CO2ERF -> Sum -> TwoLayer over steps [step_begin, step_end).
@@ -59,6 +69,7 @@ struct LoglikArgs {
 };
 
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
+hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -79,6 +80,7 @@ struct rscm_ens {
     int32_t kind = 0;
     int64_t N = 0;
     int32_t T = 0;
+    int32_t rows = 0;  // stored rows per series: T, or 1 with RSCM_FLAG_NO_SERIES
     int32_t device = 0;
     int32_t P = 0, V = 0;
     int32_t mode = RSCM_MODE_EXACT;
@@ -110,7 +112,7 @@ struct rscm_ens {
     bool params_set = false, forcing_set = false;
     std::vector<uint8_t> initial_set;  // per variable id
 
-    double* series(int32_t var) const { return d_series + (size_t)(var - 1) * (size_t)T * (size_t)N; }
+    double* series(int32_t var) const { return d_series + (size_t)(var - 1) * (size_t)rows * (size_t)N; }
     bool is_state(int32_t var) const
     {
         if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
@@ -176,7 +178,16 @@ int rscm_gpu_device_count(int32_t* out)
 int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
                     int32_t device_id, rscm_ens** out)
 {
+    return rscm_ens_create_ex(kind, n_members, n_times, time_bounds, device_id, 0, out);
+}
+
+int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
+                       int32_t device_id, uint32_t flags, rscm_ens** out)
+{
     GUARD_BEGIN
+    if (flags & ~(uint32_t)RSCM_FLAG_NO_SERIES) return fail(RSCM_ERR_INVALID, "unknown flags 0x%x", flags);
+    if ((flags & RSCM_FLAG_NO_SERIES) && kind != RSCM_KIND_TWO_LAYER)
+        return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED)
@@ -194,6 +205,7 @@ int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const doub
     h->kind = kind;
     h->N = n_members;
     h->T = n_times;
+    h->rows = (flags & RSCM_FLAG_NO_SERIES) ? 1 : n_times;
     h->device = device_id;
     h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : RSCM_CP_NPARAMS;
     h->V = kind == RSCM_KIND_TWO_LAYER ? 3 : 8;
@@ -220,7 +232,7 @@ int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const doub
     h->own_stream = true;
     CK(hipEventCreate(&h->ev0));
     CK(hipEventCreate(&h->ev1));
-    const size_t series_elems = (size_t)(h->V - 1) * (size_t)h->T * (size_t)h->N;
+    const size_t series_elems = (size_t)(h->V - 1) * (size_t)h->rows * (size_t)h->N;
     CK(hipMalloc(&h->d_params, (size_t)h->P * h->N * sizeof(double)));
     CK(hipMalloc(&h->d_series, series_elems * sizeof(double)));
     CK(hipMalloc(&h->d_status, (size_t)h->N));
@@ -399,7 +411,7 @@ int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* 
     GUARD_BEGIN
     NEED(h);
     if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
-    if (tidx < 0 || tidx >= h->T) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (tidx < 0 || tidx >= h->rows) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
     if (!values || (n_values != 1 && n_values != h->N))
         return fail(RSCM_ERR_INVALID, "state values: need 1 or n_members values, got %lld", (long long)n_values);
     if (int rc = set_device(h)) return rc;
@@ -417,7 +429,7 @@ int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* 
 int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
 {
     NEED(h);
-    if (tidx < 0 || tidx > h->T - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (tidx < 0 || tidx > h->rows - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
     if (tidx > 0)
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;  // a restored checkpoint carries its own state rows
@@ -441,6 +453,8 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
                     step_begin, step_end, h->T - 1);
     if (step_begin != h->time_index)
         return fail(RSCM_ERR_STATE, "step_begin %d != current time index %d", step_begin, h->time_index);
+    if (h->rows != h->T && step_end > step_begin)
+        return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES): use rscm_ens_run_loglik");
     if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
     if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
     for (int32_t v = 1; v < h->V; ++v)
@@ -539,6 +553,8 @@ int rscm_ens_get_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_
     if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
     if (t_begin < 0 || t_end > h->T || t_begin > t_end || t_stride < 1)
         return fail(RSCM_ERR_INVALID, "bad time range [%d, %d) stride %d", t_begin, t_end, t_stride);
+    if (h->rows != h->T && t_end > 1)
+        return fail(RSCM_ERR_STATE, "this handle stores only the initial row (RSCM_FLAG_NO_SERIES)");
     if (m_begin < 0 || m_end > h->N || m_begin > m_end || !out)
         return fail(RSCM_ERR_INVALID, "bad member range [%lld, %lld)", (long long)m_begin, (long long)m_end);
     const int64_t width = m_end - m_begin;
@@ -643,6 +659,93 @@ int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const in
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d_blob);
     if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "loglik: %s", hipGetErrorString(e));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                        const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (h->kind != RSCM_KIND_TWO_LAYER) return fail(RSCM_ERR_INVALID, "run_loglik supports the two-layer kind");
+    if (n_obs < 0 || !out || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
+        return fail(RSCM_ERR_INVALID, "bad observation arrays");
+    if (h->time_index != 0) return fail(RSCM_ERR_STATE, "run_loglik starts from time index 0 (call rscm_ens_rewind)");
+    if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
+    if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
+    for (int32_t v = 1; v < h->V; ++v)
+        if (h->is_state(v) && !h->initial_set[v])
+            return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
+    // groups: each variable contiguous, ascending time index inside a group
+    int32_t first_var = n_obs > 0 ? obs_var[0] : RSCM_TL_VAR_TS;
+    for (int32_t j = 0; j < n_obs; ++j) {
+        if (obs_var[j] != RSCM_TL_VAR_TS && obs_var[j] != RSCM_TL_VAR_TD)
+            return fail(RSCM_ERR_INVALID, "observation %d: variable %d has no stored series", j, obs_var[j]);
+        if (obs_tidx[j] < 0 || obs_tidx[j] >= h->T) return fail(RSCM_ERR_INVALID, "observation %d: time index %d out of range", j, obs_tidx[j]);
+        if (j > 0 && obs_var[j] != obs_var[j - 1] && obs_var[j] == first_var)
+            return fail(RSCM_ERR_INVALID, "observations must be grouped by variable");
+        if (j > 0 && obs_var[j] == obs_var[j - 1] && obs_tidx[j] < obs_tidx[j - 1])
+            return fail(RSCM_ERR_INVALID, "run_loglik needs ascending time indices inside a variable group "
+                                          "(use rscm_ens_run + rscm_ens_loglik for arbitrary order)");
+    }
+    if (int rc = set_device(h)) return rc;
+    if (int rc = refresh_schedule(h)) return rc;
+    // merge the (at most two) groups by time index; ties keep Surface Temperature first
+    std::vector<int32_t> order(n_obs);
+    for (int32_t j = 0; j < n_obs; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return obs_tidx[x] < obs_tidx[y]; });
+    const size_t sz_i = (size_t)n_obs * sizeof(int32_t), sz_d = (size_t)n_obs * sizeof(double);
+    std::vector<unsigned char> blob(2 * sz_d + 2 * sz_i + 16);
+    double* bv = (double*)blob.data();
+    double* bs = bv + n_obs;
+    int32_t* bt = (int32_t*)(bs + n_obs);
+    int32_t* bd = bt + n_obs;
+    for (int32_t k = 0; k < n_obs; ++k) {
+        const int32_t j = order[k];
+        bv[k] = obs_value[j];
+        bs[k] = obs_sigma[j];
+        bt[k] = obs_tidx[j];
+        bd[k] = obs_var[j] == RSCM_TL_VAR_TD ? 1 : 0;
+    }
+    if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+    void* d_blob = nullptr;
+    HIPCHK(hipMalloc(&d_blob, blob.size()));
+    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, h->stream);
+    const int32_t len = h->T - 1;
+    const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
+    rscm::TwoLayerArgs a{};
+    a.n_members = h->N;
+    a.n_times = h->T;
+    a.step_begin = 0;
+    a.step_end = h->T - 1;
+    a.n_scen = h->n_scen;
+    a.src_off = h->source == RSCM_SRC_UPSTREAM ? 1 : 0;
+    a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
+    a.params = h->d_params;
+    a.forcing = h->d_forcing;
+    a.scen = h->d_scen;
+    a.nsub = h->d_nsub_tl;
+    a.h = h->h_tl;
+    a.ts = h->series(RSCM_TL_VAR_TS);
+    a.td = h->series(RSCM_TL_VAR_TD);
+    a.status = h->d_status;
+    a.n_obs = n_obs;
+    a.normalize = normalize ? 1 : 0;
+    a.first_is_deep = first_var == RSCM_TL_VAR_TD ? 1 : 0;
+    a.obs_value = (const double*)d_blob;
+    a.obs_sigma = a.obs_value + n_obs;
+    a.obs_tidx = (const int32_t*)(a.obs_sigma + n_obs);
+    a.obs_is_deep = a.obs_tidx + n_obs;
+    a.loglik = h->d_loglik;
+    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+    if (e == hipSuccess) e = rscm::launch_two_layer_loglik(a, h->mode, h->stream);
+    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_blob);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "run_loglik: %s", hipGetErrorString(e));
+    h->timed = true;
     return RSCM_OK;
     GUARD_END
 }

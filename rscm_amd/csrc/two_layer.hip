@@ -105,7 +105,37 @@ __device__ __forceinline__ void rhs_fast(const TLFast& p, double erf_cs, double 
     dtd = p.ed * diff;
 }
 
-template <int MODE, bool LDS>
+// Per-member Gaussian log-likelihood accumulated while stepping (STORE == false): same
+// expression and summation order as loglik_kernel in ensemble_ops.hip -- per-variable partial
+// sums in time order, then the total in the caller's group order (likelihood.rs:186-250).
+struct LikAcc {
+    double part_s = 0.0, part_d = 0.0;
+    bool bad = false;
+    int32_t oi = 0;
+};
+
+__device__ __forceinline__ void lik_consume(const TwoLayerArgs& a, LikAcc& L, int32_t row, double ts,
+                                            double td)
+{
+    while (L.oi < a.n_obs && a.obs_tidx[L.oi] == row) {  // wave-uniform
+        const bool deep = a.obs_is_deep[L.oi] != 0;
+        const double m = deep ? td : ts;
+        if (!is_finite(m)) L.bad = true;
+        const double sigma = a.obs_sigma[L.oi];
+        const double residual = a.obs_value[L.oi] - m;
+        const double chi = (residual * residual) / (sigma * sigma);
+        double l = -0.5 * chi;
+        if (a.normalize) {
+            l -= 0.5 * 1.8378770664093453;  // ln(2*pi)
+            l -= log(sigma);
+        }
+        if (deep) L.part_d += l;
+        else L.part_s += l;
+        ++L.oi;
+    }
+}
+
+template <int MODE, bool LDS, bool STORE>
 __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
 {
     extern __shared__ double lds_forcing[];
@@ -146,6 +176,9 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
     const double sixth = h / 6.0;
     const int32_t last = a.step_end - 1;
 
+    LikAcc lik;
+    if constexpr (!STORE) lik_consume(a, lik, a.step_begin, ts, td);  // observations of the start row
+
     // next year's forcing and sub-step count are fetched a year ahead of their use
     double erf_next = forcing_at(a.step_begin);
     int32_t m_next = a.nsub[a.step_begin];
@@ -181,10 +214,14 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
                 int32_t unused = 0;
                 for (int32_t s = 0; s < m; ++s) rk4_step_exact<false>(p, erf, h, half_step, sixth, ts, td, unused);
             }
-            *out_ts = ts;
-            *out_td = td;
-            out_ts += N;
-            out_td += N;
+            if constexpr (STORE) {
+                *out_ts = ts;
+                *out_td = td;
+                out_ts += N;
+                out_td += N;
+            } else {
+                lik_consume(a, lik, n + 1, ts, td);
+            }
         }
     } else {
         const double inv_cs = 1.0 / cs;
@@ -212,25 +249,38 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
                 ts = __builtin_fma(k2s + k3s, third, __builtin_fma(k1s + k4s, sixth, ts));
                 td = __builtin_fma(k2d + k3d, third, __builtin_fma(k1d + k4d, sixth, td));
             }
-            *out_ts = ts;
-            *out_td = td;
-            out_ts += N;
-            out_td += N;
+            if constexpr (STORE) {
+                *out_ts = ts;
+                *out_td = td;
+                out_ts += N;
+                out_td += N;
+            } else {
+                lik_consume(a, lik, n + 1, ts, td);
+            }
         }
     }
     a.status[i] = (is_finite(ts) && is_finite(td)) ? 0 : 1;
+    if constexpr (!STORE) {
+        // observations whose row is never reached were never computed -> member failure
+        if (lik.oi < a.n_obs) lik.bad = true;
+        const double total = a.first_is_deep ? (0.0 + lik.part_d) + lik.part_s
+                                             : (0.0 + lik.part_s) + lik.part_d;
+        a.loglik[i] = lik.bad ? -__builtin_inf() : total;
+    }
 }
 
 }  // namespace
 
-hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s)
+template <bool STORE>
+static hipError_t launch_impl(const TwoLayerArgs& a, int mode, hipStream_t s)
 {
-    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    if (a.n_members <= 0) return hipSuccess;
+    if (STORE && a.step_end <= a.step_begin) return hipSuccess;
     const size_t lds = a.lds_forcing ? (size_t)a.n_scen * (a.step_end - a.step_begin) * sizeof(double) : 0;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     void (*kern)(TwoLayerArgs) =
-        mode == 0 ? (a.lds_forcing ? two_layer_kernel<0, true> : two_layer_kernel<0, false>)
-                  : (a.lds_forcing ? two_layer_kernel<1, true> : two_layer_kernel<1, false>);
+        mode == 0 ? (a.lds_forcing ? two_layer_kernel<0, true, STORE> : two_layer_kernel<0, false, STORE>)
+                  : (a.lds_forcing ? two_layer_kernel<1, true, STORE> : two_layer_kernel<1, false, STORE>);
     if (lds > (size_t)kMaxStaticLds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -238,6 +288,16 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s)
     }
     hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s)
+{
+    return launch_impl<true>(a, mode, s);
+}
+
+hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s)
+{
+    return launch_impl<false>(a, mode, s);
 }
 
 }  // namespace rscm

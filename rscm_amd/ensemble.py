@@ -17,7 +17,8 @@ from . import _lib as L
 
 
 class Ensemble:
-    def __init__(self, kind: int, n_members: int, time_bounds: Sequence[float], device: int = 0):
+    def __init__(self, kind: int, n_members: int, time_bounds: Sequence[float], device: int = 0,
+                 store_series: bool = True):
         self._lib = L.load()
         b = L.f64(time_bounds)
         if b.ndim != 1 or len(b) < 3:
@@ -30,8 +31,9 @@ class Ensemble:
         self.var_ids: Dict[str, int] = dict(L.TL_VARS if kind == L.KIND_TWO_LAYER else L.CP_VARS)
         self.n_params = 6 if kind == L.KIND_TWO_LAYER else 10
         h = C.c_void_p()
-        L.check(self._lib.rscm_ens_create(kind, self.n_members, self.n_times, L.dptr(b), device,
-                                          C.byref(h)))
+        self.store_series = bool(store_series)
+        L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
+                                             0 if store_series else L.FLAG_NO_SERIES, C.byref(h)))
         self._h = h
 
     # -- lifecycle --------------------------------------------------------------------------
@@ -202,6 +204,18 @@ class Ensemble:
         out = np.empty(self.n_members)
         L.check(self._lib.rscm_ens_loglik(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
                                           L.dptr(sig), int(normalize), L.dptr(out)))
+        return out
+
+    def run_loglik(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize: bool = False) -> np.ndarray:
+        """Fused run + Gaussian log-likelihood: no series is written (see rscm_ens_run_loglik)."""
+        ov = np.ascontiguousarray([self._var(v) for v in np.atleast_1d(obs_var)], dtype=np.int32)
+        ot = np.ascontiguousarray(obs_tidx, dtype=np.int32)
+        val, sig = L.f64(obs_value), L.f64(obs_sigma)
+        if not (len(ov) == len(ot) == len(val) == len(sig)):
+            raise ValueError("observation arrays differ in length")
+        out = np.empty(self.n_members)
+        L.check(self._lib.rscm_ens_run_loglik(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
+                                              L.dptr(sig), int(normalize), L.dptr(out)))
         return out
 
     def summary(self, var, tidx: int) -> Dict[str, float]:

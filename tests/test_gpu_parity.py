@@ -517,3 +517,74 @@ def test_checkpoint_restore_resumes_bit_identically(ra):
         e2.run()
         for k, w in want.items():
             assert_bit_equal(e2.get_series(k)[41:], w[41:], k)
+
+
+def test_fused_run_loglik_equals_stored_path(ra):
+    """rscm_ens_run_loglik (no series written) == rscm_ens_run + rscm_ens_loglik, bit for bit,
+    in both arithmetic modes, with observations on both variables incl. the initial row."""
+    from rscm_amd import RscmGpuError
+    t = axis_values()
+    b = np.append(t, t[-1] + 1.0)
+    n = 3000
+    P, F = two_layer_params(n), f_syn(t)
+    ov = np.r_[np.full(5, 2), np.full(19, 1)]            # Deep group first, then Surface
+    ot = np.r_[[0, 40, 40, 300, 750], np.arange(100, 271, 10), [750]].astype(np.int32)
+    val = np.linspace(0.0, 3.0, len(ot))
+    sig = np.linspace(0.05, 0.5, len(ot))
+    for mode in (0, 1):
+        for normalize in (False, True):
+            with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+                e.set_mode(mode)
+                e.set_params(P)
+                e.set_forcing(F)
+                e.set_initial(1, 0.1)
+                e.set_initial(2, -0.05)
+                e.run()
+                want = e.loglik(ov, ot, val, sig, normalize)
+                st = e.status()
+            with ra.Ensemble(ra.KIND_TWO_LAYER, n, b, store_series=False) as e:
+                e.set_mode(mode)
+                e.set_params(P)
+                e.set_forcing(F)
+                e.set_initial(1, 0.1)
+                e.set_initial(2, -0.05)
+                got = e.run_loglik(ov, ot, val, sig, normalize)
+                assert_bit_equal(got, want, f"mode {mode} normalize {normalize}")
+                assert (e.status() == st).all()
+                assert e.time_index == 0
+                assert (np.isinf(got) & (got < 0)).sum() == (st != 0).sum() > 0
+                with pytest.raises(RscmGpuError):  # nothing is stored on this handle
+                    e.run()
+                with pytest.raises(RscmGpuError):
+                    e.get_series(1)
+                with pytest.raises(RscmGpuError, match="ascending"):
+                    e.run_loglik([1, 1], [20, 10], [0.0, 0.0], [0.1, 0.1])
+                with pytest.raises(RscmGpuError, match="grouped"):
+                    e.run_loglik([1, 2, 1], [1, 2, 3], [0.0] * 3, [0.1] * 3)
+                assert_bit_equal(e.get_series(1, 0, 1), np.full((1, n), 0.1))
+
+
+def test_likelihood_only_ensemble_of_ten_million_members(ra):
+    """No series buffers: 1e7 members need 480 MB of parameters + 160 MB of state instead of
+    120 GB of series."""
+    t = axis_values(1750, 1850)
+    b = np.append(t, t[-1] + 1.0)
+    n = 10_000_000
+    lo = np.array([r[0] for r in TL_RANGES])
+    hi = np.array([r[1] for r in TL_RANGES])
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b, store_series=False) as e:
+        e.sample_lhs(SEED, lo, hi)
+        e.set_forcing(f_syn(t))
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        ll = e.run_loglik([1, 1], [50, 100], [0.5, 1.0], [0.2, 0.2])
+        assert ll.shape == (n,) and np.isfinite(ll).all() and (ll <= 0).all()
+        pick = np.arange(0, n, n // 257)
+        P = e.get_params()[:, pick]
+    with ra.Ensemble(ra.KIND_TWO_LAYER, len(pick), b) as e:
+        e.set_params(np.ascontiguousarray(P))
+        e.set_forcing(f_syn(t))
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run()
+        assert_bit_equal(e.loglik([1, 1], [50, 100], [0.5, 1.0], [0.2, 0.2]), ll[pick])
