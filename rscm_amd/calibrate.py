@@ -49,6 +49,12 @@ class Uniform:
     def quantile(self, u):
         return self._low + u * (self._high - self._low)
 
+    def sample_n(self, rng: np.random.Generator, n: int) -> np.ndarray:
+        return self._low + rng.random(n) * (self._high - self._low)
+
+    def ln_pdf_n(self, x: np.ndarray) -> np.ndarray:
+        return np.where((x < self._low) | (x > self._high), -np.inf, -math.log(self._high - self._low))
+
 
 class Normal:
     """distribution.rs:211-275."""
@@ -71,6 +77,13 @@ class Normal:
     def quantile(self, u):
         from scipy.special import ndtri  # exact inverse CDF (the reference approximates it by sampling)
         return self.mean + self.std_dev * ndtri(u)
+
+    def sample_n(self, rng, n):
+        return rng.normal(self.mean, self.std_dev, n)
+
+    def ln_pdf_n(self, x):
+        z = (np.asarray(x) - self.mean) / self.std_dev
+        return -0.5 * z * z - math.log(self.std_dev) - 0.5 * math.log(2.0 * math.pi)
 
 
 class ParameterSet:
@@ -102,7 +115,7 @@ class ParameterSet:
 
     def sample_random(self, n: int, rng: Optional[np.random.Generator] = None) -> np.ndarray:
         rng = rng or np.random.default_rng()
-        return np.array([[d.sample(rng) for d in self._dists] for _ in range(n)])
+        return np.column_stack([d.sample_n(rng, n) for d in self._dists])
 
     def sample_lhs(self, n: int, rng: Optional[np.random.Generator] = None) -> np.ndarray:
         """Host Latin hypercube, ``[n][P]``: per dimension one draw per stratum
@@ -122,7 +135,13 @@ class ParameterSet:
         return float(sum(d.ln_pdf(x) for d, x in zip(self._dists, params)))
 
     def log_prior_batch(self, params: np.ndarray) -> np.ndarray:
-        return np.array([self.log_prior(row) for row in params])
+        params = np.asarray(params, dtype=np.float64)
+        if params.ndim != 2 or params.shape[1] != len(self):
+            raise ValueError(f"Expected {len(self)} parameters, got {params.shape[-1]}")
+        total = np.zeros(params.shape[0])
+        for j, d in enumerate(self._dists):  # same left-to-right sum as log_prior
+            total = total + d.ln_pdf_n(params[:, j])
+        return total
 
 
 # ------------------------------------------------------------------------------------ target

@@ -54,18 +54,15 @@ def main():
     params = cal.ParameterSet()
     for k, (lo, hi) in zip(names, [(0.8, 1.5), (0.0, 0.1), (1.0, 1.8), (0.5, 1.0), (5.0, 15.0), (50.0, 200.0)]):
         params.add(k, cal.Uniform(lo, hi))
-    # vectorised prior for uniform boxes (the generic per-row loop would dominate at 1e5 walkers)
-    lo, hi = (np.array(x) for x in params.bounds())
-    logw = -np.log(hi - lo).sum()
-    params.log_prior_batch = lambda pos: np.where(((pos >= lo) & (pos <= hi)).all(axis=1), logw, -np.inf)
     sampler = cal.EnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
     rng = np.random.default_rng(20260327)  # same on every rank
     sampler.run(2, cal.WalkerInit.from_prior(), n_walkers=args.walkers, rng=rng)  # warm-up
+    start = cal.WalkerInit.explicit(params.sample_random(args.walkers, rng))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    chain = sampler.run(args.iterations, cal.WalkerInit.from_prior(), n_walkers=args.walkers, rng=rng)
+    chain = sampler.run(args.iterations, start, n_walkers=args.walkers, rng=rng)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
