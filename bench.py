@@ -72,13 +72,18 @@ def one_pass(ens):
     ens.run(sync=False)
 
 
+def _coll_device(torch, dist):
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
 def timed_passes(ens, steps, warmup, torch, dist, world, tstream):
     for _ in range(warmup):
         one_pass(ens)
     ens.sync()
     if world > 1:  # communicator creation and the first collective stay outside the timed region
         dist.barrier()
-        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=_coll_device(torch, dist)),
+                        op=dist.ReduceOp.MAX)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
@@ -94,7 +99,7 @@ def timed_passes(ens, steps, warmup, torch, dist, world, tstream):
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / steps  # HIP events on the launch stream
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        w = torch.tensor([wall], dtype=torch.float64, device=_coll_device(torch, dist))
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     return wall, kernel_ms
@@ -121,8 +126,12 @@ def cpu_baseline(threads, target_seconds=12.0):
     t0 = time.perf_counter()
     cbind.two_layer_run(b, params(n), F, 0.0, 0.0, threads=threads)
     dt = time.perf_counter() - t0
+    n1 = max(256, n // (4 * threads))
+    t0 = time.perf_counter()
+    cbind.two_layer_run(b, params(n1), F, 0.0, 0.0, threads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": n * (T1 - T0) / dt, "unit": "member-years/s", "cores": threads,
-            "kind": "port",
+            "kind": "port", "single_thread_value": n1 * (T1 - T0) / dt1,
             "sample": f"{n} members x {T1 - T0} years, oracle/rscm_oracle.c two_layer_run "
                       f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads"}
 
@@ -150,10 +159,19 @@ def main():
     _lib.load()  # no CPU fallback: fail here if the HIP extension is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    # Rehearsal knobs (not used by the driver): RSCM_BENCH_BACKEND=gloo runs the collectives on
+    # the CPU and RSCM_BENCH_DEVICE pins every rank to one GPU, so the N>1 code path can be
+    # exercised on a single-GPU box.
+    backend = os.environ.get("RSCM_BENCH_BACKEND", "nccl")
+    if "RSCM_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["RSCM_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     # a real (non-null) HIP stream shared by torch's events and the library's launches
     tstream = torch.cuda.Stream()
     stream = tstream.cuda_stream
