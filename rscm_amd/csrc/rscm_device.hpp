@@ -7,7 +7,10 @@
 
 namespace rscm {
 
-constexpr int kBlock = 256;                  // 4 wavefronts of 64: one per SIMD of a CU
+#ifndef RSCM_BLOCK
+#define RSCM_BLOCK 256
+#endif
+constexpr int kBlock = RSCM_BLOCK;           // 256 = 4 wavefronts of 64: one per SIMD of a CU
 constexpr int kMaxStaticLds = 64 * 1024;     // above this the launcher raises the dynamic limit
 constexpr int kMaxLds = 160 * 1024;          // CDNA4: 160 KiB per CU
 

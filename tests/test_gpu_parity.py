@@ -588,3 +588,35 @@ def test_likelihood_only_ensemble_of_ten_million_members(ra):
         e.set_initial(2, 0.0)
         e.run()
         assert_bit_equal(e.loglik([1, 1], [50, 100], [0.5, 1.0], [0.2, 0.2]), ll[pick])
+
+
+def test_long_axis_uses_large_dynamic_lds(ra, orc):
+    """9001-point axis (1750-2500 in 1/12-like steps of 1/8 yr... here 1/16 yr): the forcing slice
+    is 72-144 KB of LDS, above the 64 KB default dynamic limit, so the launcher raises
+    hipFuncAttributeMaxDynamicSharedMemorySize; two scenarios (144 KB) still fit 160 KB, three do
+    not and go through L2.  All three paths must give the oracle's bits."""
+    t = 1750.0 + np.arange(9001) / 16.0
+    n = 200
+    P = two_layer_params(n)
+    base = f_syn(t)
+    for S in (1, 2, 3):
+        F = np.stack([base * (1.0 + 0.1 * s) for s in range(S)])
+        scen = (np.arange(n) % S).astype(np.int32)
+        want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.0, 0.0, scen=scen, h=1.0 / 64.0,
+                                 threads=8)
+        ts, td, _ = _tl_gpu(ra, t, P, F, 0.0, 0.0, scen=scen, h=1.0 / 64.0)
+        assert_bit_equal(ts, want[0], f"S={S}")
+        assert_bit_equal(td, want[1], f"S={S}")
+
+
+def test_minimal_axis_single_step(ra, orc):
+    """T = 2: exactly one step (the shape TwoLayer.solve uses), N = 1 and N = 65."""
+    t = np.array([2000.0, 2010.0])
+    for n in (1, 65):
+        P = two_layer_params(n)
+        F = np.array([3.0, 3.0])
+        want = orc.two_layer_run(orc.bounds_from_values(t), P, F, 0.0, 0.0)
+        ts, td, _ = _tl_gpu(ra, t, P, F, 0.0, 0.0)
+        assert_bit_equal(ts, want[0])
+        assert_bit_equal(td, want[1])
+        assert ts.shape == (2, n)
