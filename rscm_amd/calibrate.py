@@ -304,6 +304,8 @@ class ModelRunner:
     def run_batch(self, param_sets) -> List[Dict[str, Dict[float, float]]]:
         """Order-preserving; per member ``{variable: {time: value}}`` of the non-NaN entries
         (extract_outputs, model_runner.rs:161-212)."""
+        if len(param_sets) == 0:  # run_batch(&[]) -> vec![]
+            return []
         m = self._run(np.asarray(param_sets, dtype=np.float64))
         times = m._axis.values()
         series = {v: m.ensemble.get_series(v) for v in self._outputs}
@@ -323,6 +325,8 @@ class ModelRunner:
         moving any series to the host.  Failed members (non-finite or never-computed values at an
         observation time) get ``-inf`` (sampler/ensemble.rs:163-172)."""
         p = np.asarray(param_sets, dtype=np.float64)
+        if p.size == 0:
+            return np.zeros(0)
         if p.ndim != 2:
             raise ValueError(f"Expected {len(self._param_names)} parameters, got {len(p)}")
         probe = self._model(1)

@@ -41,3 +41,20 @@ def test_product_never_touches_the_oracle():
                     for needle in ("import oracle", "from oracle", "librscm_oracle", "rscm_oracle",
                                    "oracle/"):
                         assert needle not in src, f"{top}/{f} references {needle!r}"
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without the HIP library every product entry point raises."""
+    import pytest
+    from rscm_amd import RscmGpuUnavailable
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "librscm_gpu.so"))
+    with pytest.raises(RscmGpuUnavailable, match="no CPU fallback"):
+        _lib.load()
+    import numpy as np
+    import rscm_amd
+    with pytest.raises(RscmGpuUnavailable):
+        rscm_amd.Ensemble(rscm_amd.KIND_TWO_LAYER, 4, np.arange(1750.0, 1760.0))
+    (tmp_path / "librscm_gpu.so").write_bytes(b"not an ELF file")
+    with pytest.raises(RscmGpuUnavailable, match="cannot load"):
+        _lib.load()
