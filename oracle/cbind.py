@@ -21,8 +21,8 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    src = os.path.join(_HERE, "rscm_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
     return so
@@ -52,6 +52,15 @@ def lib() -> C.CDLL:
                                      [C.c_int64, C.c_int64]
         L.orc_gaussian_loglik.argtypes = [C.c_int64, C.c_int32, C.POINTER(_dp), C.c_int32, _ip, _ip,
                                           _dp, _dp, C.c_int, _dp, C.c_int64, C.c_int64]
+        L.orc_udeb_n_params.restype = C.c_int32
+        L.orc_udeb_default_params.argtypes = [_dp]
+        L.orc_udeb_default_params.restype = None
+        L.orc_udeb_run.argtypes = [C.c_int64, C.c_int32, _dp, _dp, C.c_int32, _dp, _ip, _dp] + [_dp] * 7 + \
+                                  [_ip, C.c_int64, C.c_int64]
+        L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
+        L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
+        L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
+        L.orc_udeb_sst_to_air.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -193,3 +202,72 @@ def gaussian_loglik(series, obs_series, obs_tidx, obs_value, obs_sigma, normaliz
                                                _d(sg), int(normalize), _d(out), i0, i1),
           N, threads)
     return out
+
+
+# ------------------------------------------------------------------------------ ClimateUDEB
+UDEB_PARAM_NAMES = (
+    "n_layers", "mixed_layer_depth", "layer_thickness", "kappa", "kappa_min", "kappa_dkdt",
+    "w_initial", "w_variable_fraction", "w_threshold_temp_nh", "w_threshold_temp_sh", "ecs",
+    "rf_2xco2", "rlo", "feedback_q_sensitivity", "feedback_cumt_sensitivity",
+    "feedback_cumt_period", "k_lo", "k_ns", "amplify_ocean_to_land", "nh_land_fraction",
+    "sh_land_fraction", "depth_dependent_area", "temp_adjust_alpha", "temp_adjust_gamma",
+    "polar_sinking_ratio", "land_heat_capacity_enabled", "k_lg", "land_hc_eff_thickness",
+    "rf_regions_co2_0", "rf_regions_co2_1", "rf_regions_co2_2", "rf_regions_co2_3",
+    "efficacy_apply", "prescribed_efficacy_co2", "ocean_temp_profile", "steps_per_year",
+    "max_temperature")
+UDEB_VARS = ("st0", "st1", "st2", "st3", "heat_uptake", "ohc", "sst")
+
+
+def udeb_default_params(**overrides):
+    """[P] vector of ClimateUDEBParameters::default() with named overrides."""
+    n = lib().orc_udeb_n_params()
+    assert n == len(UDEB_PARAM_NAMES)
+    p = np.empty(n)
+    lib().orc_udeb_default_params(_d(p))
+    for k, v in overrides.items():
+        p[UDEB_PARAM_NAMES.index(k)] = float(v)
+    return p
+
+
+def udeb_run(bounds, params, erf, *, scen=None, st_init=(0.0, 0.0, 0.0, 0.0), threads=1):
+    """params [P][N]; erf [S][T] on the model axis.  Returns (dict of [T][N], status[N])."""
+    bounds = _f64(bounds)
+    T = len(bounds) - 1
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    erf = np.atleast_2d(_f64(erf))
+    assert erf.shape[1] == T
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    out = {k: np.full((T, N), np.nan) for k in UDEB_VARS}
+    status = np.zeros(N, dtype=np.int32)
+    init = _f64(st_init)
+    L = lib()
+    _pmap(lambda i0, i1: L.orc_udeb_run(N, T, _d(bounds), _d(params), erf.shape[0], _d(erf), _i(scen),
+                                        _d(init), *[_d(out[k]) for k in UDEB_VARS], _i(status), i0, i1),
+          N, threads)
+    return out, status
+
+
+def udeb_lamcalc(params, ecs):
+    out = np.empty(4)
+    rc = lib().orc_udeb_lamcalc(_d(_f64(params)), ecs, _d(out))
+    if rc:
+        raise RuntimeError(f"lamcalc rc={rc}")
+    return {"lambda_ocean": out[0], "lambda_land": out[1], "co2_internal_efficacy": out[2], "qfrac0": out[3]}
+
+
+def udeb_area_factors(params):
+    p = _f64(params)
+    n = int(p[0])
+    a, b, c = np.empty(n), np.empty(n), np.empty(n)
+    rc = lib().orc_udeb_area_factors(_d(p), _d(a), _d(b), _d(c))
+    if rc:
+        raise RuntimeError(f"area_factors rc={rc}")
+    return a, b, c
+
+
+def udeb_sst_to_air(params, sst):
+    return lib().orc_udeb_sst_to_air(_d(_f64(params)), sst)

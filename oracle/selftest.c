@@ -21,6 +21,12 @@ int orc_coupled_run(int64_t, int32_t, const double*, const double*, int32_t, con
 int orc_gaussian_loglik(int64_t, int32_t, const double* const*, int32_t, const int32_t*,
                         const int32_t*, const double*, const double*, int, double*, int64_t, int64_t);
 
+int32_t orc_udeb_n_params(void);
+void orc_udeb_default_params(double*);
+int orc_udeb_run(int64_t, int32_t, const double*, const double*, int32_t, const double*, const int32_t*,
+                 const double*, double*, double*, double*, double*, double*, double*, double*, int32_t*,
+                 int64_t, int64_t);
+
 #define N 37
 #define T 41
 int main(void)
@@ -54,6 +60,25 @@ int main(void)
     if (orc_aggregate_sum(agg, 3) != 4.0) return 6;
     if (fabs(orc_co2_erf(3.7, 278.0, 556.0) - 3.7) > 1e-10) return 7;
     if (orc_rk4_nsteps(1750, 1751, 0.1) != 10 || !orc_rk4_endtime_ok(1750, 1751, 0.1)) return 8;
+    {   /* ClimateUDEB: 3 members x 20 years */
+        const int P = orc_udeb_n_params(), NU = 3, TU = 21;
+        double* up = malloc(sizeof(double) * P * NU), ub[22], uf[21], init[4] = {0, 0, 0, 0};
+        double* uo[7];
+        int32_t ust[3];
+        for (int i = 0; i < NU; ++i) {
+            double d[64];
+            orc_udeb_default_params(d);
+            d[10] = 2.0 + i; /* ecs */
+            for (int j = 0; j < P; ++j) up[j * NU + i] = d[j];
+        }
+        for (int i = 0; i <= TU; ++i) ub[i] = 1850.0 + i;
+        for (int i = 0; i < TU; ++i) uf[i] = i ? 3.71 : 0.0;
+        for (int k = 0; k < 7; ++k) uo[k] = malloc(sizeof(double) * TU * NU);
+        if (orc_udeb_run(NU, TU, ub, up, 1, uf, NULL, init, uo[0], uo[1], uo[2], uo[3], uo[4], uo[5], uo[6], ust, 0, NU)) return 9;
+        if (ust[0] || !(uo[0][(TU - 1) * NU + 2] > uo[0][(TU - 1) * NU + 0])) return 10;
+        for (int k = 0; k < 7; ++k) free(uo[k]);
+        free(up);
+    }
     printf("oracle selftest ok: Ts=%.17g lnL[0]=%.17g conc=%.17g\n", ts, ll[0], y[0]);
     for (int k = 0; k < 7; ++k) free(s[k]);
     free(p);
