@@ -74,7 +74,9 @@ def main():
         "single_gather": bool(np.array_equal(gather_members(ll[se.offset:se.offset + se.count], n_total), ll)),
         "reduce": reduce_summary({"count": 2, "mean": float(rank), "min": -rank, "max": rank}),
     }
-    print("RESULT " + json.dumps(res), flush=True)
+    # one file per rank: stdout of the two ranks can interleave
+    with open(os.path.join(sys.argv[2], f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
     dist.destroy_process_group()
 
 
