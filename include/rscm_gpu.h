@@ -71,6 +71,8 @@ extern "C" {
 #define RSCM_KIND_TWO_LAYER 0 /* stand-alone TwoLayer with a forcing series                     */
 #define RSCM_KIND_COUPLED 1   /* CarbonCycle -> CO2ERF -> Sum aggregate -> TwoLayer             */
 
+#define RSCM_KIND_UDEB 2      /* rscm-magicc ClimateUDEB (4-box upwelling-diffusion EBM)          */
+
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
 #define RSCM_TL_VAR_TS 1  /* "Surface Temperature"          (state)                             */
@@ -85,6 +87,58 @@ extern "C" {
 #define RSCM_CP_VAR_CUM_EMIS 5   /* "Cumulative Emissions|CO2"       (state)                    */
 #define RSCM_CP_VAR_ERF_CO2 6    /* "Effective Radiative Forcing|CO2" (output)                  */
 #define RSCM_CP_VAR_ERF 7        /* "Effective Radiative Forcing"     (aggregate output)        */
+
+/* variable ids, kind UDEB (V = 8): crates/rscm-magicc/src/climate/udeb/mod.rs:80-91 */
+#define RSCM_UD_VAR_ERF 0          /* "Effective Radiative Forcing" (input, [S][T] shared)      */
+#define RSCM_UD_VAR_ST_NH_OCEAN 1  /* "Surface Temperature" FourBox state: NorthernOcean        */
+#define RSCM_UD_VAR_ST_NH_LAND 2   /*                                      NorthernLand         */
+#define RSCM_UD_VAR_ST_SH_OCEAN 3  /*                                      SouthernOcean        */
+#define RSCM_UD_VAR_ST_SH_LAND 4   /*                                      SouthernLand         */
+#define RSCM_UD_VAR_HEAT_UPTAKE 5  /* "Heat Uptake"              (output)                       */
+#define RSCM_UD_VAR_OHC 6          /* "Ocean Heat Content"       (output)                       */
+#define RSCM_UD_VAR_SST 7          /* "Sea Surface Temperature"  (output)                       */
+
+/* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
+ * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
+ * Rows marked [u] are structural and must be equal for every member; the device supports
+ * n_layers = 50 and ocean_temp_profile = 2 (CMIP5). */
+#define RSCM_UD_NPARAMS 37
+#define RSCM_UD_P_N_LAYERS 0              /* [u] */
+#define RSCM_UD_P_MIXED_LAYER_DEPTH 1     /* [u] */
+#define RSCM_UD_P_LAYER_THICKNESS 2       /* [u] */
+#define RSCM_UD_P_KAPPA 3
+#define RSCM_UD_P_KAPPA_MIN 4
+#define RSCM_UD_P_KAPPA_DKDT 5
+#define RSCM_UD_P_W_INITIAL 6
+#define RSCM_UD_P_W_VARIABLE_FRACTION 7
+#define RSCM_UD_P_W_THRESHOLD_TEMP_NH 8
+#define RSCM_UD_P_W_THRESHOLD_TEMP_SH 9
+#define RSCM_UD_P_ECS 10
+#define RSCM_UD_P_RF_2XCO2 11
+#define RSCM_UD_P_RLO 12
+#define RSCM_UD_P_FEEDBACK_Q_SENSITIVITY 13
+#define RSCM_UD_P_FEEDBACK_CUMT_SENSITIVITY 14
+#define RSCM_UD_P_FEEDBACK_CUMT_PERIOD 15
+#define RSCM_UD_P_K_LO 16
+#define RSCM_UD_P_K_NS 17
+#define RSCM_UD_P_AMPLIFY_OCEAN_TO_LAND 18
+#define RSCM_UD_P_NH_LAND_FRACTION 19
+#define RSCM_UD_P_SH_LAND_FRACTION 20
+#define RSCM_UD_P_DEPTH_DEPENDENT_AREA 21 /* [u] */
+#define RSCM_UD_P_TEMP_ADJUST_ALPHA 22
+#define RSCM_UD_P_TEMP_ADJUST_GAMMA 23
+#define RSCM_UD_P_POLAR_SINKING_RATIO 24
+#define RSCM_UD_P_LAND_HC_ENABLED 25      /* [u] */
+#define RSCM_UD_P_K_LG 26
+#define RSCM_UD_P_LAND_HC_EFF_THICKNESS 27
+#define RSCM_UD_P_RF_REGIONS_CO2_0 28     /* ..31: NorthernOcean, NorthernLand, SouthernOcean, SouthernLand */
+#define RSCM_UD_P_EFFICACY_APPLY 32       /* [u] */
+#define RSCM_UD_P_PRESCRIBED_EFFICACY_CO2 33
+#define RSCM_UD_P_OCEAN_TEMP_PROFILE 34   /* [u] */
+#define RSCM_UD_P_STEPS_PER_YEAR 35       /* [u] */
+#define RSCM_UD_P_MAX_TEMPERATURE 36
+/* rscm_ens_status for this kind: 0 ok, 2 invalid prescribed_efficacy_co2, 4 LAMCALC did not
+ * converge (ClimateUDEB::from_parameters returns Err; mod.rs:161-205) -- all outputs NaN. */
 
 /* parameter rows.  TWO_LAYER: P = 6, TwoLayerParameters field order (component.rs:38-90):
  *   lambda0, a, efficacy, eta, heat_capacity_surface, heat_capacity_deep

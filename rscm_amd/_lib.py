@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librscm_gpu.so")
 
 OK, ERR_INVALID, ERR_STATE, ERR_TIME_AXIS, ERR_DEVICE, ERR_NOMEM = range(6)
-KIND_TWO_LAYER, KIND_COUPLED = 0, 1
+KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB = 0, 1, 2
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -26,6 +26,25 @@ CP_VARS = {"Emissions|CO2|Anthropogenic": 0, "Surface Temperature": 1, "Deep Oce
            "Atmospheric Concentration|CO2": 3, "Cumulative Land Uptake": 4,
            "Cumulative Emissions|CO2": 5, "Effective Radiative Forcing|CO2": 6,
            "Effective Radiative Forcing": 7}
+
+UD_VARS = {"Effective Radiative Forcing": 0, "Surface Temperature|NorthernOcean": 1,
+           "Surface Temperature|NorthernLand": 2, "Surface Temperature|SouthernOcean": 3,
+           "Surface Temperature|SouthernLand": 4, "Heat Uptake": 5, "Ocean Heat Content": 6,
+           "Sea Surface Temperature": 7}
+UD_PARAM_NAMES = (
+    "n_layers", "mixed_layer_depth", "layer_thickness", "kappa", "kappa_min", "kappa_dkdt",
+    "w_initial", "w_variable_fraction", "w_threshold_temp_nh", "w_threshold_temp_sh", "ecs",
+    "rf_2xco2", "rlo", "feedback_q_sensitivity", "feedback_cumt_sensitivity",
+    "feedback_cumt_period", "k_lo", "k_ns", "amplify_ocean_to_land", "nh_land_fraction",
+    "sh_land_fraction", "depth_dependent_area", "temp_adjust_alpha", "temp_adjust_gamma",
+    "polar_sinking_ratio", "land_heat_capacity_enabled", "k_lg", "land_hc_eff_thickness",
+    "rf_regions_co2_0", "rf_regions_co2_1", "rf_regions_co2_2", "rf_regions_co2_3",
+    "efficacy_apply", "prescribed_efficacy_co2", "ocean_temp_profile", "steps_per_year",
+    "max_temperature")
+# ClimateUDEBParameters::default() (crates/rscm-magicc/src/parameters/climate_udeb.rs)
+UD_DEFAULTS = (50, 60.0, 100.0, 0.75, 0.1, -0.191, 3.5, 0.7, 8.0, 8.0, 3.0, 3.71, 1.317, 7.84e-9, 0.08,
+               300.0, 1.44, 0.31, 1.02, 0.42, 0.21, 1.0, 1.04, -0.002, 0.2, 1.0, 0.1, 300.0,
+               1.4089, 1.37045, 1.43333, 1.33257, 0.0, 1.0, 2.0, 12.0, 25.0)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -60,6 +60,30 @@ struct CoupledArgs {
     uint8_t* status;
 };
 
+// ClimateUDEB (rscm-magicc) over steps [step_begin, step_end).
+constexpr int kUdebBlock = 64;  // one wavefront per workgroup: ~250 VGPRs per lane
+constexpr int kUdebNParams = 37;
+constexpr int kUdebScalars = 10;
+
+struct UdebArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t n_scen;
+    int32_t n_layers, steps_per_year, land_hc, efficacy_apply;  // uniform over the ensemble
+    const double* params;   // [37][N], ClimateUDEBParameters order (include/rscm_gpu.h)
+    const double* erf;      // [S][T]
+    const int32_t* scen;    // [N] or nullptr
+    const double* bounds;   // [T+1] (device)
+    const double* tables;   // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] init_nh[NL] init_sh[NL]
+    double* ocean;          // [2][NL][N] layer temperatures
+    double* scal;           // [10][N] upwelling, land, ground, alpha_eff, hemi exchange (x2 hemispheres)
+    double* hist;           // [T][N] year-weighted global temperature history
+    double* st0; double* st1; double* st2; double* st3;   // Surface Temperature boxes, [T][N] each
+    double* heat_uptake; double* ohc; double* sst;        // [T][N]
+    uint8_t* status;        // [N]
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -74,6 +98,7 @@ struct LoglikArgs {
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
+hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

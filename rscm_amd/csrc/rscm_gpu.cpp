@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "rscm_device.hpp"
+#include "udeb_tables.hpp"
 
 namespace {
 
@@ -99,6 +100,15 @@ struct rscm_ens {
     int32_t source = RSCM_SRC_EXOGENOUS;
     uint8_t* d_status = nullptr;
 
+    // ClimateUDEB internal state
+    double* d_ocean = nullptr;    // [2][NL][N]
+    double* d_scal = nullptr;     // [10][N]
+    double* d_hist = nullptr;     // [T][N]
+    double* d_tables = nullptr;   // geometry tables
+    double* d_bounds = nullptr;   // [T+1]
+    int32_t udeb_n_layers = 0, udeb_steps = 0, udeb_land_hc = 0, udeb_efficacy = 0;
+    bool udeb_ready = false;
+
     double* d_partial = nullptr;  // summary scratch
     double* d_out4 = nullptr;
     double* d_loglik = nullptr;   // [N]
@@ -116,6 +126,7 @@ struct rscm_ens {
     bool is_state(int32_t var) const
     {
         if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
+        if (kind == RSCM_KIND_UDEB) return var >= RSCM_UD_VAR_ST_NH_OCEAN && var <= RSCM_UD_VAR_ST_SH_LAND;
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
 };
@@ -149,6 +160,40 @@ int refresh_schedule(rscm_ens* h)
     }
     HIPCHK(hipStreamSynchronize(h->stream));  // host vectors may be rebuilt afterwards
     h->schedule_dirty = false;
+    return RSCM_OK;
+}
+
+// ClimateUDEB: the structural parameters must be uniform over the ensemble (one set of geometry
+// tables, one unrolled column length); `row(j, i)` reads parameter j of member i.
+template <typename Row>
+int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
+{
+    static const int structural[] = {RSCM_UD_P_N_LAYERS, RSCM_UD_P_MIXED_LAYER_DEPTH, RSCM_UD_P_LAYER_THICKNESS,
+                                     RSCM_UD_P_DEPTH_DEPENDENT_AREA, RSCM_UD_P_LAND_HC_ENABLED,
+                                     RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR};
+    for (int j : structural)
+        for (int64_t i = 1; i < n_check; ++i)
+            if (row(j, i) != row(j, 0))
+                return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d must be the same for every member", j);
+    const double nl = row(RSCM_UD_P_N_LAYERS, 0), steps = row(RSCM_UD_P_STEPS_PER_YEAR, 0);
+    if (nl != 50.0) return fail(RSCM_ERR_INVALID, "ClimateUDEB on the device supports n_layers = 50, got %g", nl);
+    if (row(RSCM_UD_P_OCEAN_TEMP_PROFILE, 0) != 2.0)
+        return fail(RSCM_ERR_INVALID, "ClimateUDEB on the device supports ocean_temp_profile = 2 (CMIP5)");
+    if (!(steps >= 1.0) || steps > 1000.0 || steps != std::floor(steps))
+        return fail(RSCM_ERR_INVALID, "steps_per_year must be a positive integer, got %g", steps);
+    const double eff = row(RSCM_UD_P_EFFICACY_APPLY, 0);
+    if (eff != 0.0 && eff != 1.0 && eff != 2.0) return fail(RSCM_ERR_INVALID, "efficacy_apply must be 0, 1 or 2");
+    h->udeb_n_layers = (int32_t)nl;
+    h->udeb_steps = (int32_t)steps;
+    h->udeb_land_hc = row(RSCM_UD_P_LAND_HC_ENABLED, 0) != 0.0 ? 1 : 0;
+    h->udeb_efficacy = (int32_t)eff;
+    const std::vector<double> t = rscm::udeb_tables(h->udeb_n_layers, row(RSCM_UD_P_MIXED_LAYER_DEPTH, 0),
+                                                    row(RSCM_UD_P_LAYER_THICKNESS, 0), row(RSCM_UD_P_DEPTH_DEPENDENT_AREA, 0));
+    if (!h->d_tables) HIPCHK(hipMalloc(&h->d_tables, t.size() * sizeof(double)));
+    if (!h->d_ocean) HIPCHK(hipMalloc(&h->d_ocean, (size_t)2 * h->udeb_n_layers * h->N * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->d_tables, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->udeb_ready = true;
     return RSCM_OK;
 }
 
@@ -190,7 +235,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED)
+    if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED && kind != RSCM_KIND_UDEB)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -207,7 +252,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->T = n_times;
     h->rows = (flags & RSCM_FLAG_NO_SERIES) ? 1 : n_times;
     h->device = device_id;
-    h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : RSCM_CP_NPARAMS;
+    h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : kind == RSCM_KIND_COUPLED ? RSCM_CP_NPARAMS : RSCM_UD_NPARAMS;
     h->V = kind == RSCM_KIND_TWO_LAYER ? 3 : 8;
     h->bounds.assign(time_bounds, time_bounds + n_times + 1);
     h->initial_set.assign(h->V, 0);
@@ -240,6 +285,12 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     CK(hipMalloc(&h->d_nsub_cc, (size_t)(h->T - 1) * sizeof(int32_t)));
     CK(hipMalloc(&h->d_partial, 4 * 1024 * sizeof(double)));
     CK(hipMalloc(&h->d_out4, 4 * sizeof(double)));
+    if (kind == RSCM_KIND_UDEB) {
+        CK(hipMalloc(&h->d_scal, (size_t)rscm::kUdebScalars * h->N * sizeof(double)));
+        CK(hipMalloc(&h->d_hist, (size_t)h->T * h->N * sizeof(double)));
+        CK(hipMalloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
+        CK(hipMemcpyAsync(h->d_bounds, h->bounds.data(), (size_t)(h->T + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     CK(hipMemsetAsync(h->d_status, 0, (size_t)h->N, h->stream));
     // never-written entries are NaN (builder.rs:772-780)
     CK(rscm::launch_fill(h->d_series, (int64_t)series_elems, std::numeric_limits<double>::quiet_NaN(),
@@ -263,6 +314,11 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_nsub_tl);
     (void)hipFree(h->d_nsub_cc);
+    (void)hipFree(h->d_ocean);
+    (void)hipFree(h->d_scal);
+    (void)hipFree(h->d_hist);
+    (void)hipFree(h->d_tables);
+    (void)hipFree(h->d_bounds);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_out4);
     (void)hipFree(h->d_loglik);
@@ -330,6 +386,8 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
     NEED(h);
     if (!soa) return fail(RSCM_ERR_INVALID, "params is NULL");
     if (int rc = set_device(h)) return rc;
+    if (h->kind == RSCM_KIND_UDEB)
+        if (int rc = configure_udeb(h, h->N, [&](int j, int64_t i) { return soa[(size_t)j * h->N + i]; })) return rc;
     HIPCHK(hipMemcpyAsync(h->d_params, soa, (size_t)h->P * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -359,6 +417,8 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
     if (source != RSCM_SRC_EXOGENOUS && source != RSCM_SRC_UPSTREAM) return fail(RSCM_ERR_INVALID, "unknown source %d", source);
     if (h->kind == RSCM_KIND_COUPLED && source != RSCM_SRC_EXOGENOUS)
         return fail(RSCM_ERR_INVALID, "emissions of the coupled chain are exogenous (no component produces them)");
+    if (h->kind == RSCM_KIND_UDEB && source != RSCM_SRC_EXOGENOUS)
+        return fail(RSCM_ERR_INVALID, "ClimateUDEB reads its forcing as an exogenous series (at_start / at_end)");
     if (scenario_of_member)
         for (int64_t i = 0; i < h->N; ++i)
             if (scenario_of_member[i] < 0 || scenario_of_member[i] >= n_scen)
@@ -484,6 +544,35 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.td = h->series(RSCM_TL_VAR_TD);
         a.status = h->d_status;
         HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
+    } else if (h->kind == RSCM_KIND_UDEB) {
+        if (!h->udeb_ready) return fail(RSCM_ERR_STATE, "ClimateUDEB parameters not configured");
+        rscm::UdebArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.n_scen = h->n_scen;
+        a.n_layers = h->udeb_n_layers;
+        a.steps_per_year = h->udeb_steps;
+        a.land_hc = h->udeb_land_hc;
+        a.efficacy_apply = h->udeb_efficacy;
+        a.params = h->d_params;
+        a.erf = h->d_forcing;
+        a.scen = h->d_scen;
+        a.bounds = h->d_bounds;
+        a.tables = h->d_tables;
+        a.ocean = h->d_ocean;
+        a.scal = h->d_scal;
+        a.hist = h->d_hist;
+        a.st0 = h->series(RSCM_UD_VAR_ST_NH_OCEAN);
+        a.st1 = h->series(RSCM_UD_VAR_ST_NH_LAND);
+        a.st2 = h->series(RSCM_UD_VAR_ST_SH_OCEAN);
+        a.st3 = h->series(RSCM_UD_VAR_ST_SH_LAND);
+        a.heat_uptake = h->series(RSCM_UD_VAR_HEAT_UPTAKE);
+        a.ohc = h->series(RSCM_UD_VAR_OHC);
+        a.sst = h->series(RSCM_UD_VAR_SST);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_udeb(a, h->stream));
     } else {
         rscm::CoupledArgs a{};
         a.n_members = h->N;
@@ -781,6 +870,15 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
         return fail(RSCM_ERR_INVALID, "member block [%lld, %lld) outside the global ensemble of %lld",
                     (long long)member_offset, (long long)(member_offset + h->N), (long long)n_total);
     if (int rc = set_device(h)) return rc;
+    if (h->kind == RSCM_KIND_UDEB) {
+        static const int structural[] = {RSCM_UD_P_N_LAYERS, RSCM_UD_P_MIXED_LAYER_DEPTH, RSCM_UD_P_LAYER_THICKNESS,
+                                         RSCM_UD_P_DEPTH_DEPENDENT_AREA, RSCM_UD_P_LAND_HC_ENABLED,
+                                         RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR};
+        for (int j : structural)
+            if (low[j] != high[j])
+                return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d is structural: low must equal high", j);
+        if (int rc = configure_udeb(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
+    }
     double* d_lh = nullptr;
     HIPCHK(hipMalloc(&d_lh, 2 * (size_t)h->P * sizeof(double)));
     hipError_t e = hipMemcpyAsync(d_lh, low, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice, h->stream);

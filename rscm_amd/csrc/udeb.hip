@@ -1,0 +1,504 @@
+// ClimateUDEB ensemble kernel for gfx950 (MI355X): rscm-magicc's 4-box upwelling-diffusion
+// energy-balance model, one thread per ensemble member.
+//
+// What it replaces, per model step n (reference file:line):
+//   ClimateUDEB::solve_impl            crates/rscm-magicc/src/climate/udeb/mod.rs:399-656
+//   adjusted_ecs / LAMCALC re-solve    mod.rs:302-350, climate/lamcalc.rs
+//   step_hemisphere (implicit 50-layer column, Thomas solve), update_upwelling, diagnostics
+//                                      crates/rscm-magicc/src/climate/udeb/ocean_column.rs
+//   thomas_solve, invert_4x4           crates/rscm-core/src/utils/linear_algebra.rs
+// around the stepper conventions of crates/rscm-core/src/model/runtime.rs (ERF exogenous:
+// at_start = F[n], at_end = F[n+1]; outputs written at n+1).
+//
+// A different kernel class from two_layer.hip: ~110 doubles of private state per member and a
+// serial tridiagonal recurrence per hemisphere and sub-step.  Layout and placement:
+//   * layer temperatures  ocean[hemi][layer][N]  in HBM, member fastest: each sweep reads and
+//     writes 50 coalesced rows (19.2 KB per member-year at 12 sub-steps) -- the HBM traffic
+//     that bounds the kernel together with the VALU work;
+//   * the Thomas work arrays c', d' (2 x 50 doubles) stay in registers (layer loops fully
+//     unrolled, NL is a template constant), the two hemispheres' independent recurrences give
+//     the scheduler two chains to interleave;
+//   * everything that depends only on the ocean geometry (area factors, 1 - relative depth,
+//     the CMIP5 initial profiles) is a uniform table read through the scalar cache;
+//   * the 14 scalar state values live in registers across the whole launch and are spilled to
+//     `scal[14][N]` only at the end (resume); the temperature history for the time-varying ECS is
+//     hist[T][N].
+// Divisions in the column use the refined-reciprocal quotient of rk4_device.hpp without the
+// exponent-window replay (both Thomas divisions of a row share one reciprocal): results agree
+// with the CPU oracle to rounding (tests/test_gpu_udeb.py states 1e-9), not bit for bit.
+#include "rk4_device.hpp"
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+constexpr double kDiffCm2sToM2yr = 3155.76;  // parameters/climate_udeb.rs
+constexpr double kRhoSeawater = 1026.0;
+constexpr double kCpSeawater = 3985.0;
+constexpr double kSecondsPerYear = 31557600.0;
+
+struct UdebP {
+    double dz_mix, dz, kappa, kappa_min, kappa_dkdt, w0, f_var, t_thresh_nh, t_thresh_sh;
+    double ecs, rf_2x, rlo, fb_q, fb_cumt, fb_period, k_lo, k_ns, amplify, nh_land, sh_land;
+    double alpha, gamma, pi_ratio, k_lg, land_hc_thick, rf0, rf1, rf2, rf3, prescribed_eff, max_temp;
+    double fgno, fgnl, fgso, fgsl, q0, q1, q2, q3;  // box fractions, co2_qfrac
+};
+
+struct LamResult {
+    double lam_o, lam_l, eff;
+    bool ok;
+};
+
+__device__ __forceinline__ double heat_capacity_per_unit_area(double depth_m)
+{
+    return kRhoSeawater * kCpSeawater * depth_m / kSecondsPerYear;
+}
+
+// rscm-core/src/utils/linear_algebra.rs invert_4x4 (Gauss-Jordan, partial pivoting), rows kept in
+// registers: every index is static, row swaps are per-lane selects.
+__device__ __forceinline__ bool invert_4x4(const double m[4][4], double inv[4][4])
+{
+    double aug[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aug[i][j] = j < 4 ? m[i][j] : (j - 4 == i ? 1.0 : 0.0);
+    }
+    bool ok = true;
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+        int max_row = col;
+        double max_val = fabs(aug[col][col]);
+#pragma unroll
+        for (int row = col + 1; row < 4; ++row) {
+            const double val = fabs(aug[row][col]);
+            if (val > max_val) {
+                max_val = val;
+                max_row = row;
+            }
+        }
+        if (max_val < 1e-15) ok = false;
+#pragma unroll
+        for (int row = col + 1; row < 4; ++row) {
+            const bool sw = max_row == row;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double x = aug[col][j], y = aug[row][j];
+                aug[col][j] = sw ? y : x;
+                aug[row][j] = sw ? x : y;
+            }
+        }
+        const double pivot = aug[col][col];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aug[col][j] /= pivot;
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            if (row == col) continue;
+            const double factor = aug[row][col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) aug[row][j] -= factor * aug[col][j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inv[i][j] = aug[i][j + 4];
+    return ok;
+}
+
+// climate/lamcalc.rs lamcalc(): secant-style iteration on lambda_ocean until the land/ocean
+// warming ratio matches RLO within 1e-3; only the last three iterates are ever read.
+__device__ __noinline__ LamResult lamcalc(const UdebP& p, double ecs)
+{
+    const double q = p.rf_2x, k_lo = p.k_lo, k_ns = p.k_ns, alpha = p.amplify;
+    const double lam = q / ecs;
+    const double fgosum = p.fgno + p.fgso, fglsum = p.fgnl + p.fgsl, fratio = fgosum / fglsum;
+    const double area[4] = {p.fgno, p.fgnl, p.fgso, p.fgsl};
+    const double qfrac[4] = {p.q0, p.q1, p.q2, p.q3};
+    const double rf[4] = {p.rf0, p.rf1, p.rf2, p.rf3};
+    // lamo[i-2], lamo[i-1], lamo[i]; diff likewise (arrays start zero-filled in the reference)
+    double lamo_m2 = 0.0, lamo_m1 = lam, lamo_i = lam + 0.7;
+    double diff_m2 = 0.0, diff_m1 = 0.0;
+    double dlamo = 0.7;
+    int iflag = 0;
+    LamResult out = {0.0, 0.0, 1.0, false};
+    for (int i = 2; i <= 40; ++i) {
+        const double lam_l = lam + fratio * (lam - lamo_i) / p.rlo;
+        const double lam_o = lamo_i;
+        const double m[4][4] = {{p.fgno * lam_o + k_lo * alpha + k_ns, -k_lo, -k_ns, 0.0},
+                                {-k_lo * alpha, p.fgnl * lam_l + k_lo, 0.0, 0.0},
+                                {-k_ns, 0.0, p.fgso * lam_o + k_lo * alpha + k_ns, -k_lo},
+                                {0.0, 0.0, -k_lo * alpha, p.fgsl * lam_l + k_lo}};
+        double inv[4][4];
+        if (!invert_4x4(m, inv)) return out;
+        double temps[4];
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            double sum = 0.0;
+#pragma unroll
+            for (int col = 0; col < 4; ++col) sum += inv[row][col] * area[col] * qfrac[col];
+            temps[row] = q * sum;
+        }
+        const double ocean_mean = (p.fgno * temps[0] + p.fgso * temps[2]) / (p.fgno + p.fgso);
+        const double land_mean = (p.fgnl * temps[1] + p.fgsl * temps[3]) / (p.fgnl + p.fgsl);
+        const double diff_i = p.rlo - land_mean / ocean_mean;
+        if (fabs(diff_i) < 0.001) {
+            out.lam_o = lam_o;
+            out.lam_l = lam_l;
+            out.ok = true;
+            double rf_sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rf_sum += rf[k] * area[k];
+            if (fabs(rf_sum) <= 1e-15) {
+                out.eff = 1.0;
+            } else {
+                double t_global = 0.0;
+#pragma unroll
+                for (int row = 0; row < 4; ++row) t_global += area[row] * temps[row];
+                out.eff = t_global / ecs;
+            }
+            return out;
+        }
+        if (diff_i * diff_m1 < 0.0) iflag = 1;
+        double next;
+        if (iflag == 0) {
+            if (fabs(diff_i) > fabs(diff_m1)) dlamo = -dlamo;
+            next = lamo_i + dlamo;
+        } else if (diff_i * diff_m1 < 0.0) {
+            const double denom = diff_i - diff_m1;
+            next = fabs(denom) < 1e-30 ? lamo_i + dlamo : lamo_i - diff_i * (lamo_i - lamo_m1) / denom;
+        } else {
+            const double denom = diff_i - diff_m2;
+            next = fabs(denom) < 1e-30 ? lamo_i + dlamo : lamo_i - diff_i * (lamo_i - lamo_m2) / denom;
+        }
+        lamo_m2 = lamo_m1;
+        lamo_m1 = lamo_i;
+        lamo_i = next;
+        diff_m2 = diff_m1;
+        diff_m1 = diff_i;
+    }
+    return out;
+}
+
+__device__ __forceinline__ double sst_to_air(const UdebP& p, double sst)
+{
+    const double t_star = fabs(p.gamma) > 1e-15 ? -(p.alpha - 1.0) / (2.0 * p.gamma) : __builtin_inf();
+    if (sst < t_star) return p.alpha * sst + p.gamma * sst * sst;
+    const double delta_max = p.alpha * t_star + p.gamma * t_star * t_star - t_star;
+    return sst + delta_max;
+}
+
+__device__ __forceinline__ double land_temperature(const UdebP& p, double ocean_temp, double land_forcing,
+                                                   double land_fraction, double lambda_land)
+{
+    const double numerator = land_forcing * land_fraction + p.k_lo * p.amplify * ocean_temp;
+    const double denominator = lambda_land * land_fraction + p.k_lo;
+    return fmin(numerator / denominator, p.max_temp);
+}
+
+// n / d with the reciprocal supplied (no window replay: tolerance-parity kernel).
+__device__ __forceinline__ double qdiv(double n, double d, double r) { return spec_div(n, d, r); }
+
+// One implicit sub-step of one hemisphere's column (ocean_column.rs step_hemisphere).
+// T is this member's column in HBM with stride N between layers.  Returns the new mixed-layer
+// temperature.
+template <int NL>
+__device__ __forceinline__ double step_hemisphere(const UdebP& p, const UdebArgs& a, double* __restrict__ T,
+                                                  int64_t N, int hemi, double forcing, double dt,
+                                                  double lambda_ocean, double lambda_land, double hemi_hx,
+                                                  double ground_temp, double land_temp, double alpha_eff,
+                                                  double w)
+{
+    const double* __restrict__ af_top = a.tables;            // [NL]
+    const double* __restrict__ af_bot = a.tables + NL;       // [NL]
+    const double* __restrict__ af_diff = a.tables + 2 * NL;  // [NL]
+    const double* __restrict__ omr = a.tables + 3 * NL;      // 1 - relative depth, [NL-1]
+    const double* __restrict__ init = a.tables + 4 * NL + (size_t)hemi * NL;  // initial profile
+    const double dz = p.dz, dz_mix = p.dz_mix, pi_ratio = p.pi_ratio;
+    const double t_top = T[0];
+    const double t_bottom = T[(size_t)(NL - 1) * N];
+    const double dkdt_dT = t_top - t_bottom;
+    const double kappa_min_m2yr = p.kappa_min * kDiffCm2sToM2yr;
+    auto kappa_at = [&](int l) -> double {
+        const double k = (omr[l] * p.kappa_dkdt * dkdt_dT + p.kappa) * kDiffCm2sToM2yr;
+        return fmax(k, kappa_min_m2yr);
+    };
+    const double c_mix = heat_capacity_per_unit_area(dz_mix);
+    const double f_l_hemi = hemi == 0 ? p.nh_land / 2.0 : p.sh_land / 2.0;
+    const double f_o_hemi = 0.5 - f_l_hemi;
+    const double denominator = f_o_hemi * (p.k_lo + f_l_hemi * lambda_land);
+    const double term_feedback =
+        alpha_eff / c_mix * (lambda_ocean + lambda_land * p.k_lo * p.amplify * f_l_hemi / denominator);
+    const double dz1 = dz / 2.0;
+    const double delta_w = w - p.w0;
+    const bool dw = fabs(delta_w) > 1e-15;
+    const double t_polar = 1.0;  // state.polar_sinking_temp
+    const double dt_per_dz = dt / dz;
+
+    double cp[NL], dp[NL];
+    // ---- row 0 (mixed layer)
+    double kap_prev = kappa_at(0);
+    {
+        const double term_diff = kap_prev / (dz_mix * dz1) * dt;
+        const double term_upwell = w / dz_mix * dt;
+        const double forcing_amp = 1.0 + p.k_lo * f_l_hemi / denominator;
+        const double b0 = 1.0 + term_feedback * dt * af_top[0] + term_diff * af_bot[0] +
+                          term_upwell * pi_ratio * af_bot[0];
+        const double c0 = -(term_diff + term_upwell) * af_bot[0];
+        double d0 = t_top + (forcing * forcing_amp + hemi_hx) / c_mix * dt * af_top[0];
+        if (a.land_hc) d0 -= p.k_lg * (land_temp - ground_temp) / (c_mix * f_o_hemi) * dt * af_top[0];
+        if (dw) d0 += dt / dz_mix * delta_w * (init[1] - t_polar) * af_bot[0];
+        const double r = refined_rcp(b0);
+        cp[0] = qdiv(c0, b0, r);
+        dp[0] = qdiv(d0, b0, r);
+    }
+    // ---- interior rows and the bottom row: forward sweep
+    const double term_upwell_layer = w / dz * dt;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+        const double t_i = T[(size_t)i * N];
+        const double dz_up = i == 1 ? dz1 : dz;
+        const double term_diff_up = kap_prev / (dz * dz_up) * dt;
+        double ai, bi, ci, di;
+        if (i < NL - 1) {
+            const double kap = kappa_at(i);
+            const double term_diff_down = kap / (dz * dz) * dt;
+            ai = -term_diff_up * af_top[i];
+            bi = 1.0 + term_diff_up * af_top[i] + term_diff_down * af_bot[i] + term_upwell_layer * af_top[i];
+            ci = -(term_diff_down + term_upwell_layer) * af_bot[i];
+            di = t_i + pi_ratio * term_upwell_layer * t_top * af_diff[i];
+            if (dw) {
+                di += dt_per_dz * delta_w * (init[i + 1] * af_bot[i] - init[i] * af_top[i]);
+                di += dt_per_dz * delta_w * t_polar * af_diff[i];
+            }
+            kap_prev = kap;
+        } else {
+            ai = -term_diff_up * af_top[i];
+            bi = 1.0 + (term_diff_up + term_upwell_layer) * af_top[i];
+            ci = 0.0;
+            di = t_i + pi_ratio * term_upwell_layer * t_top * af_top[i];
+            if (dw) di += dt_per_dz * delta_w * (t_polar - init[i]) * af_top[i];
+        }
+        const double denom = bi - ai * cp[i - 1];
+        const double r = refined_rcp(denom);
+        if (i < NL - 1) cp[i] = qdiv(ci, denom, r);
+        dp[i] = qdiv(di - ai * dp[i - 1], denom, r);
+    }
+    // ---- back substitution, clamp, store
+    double x = dp[NL - 1];
+    T[(size_t)(NL - 1) * N] = fmin(x, p.max_temp);
+#pragma unroll
+    for (int i = NL - 2; i >= 0; --i) {
+        x = dp[i] - cp[i] * x;
+        T[(size_t)i * N] = fmin(x, p.max_temp);
+    }
+    // thomas_solve returns the unclamped vector; the state keeps min(x, max_temp)
+    return fmin(x, p.max_temp);
+}
+
+template <int NL>
+__global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kUdebBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    UdebP p;
+    p.dz_mix = P(1); p.dz = P(2); p.kappa = P(3); p.kappa_min = P(4); p.kappa_dkdt = P(5);
+    p.w0 = P(6); p.f_var = P(7); p.t_thresh_nh = P(8); p.t_thresh_sh = P(9);
+    p.ecs = P(10); p.rf_2x = P(11); p.rlo = P(12); p.fb_q = P(13); p.fb_cumt = P(14); p.fb_period = P(15);
+    p.k_lo = P(16); p.k_ns = P(17); p.amplify = P(18); p.nh_land = P(19); p.sh_land = P(20);
+    p.alpha = P(22); p.gamma = P(23); p.pi_ratio = P(24); p.k_lg = P(26); p.land_hc_thick = P(27);
+    p.rf0 = P(28); p.rf1 = P(29); p.rf2 = P(30); p.rf3 = P(31); p.prescribed_eff = P(33); p.max_temp = P(36);
+    p.fgnl = p.nh_land / 2.0; p.fgno = 0.5 - p.fgnl; p.fgsl = p.sh_land / 2.0; p.fgso = 0.5 - p.fgsl;
+    {   // compute_qfrac
+        const double rf_sum = p.rf0 * p.fgno + p.rf1 * p.fgnl + p.rf2 * p.fgso + p.rf3 * p.fgsl;
+        if (fabs(rf_sum) <= 1e-15) { p.q0 = p.q1 = p.q2 = p.q3 = 1.0; }
+        else { p.q0 = p.rf0 / rf_sum; p.q1 = p.rf1 / rf_sum; p.q2 = p.rf2 / rf_sum; p.q3 = p.rf3 / rf_sum; }
+    }
+    double* st[4] = {a.st0, a.st1, a.st2, a.st3};
+    double* T_nh = a.ocean + i;
+    double* T_sh = a.ocean + (size_t)NL * N + i;
+
+    // ---- construction: from_parameters (mod.rs:161-227)
+    int32_t status = 0;
+    if (!is_finite(p.prescribed_eff) || p.prescribed_eff <= 0.0) status = 2;
+    LamResult base = {0.0, 0.0, 1.0, false};
+    if (status == 0) {
+        base = lamcalc(p, p.ecs);
+        if (!base.ok) status = 4;
+    }
+    a.status[i] = (uint8_t)status;
+    if (status != 0) {  // the reference refuses to build this component: every output NaN
+        for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+            const size_t r = (size_t)(n + 1) * N + i;
+            const double nan = __builtin_nan("");
+            a.st0[r] = nan; a.st1[r] = nan; a.st2[r] = nan; a.st3[r] = nan;
+            a.heat_uptake[r] = nan; a.ohc[r] = nan; a.sst[r] = nan;
+        }
+        return;
+    }
+
+    // ---- internal state (ClimateUDEBState::new) or resume
+    double up_nh, up_sh, land_nh, land_sh, gr_nh, gr_sh, ae_nh, ae_sh, hx_nh, hx_sh;
+    if (a.step_begin == 0) {
+#pragma unroll 1
+        for (int l = 0; l < NL; ++l) {
+            T_nh[(size_t)l * N] = 0.0;
+            T_sh[(size_t)l * N] = 0.0;
+        }
+        up_nh = up_sh = p.w0;
+        land_nh = land_sh = gr_nh = gr_sh = hx_nh = hx_sh = 0.0;
+        ae_nh = ae_sh = p.alpha;
+    } else {
+        const double* s = a.scal + i;
+        up_nh = s[0 * N]; up_sh = s[1 * N]; land_nh = s[2 * N]; land_sh = s[3 * N];
+        gr_nh = s[4 * N]; gr_sh = s[5 * N]; ae_nh = s[6 * N]; ae_sh = s[7 * N];
+        hx_nh = s[8 * N]; hx_sh = s[9 * N];
+    }
+    const int32_t scen = a.scen ? a.scen[i] : 0;
+    const double* F = a.erf + (size_t)scen * a.n_times;
+    const double steps = (double)a.steps_per_year;
+    const double c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
+
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double erf_start = F[n], erf_end = F[n + 1];
+        const size_t r0 = (size_t)n * N + i, r1 = r0 + (size_t)N;
+        // warm start (mod.rs:436-446)
+        {
+            const double prev0 = st[0][r0];
+            if (T_nh[0] == 0.0 && prev0 != 0.0) {
+                T_nh[0] = prev0;
+                T_sh[0] = st[2][r0];
+                land_nh = st[1][r0];
+                land_sh = st[3][r0];
+                gr_nh = land_nh;
+                gr_sh = land_sh;
+            }
+        }
+        const double dt_year = a.bounds[n + 1] - a.bounds[n];
+        const double dt_sub = dt_year / steps;
+        // ---- time-varying ECS (adjusted_ecs) and the LAMCALC re-solve
+        const double erf_mid = (erf_start + erf_end) / 2.0;
+        double cum_t = 0.0;
+        if (n > 0) {
+            double years_remaining = p.fb_period, sum = 0.0;
+            for (int32_t k = n - 1; k >= 0; --k) {
+                if (years_remaining <= 0.0) break;
+                const double dt = a.bounds[k + 1] - a.bounds[k];
+                const double h = a.hist[(size_t)k * N + i];
+                if (dt <= years_remaining) {
+                    sum += h;
+                    years_remaining -= dt;
+                } else {
+                    sum += h * (years_remaining / dt);
+                    years_remaining = 0.0;
+                }
+            }
+            cum_t = sum;
+        }
+        const double cumt_2x = p.ecs * p.fb_period;
+        const double cumt_factor = fabs(cumt_2x) > 1e-15 ? 1.0 + p.fb_cumt * (cum_t - cumt_2x) / cumt_2x : 1.0;
+        const double q_factor = 1.0 + p.fb_q * (fmax(erf_mid, 0.0) - p.rf_2x);
+        const double adj_ecs = p.ecs * cumt_factor * q_factor;
+        double lam_o = base.lam_o, lam_l = base.lam_l, co2_eff = base.eff;
+        if (fabs(adj_ecs - p.ecs) > 1e-10) {
+            const LamResult rr = lamcalc(p, adj_ecs);
+            if (rr.ok) {
+                lam_o = rr.lam_o;
+                lam_l = rr.lam_l;
+                co2_eff = rr.eff;
+            }
+        }
+        double eff_scale = 1.0;  // apply_efficacy_and_qfrac
+        int eff_mode = 0;
+        if (a.efficacy_apply == 1) { eff_mode = 1; }
+        else if (a.efficacy_apply == 2 && is_finite(co2_eff) && co2_eff > 0.0) { eff_mode = 2; }
+        (void)eff_scale;
+        const double ae_nh_y = ae_nh, ae_sh_y = ae_sh;  // alpha_eff is fixed for the year
+        for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
+            const double frac = (double)step_idx / steps;
+            const double erf = erf_start + frac * (erf_end - erf_start);
+            double adj = erf;
+            if (eff_mode == 1) adj = erf * p.prescribed_eff;
+            else if (eff_mode == 2) adj = erf * p.prescribed_eff / co2_eff;
+            const double f0 = adj * p.q0, f1 = adj * p.q1, f2 = adj * p.q2, f3 = adj * p.q3;
+            if (a.land_hc) {
+                if (!(p.fgnl < 1e-15)) gr_nh += p.k_lg * (land_nh - gr_nh) / (p.fgnl * c_ground) * dt_sub;
+                if (!(p.fgsl < 1e-15)) gr_sh += p.k_lg * (land_sh - gr_sh) / (p.fgsl * c_ground) * dt_sub;
+            }
+            const double sst_nh = step_hemisphere<NL>(p, a, T_nh, N, 0, f0, dt_sub, lam_o, lam_l, hx_nh, gr_nh,
+                                                      land_nh, ae_nh_y, up_nh);
+            const double sst_sh = step_hemisphere<NL>(p, a, T_sh, N, 1, f2, dt_sub, lam_o, lam_l, hx_sh, gr_sh,
+                                                      land_sh, ae_sh_y, up_sh);
+            const double t_air_nho = sst_to_air(p, sst_nh), t_air_sho = sst_to_air(p, sst_sh);
+            land_nh = land_temperature(p, t_air_nho, f1, p.fgnl, lam_l);
+            land_sh = land_temperature(p, t_air_sho, f3, p.fgsl, lam_l);
+            if (p.fgno > 1e-15) hx_nh = p.k_ns / p.fgno * (t_air_sho - t_air_nho);
+            if (p.fgso > 1e-15) hx_sh = p.k_ns / p.fgso * (t_air_nho - t_air_sho);
+            const double global_temp = t_air_nho * p.fgno + land_nh * p.fgnl + t_air_sho * p.fgso + land_sh * p.fgsl;
+            {   // update_upwelling
+                const double w_min = p.w0 * (1.0 - p.f_var);
+                up_nh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp / p.t_thresh_nh, 1.0)), w_min);
+                up_sh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp / p.t_thresh_sh, 1.0)), w_min);
+            }
+        }
+        // ---- end of year
+        const double sst_nh = T_nh[0], sst_sh = T_sh[0];
+        const double air_nh = sst_to_air(p, sst_nh), air_sh = sst_to_air(p, sst_sh);
+        ae_nh = fabs(sst_nh) < 1e-15 ? p.alpha : air_nh / sst_nh;
+        ae_sh = fabs(sst_sh) < 1e-15 ? p.alpha : air_sh / sst_sh;
+        const double global_temp = air_nh * p.fgno + land_nh * p.fgnl + air_sh * p.fgso + land_sh * p.fgsl;
+        a.hist[r0] = global_temp * dt_year;
+        double adj_end = erf_end;
+        if (eff_mode == 1) adj_end = erf_end * p.prescribed_eff;
+        else if (eff_mode == 2) adj_end = erf_end * p.prescribed_eff / co2_eff;
+        {
+            const double w[4] = {p.fgno, p.fgnl, p.fgso, p.fgsl};
+            const double lambdas[4] = {lam_o, lam_l, lam_o, lam_l};
+            const double fe[4] = {adj_end * p.q0, adj_end * p.q1, adj_end * p.q2, adj_end * p.q3};
+            const double tt[4] = {air_nh, land_nh, air_sh, land_sh};
+            double q_global = 0.0, feedback_global = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q_global += w[k] * fe[k];
+                feedback_global += w[k] * lambdas[k] * tt[k];
+            }
+            a.heat_uptake[r1] = q_global - feedback_global;
+        }
+        {   // calculate_ocean_heat_content: hemisphere by hemisphere, layer by layer
+            const double rho_c = kRhoSeawater * kCpSeawater;
+            double total = 0.0;
+            total += rho_c * p.dz_mix * sst_nh;
+#pragma unroll 1
+            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * T_nh[(size_t)l * N];
+            total += rho_c * p.dz_mix * sst_sh;
+#pragma unroll 1
+            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * T_sh[(size_t)l * N];
+            a.ohc[r1] = total / 2.0;
+        }
+        a.st0[r1] = air_nh;
+        a.st1[r1] = land_nh;
+        a.st2[r1] = air_sh;
+        a.st3[r1] = land_sh;
+        a.sst[r1] = (sst_nh + sst_sh) / 2.0;
+    }
+    double* s = a.scal + i;
+    s[0 * N] = up_nh; s[1 * N] = up_sh; s[2 * N] = land_nh; s[3 * N] = land_sh;
+    s[4 * N] = gr_nh; s[5 * N] = gr_sh; s[6 * N] = ae_nh; s[7 * N] = ae_sh;
+    s[8 * N] = hx_nh; s[9 * N] = hx_sh;
+}
+
+}  // namespace
+
+hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
+{
+    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    if (a.n_layers != 50) return hipErrorInvalidValue;  // the column is unrolled for NL = 50
+    const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
+    hipLaunchKernelGGL(udeb_kernel<50>, grid, dim3(kUdebBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace rscm

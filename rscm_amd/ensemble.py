@@ -28,8 +28,9 @@ class Ensemble:
         self.n_times = len(b) - 1
         self.bounds = b
         self.device = device
-        self.var_ids: Dict[str, int] = dict(L.TL_VARS if kind == L.KIND_TWO_LAYER else L.CP_VARS)
-        self.n_params = 6 if kind == L.KIND_TWO_LAYER else 10
+        self.var_ids: Dict[str, int] = dict({L.KIND_TWO_LAYER: L.TL_VARS, L.KIND_COUPLED: L.CP_VARS,
+                                             L.KIND_UDEB: L.UD_VARS}[kind])
+        self.n_params = {L.KIND_TWO_LAYER: 6, L.KIND_COUPLED: 10, L.KIND_UDEB: 37}[kind]
         h = C.c_void_p()
         self.store_series = bool(store_series)
         L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
@@ -146,6 +147,9 @@ class Ensemble:
     def state_vars(self) -> Dict[str, int]:
         if self.kind == L.KIND_TWO_LAYER:
             return {k: v for k, v in self.var_ids.items() if v in (1, 2)}
+        if self.kind == L.KIND_UDEB:
+            raise NotImplementedError("ClimateUDEB keeps internal ocean state on the device; "
+                                      "host checkpoints are not available for this kind yet")
         return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}
 
     def checkpoint(self) -> Dict[str, object]:

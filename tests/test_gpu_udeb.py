@@ -1,0 +1,145 @@
+"""GPU tier: the ClimateUDEB kernel (RSCM_KIND_UDEB) against the CPU oracle and, through it,
+against the MAGICC7 outputs the reference's regression tests hold.
+
+Parity bar (stated): |gpu - oracle| <= 1e-9 * max(1, |oracle|) for every output and year.  The
+column solver on the device uses the refined-reciprocal quotient without the exact-division
+replay (rk4_device.hpp), so agreement is to rounding, not bit for bit; status codes, NaN
+placement and the time indexing are exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_oracle_udeb import PHASED, RECORDED, W, phased_ok, scenario_inputs
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "udeb_magicc7.json")
+NAMES = {"st0": "Surface Temperature|NorthernOcean", "st1": "Surface Temperature|NorthernLand",
+         "st2": "Surface Temperature|SouthernOcean", "st3": "Surface Temperature|SouthernLand",
+         "heat_uptake": "Heat Uptake", "ohc": "Ocean Heat Content", "sst": "Sea Surface Temperature"}
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rscm_amd
+    from rscm_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1
+    return rscm_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import cbind
+    return cbind
+
+
+def _gpu(ra, bounds, P, erf, scen=None, chunks=()):
+    with ra.Ensemble(ra.KIND_UDEB, P.shape[1], bounds) as e:
+        e.set_params(P)
+        e.set_forcing(erf, scen)
+        for k in range(1, 5):
+            e.set_initial(k, 0.0)
+        for c in chunks:
+            e.run(c)
+        e.run()
+        return {k: e.get_series(v) for k, v in NAMES.items()}, e.status()
+
+
+def _assert_close(got, want, what=""):
+    for k in NAMES:
+        g, w = got[k], want[k]
+        assert (np.isnan(g) == np.isnan(w)).all(), f"{what} {k}: NaN placement"
+        ok = ~np.isnan(w)
+        err = np.abs(g[ok] - w[ok]) / np.maximum(1.0, np.abs(w[ok]))
+        assert err.max() <= RTOL, f"{what} {k}: max rel err {err.max():.3e}"
+
+
+@pytest.mark.parametrize("name", sorted(PHASED) + sorted(RECORDED) + ["11_efficacy_ar6", "12_efficacy_ar6_1pctco2"])
+def test_udeb_gpu_magicc7_scenarios(ra, orc, name):
+    g = json.load(open(GOLDEN))[name]
+    kw, years, erf = scenario_inputs(name, g)
+    b = np.append(years, years[-1] + 1.0)
+    p = orc.udeb_default_params(**kw).reshape(-1, 1).copy()
+    want, wst = orc.udeb_run(b, p, erf)
+    got, st = _gpu(ra, b, p, erf)
+    assert st[0] == wst[0] == 0
+    _assert_close(got, want, name)
+    actual = np.stack([got[f"st{k}"][:, 0] for k in range(4)], axis=1) @ W
+    expected = np.array(g["surface_temperature"])
+    if name in PHASED:  # the reference's own acceptance test against MAGICC7, through the GPU
+        ok, worst = phased_ok(actual, expected, **PHASED[name])
+        assert ok, worst
+    else:
+        m = np.abs(expected) > 1e-6
+        assert np.all(np.abs(actual[m] - expected[m]) <= 0.1 * np.abs(expected[m]))
+
+
+def _ensemble_params(orc, n, seed=0, **fixed):
+    rng = np.random.default_rng(seed)
+    P = np.repeat(orc.udeb_default_params(**fixed).reshape(-1, 1), n, axis=1)
+    idx = orc.UDEB_PARAM_NAMES.index
+    for name, (lo, hi) in dict(ecs=(1.8, 5.5), kappa=(0.4, 1.6), rlo=(1.15, 1.5), k_lo=(1.0, 2.0),
+                               k_ns=(0.1, 0.6), w_initial=(2.0, 5.0), w_variable_fraction=(0.3, 0.9),
+                               kappa_dkdt=(-0.3, 0.0), amplify_ocean_to_land=(1.0, 1.1),
+                               temp_adjust_alpha=(1.0, 1.1), feedback_cumt_sensitivity=(0.0, 0.15),
+                               polar_sinking_ratio=(0.1, 0.3), k_lg=(0.05, 0.2)).items():
+        P[idx(name)] = rng.uniform(lo, hi, n)
+    return P
+
+
+def test_udeb_gpu_ensemble_vs_oracle(ra, orc):
+    years = np.arange(1850.0, 1951.0)
+    b = np.append(years, 1951.0)
+    n = 257
+    P = _ensemble_params(orc, n)
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0),
+                  3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0),
+                  -1.5 * np.ones(len(years))])
+    scen = (np.arange(n) % 3).astype(np.int32)
+    want, wst = orc.udeb_run(b, P, F, scen=scen, threads=8)
+    got, st = _gpu(ra, b, P, F, scen=scen)
+    assert (st == wst).all()
+    _assert_close(got, want, "ensemble")
+    # resume: three launches give the same bits as one
+    again, _ = _gpu(ra, b, P, F, scen=scen, chunks=(1, 37))
+    for k in NAMES:
+        assert np.array_equal(again[k], got[k], equal_nan=True), k
+
+
+def test_udeb_gpu_failed_construction_is_flagged(ra, orc):
+    years = np.arange(1850.0, 1871.0)
+    b = np.append(years, 1871.0)
+    P = _ensemble_params(orc, 8, seed=3)
+    idx = orc.UDEB_PARAM_NAMES.index
+    P[idx("prescribed_efficacy_co2"), 2] = -1.0      # rejected by from_parameters (status 2)
+    P[idx("rlo"), 5] = 50.0                           # LAMCALC cannot match this ratio (status 4)
+    erf = np.where(years >= 1851, 3.71, 0.0)
+    want, wst = orc.udeb_run(b, P, erf)
+    got, st = _gpu(ra, b, P, erf)
+    assert wst[2] == 2 and wst[5] == 4
+    assert (st == wst).all()
+    _assert_close(got, want, "failed members")
+    assert np.isnan(got["st0"][1:, 2]).all() and np.isnan(got["st0"][1:, 5]).all()
+
+
+def test_udeb_structural_parameters_must_be_uniform(ra, orc):
+    from rscm_amd import RscmGpuError
+    years = np.arange(1850.0, 1861.0)
+    b = np.append(years, 1861.0)
+    P = _ensemble_params(orc, 4)
+    with ra.Ensemble(ra.KIND_UDEB, 4, b) as e:
+        bad = P.copy()
+        bad[orc.UDEB_PARAM_NAMES.index("land_heat_capacity_enabled"), 1] = 0.0
+        with pytest.raises(RscmGpuError, match="same for every member"):
+            e.set_params(bad)
+        bad = P.copy()
+        bad[0] = 40.0
+        with pytest.raises(RscmGpuError, match="n_layers = 50"):
+            e.set_params(bad)
+        e.set_params(P)
+        e.set_forcing(np.zeros(len(years)))
+        with pytest.raises(RscmGpuError, match="MissingInitialValue"):
+            e.run()
