@@ -75,7 +75,9 @@ struct UdebArgs {
     const double* erf;      // [S][T]
     const int32_t* scen;    // [N] or nullptr
     const double* bounds;   // [T+1] (device)
-    const double* tables;   // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] init_nh[NL] init_sh[NL]
+    // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] init_nh[NL] init_sh[NL], NL = 50: passed BY
+    // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
+    double tables[6 * 50];
     double* ocean;          // [2][NL][N] layer temperatures
     double* scal;           // [10][N] upwelling, land, ground, alpha_eff, hemi exchange (x2 hemispheres)
     double* hist;           // [T][N] year-weighted global temperature history

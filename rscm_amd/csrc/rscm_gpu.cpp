@@ -108,6 +108,7 @@ struct rscm_ens {
     double* d_bounds = nullptr;   // [T+1]
     int32_t udeb_n_layers = 0, udeb_steps = 0, udeb_land_hc = 0, udeb_efficacy = 0;
     bool udeb_ready = false;
+    std::vector<double> udeb_tables;
 
     double* d_partial = nullptr;  // summary scratch
     double* d_out4 = nullptr;
@@ -189,10 +190,8 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
     h->udeb_efficacy = (int32_t)eff;
     const std::vector<double> t = rscm::udeb_tables(h->udeb_n_layers, row(RSCM_UD_P_MIXED_LAYER_DEPTH, 0),
                                                     row(RSCM_UD_P_LAYER_THICKNESS, 0), row(RSCM_UD_P_DEPTH_DEPENDENT_AREA, 0));
-    if (!h->d_tables) HIPCHK(hipMalloc(&h->d_tables, t.size() * sizeof(double)));
+    h->udeb_tables = t;
     if (!h->d_ocean) HIPCHK(hipMalloc(&h->d_ocean, (size_t)2 * h->udeb_n_layers * h->N * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(h->d_tables, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     h->udeb_ready = true;
     return RSCM_OK;
 }
@@ -560,7 +559,8 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.erf = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
-        a.tables = h->d_tables;
+        if (h->udeb_tables.size() != sizeof(a.tables) / sizeof(double)) return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
+        memcpy(a.tables, h->udeb_tables.data(), sizeof(a.tables));
         a.ocean = h->d_ocean;
         a.scal = h->d_scal;
         a.hist = h->d_hist;

@@ -200,21 +200,32 @@ __device__ __forceinline__ double land_temperature(const UdebP& p, double ocean_
 // n / d with the reciprocal supplied (no window replay: tolerance-parity kernel).
 __device__ __forceinline__ double qdiv(double n, double d, double r) { return spec_div(n, d, r); }
 
+// Denominators that depend only on the (uniform) column geometry: reciprocals hoisted out of
+// the sub-step loop so each of the ~60 divisions per column solve costs 3 instructions.
+struct GeomRcp {
+    double dzmix_dz1, r_dzmix_dz1;  // dz_mix * (dz/2)
+    double dz_dz1, r_dz_dz1;        // dz * (dz/2)
+    double dz_dz, r_dz_dz;          // dz * dz
+    double r_dzmix, r_dz;           // 1/dz_mix, 1/dz
+    double c_mix, r_c_mix;          // mixed-layer heat capacity
+};
+
 // One implicit sub-step of one hemisphere's column (ocean_column.rs step_hemisphere).
 // T is this member's column in HBM with stride N between layers.  Returns the new mixed-layer
 // temperature.
 template <int NL>
-__device__ __forceinline__ double step_hemisphere(const UdebP& p, const UdebArgs& a, double* __restrict__ T,
-                                                  int64_t N, int hemi, double forcing, double dt,
-                                                  double lambda_ocean, double lambda_land, double hemi_hx,
-                                                  double ground_temp, double land_temp, double alpha_eff,
-                                                  double w)
+__device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp& g,
+                                                  const double* tables, int32_t land_hc,
+                                                  double* __restrict__ T, int64_t N, int hemi,
+                                                  double forcing, double dt, double lambda_ocean,
+                                                  double lambda_land, double hemi_hx, double ground_temp,
+                                                  double land_temp, double alpha_eff, double w)
 {
-    const double* __restrict__ af_top = a.tables;            // [NL]
-    const double* __restrict__ af_bot = a.tables + NL;       // [NL]
-    const double* __restrict__ af_diff = a.tables + 2 * NL;  // [NL]
-    const double* __restrict__ omr = a.tables + 3 * NL;      // 1 - relative depth, [NL-1]
-    const double* __restrict__ init = a.tables + 4 * NL + (size_t)hemi * NL;  // initial profile
+    const double* af_top = tables;            // [NL]
+    const double* af_bot = tables + NL;       // [NL]
+    const double* af_diff = tables + 2 * NL;  // [NL]
+    const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
+    const double* init = tables + 4 * NL + (size_t)hemi * NL;  // initial profile
     const double dz = p.dz, dz_mix = p.dz_mix, pi_ratio = p.pi_ratio;
     const double t_top = T[0];
     const double t_bottom = T[(size_t)(NL - 1) * N];
@@ -224,61 +235,59 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const UdebArgs
         const double k = (omr[l] * p.kappa_dkdt * dkdt_dT + p.kappa) * kDiffCm2sToM2yr;
         return fmax(k, kappa_min_m2yr);
     };
-    const double c_mix = heat_capacity_per_unit_area(dz_mix);
+    const double c_mix = g.c_mix;
     const double f_l_hemi = hemi == 0 ? p.nh_land / 2.0 : p.sh_land / 2.0;
     const double f_o_hemi = 0.5 - f_l_hemi;
     const double denominator = f_o_hemi * (p.k_lo + f_l_hemi * lambda_land);
     const double term_feedback =
-        alpha_eff / c_mix * (lambda_ocean + lambda_land * p.k_lo * p.amplify * f_l_hemi / denominator);
-    const double dz1 = dz / 2.0;
+        qdiv(alpha_eff, c_mix, g.r_c_mix) * (lambda_ocean + lambda_land * p.k_lo * p.amplify * f_l_hemi / denominator);
     const double delta_w = w - p.w0;
-    const bool dw = fabs(delta_w) > 1e-15;
+    // |delta_w| <= 1e-15: the reference skips the profile-advection terms; adding exact zeros is
+    // the same thing without a branch per row
+    const double dwv = fabs(delta_w) > 1e-15 ? delta_w : 0.0;
     const double t_polar = 1.0;  // state.polar_sinking_temp
-    const double dt_per_dz = dt / dz;
+    const double dt_per_dz = qdiv(dt, dz, g.r_dz);
 
     double cp[NL], dp[NL];
     // ---- row 0 (mixed layer)
     double kap_prev = kappa_at(0);
     {
-        const double term_diff = kap_prev / (dz_mix * dz1) * dt;
-        const double term_upwell = w / dz_mix * dt;
+        const double term_diff = qdiv(kap_prev, g.dzmix_dz1, g.r_dzmix_dz1) * dt;
+        const double term_upwell = qdiv(w, dz_mix, g.r_dzmix) * dt;
         const double forcing_amp = 1.0 + p.k_lo * f_l_hemi / denominator;
         const double b0 = 1.0 + term_feedback * dt * af_top[0] + term_diff * af_bot[0] +
                           term_upwell * pi_ratio * af_bot[0];
         const double c0 = -(term_diff + term_upwell) * af_bot[0];
-        double d0 = t_top + (forcing * forcing_amp + hemi_hx) / c_mix * dt * af_top[0];
-        if (a.land_hc) d0 -= p.k_lg * (land_temp - ground_temp) / (c_mix * f_o_hemi) * dt * af_top[0];
-        if (dw) d0 += dt / dz_mix * delta_w * (init[1] - t_polar) * af_bot[0];
+        double d0 = t_top + qdiv(forcing * forcing_amp + hemi_hx, c_mix, g.r_c_mix) * dt * af_top[0];
+        if (land_hc) d0 -= p.k_lg * (land_temp - ground_temp) / (c_mix * f_o_hemi) * dt * af_top[0];
+        d0 += qdiv(dt, dz_mix, g.r_dzmix) * dwv * (init[1] - t_polar) * af_bot[0];
         const double r = refined_rcp(b0);
         cp[0] = qdiv(c0, b0, r);
         dp[0] = qdiv(d0, b0, r);
     }
     // ---- interior rows and the bottom row: forward sweep
-    const double term_upwell_layer = w / dz * dt;
+    const double term_upwell_layer = qdiv(w, dz, g.r_dz) * dt;
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
         const double t_i = T[(size_t)i * N];
-        const double dz_up = i == 1 ? dz1 : dz;
-        const double term_diff_up = kap_prev / (dz * dz_up) * dt;
+        const double term_diff_up = (i == 1 ? qdiv(kap_prev, g.dz_dz1, g.r_dz_dz1) : qdiv(kap_prev, g.dz_dz, g.r_dz_dz)) * dt;
         double ai, bi, ci, di;
         if (i < NL - 1) {
             const double kap = kappa_at(i);
-            const double term_diff_down = kap / (dz * dz) * dt;
+            const double term_diff_down = qdiv(kap, g.dz_dz, g.r_dz_dz) * dt;
             ai = -term_diff_up * af_top[i];
             bi = 1.0 + term_diff_up * af_top[i] + term_diff_down * af_bot[i] + term_upwell_layer * af_top[i];
             ci = -(term_diff_down + term_upwell_layer) * af_bot[i];
             di = t_i + pi_ratio * term_upwell_layer * t_top * af_diff[i];
-            if (dw) {
-                di += dt_per_dz * delta_w * (init[i + 1] * af_bot[i] - init[i] * af_top[i]);
-                di += dt_per_dz * delta_w * t_polar * af_diff[i];
-            }
+            di += dt_per_dz * dwv * (init[i + 1] * af_bot[i] - init[i] * af_top[i]);
+            di += dt_per_dz * dwv * t_polar * af_diff[i];
             kap_prev = kap;
         } else {
             ai = -term_diff_up * af_top[i];
             bi = 1.0 + (term_diff_up + term_upwell_layer) * af_top[i];
             ci = 0.0;
             di = t_i + pi_ratio * term_upwell_layer * t_top * af_top[i];
-            if (dw) di += dt_per_dz * delta_w * (t_polar - init[i]) * af_top[i];
+            di += dt_per_dz * dwv * (t_polar - init[i]) * af_top[i];
         }
         const double denom = bi - ai * cp[i - 1];
         const double r = refined_rcp(denom);
@@ -361,6 +370,19 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     const double* F = a.erf + (size_t)scen * a.n_times;
     const double steps = (double)a.steps_per_year;
     const double c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
+    GeomRcp g;
+    {
+        const double dz1 = p.dz / 2.0;
+        g.dzmix_dz1 = p.dz_mix * dz1; g.r_dzmix_dz1 = refined_rcp(g.dzmix_dz1);
+        g.dz_dz1 = p.dz * dz1;        g.r_dz_dz1 = refined_rcp(g.dz_dz1);
+        g.dz_dz = p.dz * p.dz;        g.r_dz_dz = refined_rcp(g.dz_dz);
+        g.r_dzmix = refined_rcp(p.dz_mix);
+        g.r_dz = refined_rcp(p.dz);
+        g.c_mix = heat_capacity_per_unit_area(p.dz_mix);
+        g.r_c_mix = refined_rcp(g.c_mix);
+    }
+    const double* tables = a.tables;  // kernarg segment
+    const double* __restrict__ bounds = a.bounds;
 
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         const double erf_start = F[n], erf_end = F[n + 1];
@@ -377,25 +399,37 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
                 gr_sh = land_sh;
             }
         }
-        const double dt_year = a.bounds[n + 1] - a.bounds[n];
+        const double dt_year = bounds[n + 1] - bounds[n];
         const double dt_sub = dt_year / steps;
         // ---- time-varying ECS (adjusted_ecs) and the LAMCALC re-solve
         const double erf_mid = (erf_start + erf_end) / 2.0;
         double cum_t = 0.0;
-        if (n > 0) {
-            double years_remaining = p.fb_period, sum = 0.0;
+        if (n > 0 && p.fb_cumt != 0.0) {
+            // Phase 1 (time axis only, scalar loads): how far back the window reaches for this
+            // member and the weight of its oldest, partially covered entry.
+            double years_remaining = p.fb_period;
+            int32_t k_full = n;        // entries [k_full, n) enter whole
+            double part_w = 0.0;       // weight of entry k_full - 1, if partially covered
+            bool part = false;
             for (int32_t k = n - 1; k >= 0; --k) {
                 if (years_remaining <= 0.0) break;
-                const double dt = a.bounds[k + 1] - a.bounds[k];
-                const double h = a.hist[(size_t)k * N + i];
+                const double dt = bounds[k + 1] - bounds[k];
                 if (dt <= years_remaining) {
-                    sum += h;
+                    k_full = k;
                     years_remaining -= dt;
                 } else {
-                    sum += h * (years_remaining / dt);
+                    part = true;
+                    part_w = years_remaining / dt;
                     years_remaining = 0.0;
                 }
             }
+            // Phase 2: the same newest-to-oldest summation as the reference, with a trip count
+            // known up front so the loads pipeline.
+            double sum = 0.0;
+            const double* hcol = a.hist + i;
+#pragma unroll 8
+            for (int32_t k = n - 1; k >= k_full; --k) sum += hcol[(size_t)k * N];
+            if (part) sum += hcol[(size_t)(k_full - 1) * N] * part_w;
             cum_t = sum;
         }
         const double cumt_2x = p.ecs * p.fb_period;
@@ -428,10 +462,17 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
                 if (!(p.fgnl < 1e-15)) gr_nh += p.k_lg * (land_nh - gr_nh) / (p.fgnl * c_ground) * dt_sub;
                 if (!(p.fgsl < 1e-15)) gr_sh += p.k_lg * (land_sh - gr_sh) / (p.fgsl * c_ground) * dt_sub;
             }
-            const double sst_nh = step_hemisphere<NL>(p, a, T_nh, N, 0, f0, dt_sub, lam_o, lam_l, hx_nh, gr_nh,
-                                                      land_nh, ae_nh_y, up_nh);
-            const double sst_sh = step_hemisphere<NL>(p, a, T_sh, N, 1, f2, dt_sub, lam_o, lam_l, hx_sh, gr_sh,
-                                                      land_sh, ae_sh_y, up_sh);
+            // one copy of the column solver, run for NH then SH (uniform selects)
+            double sst_pair[2];
+#pragma unroll 1
+            for (int hemi = 0; hemi < 2; ++hemi) {
+                const bool sh = hemi != 0;
+                sst_pair[hemi] = step_hemisphere<NL>(p, g, tables, a.land_hc, sh ? T_sh : T_nh, N, hemi, sh ? f2 : f0,
+                                                     dt_sub, lam_o, lam_l, sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
+                                                     sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
+                                                     sh ? up_sh : up_nh);
+            }
+            const double sst_nh = sst_pair[0], sst_sh = sst_pair[1];
             const double t_air_nho = sst_to_air(p, sst_nh), t_air_sho = sst_to_air(p, sst_sh);
             land_nh = land_temperature(p, t_air_nho, f1, p.fgnl, lam_l);
             land_sh = land_temperature(p, t_air_sho, f3, p.fgsl, lam_l);

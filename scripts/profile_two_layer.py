@@ -20,7 +20,18 @@ b = np.append(t, 2501.0)
 F = 4.0 * (1.0 - np.exp(-(t - 1750.0) / 120.0)) + 0.3 * np.sin(2 * np.pi * (t - 1750.0) / 11.0)
 lo = np.array([0.8, 0.0, 1.0, 0.5, 5.0, 50.0, 15.0, 278.0, 0.0, 3.7])
 hi = np.array([1.5, 0.1, 1.8, 1.0, 15.0, 200.0, 40.0, 278.0, 0.1, 3.7])
-P = 6 if kind == 0 else 10
+if kind == 2:  # ClimateUDEB: defaults, ECS / kappa / RLO / k_lo varied
+    from rscm_amd import _lib
+    lo = np.array(_lib.UD_DEFAULTS, dtype=float)
+    hi = lo.copy()
+    for name, (a_, b_) in dict(ecs=(2.0, 5.0), kappa=(0.5, 1.5), rlo=(1.2, 1.45), k_lo=(1.0, 2.0)).items():
+        j = _lib.UD_PARAM_NAMES.index(name)
+        lo[j], hi[j] = a_, b_
+    if os.environ.get("UDEB_NOFB"):  # constant ECS: no LAMCALC re-solve per year
+        for name in ("feedback_q_sensitivity", "feedback_cumt_sensitivity"):
+            j = _lib.UD_PARAM_NAMES.index(name)
+            lo[j] = hi[j] = 0.0
+P = {0: 6, 1: 10, 2: 37}[kind]
 with rscm_amd.Ensemble(kind, members, b) as e:
     e.set_mode(mode)
     e.sample_lhs(20260327, lo[:P], hi[:P])
@@ -28,6 +39,10 @@ with rscm_amd.Ensemble(kind, members, b) as e:
         e.set_forcing(F)
         e.set_initial(1, 0.0)
         e.set_initial(2, 0.0)
+    elif kind == 2:
+        e.set_forcing(F)
+        for v in (1, 2, 3, 4):
+            e.set_initial(v, 0.0)
     else:
         yrs = np.array([1750.0, 1850.0, 1950.0, 2000.0, 2020.0, 2050.0, 2100.0])
         e.set_forcing(np.interp(t, yrs, [0.0, 0.5, 3.0, 7.0, 10.0, 5.0, 1.0]))
