@@ -227,8 +227,13 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
     const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
     const double* init = tables + 4 * NL + (size_t)hemi * NL;  // initial profile
     const double dz = p.dz, dz_mix = p.dz_mix, pi_ratio = p.pi_ratio;
-    const double t_top = T[0];
-    const double t_bottom = T[(size_t)(NL - 1) * N];
+    // the whole column is fetched up front (50 independent coalesced loads in flight at once);
+    // slot i later holds d'[i], so the column and the d' array share registers
+    double dp[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) dp[i] = T[(size_t)i * N];
+    const double t_top = dp[0];
+    const double t_bottom = dp[NL - 1];
     const double dkdt_dT = t_top - t_bottom;
     const double kappa_min_m2yr = p.kappa_min * kDiffCm2sToM2yr;
     auto kappa_at = [&](int l) -> double {
@@ -248,7 +253,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
     const double t_polar = 1.0;  // state.polar_sinking_temp
     const double dt_per_dz = qdiv(dt, dz, g.r_dz);
 
-    double cp[NL], dp[NL];
+    double cp[NL];
     // ---- row 0 (mixed layer)
     double kap_prev = kappa_at(0);
     {
@@ -269,7 +274,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
     const double term_upwell_layer = qdiv(w, dz, g.r_dz) * dt;
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
-        const double t_i = T[(size_t)i * N];
+        const double t_i = dp[i];
         const double term_diff_up = (i == 1 ? qdiv(kap_prev, g.dz_dz1, g.r_dz_dz1) : qdiv(kap_prev, g.dz_dz, g.r_dz_dz)) * dt;
         double ai, bi, ci, di;
         if (i < NL - 1) {
