@@ -67,6 +67,26 @@ def make_ensemble(members, device, rank, world, mode, stream=None, coupled=False
     return ens
 
 
+def make_udeb_ensemble(members, device, stream=None):
+    """ClimateUDEB defaults with ECS, kappa, RLO and k_lo drawn from a Latin hypercube."""
+    import rscm_amd
+    from rscm_amd import _lib
+    t = np.arange(T0, T1 + 1, dtype=np.float64)
+    ens = rscm_amd.Ensemble(rscm_amd.KIND_UDEB, members, np.append(t, t[-1] + 1.0), device=device)
+    if stream is not None:
+        ens.set_stream(stream)
+    lo = np.array(_lib.UD_DEFAULTS, dtype=np.float64)
+    hi = lo.copy()
+    for name, (a, b) in dict(ecs=(2.0, 5.0), kappa=(0.5, 1.5), rlo=(1.2, 1.45), k_lo=(1.0, 2.0)).items():
+        j = _lib.UD_PARAM_NAMES.index(name)
+        lo[j], hi[j] = a, b
+    ens.sample_lhs(SEED, lo, hi)
+    ens.set_forcing(f_syn(t))
+    for v in (1, 2, 3, 4):
+        ens.set_initial(v, 0.0)
+    return ens
+
+
 def one_pass(ens):
     ens.rewind()
     ens.run(sync=False)
@@ -202,6 +222,12 @@ def main():
             bpy = 56.0 if cp else ALG_BYTES_PER_MEMBER_YEAR
             extra[label] = {"member_years_per_s": members * years * k / w2, "kernel_ms": k2,
                             "hbm_frac": bpy * members * years / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # next row: rscm-magicc ClimateUDEB, 1e5 members, 12 sub-steps per year
+        e3 = make_udeb_ensemble(100_000, local_rank, stream)
+        w3, k3 = timed_passes(e3, 2, 1, torch, dist, 1, tstream)
+        e3.close()
+        extra["udeb_1e5"] = {"member_years_per_s": 100_000 * years * 2 / w3, "kernel_ms": k3,
+                             "hbm_frac": 19.2e3 * 100_000 * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
