@@ -225,12 +225,55 @@ class Timeseries:
         return Timeseries(out, new_axis, self._units, self._strategy)
 
 
+class FourBoxTimeseries:
+    """FourBox grid timeseries: values (n_times, 4) in the order NorthernOcean, NorthernLand,
+    SouthernOcean, SouthernLand (python/rscm/_lib/core/__init__.pyi:95-106)."""
+
+    def __init__(self, values, time_axis: TimeAxis, units: str = ""):
+        v = np.array(values, dtype=np.float64)
+        if v.shape != (len(time_axis), 4):
+            raise ValueError(f"FourBox values must be ({len(time_axis)}, 4), got {v.shape}")
+        self._values, self._axis, self._units = v, time_axis, units
+
+    def __len__(self) -> int:
+        return len(self._values)
+
+    def values(self) -> np.ndarray:
+        return self._values.copy()
+
+    @property
+    def units(self) -> str:
+        return self._units
+
+    @property
+    def time_axis(self) -> TimeAxis:
+        return self._axis
+
+    @property
+    def latest(self) -> int:
+        ok = np.nonzero(~np.isnan(self._values[:, 0]))[0]
+        return int(ok[-1]) if len(ok) else 0
+
+
+class GridType(enum.Enum):
+    Scalar = enum.auto()
+    FourBox = enum.auto()
+    Hemispheric = enum.auto()
+
+
 class TimeseriesCollection:
     """python/rscm/_lib/core/__init__.pyi:119-190; kept sorted by name like the reference's
     ``Vec<TimeseriesItem>`` (crates/rscm-core/src/timeseries_collection.rs:318-321)."""
 
     def __init__(self) -> None:
         self._items: Dict[str, Tuple[Timeseries, VariableType]] = {}
+        self._fourbox: Dict[str, FourBoxTimeseries] = {}
+
+    def add_fourbox_timeseries(self, name: str, timeseries: FourBoxTimeseries) -> None:
+        self._fourbox[name] = timeseries
+
+    def get_fourbox_timeseries_by_name(self, name: str) -> Optional[FourBoxTimeseries]:
+        return self._fourbox.get(name)
 
     def add_timeseries(self, name: str, timeseries: Timeseries,
                        variable_type: VariableType = VariableType.Exogenous) -> None:
@@ -250,10 +293,10 @@ class TimeseriesCollection:
         return item[1] if item else None
 
     def names(self) -> List[str]:
-        return sorted(self._items)
+        return sorted(list(self._items) + list(self._fourbox))
 
     def timeseries(self) -> List[Timeseries]:
-        return [self.get_timeseries_by_name(n) for n in self.names()]
+        return [self.get_timeseries_by_name(n) for n in sorted(self._items)]
 
     def __contains__(self, name: str) -> bool:
         return name in self._items
@@ -327,7 +370,8 @@ class ComponentBuilder:
 
 
 # ------------------------------------------------------------------------------------ builder
-SUPPORTED = ("[TwoLayer] with exogenous or upstream 'Effective Radiative Forcing'",
+SUPPORTED = ("[ClimateUDEB] with exogenous 'Effective Radiative Forcing'",
+             "[TwoLayer] with exogenous or upstream 'Effective Radiative Forcing'",
              "[CarbonCycle, CO2ERF, TwoLayer] + Sum aggregate 'Effective Radiative Forcing' "
              "over ['Effective Radiative Forcing|CO2'] (registration order as listed)")
 
@@ -457,6 +501,14 @@ class ModelBuilder:
                       [cc.parameters["tau"], cc.parameters["conc_pi"],
                        cc.parameters["alpha_temperature"], ce.parameters["erf_2xco2"]])
             h = {L.COMP_TWO_LAYER: 0.1, L.COMP_CARBON_CYCLE: cc.step_size}
+        elif types == ["ClimateUDEB"] and not aggregates:
+            kind = L.KIND_UDEB
+            forcing = self._exogenous_on_axis(erf, exo_names)
+            if forcing is None:
+                forcing = np.full(len(self._axis), NAN)
+            src = L.SRC_EXOGENOUS
+            params = self._components[0].param_vector()
+            h = {}
         else:
             raise NotImplementedError(
                 f"component graph {types} (aggregates {list(aggregates)}) has no fused GPU kernel; "
@@ -472,7 +524,11 @@ class ModelBuilder:
         for name, vid in ens.var_ids.items():
             if vid > 0 and name in self._initial:
                 ens.set_initial(vid, self._initial[name])
-        param_order = TL_PARAM_ORDER if kind == L.KIND_TWO_LAYER else CP_PARAM_ORDER
+            elif vid > 0 and "|" in name and name.split("|")[0] in self._initial and kind == L.KIND_UDEB:
+                # a FourBox state initialised with one scalar sets all four regions (builder.rs:797-804)
+                ens.set_initial(vid, self._initial[name.split("|")[0]])
+        param_order = {L.KIND_TWO_LAYER: TL_PARAM_ORDER, L.KIND_COUPLED: CP_PARAM_ORDER,
+                       L.KIND_UDEB: L.UD_PARAM_NAMES}[kind]
         return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
                      np.array(params, dtype=np.float64))
 
@@ -517,7 +573,13 @@ class Model:
     def timeseries(self, member: int = 0) -> TimeseriesCollection:
         coll = TimeseriesCollection()
         input_name = [n for n, v in self.ensemble.var_ids.items() if v == 0][0]
+        if self.ensemble.kind == L.KIND_UDEB:
+            boxes = np.stack([self.ensemble.get_series(v, m_begin=member, m_end=member + 1)[:, 0]
+                              for v in (1, 2, 3, 4)], axis=1)
+            coll.add_fourbox_timeseries("Surface Temperature", FourBoxTimeseries(boxes, self._axis, "K"))
         for name, vid in self.ensemble.var_ids.items():
+            if self.ensemble.kind == L.KIND_UDEB and 1 <= vid <= 4:
+                continue
             if vid == 0:
                 vals, vt = self._forcing, VariableType.Exogenous
             else:

@@ -143,3 +143,38 @@ def test_udeb_structural_parameters_must_be_uniform(ra, orc):
         e.set_forcing(np.zeros(len(years)))
         with pytest.raises(RscmGpuError, match="MissingInitialValue"):
             e.run()
+
+
+def test_udeb_through_the_reference_shaped_front(ra, orc):
+    """The model construction of tests/regression/test_ocean_udeb.py:57-130 (ClimateUDEBBuilder,
+    schema with a FourBox 'Surface Temperature', exogenous Linear ERF, scalar initial value)
+    through rscm_amd's mirror, on scenario 10 (full defaults, 1pctCO2)."""
+    from rscm_amd import core
+    from rscm_amd.magicc import ClimateUDEBBuilder
+    g = json.load(open(GOLDEN))["10_full_default"]
+    kw, years, erf = scenario_inputs("10_full_default", g)
+    climate = ClimateUDEBBuilder.from_parameters({"ecs": kw["ecs"], "rf_2xco2": kw["rf_2xco2"]}).build()
+    axis = core.TimeAxis.from_bounds(np.concatenate([years, [years[-1] + 1.0]]))
+    erf_ts = core.Timeseries(erf, axis, "W/m^2", core.InterpolationStrategy.Linear)
+    schema = core.VariableSchema()
+    schema.add_variable("Effective Radiative Forcing", "W/m^2")
+    schema.add_variable("Surface Temperature", "K", core.GridType.FourBox)
+    for n, u in (("Heat Uptake", "W/m^2"), ("Ocean Heat Content", "J/m^2"), ("Sea Surface Temperature", "K")):
+        schema.add_variable(n, u)
+    model = (core.ModelBuilder().with_time_axis(axis).with_schema(schema).with_rust_component(climate)
+             .with_exogenous_variable("Effective Radiative Forcing", erf_ts)
+             .with_initial_values({"Surface Temperature": 0.0}).build())
+    model.run()
+    res = model.timeseries()
+    t4 = res.get_fourbox_timeseries_by_name("Surface Temperature")
+    assert t4 is not None and t4.values().shape == (len(years), 4)
+    actual = t4.values() @ W
+    expected = np.array(g["surface_temperature"])
+    m = np.abs(expected) > 1e-6
+    assert np.all(np.abs(actual[m] - expected[m]) <= 0.1 * np.abs(expected[m]))  # the reference's bar
+    assert np.abs((actual[5:] - expected[5:]) / expected[5:]).max() < 0.013
+    sst = res.get_timeseries_by_name("Sea Surface Temperature").values()
+    assert np.isnan(sst[0]) and np.all(np.isfinite(sst[1:]))
+    with pytest.raises(ValueError, match="unknown field"):
+        ClimateUDEBBuilder.from_parameters({"nope": 1.0})
+    model.close()
