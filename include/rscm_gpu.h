@@ -118,7 +118,7 @@ extern "C" {
 #define RSCM_UD_P_RLO 12
 #define RSCM_UD_P_FEEDBACK_Q_SENSITIVITY 13
 #define RSCM_UD_P_FEEDBACK_CUMT_SENSITIVITY 14
-#define RSCM_UD_P_FEEDBACK_CUMT_PERIOD 15
+#define RSCM_UD_P_FEEDBACK_CUMT_PERIOD 15   /* [u] */
 #define RSCM_UD_P_K_LO 16
 #define RSCM_UD_P_K_NS 17
 #define RSCM_UD_P_AMPLIFY_OCEAN_TO_LAND 18

@@ -75,6 +75,8 @@ struct UdebArgs {
     const double* erf;      // [S][T]
     const int32_t* scen;    // [N] or nullptr
     const double* bounds;   // [T+1] (device)
+    const int32_t* win_kfull;  // [T] first history entry that enters the cumulative-T window whole
+    const double* win_partw;   // [T] weight of entry win_kfull-1 (0: not in the window)
     // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] init_nh[NL] init_sh[NL], NL = 50: passed BY
     // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
     double tables[6 * 50];

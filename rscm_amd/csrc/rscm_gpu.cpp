@@ -106,6 +106,8 @@ struct rscm_ens {
     double* d_hist = nullptr;     // [T][N]
     double* d_tables = nullptr;   // geometry tables
     double* d_bounds = nullptr;   // [T+1]
+    int32_t* d_win_kfull = nullptr;  // [T]
+    double* d_win_partw = nullptr;   // [T]
     int32_t udeb_n_layers = 0, udeb_steps = 0, udeb_land_hc = 0, udeb_efficacy = 0;
     bool udeb_ready = false;
     std::vector<double> udeb_tables;
@@ -171,7 +173,8 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
 {
     static const int structural[] = {RSCM_UD_P_N_LAYERS, RSCM_UD_P_MIXED_LAYER_DEPTH, RSCM_UD_P_LAYER_THICKNESS,
                                      RSCM_UD_P_DEPTH_DEPENDENT_AREA, RSCM_UD_P_LAND_HC_ENABLED,
-                                     RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR};
+                                     RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR,
+                                     RSCM_UD_P_FEEDBACK_CUMT_PERIOD};
     for (int j : structural)
         for (int64_t i = 1; i < n_check; ++i)
             if (row(j, i) != row(j, 0))
@@ -191,6 +194,34 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
     const std::vector<double> t = rscm::udeb_tables(h->udeb_n_layers, row(RSCM_UD_P_MIXED_LAYER_DEPTH, 0),
                                                     row(RSCM_UD_P_LAYER_THICKNESS, 0), row(RSCM_UD_P_DEPTH_DEPENDENT_AREA, 0));
     h->udeb_tables = t;
+    {   // the backwards walk of adjusted_ecs() (mod.rs:302-331) over the time axis, once per year
+        const double period = row(RSCM_UD_P_FEEDBACK_CUMT_PERIOD, 0);
+        std::vector<int32_t> kfull((size_t)h->T, 0);
+        std::vector<double> partw((size_t)h->T, 0.0);
+        for (int32_t n = 0; n < h->T; ++n) {
+            double years_remaining = period;
+            int32_t kf = n;
+            double pw = 0.0;
+            for (int32_t k = n - 1; k >= 0; --k) {
+                if (years_remaining <= 0.0) break;
+                const double dt = h->bounds[k + 1] - h->bounds[k];
+                if (dt <= years_remaining) {
+                    kf = k;
+                    years_remaining -= dt;
+                } else {
+                    pw = years_remaining / dt;
+                    years_remaining = 0.0;
+                }
+            }
+            kfull[n] = kf;
+            partw[n] = pw;
+        }
+        if (!h->d_win_kfull) HIPCHK(hipMalloc(&h->d_win_kfull, (size_t)h->T * sizeof(int32_t)));
+        if (!h->d_win_partw) HIPCHK(hipMalloc(&h->d_win_partw, (size_t)h->T * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(h->d_win_kfull, kfull.data(), kfull.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_win_partw, partw.data(), partw.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if (!h->d_ocean) HIPCHK(hipMalloc(&h->d_ocean, (size_t)2 * h->udeb_n_layers * h->N * sizeof(double)));
     h->udeb_ready = true;
     return RSCM_OK;
@@ -318,6 +349,8 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_hist);
     (void)hipFree(h->d_tables);
     (void)hipFree(h->d_bounds);
+    (void)hipFree(h->d_win_kfull);
+    (void)hipFree(h->d_win_partw);
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_out4);
     (void)hipFree(h->d_loglik);
@@ -559,6 +592,8 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.erf = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
+        a.win_kfull = h->d_win_kfull;
+        a.win_partw = h->d_win_partw;
         if (h->udeb_tables.size() != sizeof(a.tables) / sizeof(double)) return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
         memcpy(a.tables, h->udeb_tables.data(), sizeof(a.tables));
         a.ocean = h->d_ocean;
@@ -873,7 +908,8 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
     if (h->kind == RSCM_KIND_UDEB) {
         static const int structural[] = {RSCM_UD_P_N_LAYERS, RSCM_UD_P_MIXED_LAYER_DEPTH, RSCM_UD_P_LAYER_THICKNESS,
                                          RSCM_UD_P_DEPTH_DEPENDENT_AREA, RSCM_UD_P_LAND_HC_ENABLED,
-                                         RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR};
+                                         RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR,
+                                         RSCM_UD_P_FEEDBACK_CUMT_PERIOD};
         for (int j : structural)
             if (low[j] != high[j])
                 return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d is structural: low must equal high", j);

@@ -89,9 +89,12 @@ __device__ __forceinline__ bool invert_4x4(const double m[4][4], double inv[4][4
                 aug[row][j] = sw ? x : y;
             }
         }
+        // aug[col][j] /= pivot for j = 0..7: one refined reciprocal, then the 3-instruction
+        // quotient (identical to IEEE division for these O(1) operands; rk4_device.hpp)
         const double pivot = aug[col][col];
+        const double rp = refined_rcp(pivot);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) aug[col][j] /= pivot;
+        for (int j = 0; j < 8; ++j) aug[col][j] = spec_div(aug[col][j], pivot, rp);
 #pragma unroll
         for (int row = 0; row < 4; ++row) {
             if (row == col) continue;
@@ -410,31 +413,18 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         const double erf_mid = (erf_start + erf_end) / 2.0;
         double cum_t = 0.0;
         if (n > 0 && p.fb_cumt != 0.0) {
-            // Phase 1 (time axis only, scalar loads): how far back the window reaches for this
-            // member and the weight of its oldest, partially covered entry.
-            double years_remaining = p.fb_period;
-            int32_t k_full = n;        // entries [k_full, n) enter whole
-            double part_w = 0.0;       // weight of entry k_full - 1, if partially covered
-            bool part = false;
-            for (int32_t k = n - 1; k >= 0; --k) {
-                if (years_remaining <= 0.0) break;
-                const double dt = bounds[k + 1] - bounds[k];
-                if (dt <= years_remaining) {
-                    k_full = k;
-                    years_remaining -= dt;
-                } else {
-                    part = true;
-                    part_w = years_remaining / dt;
-                    years_remaining = 0.0;
-                }
-            }
-            // Phase 2: the same newest-to-oldest summation as the reference, with a trip count
-            // known up front so the loads pipeline.
+            // The window of adjusted_ecs() depends only on the time axis and the (uniform)
+            // feedback_cumt_period: the host walked it once per year (rscm_gpu.cpp, udeb_window):
+            // entries [k_full, n) enter whole, entry k_full-1 with weight part_w if part_w > 0.
+            // Summation runs newest to oldest like the reference; the trip count is uniform, so
+            // the coalesced history loads pipeline.
+            const int32_t k_full = a.win_kfull[n];
+            const double part_w = a.win_partw[n];
             double sum = 0.0;
             const double* hcol = a.hist + i;
 #pragma unroll 8
             for (int32_t k = n - 1; k >= k_full; --k) sum += hcol[(size_t)k * N];
-            if (part) sum += hcol[(size_t)(k_full - 1) * N] * part_w;
+            if (part_w > 0.0) sum += hcol[(size_t)(k_full - 1) * N] * part_w;
             cum_t = sum;
         }
         const double cumt_2x = p.ecs * p.fb_period;
