@@ -273,29 +273,35 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
         cp[0] = qdiv(c0, b0, r);
         dp[0] = qdiv(d0, b0, r);
     }
-    // ---- interior rows and the bottom row: forward sweep
+    // ---- interior rows and the bottom row: forward sweep.  Row-invariant products are hoisted
+    // in the reference's own association ((pi*tul)*T0, (dt/dz)*dw), and kappas[i-1]/(dz*dz)*dt of
+    // row i is the value row i-1 already formed as its "down" term.
     const double term_upwell_layer = qdiv(w, dz, g.r_dz) * dt;
+    const double pi_tul_t0 = pi_ratio * term_upwell_layer * t_top;
+    const double dtdz_dw = dt_per_dz * dwv;
+    const double dtdz_dw_tp = dtdz_dw * t_polar;
+    double tdu = qdiv(kap_prev, g.dz_dz1, g.r_dz_dz1) * dt;  // row 1: dz_up = dz/2
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
         const double t_i = dp[i];
-        const double term_diff_up = (i == 1 ? qdiv(kap_prev, g.dz_dz1, g.r_dz_dz1) : qdiv(kap_prev, g.dz_dz, g.r_dz_dz)) * dt;
         double ai, bi, ci, di;
         if (i < NL - 1) {
             const double kap = kappa_at(i);
-            const double term_diff_down = qdiv(kap, g.dz_dz, g.r_dz_dz) * dt;
-            ai = -term_diff_up * af_top[i];
-            bi = 1.0 + term_diff_up * af_top[i] + term_diff_down * af_bot[i] + term_upwell_layer * af_top[i];
-            ci = -(term_diff_down + term_upwell_layer) * af_bot[i];
-            di = t_i + pi_ratio * term_upwell_layer * t_top * af_diff[i];
-            di += dt_per_dz * dwv * (init[i + 1] * af_bot[i] - init[i] * af_top[i]);
-            di += dt_per_dz * dwv * t_polar * af_diff[i];
-            kap_prev = kap;
+            const double tdd = qdiv(kap, g.dz_dz, g.r_dz_dz) * dt;
+            const double tdu_aft = tdu * af_top[i];
+            ai = -tdu_aft;
+            bi = 1.0 + tdu_aft + tdd * af_bot[i] + term_upwell_layer * af_top[i];
+            ci = -(tdd + term_upwell_layer) * af_bot[i];
+            di = t_i + pi_tul_t0 * af_diff[i];
+            di += dtdz_dw * (init[i + 1] * af_bot[i] - init[i] * af_top[i]);
+            di += dtdz_dw_tp * af_diff[i];
+            tdu = tdd;
         } else {
-            ai = -term_diff_up * af_top[i];
-            bi = 1.0 + (term_diff_up + term_upwell_layer) * af_top[i];
+            ai = -tdu * af_top[i];
+            bi = 1.0 + (tdu + term_upwell_layer) * af_top[i];
             ci = 0.0;
-            di = t_i + pi_ratio * term_upwell_layer * t_top * af_top[i];
-            di += dt_per_dz * dwv * (t_polar - init[i]) * af_top[i];
+            di = t_i + pi_tul_t0 * af_top[i];
+            di += dtdz_dw * (t_polar - init[i]) * af_top[i];
         }
         const double denom = bi - ai * cp[i - 1];
         const double r = refined_rcp(denom);
