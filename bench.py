@@ -185,6 +185,8 @@ def main():
     backend = os.environ.get("RSCM_BENCH_BACKEND", "nccl")
     if "RSCM_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["RSCM_BENCH_DEVICE"])
+    if local_rank >= torch.cuda.device_count():  # launcher exposes one GPU per rank as device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":

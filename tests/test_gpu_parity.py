@@ -620,3 +620,44 @@ def test_minimal_axis_single_step(ra, orc):
         assert_bit_equal(ts, want[0])
         assert_bit_equal(td, want[1])
         assert ts.shape == (2, n)
+
+
+def test_external_stream_and_async_run(ra, orc, tmp_path):
+    """rscm_ens_set_stream with a caller-owned HIP stream (torch's), rscm_ens_run_async + sync,
+    HIP-event timing of the launch; results identical to the default path.  Runs in a fresh
+    process that imports torch FIRST: torch bundles its own HIP runtime, and a process must not
+    initialise two of them (bench.py imports torch first for the same reason)."""
+    import subprocess
+    import sys
+    t = axis_values(1750, 1900)
+    P, F = two_layer_params(5000), f_syn(t)
+    want = _tl_gpu(ra, t, P, F, 0.0, 0.0)
+    np.savez(tmp_path / "in.npz", t=t, P=P, F=F)
+    code = f"""
+import sys, numpy as np, torch
+assert torch.cuda.is_available()
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import rscm_amd
+d = np.load({str(tmp_path / 'in.npz')!r})
+t, P, F = d['t'], d['P'], d['F']
+b = np.append(t, t[-1] + 1.0)
+stream = torch.cuda.Stream()
+with rscm_amd.Ensemble(rscm_amd.KIND_TWO_LAYER, 5000, b) as e:
+    e.set_stream(stream.cuda_stream)
+    e.set_params(P); e.set_forcing(F); e.set_initial(1, 0.0); e.set_initial(2, 0.0)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream); e.run(sync=False); ev1.record(stream)
+    e.sync(); torch.cuda.synchronize()
+    assert e.finished()
+    assert 0.0 < e.last_run_ms() <= ev0.elapsed_time(ev1) + 0.05, (e.last_run_ms(), ev0.elapsed_time(ev1))
+    ts = e.get_series(1)
+    e.set_stream(None)
+    e.rewind(); e.run()
+    td = e.get_series(2)
+np.savez({str(tmp_path / 'out.npz')!r}, ts=ts, td=td)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = np.load(tmp_path / "out.npz")
+    assert_bit_equal(out["ts"], want[0])
+    assert_bit_equal(out["td"], want[1])
