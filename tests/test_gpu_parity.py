@@ -661,3 +661,45 @@ np.savez({str(tmp_path / 'out.npz')!r}, ts=ts, td=td)
     out = np.load(tmp_path / "out.npz")
     assert_bit_equal(out["ts"], want[0])
     assert_bit_equal(out["td"], want[1])
+
+
+def test_handle_churn_does_not_leak(ra):
+    """300 create/configure/run/destroy cycles (all three kinds) leave device memory where it was."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free0, total = C.c_size_t(), C.c_size_t()
+    t = axis_values(1750, 1770)
+    b = np.append(t, t[-1] + 1.0)
+
+    def cycle(kind):
+        n = 4096
+        with ra.Ensemble(kind, n, b) as e:
+            if kind == ra.KIND_TWO_LAYER:
+                e.set_params(two_layer_params(n))
+                e.set_forcing(f_syn(t))
+                e.set_initial(1, 0.0)
+                e.set_initial(2, 0.0)
+            elif kind == ra.KIND_COUPLED:
+                e.set_params(coupled_params(n))
+                e.set_forcing(emissions_syn(t))
+                for k, v in CP_INIT.items():
+                    e.set_initial(k, v)
+            else:
+                from rscm_amd import _lib
+                e.set_params(np.repeat(np.array(_lib.UD_DEFAULTS, dtype=float)[:, None], n, axis=1))
+                e.set_forcing(f_syn(t))
+                for v in (1, 2, 3, 4):
+                    e.set_initial(v, 0.0)
+            e.run()
+            e.loglik([1], [5], [0.0], [1.0])
+            e.summary(1, 5)
+
+    for kind in (ra.KIND_TWO_LAYER, ra.KIND_COUPLED, ra.KIND_UDEB):
+        cycle(kind)  # warm any lazy allocations
+    assert hip.hipMemGetInfo(C.byref(free0), C.byref(total)) == 0
+    for _ in range(100):
+        for kind in (ra.KIND_TWO_LAYER, ra.KIND_COUPLED, ra.KIND_UDEB):
+            cycle(kind)
+    free1 = C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free1), C.byref(total)) == 0
+    assert free0.value - free1.value < 64 << 20, (free0.value, free1.value)

@@ -178,3 +178,42 @@ def test_udeb_through_the_reference_shaped_front(ra, orc):
     with pytest.raises(ValueError, match="unknown field"):
         ClimateUDEBBuilder.from_parameters({"nope": 1.0})
     model.close()
+
+
+def test_udeb_model_runner_and_device_likelihood(ra, orc):
+    """The calibration front over the UDEB kind: ModelRunner varies ecs and kappa per member,
+    every other ClimateUDEB parameter stays at the builder's value; device log-likelihood equals
+    the host formula over the extracted outputs."""
+    from rscm_amd import calibrate as cal
+    from rscm_amd import core
+    from rscm_amd.magicc import ClimateUDEBBuilder
+    years = np.arange(1850.0, 1921.0)
+    axis = core.TimeAxis.from_values(years)
+    erf = np.where(years >= 1851.0, 3.71, 0.0)
+    b = (core.ModelBuilder().with_time_axis(axis)
+         .with_rust_component(ClimateUDEBBuilder.from_parameters({}).build())
+         .with_exogenous_variable("Effective Radiative Forcing",
+                                  core.Timeseries(erf, axis, "W/m^2", core.InterpolationStrategy.Previous))
+         .with_initial_values({"Surface Temperature": 0.0}))
+    runner = cal.ModelRunner(b, ["ecs", "kappa"], ["Sea Surface Temperature", "Heat Uptake"])
+    sets = np.column_stack([np.linspace(2.0, 5.0, 9), np.linspace(0.5, 1.5, 9)])
+    outs = runner.run_batch(sets)
+    assert len(outs) == 9
+    P = np.repeat(orc.udeb_default_params().reshape(-1, 1), 9, axis=1)
+    P[orc.UDEB_PARAM_NAMES.index("ecs")] = sets[:, 0]
+    P[orc.UDEB_PARAM_NAMES.index("kappa")] = sets[:, 1]
+    want, _ = orc.udeb_run(np.append(years, years[-1] + 1.0), P, erf)
+    for i, o in enumerate(outs):
+        assert 1850.0 not in o["Sea Surface Temperature"]  # index 0 is NaN -> skipped
+        got = np.array([o["Sea Surface Temperature"][float(y)] for y in years[1:]])
+        assert np.abs(got - want["sst"][1:, i]).max() <= RTOL * max(1.0, np.abs(want["sst"][1:, i]).max())
+    sst = np.array([outs[k]["Sea Surface Temperature"][1920.0] for k in range(9)])
+    assert np.all(np.diff(sst) > 0)  # higher ECS (and kappa) -> warmer after 70 years here
+    target = cal.Target()
+    for y in (1870.0, 1900.0, 1920.0):
+        target.add_observation("Sea Surface Temperature", y, outs[4]["Sea Surface Temperature"][y], 0.05)
+    lik = cal.GaussianLikelihood()
+    dev = runner.log_likelihood_batch(sets, target, lik)
+    host = np.array([lik.ln_likelihood(o, target) for o in outs])
+    assert np.allclose(dev, host, rtol=1e-12, atol=1e-12) and dev[4] == 0.0 and np.argmax(dev) == 4
+    runner.close()
