@@ -214,12 +214,13 @@ struct GeomRcp {
 };
 
 // One implicit sub-step of one hemisphere's column (ocean_column.rs step_hemisphere).
-// T is this member's column in HBM with stride N between layers.  Returns the new mixed-layer
-// temperature.
+// dp[] holds this member's column on entry (registers) and the new column on return; slot i
+// holds d'[i] in between, so the column and the d' array share registers.  Returns the new
+// mixed-layer temperature.
 template <int NL>
 __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp& g,
                                                   const double* tables, int32_t land_hc,
-                                                  double* __restrict__ T, int64_t N, int hemi,
+                                                  double (&dp)[NL], int hemi,
                                                   double forcing, double dt, double lambda_ocean,
                                                   double lambda_land, double hemi_hx, double ground_temp,
                                                   double land_temp, double alpha_eff, double w)
@@ -230,11 +231,6 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
     const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
     const double* init = tables + 4 * NL + (size_t)hemi * NL;  // initial profile
     const double dz = p.dz, dz_mix = p.dz_mix, pi_ratio = p.pi_ratio;
-    // the whole column is fetched up front (50 independent coalesced loads in flight at once);
-    // slot i later holds d'[i], so the column and the d' array share registers
-    double dp[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) dp[i] = T[(size_t)i * N];
     const double t_top = dp[0];
     const double t_bottom = dp[NL - 1];
     const double dkdt_dT = t_top - t_bottom;
@@ -308,21 +304,28 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
         if (i < NL - 1) cp[i] = qdiv(ci, denom, r);
         dp[i] = qdiv(di - ai * dp[i - 1], denom, r);
     }
-    // ---- back substitution, clamp, store
+    // ---- back substitution, clamp.  thomas_solve returns the unclamped vector; the state keeps
+    // min(x, max_temp)
     double x = dp[NL - 1];
-    T[(size_t)(NL - 1) * N] = fmin(x, p.max_temp);
+    dp[NL - 1] = fmin(x, p.max_temp);
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) {
         x = dp[i] - cp[i] * x;
-        T[(size_t)i * N] = fmin(x, p.max_temp);
+        dp[i] = fmin(x, p.max_temp);
     }
-    // thomas_solve returns the unclamped vector; the state keeps min(x, max_temp)
-    return fmin(x, p.max_temp);
+    return dp[0];
 }
 
 template <int NL>
 __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 {
+    // The two 50-layer columns never leave the chip during a launch: the active hemisphere is in
+    // registers (col[], shared with the solver's d' array), the other one is parked in this
+    // lane's LDS slots and the two are exchanged after every column solve.  25.6 KB of LDS per
+    // wavefront, each lane touches only its own slots (no barriers, no bank conflicts:
+    // consecutive lanes, consecutive 8-byte words).
+    __shared__ double park[NL][kUdebBlock];
+    const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kUdebBlock + threadIdx.x;
     if (i >= a.n_members) return;
     const int64_t N = a.n_members;
@@ -365,11 +368,12 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 
     // ---- internal state (ClimateUDEBState::new) or resume
     double up_nh, up_sh, land_nh, land_sh, gr_nh, gr_sh, ae_nh, ae_sh, hx_nh, hx_sh;
+    double col[NL];
     if (a.step_begin == 0) {
-#pragma unroll 1
+#pragma unroll
         for (int l = 0; l < NL; ++l) {
-            T_nh[(size_t)l * N] = 0.0;
-            T_sh[(size_t)l * N] = 0.0;
+            col[l] = 0.0;
+            park[l][lane] = 0.0;
         }
         up_nh = up_sh = p.w0;
         land_nh = land_sh = gr_nh = gr_sh = hx_nh = hx_sh = 0.0;
@@ -379,6 +383,11 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         up_nh = s[0 * N]; up_sh = s[1 * N]; land_nh = s[2 * N]; land_sh = s[3 * N];
         gr_nh = s[4 * N]; gr_sh = s[5 * N]; ae_nh = s[6 * N]; ae_sh = s[7 * N];
         hx_nh = s[8 * N]; hx_sh = s[9 * N];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            col[l] = T_nh[(size_t)l * N];
+            park[l][lane] = T_sh[(size_t)l * N];
+        }
     }
     const int32_t scen = a.scen ? a.scen[i] : 0;
     const double* F = a.erf + (size_t)scen * a.n_times;
@@ -404,9 +413,9 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         // warm start (mod.rs:436-446)
         {
             const double prev0 = st[0][r0];
-            if (T_nh[0] == 0.0 && prev0 != 0.0) {
-                T_nh[0] = prev0;
-                T_sh[0] = st[2][r0];
+            if (col[0] == 0.0 && prev0 != 0.0) {
+                col[0] = prev0;
+                park[0][lane] = st[2][r0];
                 land_nh = st[1][r0];
                 land_sh = st[3][r0];
                 gr_nh = land_nh;
@@ -468,10 +477,17 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 #pragma unroll 1
             for (int hemi = 0; hemi < 2; ++hemi) {
                 const bool sh = hemi != 0;
-                sst_pair[hemi] = step_hemisphere<NL>(p, g, tables, a.land_hc, sh ? T_sh : T_nh, N, hemi, sh ? f2 : f0,
+                sst_pair[hemi] = step_hemisphere<NL>(p, g, tables, a.land_hc, col, hemi, sh ? f2 : f0,
                                                      dt_sub, lam_o, lam_l, sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
                                                      sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
                                                      sh ? up_sh : up_nh);
+                // exchange the solved column with the parked hemisphere
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const double other = park[l][lane];
+                    park[l][lane] = col[l];
+                    col[l] = other;
+                }
             }
             const double sst_nh = sst_pair[0], sst_sh = sst_pair[1];
             const double t_air_nho = sst_to_air(p, sst_nh), t_air_sho = sst_to_air(p, sst_sh);
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
             }
         }
         // ---- end of year
-        const double sst_nh = T_nh[0], sst_sh = T_sh[0];
+        const double sst_nh = col[0], sst_sh = park[0][lane];
         const double air_nh = sst_to_air(p, sst_nh), air_sh = sst_to_air(p, sst_sh);
         ae_nh = fabs(sst_nh) < 1e-15 ? p.alpha : air_nh / sst_nh;
         ae_sh = fabs(sst_sh) < 1e-15 ? p.alpha : air_sh / sst_sh;
@@ -513,11 +529,11 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
             const double rho_c = kRhoSeawater * kCpSeawater;
             double total = 0.0;
             total += rho_c * p.dz_mix * sst_nh;
-#pragma unroll 1
-            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * T_nh[(size_t)l * N];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
             total += rho_c * p.dz_mix * sst_sh;
 #pragma unroll 1
-            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * T_sh[(size_t)l * N];
+            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * park[l][lane];
             a.ohc[r1] = total / 2.0;
         }
         a.st0[r1] = air_nh;
@@ -530,6 +546,12 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     s[0 * N] = up_nh; s[1 * N] = up_sh; s[2 * N] = land_nh; s[3 * N] = land_sh;
     s[4 * N] = gr_nh; s[5 * N] = gr_sh; s[6 * N] = ae_nh; s[7 * N] = ae_sh;
     s[8 * N] = hx_nh; s[9 * N] = hx_sh;
+    // the columns go back to HBM once per launch (rscm_ens_run resumes from them)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        T_nh[(size_t)l * N] = col[l];
+        T_sh[(size_t)l * N] = park[l][lane];
+    }
 }
 
 }  // namespace
