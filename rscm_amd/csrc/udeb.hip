@@ -200,109 +200,94 @@ __device__ __forceinline__ double land_temperature(const UdebP& p, double ocean_
     return fmin(numerator / denominator, p.max_temp);
 }
 
-// n / d with the reciprocal supplied (no window replay: tolerance-parity kernel).
-__device__ __forceinline__ double qdiv(double n, double d, double r) { return spec_div(n, d, r); }
-
-// Denominators that depend only on the (uniform) column geometry: reciprocals hoisted out of
-// the sub-step loop so each of the ~60 divisions per column solve costs 3 instructions.
-struct GeomRcp {
-    double dzmix_dz1, r_dzmix_dz1;  // dz_mix * (dz/2)
-    double dz_dz1, r_dz_dz1;        // dz * (dz/2)
-    double dz_dz, r_dz_dz;          // dz * dz
-    double r_dzmix, r_dz;           // 1/dz_mix, 1/dz
-    double c_mix, r_c_mix;          // mixed-layer heat capacity
+// Per-member geometry folded with this year's sub-step length, and everything else of a column
+// solve that only changes once a year (the lambdas come out of LAMCALC per year): the sub-step
+// loop is left with multiplies.  ClimateUDEB is a tolerance-parity kind (tests/test_gpu_udeb.py
+// states 1e-9 against the CPU oracle), so quotients by these denominators are products with a
+// refined reciprocal and sums of products are fused; the bit-exact two-layer kernel does neither.
+struct YearGeom {
+    double dt_dz, dt_dzmix, dt_cmix;        // dt/dz, dt/dz_mix, dt/c_mix
+    double dt_dz2, dt_dzdz1, dt_dzmixdz1;   // dt/(dz*dz), dt/(dz*dz/2), dt/(dz_mix*dz/2)
+    double kC, kdC, kminC;                  // kappa, dkappa/dT, kappa_min in m^2/yr
+    double fb[2];                           // (lambda_o + lambda_l*k_lo*amp*f_l/den) * dt/c_mix
+    double famp[2];                         // 1 + k_lo*f_l/den
+    double lhc[2];                          // k_lg * dt / (c_mix * f_o), land heat capacity only
 };
 
 // One implicit sub-step of one hemisphere's column (ocean_column.rs step_hemisphere).
 // dp[] holds this member's column on entry (registers) and the new column on return; slot i
 // holds d'[i] in between, so the column and the d' array share registers.  Returns the new
 // mixed-layer temperature.
+//
+// Row algebra relative to the reference (same tridiagonal system, regrouped):
+//   kappa_l    = max(omr[l]*(dkdt*C*(T0-Tbottom)) + kappa*C, kappa_min*C)
+//   b_i        = 1 + (tdu + tul)*af_top[i] + tdd*af_bot[i]
+//   d_i        = T_i + (pi*tul*T0)*af_diff[i] + (dt/dz*dw)*G[i]
+//   G[i]       = init[i+1]*af_bot[i] - init[i]*af_top[i] + T_polar*af_diff[i]   (host table)
+// and the Thomas recurrences with one refined reciprocal per row; c' is kept negated.
 template <int NL>
-__device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp& g,
+__device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom& y,
                                                   const double* tables, int32_t land_hc,
                                                   double (&dp)[NL], int hemi,
-                                                  double forcing, double dt, double lambda_ocean,
-                                                  double lambda_land, double hemi_hx, double ground_temp,
+                                                  double forcing, double hemi_hx, double ground_temp,
                                                   double land_temp, double alpha_eff, double w)
 {
     const double* af_top = tables;            // [NL]
     const double* af_bot = tables + NL;       // [NL]
     const double* af_diff = tables + 2 * NL;  // [NL]
     const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
-    const double* init = tables + 4 * NL + (size_t)hemi * NL;  // initial profile
-    const double dz = p.dz, dz_mix = p.dz_mix, pi_ratio = p.pi_ratio;
+    const double* G = tables + 4 * NL + (size_t)hemi * NL;  // profile-advection weights
+    const bool sh = hemi != 0;
     const double t_top = dp[0];
-    const double t_bottom = dp[NL - 1];
-    const double dkdt_dT = t_top - t_bottom;
-    const double kappa_min_m2yr = p.kappa_min * kDiffCm2sToM2yr;
-    auto kappa_at = [&](int l) -> double {
-        const double k = (omr[l] * p.kappa_dkdt * dkdt_dT + p.kappa) * kDiffCm2sToM2yr;
-        return fmax(k, kappa_min_m2yr);
-    };
-    const double c_mix = g.c_mix;
-    const double f_l_hemi = hemi == 0 ? p.nh_land / 2.0 : p.sh_land / 2.0;
-    const double f_o_hemi = 0.5 - f_l_hemi;
-    const double denominator = f_o_hemi * (p.k_lo + f_l_hemi * lambda_land);
-    const double term_feedback =
-        qdiv(alpha_eff, c_mix, g.r_c_mix) * (lambda_ocean + lambda_land * p.k_lo * p.amplify * f_l_hemi / denominator);
+    const double kslope = y.kdC * (t_top - dp[NL - 1]);
+    auto kappa_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope, y.kC), y.kminC); };
     const double delta_w = w - p.w0;
     // |delta_w| <= 1e-15: the reference skips the profile-advection terms; adding exact zeros is
     // the same thing without a branch per row
     const double dwv = fabs(delta_w) > 1e-15 ? delta_w : 0.0;
-    const double t_polar = 1.0;  // state.polar_sinking_temp
-    const double dt_per_dz = qdiv(dt, dz, g.r_dz);
 
-    double cp[NL];
-    // ---- row 0 (mixed layer)
-    double kap_prev = kappa_at(0);
-    {
-        const double term_diff = qdiv(kap_prev, g.dzmix_dz1, g.r_dzmix_dz1) * dt;
-        const double term_upwell = qdiv(w, dz_mix, g.r_dzmix) * dt;
-        const double forcing_amp = 1.0 + p.k_lo * f_l_hemi / denominator;
-        const double b0 = 1.0 + term_feedback * dt * af_top[0] + term_diff * af_bot[0] +
-                          term_upwell * pi_ratio * af_bot[0];
-        const double c0 = -(term_diff + term_upwell) * af_bot[0];
-        double d0 = t_top + qdiv(forcing * forcing_amp + hemi_hx, c_mix, g.r_c_mix) * dt * af_top[0];
-        if (land_hc) d0 -= p.k_lg * (land_temp - ground_temp) / (c_mix * f_o_hemi) * dt * af_top[0];
-        d0 += qdiv(dt, dz_mix, g.r_dzmix) * dwv * (init[1] - t_polar) * af_bot[0];
+    double ncp[NL];  // -c'
+    const double kap0 = kappa_at(0);
+    {   // ---- row 0 (mixed layer)
+        const double term_diff = kap0 * y.dt_dzmixdz1;
+        const double term_upwell = w * y.dt_dzmix;
+        const double tf = alpha_eff * (sh ? y.fb[1] : y.fb[0]);
+        const double b0 = __builtin_fma(tf, af_top[0],
+                                        __builtin_fma(__builtin_fma(term_upwell, p.pi_ratio, term_diff), af_bot[0], 1.0));
+        const double nc0 = (term_diff + term_upwell) * af_bot[0];
+        const double q = __builtin_fma(forcing, sh ? y.famp[1] : y.famp[0], hemi_hx) * y.dt_cmix;
+        double d0 = __builtin_fma(q, af_top[0], t_top);
+        if (land_hc) d0 = __builtin_fma(-(land_temp - ground_temp) * (sh ? y.lhc[1] : y.lhc[0]), af_top[0], d0);
+        d0 = __builtin_fma(y.dt_dzmix * dwv, G[0], d0);
         const double r = refined_rcp(b0);
-        cp[0] = qdiv(c0, b0, r);
-        dp[0] = qdiv(d0, b0, r);
+        ncp[0] = nc0 * r;
+        dp[0] = d0 * r;
     }
-    // ---- interior rows and the bottom row: forward sweep.  Row-invariant products are hoisted
-    // in the reference's own association ((pi*tul)*T0, (dt/dz)*dw), and kappas[i-1]/(dz*dz)*dt of
-    // row i is the value row i-1 already formed as its "down" term.
-    const double term_upwell_layer = qdiv(w, dz, g.r_dz) * dt;
-    const double pi_tul_t0 = pi_ratio * term_upwell_layer * t_top;
-    const double dtdz_dw = dt_per_dz * dwv;
-    const double dtdz_dw_tp = dtdz_dw * t_polar;
-    double tdu = qdiv(kap_prev, g.dz_dz1, g.r_dz_dz1) * dt;  // row 1: dz_up = dz/2
+    // ---- interior rows and the bottom row: forward sweep
+    const double tul = w * y.dt_dz;
+    const double s_afd = p.pi_ratio * tul * t_top;
+    const double dwq = y.dt_dz * dwv;
+    double tdu = kap0 * y.dt_dzdz1;  // row 1: dz_up = dz/2
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
         const double t_i = dp[i];
-        double ai, bi, ci, di;
+        const double tdu_aft = tdu * af_top[i];
+        double bi, di;
         if (i < NL - 1) {
-            const double kap = kappa_at(i);
-            const double tdd = qdiv(kap, g.dz_dz, g.r_dz_dz) * dt;
-            const double tdu_aft = tdu * af_top[i];
-            ai = -tdu_aft;
-            bi = 1.0 + tdu_aft + tdd * af_bot[i] + term_upwell_layer * af_top[i];
-            ci = -(tdd + term_upwell_layer) * af_bot[i];
-            di = t_i + pi_tul_t0 * af_diff[i];
-            di += dtdz_dw * (init[i + 1] * af_bot[i] - init[i] * af_top[i]);
-            di += dtdz_dw_tp * af_diff[i];
+            const double tdd = kappa_at(i) * y.dt_dz2;
+            bi = __builtin_fma(tdu + tul, af_top[i], __builtin_fma(tdd, af_bot[i], 1.0));
+            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_diff[i], t_i));
+            const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
+            const double r = refined_rcp(denom);
+            ncp[i] = (tdd + tul) * af_bot[i] * r;
+            dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * r;
             tdu = tdd;
         } else {
-            ai = -tdu * af_top[i];
-            bi = 1.0 + (tdu + term_upwell_layer) * af_top[i];
-            ci = 0.0;
-            di = t_i + pi_tul_t0 * af_top[i];
-            di += dtdz_dw * (t_polar - init[i]) * af_top[i];
+            bi = __builtin_fma(tdu + tul, af_top[i], 1.0);
+            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_top[i], t_i));
+            const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
+            dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
         }
-        const double denom = bi - ai * cp[i - 1];
-        const double r = refined_rcp(denom);
-        if (i < NL - 1) cp[i] = qdiv(ci, denom, r);
-        dp[i] = qdiv(di - ai * dp[i - 1], denom, r);
     }
     // ---- back substitution, clamp.  thomas_solve returns the unclamped vector; the state keeps
     // min(x, max_temp)
@@ -310,7 +295,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const GeomRcp&
     dp[NL - 1] = fmin(x, p.max_temp);
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) {
-        x = dp[i] - cp[i] * x;
+        x = __builtin_fma(ncp[i], x, dp[i]);
         dp[i] = fmin(x, p.max_temp);
     }
     return dp[0];
@@ -393,17 +378,7 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     const double* F = a.erf + (size_t)scen * a.n_times;
     const double steps = (double)a.steps_per_year;
     const double c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
-    GeomRcp g;
-    {
-        const double dz1 = p.dz / 2.0;
-        g.dzmix_dz1 = p.dz_mix * dz1; g.r_dzmix_dz1 = refined_rcp(g.dzmix_dz1);
-        g.dz_dz1 = p.dz * dz1;        g.r_dz_dz1 = refined_rcp(g.dz_dz1);
-        g.dz_dz = p.dz * p.dz;        g.r_dz_dz = refined_rcp(g.dz_dz);
-        g.r_dzmix = refined_rcp(p.dz_mix);
-        g.r_dz = refined_rcp(p.dz);
-        g.c_mix = heat_capacity_per_unit_area(p.dz_mix);
-        g.r_c_mix = refined_rcp(g.c_mix);
-    }
+    const double c_mix = heat_capacity_per_unit_area(p.dz_mix);
     const double* tables = a.tables;  // kernarg segment
     const double* __restrict__ bounds = a.bounds;
 
@@ -461,6 +436,28 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         else if (a.efficacy_apply == 2 && is_finite(co2_eff) && co2_eff > 0.0) { eff_mode = 2; }
         (void)eff_scale;
         const double ae_nh_y = ae_nh, ae_sh_y = ae_sh;  // alpha_eff is fixed for the year
+        YearGeom y;
+        {
+            const double dz1 = p.dz / 2.0;
+            y.dt_dz = dt_sub / p.dz;
+            y.dt_dzmix = dt_sub / p.dz_mix;
+            y.dt_cmix = dt_sub / c_mix;
+            y.dt_dz2 = dt_sub / (p.dz * p.dz);
+            y.dt_dzdz1 = dt_sub / (p.dz * dz1);
+            y.dt_dzmixdz1 = dt_sub / (p.dz_mix * dz1);
+            y.kC = p.kappa * kDiffCm2sToM2yr;
+            y.kdC = p.kappa_dkdt * kDiffCm2sToM2yr;
+            y.kminC = p.kappa_min * kDiffCm2sToM2yr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double f_l = (h == 0 ? p.nh_land : p.sh_land) / 2.0;
+                const double f_o = 0.5 - f_l;
+                const double den = f_o * (p.k_lo + f_l * lam_l);
+                y.fb[h] = (lam_o + lam_l * p.k_lo * p.amplify * f_l / den) * y.dt_cmix;
+                y.famp[h] = 1.0 + p.k_lo * f_l / den;
+                y.lhc[h] = a.land_hc ? p.k_lg * dt_sub / (c_mix * f_o) : 0.0;
+            }
+        }
         for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
             const double frac = (double)step_idx / steps;
             const double erf = erf_start + frac * (erf_end - erf_start);
@@ -477,8 +474,8 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 #pragma unroll 1
             for (int hemi = 0; hemi < 2; ++hemi) {
                 const bool sh = hemi != 0;
-                sst_pair[hemi] = step_hemisphere<NL>(p, g, tables, a.land_hc, col, hemi, sh ? f2 : f0,
-                                                     dt_sub, lam_o, lam_l, sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
+                sst_pair[hemi] = step_hemisphere<NL>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
+                                                     sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
                                                      sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
                                                      sh ? up_sh : up_nh);
                 // exchange the solved column with the parked hemisphere

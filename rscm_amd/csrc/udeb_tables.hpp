@@ -52,7 +52,12 @@ inline double ocean_area_at_depth(double depth_m, double depth_dependent_area)
     return 1.0 + depth_dependent_area * (hydro - 1.0);
 }
 
-// af_top[n] af_bot[n] af_diff[n] one_minus_rel[n] init_nh[n] init_sh[n]
+// af_top[n] af_bot[n] af_diff[n] one_minus_rel[n] G_nh[n] G_sh[n], where G folds the initial
+// profile and the polar sinking temperature (ClimateUDEBState::new: 1.0) into the weight the
+// profile-advection term of row l carries (ocean_column.rs step_hemisphere):
+//   G[0]     = (init[1] - T_polar) * af_bot[0]
+//   G[l]     = init[l+1]*af_bot[l] - init[l]*af_top[l] + T_polar*af_diff[l]      0 < l < n-1
+//   G[n-1]   = (T_polar - init[n-1]) * af_top[n-1]
 inline std::vector<double> udeb_tables(int n, double dz_mix, double dz, double depth_dependent_area)
 {
     std::vector<double> t(6 * (size_t)n, 0.0);
@@ -72,8 +77,15 @@ inline std::vector<double> udeb_tables(int n, double dz_mix, double dz, double d
         const double depth = dz_mix + (double)l * dz;
         t[3 * n + l] = 1.0 - depth / total_depth;
     }
-    for (int hemi = 0; hemi < 2; ++hemi)
-        for (int l = 0; l < n; ++l) t[(4 + hemi) * n + l] = l < 50 ? cmip5_profile(hemi)[l] : cmip5_profile(hemi)[49];
+    const double t_polar = 1.0;
+    for (int hemi = 0; hemi < 2; ++hemi) {
+        auto init = [&](int l) { return l < 50 ? cmip5_profile(hemi)[l] : cmip5_profile(hemi)[49]; };
+        double* G = &t[(4 + (size_t)hemi) * n];
+        const double *aft = &t[0], *afb = &t[n], *afd = &t[2 * (size_t)n];
+        G[0] = (init(1) - t_polar) * afb[0];
+        for (int l = 1; l < n - 1; ++l) G[l] = init(l + 1) * afb[l] - init(l) * aft[l] + t_polar * afd[l];
+        G[n - 1] = (t_polar - init(n - 1)) * aft[n - 1];
+    }
     return t;
 }
 
