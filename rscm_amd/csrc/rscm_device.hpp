@@ -63,7 +63,7 @@ struct CoupledArgs {
 // ClimateUDEB (rscm-magicc) over steps [step_begin, step_end).
 constexpr int kUdebBlock = 64;  // one wavefront per workgroup: ~250 VGPRs per lane
 constexpr int kUdebNParams = 37;
-constexpr int kUdebScalars = 10;
+constexpr int kUdebScalars = 11;
 
 struct UdebArgs {
     int64_t n_members;

@@ -102,7 +102,7 @@ struct rscm_ens {
 
     // ClimateUDEB internal state
     double* d_ocean = nullptr;    // [2][NL][N]
-    double* d_scal = nullptr;     // [10][N]
+    double* d_scal = nullptr;     // [kUdebScalars][N]
     double* d_hist = nullptr;     // [T][N]
     double* d_tables = nullptr;   // geometry tables
     double* d_bounds = nullptr;   // [T+1]

@@ -110,16 +110,53 @@ __device__ __forceinline__ bool invert_4x4(const double m[4][4], double inv[4][4
     return ok;
 }
 
-// climate/lamcalc.rs lamcalc(): secant-style iteration on lambda_ocean until the land/ocean
-// warming ratio matches RLO within 1e-3; only the last three iterates are ever read.
-__device__ __noinline__ LamResult lamcalc(const UdebP& p, double ecs)
+// Equilibrium box temperatures per unit forcing for one (lambda_ocean, lambda_land) pair the way
+// the reference forms them (lamcalc.rs: build the 4x4 exchange matrix, invert_4x4, multiply by
+// area*qfrac).  Used only for the lanes whose matrix is too close to singular for the direct
+// elimination below -- it keeps the reference's partial pivoting and its singularity verdict.
+__device__ __noinline__ bool lam_box_temps_general(const UdebP& p, double lam_o, double lam_l, double x[4])
 {
-    const double q = p.rf_2x, k_lo = p.k_lo, k_ns = p.k_ns, alpha = p.amplify;
-    const double lam = q / ecs;
-    const double fgosum = p.fgno + p.fgso, fglsum = p.fgnl + p.fgsl, fratio = fgosum / fglsum;
+    const double k_lo = p.k_lo, k_ns = p.k_ns, alpha = p.amplify;
     const double area[4] = {p.fgno, p.fgnl, p.fgso, p.fgsl};
     const double qfrac[4] = {p.q0, p.q1, p.q2, p.q3};
-    const double rf[4] = {p.rf0, p.rf1, p.rf2, p.rf3};
+    const double m[4][4] = {{p.fgno * lam_o + k_lo * alpha + k_ns, -k_lo, -k_ns, 0.0},
+                            {-k_lo * alpha, p.fgnl * lam_l + k_lo, 0.0, 0.0},
+                            {-k_ns, 0.0, p.fgso * lam_o + k_lo * alpha + k_ns, -k_lo},
+                            {0.0, 0.0, -k_lo * alpha, p.fgsl * lam_l + k_lo}};
+    double inv[4][4];
+    if (!invert_4x4(m, inv)) return false;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        double sum = 0.0;
+#pragma unroll
+        for (int col = 0; col < 4; ++col) sum += inv[row][col] * area[col] * qfrac[col];
+        x[row] = sum;
+    }
+    return true;
+}
+
+// climate/lamcalc.rs lamcalc(): secant-style iteration on lambda_ocean until the land/ocean
+// warming ratio matches RLO within 1e-3; only the last three iterates are ever read.
+//
+// The exchange matrix couples each land box to its own ocean box only,
+//     [ A0   -k   -n    0 ]        A0 = fgno*lam_o + k*a + n     k = k_lo, n = k_ns, a = amplify
+//     [-k*a   B1   0    0 ]        B1 = fgnl*lam_l + k
+//     [ -n    0    A2  -k ]        A2 = fgso*lam_o + k*a + n
+//     [  0    0  -k*a   B3]        B3 = fgsl*lam_l + k
+// so M x = v is solved by eliminating the two land rows and applying Cramer's rule to the 2x2
+// ocean system: ~40 flops and three reciprocals per iterate where the general inverse costs ~600
+// instructions.  Tolerance parity like the rest of this kernel; an ill-conditioned elimination
+// (small B1, B3 or determinant) takes the reference's pivoted inverse instead.
+__device__ __forceinline__ LamResult lamcalc(const UdebP& p, double ecs)
+{
+    const double q = p.rf_2x, k_lo = p.k_lo, k_ns = p.k_ns;
+    const double ka = k_lo * p.amplify, kka = k_lo * ka, nn = k_ns * k_ns, kan = ka + k_ns;
+    const double lam = q / ecs;
+    const double fgosum = p.fgno + p.fgso, fglsum = p.fgnl + p.fgsl, fratio = fgosum / fglsum;
+    const double fr_rlo = fratio / p.rlo;
+    const double r_fo = 1.0 / fgosum, r_fl = 1.0 / fglsum;
+    const double v0 = p.fgno * p.q0, v1 = p.fgnl * p.q1, v2 = p.fgso * p.q2, v3 = p.fgsl * p.q3;
+    const double kv1 = k_lo * v1, kv3 = k_lo * v3;
     // lamo[i-2], lamo[i-1], lamo[i]; diff likewise (arrays start zero-filled in the reference)
     double lamo_m2 = 0.0, lamo_m1 = lam, lamo_i = lam + 0.7;
     double diff_m2 = 0.0, diff_m1 = 0.0;
@@ -127,38 +164,39 @@ __device__ __noinline__ LamResult lamcalc(const UdebP& p, double ecs)
     int iflag = 0;
     LamResult out = {0.0, 0.0, 1.0, false};
     for (int i = 2; i <= 40; ++i) {
-        const double lam_l = lam + fratio * (lam - lamo_i) / p.rlo;
+        const double lam_l = __builtin_fma(fr_rlo, lam - lamo_i, lam);
         const double lam_o = lamo_i;
-        const double m[4][4] = {{p.fgno * lam_o + k_lo * alpha + k_ns, -k_lo, -k_ns, 0.0},
-                                {-k_lo * alpha, p.fgnl * lam_l + k_lo, 0.0, 0.0},
-                                {-k_ns, 0.0, p.fgso * lam_o + k_lo * alpha + k_ns, -k_lo},
-                                {0.0, 0.0, -k_lo * alpha, p.fgsl * lam_l + k_lo}};
-        double inv[4][4];
-        if (!invert_4x4(m, inv)) return out;
-        double temps[4];
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            double sum = 0.0;
-#pragma unroll
-            for (int col = 0; col < 4; ++col) sum += inv[row][col] * area[col] * qfrac[col];
-            temps[row] = q * sum;
+        const double A0 = __builtin_fma(p.fgno, lam_o, kan), A2 = __builtin_fma(p.fgso, lam_o, kan);
+        const double B1 = __builtin_fma(p.fgnl, lam_l, k_lo), B3 = __builtin_fma(p.fgsl, lam_l, k_lo);
+        const double r1 = refined_rcp(B1), r3 = refined_rcp(B3);
+        const double P = __builtin_fma(-kka, r1, A0), Q = __builtin_fma(-kka, r3, A2);
+        const double e0 = __builtin_fma(kv1, r1, v0), e2 = __builtin_fma(kv3, r3, v2);
+        const double pq = P * Q;
+        const double det = pq - nn;
+        double x[4];
+        const bool direct = fabs(B1) > 0.05 * k_lo && fabs(B3) > 0.05 * k_lo && fabs(det) > 0.01 * (fabs(pq) + nn);
+        if (__builtin_expect(direct, 1)) {
+            const double rd = refined_rcp(det);
+            x[0] = __builtin_fma(e0, Q, k_ns * e2) * rd;
+            x[2] = __builtin_fma(P, e2, k_ns * e0) * rd;
+            x[1] = __builtin_fma(ka, x[0], v1) * r1;
+            x[3] = __builtin_fma(ka, x[2], v3) * r3;
+        } else if (!lam_box_temps_general(p, lam_o, lam_l, x)) {
+            return out;
         }
-        const double ocean_mean = (p.fgno * temps[0] + p.fgso * temps[2]) / (p.fgno + p.fgso);
-        const double land_mean = (p.fgnl * temps[1] + p.fgsl * temps[3]) / (p.fgnl + p.fgsl);
+        const double t0 = q * x[0], t1 = q * x[1], t2 = q * x[2], t3 = q * x[3];
+        const double ocean_mean = __builtin_fma(p.fgno, t0, p.fgso * t2) * r_fo;
+        const double land_mean = __builtin_fma(p.fgnl, t1, p.fgsl * t3) * r_fl;
         const double diff_i = p.rlo - land_mean / ocean_mean;
         if (fabs(diff_i) < 0.001) {
             out.lam_o = lam_o;
             out.lam_l = lam_l;
             out.ok = true;
-            double rf_sum = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rf_sum += rf[k] * area[k];
+            const double rf_sum = p.rf0 * p.fgno + p.rf1 * p.fgnl + p.rf2 * p.fgso + p.rf3 * p.fgsl;
             if (fabs(rf_sum) <= 1e-15) {
                 out.eff = 1.0;
             } else {
-                double t_global = 0.0;
-#pragma unroll
-                for (int row = 0; row < 4; ++row) t_global += area[row] * temps[row];
+                const double t_global = p.fgno * t0 + p.fgnl * t1 + p.fgso * t2 + p.fgsl * t3;
                 out.eff = t_global / ecs;
             }
             return out;
@@ -354,6 +392,9 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     // ---- internal state (ClimateUDEBState::new) or resume
     double up_nh, up_sh, land_nh, land_sh, gr_nh, gr_sh, ae_nh, ae_sh, hx_nh, hx_sh;
     double col[NL];
+    // running window sum of the temperature history: entries [win_lo, n-1) after year n-1
+    double win_sum = 0.0, hist_last = 0.0;
+    int32_t win_lo = 0;
     if (a.step_begin == 0) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -368,6 +409,9 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         up_nh = s[0 * N]; up_sh = s[1 * N]; land_nh = s[2 * N]; land_sh = s[3 * N];
         gr_nh = s[4 * N]; gr_sh = s[5 * N]; ae_nh = s[6 * N]; ae_sh = s[7 * N];
         hx_nh = s[8 * N]; hx_sh = s[9 * N];
+        win_sum = s[10 * N];
+        win_lo = a.step_begin > 1 ? a.win_kfull[a.step_begin - 1] : 0;
+        hist_last = a.hist[(size_t)(a.step_begin - 1) * N + i];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             col[l] = T_nh[(size_t)l * N];
@@ -402,20 +446,23 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         // ---- time-varying ECS (adjusted_ecs) and the LAMCALC re-solve
         const double erf_mid = (erf_start + erf_end) / 2.0;
         double cum_t = 0.0;
-        if (n > 0 && p.fb_cumt != 0.0) {
+        if (n > 0) {
             // The window of adjusted_ecs() depends only on the time axis and the (uniform)
-            // feedback_cumt_period: the host walked it once per year (rscm_gpu.cpp, udeb_window):
-            // entries [k_full, n) enter whole, entry k_full-1 with weight part_w if part_w > 0.
-            // Summation runs newest to oldest like the reference; the trip count is uniform, so
-            // the coalesced history loads pipeline.
+            // feedback_cumt_period: the host walked it once per year (rscm_gpu.cpp): entries
+            // [k_full, n) enter whole, entry k_full-1 with weight part_w if part_w > 0.  The whole
+            // part is a running sum (last year's entry comes in from a register, the entries the
+            // window has moved past are read back and subtracted: 0-2 loads a year instead of a
+            // 300-year walk); the reference re-sums newest to oldest, which this matches to
+            // rounding.
             const int32_t k_full = a.win_kfull[n];
             const double part_w = a.win_partw[n];
-            double sum = 0.0;
             const double* hcol = a.hist + i;
-#pragma unroll 8
-            for (int32_t k = n - 1; k >= k_full; --k) sum += hcol[(size_t)k * N];
-            if (part_w > 0.0) sum += hcol[(size_t)(k_full - 1) * N] * part_w;
-            cum_t = sum;
+            win_sum += hist_last;
+            for (; win_lo < k_full; ++win_lo) win_sum -= hcol[(size_t)win_lo * N];
+            if (p.fb_cumt != 0.0) {
+                cum_t = win_sum;
+                if (part_w > 0.0) cum_t += hcol[(size_t)(k_full - 1) * N] * part_w;
+            }
         }
         const double cumt_2x = p.ecs * p.fb_period;
         const double cumt_factor = fabs(cumt_2x) > 1e-15 ? 1.0 + p.fb_cumt * (cum_t - cumt_2x) / cumt_2x : 1.0;
@@ -505,7 +552,8 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         ae_nh = fabs(sst_nh) < 1e-15 ? p.alpha : air_nh / sst_nh;
         ae_sh = fabs(sst_sh) < 1e-15 ? p.alpha : air_sh / sst_sh;
         const double global_temp = air_nh * p.fgno + land_nh * p.fgnl + air_sh * p.fgso + land_sh * p.fgsl;
-        a.hist[r0] = global_temp * dt_year;
+        hist_last = global_temp * dt_year;
+        a.hist[r0] = hist_last;
         double adj_end = erf_end;
         if (eff_mode == 1) adj_end = erf_end * p.prescribed_eff;
         else if (eff_mode == 2) adj_end = erf_end * p.prescribed_eff / co2_eff;
@@ -543,6 +591,7 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     s[0 * N] = up_nh; s[1 * N] = up_sh; s[2 * N] = land_nh; s[3 * N] = land_sh;
     s[4 * N] = gr_nh; s[5 * N] = gr_sh; s[6 * N] = ae_nh; s[7 * N] = ae_sh;
     s[8 * N] = hx_nh; s[9 * N] = hx_sh;
+    s[10 * N] = win_sum;
     // the columns go back to HBM once per launch (rscm_ens_run resumes from them)
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
