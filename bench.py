@@ -229,7 +229,12 @@ def main():
         w3, k3 = timed_passes(e3, 2, 1, torch, dist, 1, tstream)
         e3.close()
         extra["udeb_1e5"] = {"member_years_per_s": 100_000 * years * 2 / w3, "kernel_ms": k3,
-                             "hbm_frac": 19.2e3 * 100_000 * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             # 7 output rows + the history row written, ~1 history entry read back;
+                             # the ocean columns stay in registers/LDS for the whole launch
+                             "hbm_frac": 72.0 * 100_000 * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             # ~26.4e3 f64 VALU instructions per member-year (24 column solves of
+                             # ~1055 + LAMCALC + bookkeeping) against 39.3 T f64 lane-ops/s
+                             "fp64_valu_frac": 26.4e3 * 100_000 * years / (k3 * 1e-3) / 39.3e12}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -168,6 +168,9 @@ RSCM_API int rscm_gpu_abi_version(void);
 /* Thread-local text of the last error raised by any call on this thread ("" if none). */
 RSCM_API const char* rscm_gpu_last_error(void);
 RSCM_API int rscm_gpu_device_count(int32_t* out);
+/* Free and total HBM of `device_id` in bytes (sizing an ensemble against the 288 GB of an
+ * MI355X: docs in DESIGN.md give the bytes per member of each kind). */
+RSCM_API int rscm_gpu_mem_info(int32_t device_id, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 /* time_bounds has n_times+1 entries (TimeAxis.bounds, timeseries.rs:66-77) and must increase

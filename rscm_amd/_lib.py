@@ -56,6 +56,7 @@ SIGNATURES = {
     "rscm_gpu_abi_version": (C.c_int, []),
     "rscm_gpu_last_error": (C.c_char_p, []),
     "rscm_gpu_device_count": (C.c_int, [_ip]),
+    "rscm_gpu_mem_info": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rscm_ens_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.POINTER(_h)]),
     "rscm_ens_create_ex": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_uint32,
                                      C.POINTER(_h)]),
@@ -140,6 +141,13 @@ def device_count() -> int:
     n = C.c_int32(0)
     rc = load().rscm_gpu_device_count(C.byref(n))
     return n.value if rc == OK else 0
+
+
+def mem_info(device_id: int = 0):
+    """(free, total) bytes of HBM on ``device_id``."""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    check(load().rscm_gpu_mem_info(device_id, C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def f64(a) -> np.ndarray:

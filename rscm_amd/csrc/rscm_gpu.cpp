@@ -250,6 +250,21 @@ int rscm_gpu_device_count(int32_t* out)
     GUARD_END
 }
 
+int rscm_gpu_mem_info(int32_t device_id, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    GUARD_BEGIN
+    if (!free_bytes || !total_bytes) return fail(RSCM_ERR_INVALID, "output pointer is NULL");
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    size_t f = 0, t = 0;
+    e = hipMemGetInfo(&f, &t);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "hipMemGetInfo: %s", hipGetErrorString(e));
+    *free_bytes = (uint64_t)f;
+    *total_bytes = (uint64_t)t;
+    return RSCM_OK;
+    GUARD_END
+}
+
 int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
                     int32_t device_id, rscm_ens** out)
 {

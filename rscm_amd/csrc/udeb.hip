@@ -12,20 +12,28 @@
 //
 // A different kernel class from two_layer.hip: ~110 doubles of private state per member and a
 // serial tridiagonal recurrence per hemisphere and sub-step.  Layout and placement:
-//   * layer temperatures  ocean[hemi][layer][N]  in HBM, member fastest: each sweep reads and
-//     writes 50 coalesced rows (19.2 KB per member-year at 12 sub-steps) -- the HBM traffic
-//     that bounds the kernel together with the VALU work;
-//   * the Thomas work arrays c', d' (2 x 50 doubles) stay in registers (layer loops fully
-//     unrolled, NL is a template constant), the two hemispheres' independent recurrences give
-//     the scheduler two chains to interleave;
-//   * everything that depends only on the ocean geometry (area factors, 1 - relative depth,
-//     the CMIP5 initial profiles) is a uniform table read through the scalar cache;
-//   * the 14 scalar state values live in registers across the whole launch and are spilled to
-//     `scal[14][N]` only at the end (resume); the temperature history for the time-varying ECS is
-//     hist[T][N].
-// Divisions in the column use the refined-reciprocal quotient of rk4_device.hpp without the
-// exponent-window replay (both Thomas divisions of a row share one reciprocal): results agree
-// with the CPU oracle to rounding (tests/test_gpu_udeb.py states 1e-9), not bit for bit.
+//   * the two 50-layer columns stay on chip for the whole launch: the hemisphere being solved is
+//     in registers (shared with the Thomas d' array), the other one is parked in the lane's LDS
+//     slots (25.6 KB per wavefront) and the two are exchanged after every solve.  HBM sees the
+//     columns once at the start (resume) and once at the end: ocean[hemi][layer][N], member
+//     fastest.  Keeping them in HBM cost 19.2 KB of traffic per member-year and left the single
+//     resident wavefront per SIMD waiting on it (profiles/r1_udeb_5e4.txt, the earlier layout);
+//   * the Thomas work array c' (50 doubles) stays in registers (layer loops fully unrolled, NL is
+//     a template constant); one copy of the solver serves both hemispheres;
+//   * everything that depends only on the ocean geometry (area factors, 1 - relative depth, the
+//     profile-advection weights built from the CMIP5 initial profiles) is a uniform table in the
+//     kernel-argument segment, read through the scalar cache;
+//   * the scalar state values live in registers across the whole launch and go to
+//     `scal[kUdebScalars][N]` only at the end (resume); the temperature history for the
+//     time-varying ECS is hist[T][N], consumed through a running window sum.
+// Tolerance parity: quotients are products with refined reciprocals, sums of products are fused,
+// the row coefficients are regrouped (step_hemisphere) and LAMCALC solves its 4x4 system by
+// structured elimination.  Measured deviation from the CPU oracle over a 1024-member, 400-year
+// ensemble: 5e-14 relative (scripts/udeb_deviation.py); tests/test_gpu_udeb.py states 1e-9.
+// LAMCALC's convergence test and the |adjusted ECS - ECS| > 1e-10 switch are discontinuous in
+// their inputs, so a member sitting within rounding of one of those thresholds may take the
+// other branch than the reference for that year (an O(1e-3) relative change of lambda for one
+// year); no such member occurs in the test ensembles.
 #include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
