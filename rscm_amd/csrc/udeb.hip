@@ -324,9 +324,16 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
             bi = __builtin_fma(tdu + tul, af_top[i], __builtin_fma(tdd, af_bot[i], 1.0));
             di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_diff[i], t_i));
             const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
-            const double r = refined_rcp(denom);
-            ncp[i] = (tdd + tul) * af_bot[i] * r;
-            dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * r;
+            // 1/denom = r0 (1 + e + e^2 + ...), e = 1 - denom*r0: the hardware estimate is good
+            // to ~2^-23, so the series cut after e^2 is exact to rounding, and the c' chain that
+            // feeds the next row's denominator is five dependent operations instead of seven
+            const double r0 = __builtin_amdgcn_rcp(denom);
+            const double e = __builtin_fma(-denom, r0, 1.0);
+            const double u = __builtin_fma(e, e, e);
+            const double t = (tdd + tul) * af_bot[i] * r0;
+            ncp[i] = __builtin_fma(t, u, t);
+            const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
+            dp[i] = __builtin_fma(sdp, u, sdp);
             tdu = tdd;
         } else {
             bi = __builtin_fma(tdu + tul, af_top[i], 1.0);
