@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
@@ -57,6 +57,14 @@ def lib() -> C.CDLL:
         L.orc_udeb_default_params.restype = None
         L.orc_udeb_run.argtypes = [C.c_int64, C.c_int32, _dp, _dp, C.c_int32, _dp, _ip, _dp] + [_dp] * 7 + \
                                   [_ip, C.c_int64, C.c_int64]
+        L.orc_ghg_n_params.restype = C.c_int32
+        L.orc_ghg_default_params.argtypes = [_dp]
+        L.orc_ghg_default_params.restype = None
+        L.orc_ghg_forcings.argtypes = [_dp, C.c_double, C.c_double, C.c_double, _dp]
+        L.orc_ghg_forcings.restype = None
+        L.orc_ghg_run.argtypes = [C.c_int64, C.c_int32, _dp, C.c_int32, _dp, _ip, _dp, _dp, _dp,
+                                  C.c_int64, C.c_int64]
+        L.orc_ghg_run.restype = None
         L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
         L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
@@ -271,3 +279,47 @@ def udeb_area_factors(params):
 
 def udeb_sst_to_air(params, sst):
     return lib().orc_udeb_sst_to_air(_d(_f64(params)), sst)
+
+
+# ---------------------------------------------------------------------------- GhgForcing
+GHG_PARAM_NAMES = ("method", "co2_pi", "ch4_pi", "n2o_pi", "delq2xco2", "ch4_radeff", "n2o_radeff",
+                   "olbl_co2_a1", "olbl_co2_b1", "olbl_co2_c1", "olbl_co2_d1",
+                   "olbl_ch4_a3", "olbl_ch4_b3", "olbl_ch4_d3",
+                   "olbl_n2o_a2", "olbl_n2o_b2", "olbl_n2o_c2", "olbl_n2o_d2",
+                   "adjust_co2", "adjust_ch4", "adjust_n2o")
+GHG_VARS = ("co2_erf", "ch4_erf", "n2o_erf")
+GHG_METHODS = {"Ipcctar": 0.0, "Olbl": 1.0}
+
+
+def ghg_default_params(**over) -> np.ndarray:
+    """GhgForcingParameters::default() as the 21-entry vector; ``method`` may be a name."""
+    p = np.empty(lib().orc_ghg_n_params())
+    lib().orc_ghg_default_params(_d(p))
+    for k, v in over.items():
+        p[GHG_PARAM_NAMES.index(k)] = GHG_METHODS[v] if isinstance(v, str) else v
+    return p
+
+
+def ghg_forcings(params, co2, ch4, n2o):
+    out = np.empty(3)
+    lib().orc_ghg_forcings(_d(_f64(params)), co2, ch4, n2o, _d(out))
+    return dict(zip(GHG_VARS, out))
+
+
+def ghg_run(n_times, params, conc, *, scen=None, threads=1):
+    """params [21][N]; conc [S][3][T] (CO2, CH4, N2O).  Returns dict of [T][N]; row 0 is NaN."""
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    conc = _f64(conc)
+    if conc.ndim == 2:
+        conc = conc[None]
+    assert conc.shape[1:] == (3, n_times)
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    out = {k: np.full((n_times, N), np.nan) for k in GHG_VARS}
+    L = lib()
+    _pmap(lambda i0, i1: L.orc_ghg_run(N, n_times, _d(params), conc.shape[0], _d(conc), _i(scen),
+                                       *[_d(out[k]) for k in GHG_VARS], i0, i1), N, threads)
+    return out
