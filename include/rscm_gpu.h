@@ -72,6 +72,7 @@ extern "C" {
 #define RSCM_KIND_COUPLED 1   /* CarbonCycle -> CO2ERF -> Sum aggregate -> TwoLayer             */
 
 #define RSCM_KIND_UDEB 2      /* rscm-magicc ClimateUDEB (4-box upwelling-diffusion EBM)          */
+#define RSCM_KIND_GHG_FORCING 3 /* rscm-magicc GhgForcing (CO2/CH4/N2O concentrations -> ERF)     */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -97,6 +98,38 @@ extern "C" {
 #define RSCM_UD_VAR_HEAT_UPTAKE 5  /* "Heat Uptake"              (output)                       */
 #define RSCM_UD_VAR_OHC 6          /* "Ocean Heat Content"       (output)                       */
 #define RSCM_UD_VAR_SST 7          /* "Sea Surface Temperature"  (output)                       */
+
+/* GhgForcing (crates/rscm-magicc/src/forcing/ghg.rs:69-83).  The shared input of this kind is a
+ * block of three rows per scenario, series[n_scen][3][n_times]: "Atmospheric Concentration|CO2"
+ * (ppm), "...|CH4" (ppb), "...|N2O" (ppb). */
+#define RSCM_GH_VAR_CONC 0     /* the three concentration rows (input, [S][3][T] shared)         */
+#define RSCM_GH_VAR_ERF_CO2 1  /* "Effective Radiative Forcing|CO2" (output)                     */
+#define RSCM_GH_VAR_ERF_CH4 2  /* "Effective Radiative Forcing|CH4" (output)                     */
+#define RSCM_GH_VAR_ERF_N2O 3  /* "Effective Radiative Forcing|N2O" (output)                     */
+/* GhgForcing parameter rows (P = 21): GhgForcingParameters field order
+ * (crates/rscm-magicc/src/parameters/ghg_forcing.rs); method 0 = Ipcctar, 1 = Olbl, [u] uniform. */
+#define RSCM_GH_NPARAMS 21
+#define RSCM_GH_P_METHOD 0      /* [u] */
+#define RSCM_GH_P_CO2_PI 1
+#define RSCM_GH_P_CH4_PI 2
+#define RSCM_GH_P_N2O_PI 3
+#define RSCM_GH_P_DELQ2XCO2 4
+#define RSCM_GH_P_CH4_RADEFF 5
+#define RSCM_GH_P_N2O_RADEFF 6
+#define RSCM_GH_P_OLBL_CO2_A1 7
+#define RSCM_GH_P_OLBL_CO2_B1 8
+#define RSCM_GH_P_OLBL_CO2_C1 9
+#define RSCM_GH_P_OLBL_CO2_D1 10
+#define RSCM_GH_P_OLBL_CH4_A3 11
+#define RSCM_GH_P_OLBL_CH4_B3 12
+#define RSCM_GH_P_OLBL_CH4_D3 13
+#define RSCM_GH_P_OLBL_N2O_A2 14
+#define RSCM_GH_P_OLBL_N2O_B2 15
+#define RSCM_GH_P_OLBL_N2O_C2 16
+#define RSCM_GH_P_OLBL_N2O_D2 17
+#define RSCM_GH_P_ADJUST_CO2 18
+#define RSCM_GH_P_ADJUST_CH4 19
+#define RSCM_GH_P_ADJUST_N2O 20
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
@@ -198,7 +231,8 @@ RSCM_API int rscm_ens_set_step_size(rscm_ens* h, int32_t component, double step)
 RSCM_API int rscm_ens_set_params(rscm_ens* h, const double* soa);
 /* [N][P] row-major, the shape ModelRunner::run_batch receives (&[Vec<f64>]). */
 RSCM_API int rscm_ens_set_params_aos(rscm_ens* h, const double* aos);
-/* Shared input series already on the model axis: series[n_scen][n_times];
+/* Shared input series already on the model axis: series[n_scen][n_times]
+ * (RSCM_KIND_GHG_FORCING: series[n_scen][3][n_times], see RSCM_GH_VAR_CONC);
  * scenario_of_member[N] or NULL (all members use scenario 0). */
 RSCM_API int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const double* series,
                          const int32_t* scenario_of_member, int32_t source);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librscm_gpu.so")
 
 OK, ERR_INVALID, ERR_STATE, ERR_TIME_AXIS, ERR_DEVICE, ERR_NOMEM = range(6)
-KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB = 0, 1, 2
+KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB, KIND_GHG_FORCING = 0, 1, 2, 3
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -45,6 +45,21 @@ UD_PARAM_NAMES = (
 UD_DEFAULTS = (50, 60.0, 100.0, 0.75, 0.1, -0.191, 3.5, 0.7, 8.0, 8.0, 3.0, 3.71, 1.317, 7.84e-9, 0.08,
                300.0, 1.44, 0.31, 1.02, 0.42, 0.21, 1.0, 1.04, -0.002, 0.2, 1.0, 0.1, 300.0,
                1.4089, 1.37045, 1.43333, 1.33257, 0.0, 1.0, 2.0, 12.0, 25.0)
+
+# GhgForcing (crates/rscm-magicc/src/forcing/ghg.rs:69-83): variable 0 is the block of the three
+# concentration rows GH_INPUTS, [S][3][T]
+GH_INPUTS = ("Atmospheric Concentration|CO2", "Atmospheric Concentration|CH4", "Atmospheric Concentration|N2O")
+GH_VARS = {"Atmospheric Concentration": 0, "Effective Radiative Forcing|CO2": 1,
+           "Effective Radiative Forcing|CH4": 2, "Effective Radiative Forcing|N2O": 3}
+GH_PARAM_NAMES = ("method", "co2_pi", "ch4_pi", "n2o_pi", "delq2xco2", "ch4_radeff", "n2o_radeff",
+                  "olbl_co2_a1", "olbl_co2_b1", "olbl_co2_c1", "olbl_co2_d1",
+                  "olbl_ch4_a3", "olbl_ch4_b3", "olbl_ch4_d3",
+                  "olbl_n2o_a2", "olbl_n2o_b2", "olbl_n2o_c2", "olbl_n2o_d2",
+                  "adjust_co2", "adjust_ch4", "adjust_n2o")
+GH_METHODS = {"Ipcctar": 0.0, "Olbl": 1.0}
+# GhgForcingParameters::default() (crates/rscm-magicc/src/parameters/ghg_forcing.rs)
+GH_DEFAULTS = (1.0, 278.0, 722.0, 270.0, 3.71, 0.036, 0.12, -2.4785e-7, 7.5906e-4, -2.1492e-3, 5.2,
+               -8.9603e-5, -1.2462e-4, 0.045, -3.4197e-4, 2.5455e-4, -2.4357e-4, 0.14, 1.05, 0.86, 1.0)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

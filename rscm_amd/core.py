@@ -371,6 +371,7 @@ class ComponentBuilder:
 
 # ------------------------------------------------------------------------------------ builder
 SUPPORTED = ("[ClimateUDEB] with exogenous 'Effective Radiative Forcing'",
+             "[GhgForcing] with the three exogenous 'Atmospheric Concentration|CO2/CH4/N2O' series",
              "[TwoLayer] with exogenous or upstream 'Effective Radiative Forcing'",
              "[CarbonCycle, CO2ERF, TwoLayer] + Sum aggregate 'Effective Radiative Forcing' "
              "over ['Effective Radiative Forcing|CO2'] (registration order as listed)")
@@ -509,6 +510,13 @@ class ModelBuilder:
             src = L.SRC_EXOGENOUS
             params = self._components[0].param_vector()
             h = {}
+        elif types == ["GhgForcing"] and not aggregates:
+            kind = L.KIND_GHG_FORCING
+            rows = [self._exogenous_on_axis(name, exo_names) for name in L.GH_INPUTS]
+            forcing = np.stack([np.full(len(self._axis), NAN) if r is None else r for r in rows])
+            src = L.SRC_EXOGENOUS
+            params = self._components[0].param_vector()
+            h = {}
         else:
             raise NotImplementedError(
                 f"component graph {types} (aggregates {list(aggregates)}) has no fused GPU kernel; "
@@ -528,7 +536,7 @@ class ModelBuilder:
                 # a FourBox state initialised with one scalar sets all four regions (builder.rs:797-804)
                 ens.set_initial(vid, self._initial[name.split("|")[0]])
         param_order = {L.KIND_TWO_LAYER: TL_PARAM_ORDER, L.KIND_COUPLED: CP_PARAM_ORDER,
-                       L.KIND_UDEB: L.UD_PARAM_NAMES}[kind]
+                       L.KIND_UDEB: L.UD_PARAM_NAMES, L.KIND_GHG_FORCING: L.GH_PARAM_NAMES}[kind]
         return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
                      np.array(params, dtype=np.float64))
 
@@ -579,6 +587,11 @@ class Model:
             coll.add_fourbox_timeseries("Surface Temperature", FourBoxTimeseries(boxes, self._axis, "K"))
         for name, vid in self.ensemble.var_ids.items():
             if self.ensemble.kind == L.KIND_UDEB and 1 <= vid <= 4:
+                continue
+            if vid == 0 and self.ensemble.kind == L.KIND_GHG_FORCING:
+                for k, input_row in enumerate(L.GH_INPUTS):  # the input block holds three series
+                    coll.add_timeseries(input_row, Timeseries(self._forcing[k], self._axis, "",
+                                                              InterpolationStrategy.Linear), VariableType.Exogenous)
                 continue
             if vid == 0:
                 vals, vt = self._forcing, VariableType.Exogenous

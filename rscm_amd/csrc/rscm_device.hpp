@@ -88,6 +88,27 @@ struct UdebArgs {
     uint8_t* status;        // [N]
 };
 
+// GhgForcing: scenario table rows built by the host (rscm_gpu.cpp, ghg_tables), [S][kGhgRows][T]
+enum GhgRow {
+    kGhgCo2 = 0, kGhgLnCo2, kGhgSqrtCo2, kGhgSqrtCh4, kGhgSqrtN2o,
+    kGhgCh4P75, kGhgCh4TimesP152,  // CH4^0.75, CH4 * CH4^1.52
+    kGhgN2oP75, kGhgN2oP152,       // N2O^0.75, N2O^1.52
+    kGhgRows
+};
+
+struct GhgArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t rows;            // stored rows per series (T)
+    int32_t method;          // 0 = IPCCTAR, 1 = OLBL (uniform over the ensemble)
+    const double* params;    // [21][N]
+    const double* tables;    // [S][kGhgRows][T]
+    const int32_t* scen;     // [N] or null
+    double* erf_co2; double* erf_ch4; double* erf_n2o;  // [T][N] each
+    uint8_t* status;
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -103,6 +124,7 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
+hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

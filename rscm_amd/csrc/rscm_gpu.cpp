@@ -77,6 +77,31 @@ bool rk4_schedule(const std::vector<double>& bounds, double h, std::vector<int32
 
 }  // namespace
 
+// GhgForcing: everything that depends on the concentrations alone, once per scenario and year
+// (forcing/ghg.rs:119-269 evaluates these per call; csrc/ghg.hip documents the factorisation).
+// conc is [S][3][T] (CO2, CH4, N2O); the result [S][kGhgRows][T].
+static std::vector<double> ghg_tables(const double* conc, int32_t n_scen, int32_t T)
+{
+    std::vector<double> t((size_t)n_scen * rscm::kGhgRows * T);
+    for (int32_t s = 0; s < n_scen; ++s) {
+        const double* c = conc + (size_t)s * 3 * T;
+        double* o = t.data() + (size_t)s * rscm::kGhgRows * T;
+        for (int32_t n = 0; n < T; ++n) {
+            const double co2 = c[n], ch4 = c[(size_t)T + n], n2o = c[(size_t)2 * T + n];
+            o[(size_t)rscm::kGhgCo2 * T + n] = co2;
+            o[(size_t)rscm::kGhgLnCo2 * T + n] = std::log(co2);
+            o[(size_t)rscm::kGhgSqrtCo2 * T + n] = std::sqrt(co2);
+            o[(size_t)rscm::kGhgSqrtCh4 * T + n] = std::sqrt(ch4);
+            o[(size_t)rscm::kGhgSqrtN2o * T + n] = std::sqrt(n2o);
+            o[(size_t)rscm::kGhgCh4P75 * T + n] = std::pow(ch4, 0.75);
+            o[(size_t)rscm::kGhgCh4TimesP152 * T + n] = ch4 * std::pow(ch4, 1.52);
+            o[(size_t)rscm::kGhgN2oP75 * T + n] = std::pow(n2o, 0.75);
+            o[(size_t)rscm::kGhgN2oP152 * T + n] = std::pow(n2o, 1.52);
+        }
+    }
+    return t;
+}
+
 struct rscm_ens {
     int32_t kind = 0;
     int64_t N = 0;
@@ -94,7 +119,10 @@ struct rscm_ens {
 
     double* d_params = nullptr;  // [P][N]
     double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
-    double* d_forcing = nullptr; // [S][T]
+    double* d_forcing = nullptr; // [S][n_inputs][T]
+    int32_t n_inputs = 1;        // rows per scenario of the shared input block
+    double* d_ghg_tables = nullptr;  // GhgForcing: [S][kGhgRows][T] derived scenario rows
+    int32_t ghg_method = 1;
     int32_t* d_scen = nullptr;   // [N] or null
     int32_t n_scen = 0;
     int32_t source = RSCM_SRC_EXOGENOUS;
@@ -130,6 +158,7 @@ struct rscm_ens {
     {
         if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
         if (kind == RSCM_KIND_UDEB) return var >= RSCM_UD_VAR_ST_NH_OCEAN && var <= RSCM_UD_VAR_ST_SH_LAND;
+        if (kind == RSCM_KIND_GHG_FORCING) return false;  // a stateless component
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
 };
@@ -145,6 +174,10 @@ int set_device(const rscm_ens* h)
 int refresh_schedule(rscm_ens* h)
 {
     if (!h->schedule_dirty) return RSCM_OK;
+    if (h->kind != RSCM_KIND_TWO_LAYER && h->kind != RSCM_KIND_COUPLED) {  // no RK4 component
+        h->schedule_dirty = false;
+        return RSCM_OK;
+    }
     int32_t bad = -1;
     if (!rk4_schedule(h->bounds, h->h_tl, h->nsub_tl, &bad))
         return fail(RSCM_ERR_TIME_AXIS,
@@ -280,7 +313,8 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED && kind != RSCM_KIND_UDEB)
+    if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED && kind != RSCM_KIND_UDEB &&
+        kind != RSCM_KIND_GHG_FORCING)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -297,8 +331,10 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->T = n_times;
     h->rows = (flags & RSCM_FLAG_NO_SERIES) ? 1 : n_times;
     h->device = device_id;
-    h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : kind == RSCM_KIND_COUPLED ? RSCM_CP_NPARAMS : RSCM_UD_NPARAMS;
-    h->V = kind == RSCM_KIND_TWO_LAYER ? 3 : 8;
+    h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : kind == RSCM_KIND_COUPLED ? RSCM_CP_NPARAMS
+         : kind == RSCM_KIND_UDEB ? RSCM_UD_NPARAMS : RSCM_GH_NPARAMS;
+    h->V = kind == RSCM_KIND_TWO_LAYER ? 3 : kind == RSCM_KIND_GHG_FORCING ? 4 : 8;
+    h->n_inputs = kind == RSCM_KIND_GHG_FORCING ? 3 : 1;
     h->bounds.assign(time_bounds, time_bounds + n_times + 1);
     h->initial_set.assign(h->V, 0);
 
@@ -359,6 +395,7 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_nsub_tl);
     (void)hipFree(h->d_nsub_cc);
+    (void)hipFree(h->d_ghg_tables);
     (void)hipFree(h->d_ocean);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
@@ -435,6 +472,14 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
     if (int rc = set_device(h)) return rc;
     if (h->kind == RSCM_KIND_UDEB)
         if (int rc = configure_udeb(h, h->N, [&](int j, int64_t i) { return soa[(size_t)j * h->N + i]; })) return rc;
+    if (h->kind == RSCM_KIND_GHG_FORCING) {  // one forcing method per ensemble (one kernel instance)
+        const double m = soa[(size_t)RSCM_GH_P_METHOD * h->N];
+        if (m != 0.0 && m != 1.0) return fail(RSCM_ERR_INVALID, "GhgForcing method must be 0 (Ipcctar) or 1 (Olbl), got %g", m);
+        for (int64_t i = 1; i < h->N; ++i)
+            if (soa[(size_t)RSCM_GH_P_METHOD * h->N + i] != m)
+                return fail(RSCM_ERR_INVALID, "GhgForcing parameter row %d (method) must be the same for every member", RSCM_GH_P_METHOD);
+        h->ghg_method = (int32_t)m;
+    }
     HIPCHK(hipMemcpyAsync(h->d_params, soa, (size_t)h->P * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -466,6 +511,8 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
         return fail(RSCM_ERR_INVALID, "emissions of the coupled chain are exogenous (no component produces them)");
     if (h->kind == RSCM_KIND_UDEB && source != RSCM_SRC_EXOGENOUS)
         return fail(RSCM_ERR_INVALID, "ClimateUDEB reads its forcing as an exogenous series (at_start / at_end)");
+    if (h->kind == RSCM_KIND_GHG_FORCING && source != RSCM_SRC_EXOGENOUS)
+        return fail(RSCM_ERR_INVALID, "GhgForcing on the device reads its concentrations as exogenous series");
     if (scenario_of_member)
         for (int64_t i = 0; i < h->N; ++i)
             if (scenario_of_member[i] < 0 || scenario_of_member[i] >= n_scen)
@@ -476,9 +523,19 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
     if (n_scen != h->n_scen || !h->d_forcing) {
         HIPCHK(hipFree(h->d_forcing));
         h->d_forcing = nullptr;
-        HIPCHK(hipMalloc(&h->d_forcing, (size_t)n_scen * h->T * sizeof(double)));
+        HIPCHK(hipMalloc(&h->d_forcing, (size_t)n_scen * h->n_inputs * h->T * sizeof(double)));
+        if (h->kind == RSCM_KIND_GHG_FORCING) {
+            HIPCHK(hipFree(h->d_ghg_tables));
+            h->d_ghg_tables = nullptr;
+            HIPCHK(hipMalloc(&h->d_ghg_tables, (size_t)n_scen * rscm::kGhgRows * h->T * sizeof(double)));
+        }
     }
-    HIPCHK(hipMemcpyAsync(h->d_forcing, series, (size_t)n_scen * h->T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_forcing, series, (size_t)n_scen * h->n_inputs * h->T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    std::vector<double> ghg_tab;  // must outlive the copy below (synchronised before return)
+    if (h->kind == RSCM_KIND_GHG_FORCING) {
+        ghg_tab = ghg_tables(series, n_scen, h->T);
+        HIPCHK(hipMemcpyAsync(h->d_ghg_tables, ghg_tab.data(), ghg_tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
     if (scenario_of_member) {
         if (!h->d_scen) HIPCHK(hipMalloc(&h->d_scen, (size_t)h->N * sizeof(int32_t)));
         HIPCHK(hipMemcpyAsync(h->d_scen, scenario_of_member, (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
@@ -591,6 +648,22 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.td = h->series(RSCM_TL_VAR_TD);
         a.status = h->d_status;
         HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
+    } else if (h->kind == RSCM_KIND_GHG_FORCING) {
+        rscm::GhgArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.rows = h->rows;
+        a.method = h->ghg_method;
+        a.params = h->d_params;
+        a.tables = h->d_ghg_tables;
+        a.scen = h->d_scen;
+        a.erf_co2 = h->series(RSCM_GH_VAR_ERF_CO2);
+        a.erf_ch4 = h->series(RSCM_GH_VAR_ERF_CH4);
+        a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_ghg(a, h->stream));
     } else if (h->kind == RSCM_KIND_UDEB) {
         if (!h->udeb_ready) return fail(RSCM_ERR_STATE, "ClimateUDEB parameters not configured");
         rscm::UdebArgs a{};
@@ -929,6 +1002,12 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
             if (low[j] != high[j])
                 return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d is structural: low must equal high", j);
         if (int rc = configure_udeb(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
+    }
+    if (h->kind == RSCM_KIND_GHG_FORCING) {
+        const double m = low[RSCM_GH_P_METHOD];
+        if (m != high[RSCM_GH_P_METHOD] || (m != 0.0 && m != 1.0))
+            return fail(RSCM_ERR_INVALID, "GhgForcing method is structural: low must equal high and be 0 or 1");
+        h->ghg_method = (int32_t)m;
     }
     double* d_lh = nullptr;
     HIPCHK(hipMalloc(&d_lh, 2 * (size_t)h->P * sizeof(double)));

@@ -29,8 +29,10 @@ class Ensemble:
         self.bounds = b
         self.device = device
         self.var_ids: Dict[str, int] = dict({L.KIND_TWO_LAYER: L.TL_VARS, L.KIND_COUPLED: L.CP_VARS,
-                                             L.KIND_UDEB: L.UD_VARS}[kind])
-        self.n_params = {L.KIND_TWO_LAYER: 6, L.KIND_COUPLED: 10, L.KIND_UDEB: 37}[kind]
+                                             L.KIND_UDEB: L.UD_VARS, L.KIND_GHG_FORCING: L.GH_VARS}[kind])
+        self.n_params = {L.KIND_TWO_LAYER: 6, L.KIND_COUPLED: 10, L.KIND_UDEB: 37,
+                         L.KIND_GHG_FORCING: 21}[kind]
+        self.n_inputs = 3 if kind == L.KIND_GHG_FORCING else 1
         h = C.c_void_p()
         self.store_series = bool(store_series)
         L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
@@ -81,9 +83,17 @@ class Ensemble:
 
     def set_forcing(self, series, scenario_of_member=None, source: int = L.SRC_EXOGENOUS,
                     var=0) -> None:
-        s = np.atleast_2d(L.f64(series))
-        if s.shape[1] != self.n_times:
-            raise ValueError(f"forcing must have {self.n_times} time points, got {s.shape[1]}")
+        s = L.f64(series)
+        if self.n_inputs > 1:  # a block of rows per scenario: [S][n_inputs][T] or [n_inputs][T]
+            if s.ndim == 2:
+                s = s[None]
+            if s.ndim != 3 or s.shape[1:] != (self.n_inputs, self.n_times):
+                raise ValueError(f"input block must be [S][{self.n_inputs}][{self.n_times}], got {s.shape}")
+            s = np.ascontiguousarray(s)
+        else:
+            s = np.atleast_2d(s)
+            if s.shape[1] != self.n_times:
+                raise ValueError(f"forcing must have {self.n_times} time points, got {s.shape[1]}")
         sc = None
         if scenario_of_member is not None:
             sc = np.ascontiguousarray(scenario_of_member, dtype=np.int32)
@@ -150,6 +160,8 @@ class Ensemble:
         if self.kind == L.KIND_UDEB:
             raise NotImplementedError("ClimateUDEB keeps internal ocean state on the device; "
                                       "host checkpoints are not available for this kind yet")
+        if self.kind == L.KIND_GHG_FORCING:
+            return {}  # a stateless component
         return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}
 
     def checkpoint(self) -> Dict[str, object]:
