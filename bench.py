@@ -87,6 +87,28 @@ def make_udeb_ensemble(members, device, stream=None):
     return ens
 
 
+def make_ghg_ensemble(members, device, method, stream=None):
+    """GhgForcing (rscm-magicc): pre-industrial concentrations, CO2 sensitivity and the rapid
+    adjustments drawn from a Latin hypercube; a smooth synthetic concentration scenario."""
+    import rscm_amd
+    from rscm_amd import _lib
+    t = np.arange(T0, T1 + 1, dtype=np.float64)
+    ens = rscm_amd.Ensemble(rscm_amd.KIND_GHG_FORCING, members, np.append(t, t[-1] + 1.0), device=device)
+    if stream is not None:
+        ens.set_stream(stream)
+    lo = np.array(_lib.GH_DEFAULTS, dtype=np.float64)
+    lo[0] = _lib.GH_METHODS[method]
+    hi = lo.copy()
+    for name, (a, b) in dict(co2_pi=(275.0, 281.0), ch4_pi=(700.0, 740.0), n2o_pi=(265.0, 275.0), delq2xco2=(3.5, 4.0),
+                             adjust_co2=(0.95, 1.1), adjust_ch4=(0.8, 0.95), adjust_n2o=(0.9, 1.05)).items():
+        j = _lib.GH_PARAM_NAMES.index(name)
+        lo[j], hi[j] = a, b
+    ens.sample_lhs(SEED, lo, hi)
+    yr = t - T0
+    ens.set_forcing(np.stack([278.0 * 1.0015 ** yr, 722.0 + 2.0 * yr, 270.0 + 0.1 * yr]))
+    return ens
+
+
 def one_pass(ens):
     ens.rewind()
     ens.run(sync=False)
@@ -235,6 +257,14 @@ def main():
                              # ~26.4e3 f64 VALU instructions per member-year (24 column solves of
                              # ~1055 + LAMCALC + bookkeeping) against 39.3 T f64 lane-ops/s
                              "fp64_valu_frac": 26.4e3 * 100_000 * years / (k3 * 1e-3) / 39.3e12}
+
+        # rscm-magicc GhgForcing: a pointwise component, 24 B of ERF written per member-year
+        for label, method in (("ghg_olbl_1e6", "Olbl"), ("ghg_ipcctar_1e6", "Ipcctar")):
+            e4 = make_ghg_ensemble(1_000_000, local_rank, method, stream)
+            w4, k4 = timed_passes(e4, 5, 2, torch, dist, 1, tstream)
+            e4.close()
+            extra[label] = {"member_years_per_s": 1_000_000 * years * 5 / w4, "kernel_ms": k4,
+                            "hbm_frac": 24.0 * 1_000_000 * years / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

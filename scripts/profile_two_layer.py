@@ -1,6 +1,7 @@
 """Profiling driver: a few passes of the two-layer kernel through the C-ABI (no torch), for
 rocprofv3 --kernel-trace --stats and --pmc runs.  Usage:
-    python3 scripts/profile_two_layer.py [members] [mode 0|1] [passes] [kind 0|1]
+    python3 scripts/profile_two_layer.py [members] [mode 0|1] [passes] [kind 0|1|2|3]
+kind 3 = GhgForcing; mode selects its method there (0 = IPCCTAR, 1 = OLBL).
 """
 import os
 import sys
@@ -31,9 +32,19 @@ if kind == 2:  # ClimateUDEB: defaults, ECS / kappa / RLO / k_lo varied
         for name in ("feedback_q_sensitivity", "feedback_cumt_sensitivity"):
             j = _lib.UD_PARAM_NAMES.index(name)
             lo[j] = hi[j] = 0.0
-P = {0: 6, 1: 10, 2: 37}[kind]
+if kind == 3:  # GhgForcing: pre-industrial values, CO2 sensitivity and adjustments varied
+    from rscm_amd import _lib
+    lo = np.array(_lib.GH_DEFAULTS, dtype=float)
+    lo[0] = float(mode)
+    hi = lo.copy()
+    for name, (a_, b_) in dict(co2_pi=(275.0, 281.0), ch4_pi=(700.0, 740.0), n2o_pi=(265.0, 275.0), delq2xco2=(3.5, 4.0),
+                               adjust_co2=(0.95, 1.1), adjust_ch4=(0.8, 0.95), adjust_n2o=(0.9, 1.05)).items():
+        j = _lib.GH_PARAM_NAMES.index(name)
+        lo[j], hi[j] = a_, b_
+P = {0: 6, 1: 10, 2: 37, 3: 21}[kind]
 with rscm_amd.Ensemble(kind, members, b) as e:
-    e.set_mode(mode)
+    if kind != 3:
+        e.set_mode(mode)
     e.sample_lhs(20260327, lo[:P], hi[:P])
     if kind == 0:
         e.set_forcing(F)
@@ -43,6 +54,9 @@ with rscm_amd.Ensemble(kind, members, b) as e:
         e.set_forcing(F)
         for v in (1, 2, 3, 4):
             e.set_initial(v, 0.0)
+    elif kind == 3:
+        yr = t - 1750.0
+        e.set_forcing(np.stack([278.0 * 1.0015 ** yr, 722.0 + 2.0 * yr, 270.0 + 0.1 * yr]))
     else:
         yrs = np.array([1750.0, 1850.0, 1950.0, 2000.0, 2020.0, 2050.0, 2100.0])
         e.set_forcing(np.interp(t, yrs, [0.0, 0.5, 3.0, 7.0, 10.0, 5.0, 1.0]))
