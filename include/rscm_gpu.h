@@ -73,6 +73,9 @@ extern "C" {
 
 #define RSCM_KIND_UDEB 2      /* rscm-magicc ClimateUDEB (4-box upwelling-diffusion EBM)          */
 #define RSCM_KIND_GHG_FORCING 3 /* rscm-magicc GhgForcing (CO2/CH4/N2O concentrations -> ERF)     */
+#define RSCM_KIND_OZONE_FORCING 4    /* rscm-magicc OzoneForcing                                  */
+#define RSCM_KIND_AEROSOL_DIRECT 5   /* rscm-magicc AerosolDirect (FourBox output)                */
+#define RSCM_KIND_AEROSOL_INDIRECT 6 /* rscm-magicc AerosolIndirect                               */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -130,6 +133,35 @@ extern "C" {
 #define RSCM_GH_P_ADJUST_CO2 18
 #define RSCM_GH_P_ADJUST_CH4 19
 #define RSCM_GH_P_ADJUST_N2O 20
+
+/* The three stateless forcing components below follow the same convention: variable 0 is the
+ * block of input rows per scenario, series[n_scen][n_inputs][n_times], in the order of the
+ * component's #[inputs(...)] declaration; variables 1.. are the outputs; the parameter rows are
+ * the fields of the parameter struct in declaration order (arrays expanded, booleans as 0/1).
+ *
+ * OzoneForcing (crates/rscm-magicc/src/forcing/ozone.rs:69-85, parameters/ozone_forcing.rs):
+ *   inputs  EESC, Atmospheric Concentration|CH4, Emissions|NOx, Emissions|CO, Emissions|NMVOC,
+ *           Surface Temperature
+ *   outputs 1 ERF|O3|Stratospheric, 2 ERF|O3|Tropospheric, 3 ERF|O3|Temperature Feedback
+ *   params  eesc_reference, strat_o3_scale, strat_cl_exponent, trop_radeff, trop_oz_ch4,
+ *           trop_oz_nox, trop_oz_co, trop_oz_voc, ch4_pi, nox_pi, co_pi, nmvoc_pi,
+ *           temp_feedback_scale */
+#define RSCM_OZ_NINPUTS 6
+#define RSCM_OZ_NPARAMS 13
+/* AerosolDirect (forcing/aerosol_direct.rs:53-63, parameters/aerosol.rs:6-70):
+ *   inputs  Emissions|SOx, Emissions|BC, Emissions|OC, Emissions|NOx
+ *   outputs 1-4 ERF|Aerosol|Direct in NorthernOcean, NorthernLand, SouthernOcean, SouthernLand
+ *   params  sox/bc/oc/nitrate_coefficient, sox_regional[4], bc_regional[4], oc_regional[4],
+ *           nitrate_regional[4], sox_pi, bc_pi, oc_pi, nox_pi, harmonize, harmonize_year,
+ *           harmonize_target (the last three are carried but unused by solve, as upstream) */
+#define RSCM_AD_NINPUTS 4
+#define RSCM_AD_NPARAMS 27
+/* AerosolIndirect (forcing/aerosol_indirect.rs:52-60, parameters/aerosol.rs:75-117):
+ *   inputs  Emissions|SOx, Emissions|OC;   output 1 ERF|Aerosol|Indirect
+ *   params  cloud_albedo_coefficient, reference_burden, sox_weight, oc_weight, sox_pi, oc_pi,
+ *           harmonize, harmonize_year, harmonize_target */
+#define RSCM_AI_NINPUTS 2
+#define RSCM_AI_NPARAMS 9
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
@@ -232,7 +264,8 @@ RSCM_API int rscm_ens_set_params(rscm_ens* h, const double* soa);
 /* [N][P] row-major, the shape ModelRunner::run_batch receives (&[Vec<f64>]). */
 RSCM_API int rscm_ens_set_params_aos(rscm_ens* h, const double* aos);
 /* Shared input series already on the model axis: series[n_scen][n_times]
- * (RSCM_KIND_GHG_FORCING: series[n_scen][3][n_times], see RSCM_GH_VAR_CONC);
+ * (kinds with several inputs -- RSCM_KIND_GHG_FORCING and the three after it -- take the block
+ * series[n_scen][n_inputs][n_times], see RSCM_GH_VAR_CONC);
  * scenario_of_member[N] or NULL (all members use scenario 0). */
 RSCM_API int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const double* series,
                          const int32_t* scenario_of_member, int32_t source);

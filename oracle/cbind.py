@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
@@ -65,6 +65,15 @@ def lib() -> C.CDLL:
         L.orc_ghg_run.argtypes = [C.c_int64, C.c_int32, _dp, C.c_int32, _dp, _ip, _dp, _dp, _dp,
                                   C.c_int64, C.c_int64]
         L.orc_ghg_run.restype = None
+        for f in ("n_params", "n_inputs", "n_outputs"):
+            getattr(L, "orc_pointwise_" + f).argtypes = [C.c_int32]
+            getattr(L, "orc_pointwise_" + f).restype = C.c_int32
+        L.orc_pointwise_default_params.argtypes = [C.c_int32, _dp]
+        L.orc_pointwise_default_params.restype = None
+        L.orc_pointwise_eval.argtypes = [C.c_int32, _dp, _dp, _dp]
+        L.orc_pointwise_eval.restype = C.c_int32
+        L.orc_pointwise_run.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, _dp, _ip, _dp, C.c_int64, C.c_int64]
+        L.orc_pointwise_run.restype = C.c_int32
         L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
         L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
@@ -322,4 +331,54 @@ def ghg_run(n_times, params, conc, *, scen=None, threads=1):
     L = lib()
     _pmap(lambda i0, i1: L.orc_ghg_run(N, n_times, _d(params), conc.shape[0], _d(conc), _i(scen),
                                        *[_d(out[k]) for k in GHG_VARS], i0, i1), N, threads)
+    return out
+
+
+# ------------------------------------------------- OzoneForcing / AerosolDirect / AerosolIndirect
+PW_OZONE, PW_AEROSOL_DIRECT, PW_AEROSOL_INDIRECT = 4, 5, 6
+PW_PARAM_NAMES = {
+    PW_OZONE: ("eesc_reference", "strat_o3_scale", "strat_cl_exponent", "trop_radeff", "trop_oz_ch4",
+               "trop_oz_nox", "trop_oz_co", "trop_oz_voc", "ch4_pi", "nox_pi", "co_pi", "nmvoc_pi",
+               "temp_feedback_scale"),
+    PW_AEROSOL_DIRECT: ("sox_coefficient", "bc_coefficient", "oc_coefficient", "nitrate_coefficient")
+    + tuple(f"{s}_regional_{i}" for s in ("sox", "bc", "oc", "nitrate") for i in range(4))
+    + ("sox_pi", "bc_pi", "oc_pi", "nox_pi", "harmonize", "harmonize_year", "harmonize_target"),
+    PW_AEROSOL_INDIRECT: ("cloud_albedo_coefficient", "reference_burden", "sox_weight", "oc_weight",
+                          "sox_pi", "oc_pi", "harmonize", "harmonize_year", "harmonize_target"),
+}
+
+
+def pointwise_default_params(kind, **over) -> np.ndarray:
+    p = np.empty(lib().orc_pointwise_n_params(kind))
+    assert len(p) == len(PW_PARAM_NAMES[kind])
+    lib().orc_pointwise_default_params(kind, _d(p))
+    for k, v in over.items():
+        p[PW_PARAM_NAMES[kind].index(k)] = v
+    return p
+
+
+def pointwise_eval(kind, params, inputs) -> np.ndarray:
+    out = np.empty(lib().orc_pointwise_n_outputs(kind))
+    x = _f64(inputs)
+    assert len(x) == lib().orc_pointwise_n_inputs(kind)
+    assert lib().orc_pointwise_eval(kind, _d(_f64(params)), _d(x), _d(out)) == 0
+    return out
+
+
+def pointwise_run(kind, n_times, params, inputs, *, scen=None, threads=1) -> np.ndarray:
+    """params [P][N]; inputs [S][n_inputs][T].  Returns [n_outputs][T][N]; row 0 is NaN."""
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    inputs = _f64(inputs)
+    if inputs.ndim == 2:
+        inputs = inputs[None]
+    L = lib()
+    assert inputs.shape[1:] == (L.orc_pointwise_n_inputs(kind), n_times)
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    out = np.full((L.orc_pointwise_n_outputs(kind), n_times, N), np.nan)
+    _pmap(lambda i0, i1: L.orc_pointwise_run(kind, N, n_times, _d(params), _d(inputs), _i(scen), _d(out), i0, i1),
+          N, threads)
     return out

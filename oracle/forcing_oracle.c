@@ -1,0 +1,146 @@
+/*
+ * CPU ORACLE for rscm-magicc's stateless forcing components OzoneForcing, AerosolDirect and
+ * AerosolIndirect -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of
+ *   OzoneForcing::calculate_forcings / solve      crates/rscm-magicc/src/forcing/ozone.rs:99-238
+ *   AerosolDirect::calculate_forcing / solve      crates/rscm-magicc/src/forcing/aerosol_direct.rs:86-239
+ *   AerosolIndirect::calculate_forcing / solve    crates/rscm-magicc/src/forcing/aerosol_indirect.rs:75-170
+ *   their parameter structs (+ Default)           crates/rscm-magicc/src/parameters/{ozone_forcing,aerosol}.rs
+ * under the stepper conventions of crates/rscm-core/src/model/runtime.rs: every input is read as
+ * an exogenous series (index n), outputs are written at index n+1, index 0 stays NaN.
+ *
+ * Parity pin: the reference holds no golden vectors for these three components (its only
+ * full-chain regression scenario is marked xfail upstream); the restatement is checked against
+ * the known answers of the components' in-file unit tests (tests/test_oracle_forcing.py).
+ * Numeric agreement with the Rust binary is therefore "parity unpinned" beyond those.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
+ */
+#include <math.h>
+#include <stdint.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* kinds, matching include/rscm_gpu.h */
+enum { PW_OZONE = 4, PW_AEROSOL_DIRECT = 5, PW_AEROSOL_INDIRECT = 6 };
+
+/* OzoneForcingParameters field order */
+enum { O_EESC_REF = 0, O_STRAT_SCALE, O_STRAT_EXP, O_TROP_RADEFF, O_TROP_CH4, O_TROP_NOX, O_TROP_CO,
+       O_TROP_VOC, O_CH4_PI, O_NOX_PI, O_CO_PI, O_NMVOC_PI, O_TEMP_FB, O_NPARAMS };
+/* AerosolDirectParameters field order (regional patterns NO, NL, SO, SL) */
+enum { D_SOX_C = 0, D_BC_C, D_OC_C, D_NIT_C, D_SOX_R = 4, D_BC_R = 8, D_OC_R = 12, D_NIT_R = 16,
+       D_SOX_PI = 20, D_BC_PI, D_OC_PI, D_NOX_PI, D_HARMONIZE, D_HARM_YEAR, D_HARM_TARGET, D_NPARAMS };
+/* AerosolIndirectParameters field order */
+enum { I_COEF = 0, I_REF_BURDEN, I_SOX_W, I_OC_W, I_SOX_PI, I_OC_PI, I_HARMONIZE, I_HARM_YEAR,
+       I_HARM_TARGET, I_NPARAMS };
+
+ORC_API int32_t orc_pointwise_n_params(int32_t kind)
+{
+    return kind == PW_OZONE ? O_NPARAMS : kind == PW_AEROSOL_DIRECT ? D_NPARAMS : kind == PW_AEROSOL_INDIRECT ? I_NPARAMS : -1;
+}
+ORC_API int32_t orc_pointwise_n_inputs(int32_t kind)
+{
+    return kind == PW_OZONE ? 6 : kind == PW_AEROSOL_DIRECT ? 4 : kind == PW_AEROSOL_INDIRECT ? 2 : -1;
+}
+ORC_API int32_t orc_pointwise_n_outputs(int32_t kind)
+{
+    return kind == PW_OZONE ? 3 : kind == PW_AEROSOL_DIRECT ? 4 : kind == PW_AEROSOL_INDIRECT ? 1 : -1;
+}
+
+ORC_API void orc_pointwise_default_params(int32_t kind, double* p)
+{
+    if (kind == PW_OZONE) { /* parameters/ozone_forcing.rs Default */
+        p[O_EESC_REF] = 1420.0; p[O_STRAT_SCALE] = -0.0043; p[O_STRAT_EXP] = 1.7;
+        p[O_TROP_RADEFF] = 0.032; p[O_TROP_CH4] = 5.7; p[O_TROP_NOX] = 0.168; p[O_TROP_CO] = 0.00396;
+        p[O_TROP_VOC] = 0.01008; p[O_CH4_PI] = 700.0; p[O_NOX_PI] = 0.0; p[O_CO_PI] = 0.0; p[O_NMVOC_PI] = 0.0;
+        p[O_TEMP_FB] = -0.037;
+    } else if (kind == PW_AEROSOL_DIRECT) { /* parameters/aerosol.rs:44-70 */
+        static const double d[D_NPARAMS] = {-0.0035, 0.0077, -0.002, -0.001,
+                                            0.15, 0.55, 0.10, 0.20, 0.15, 0.50, 0.15, 0.20,
+                                            0.15, 0.45, 0.15, 0.25, 0.15, 0.50, 0.15, 0.20,
+                                            1.0, 2.5, 10.0, 10.0, 0.0, 2019.0, -0.22};
+        for (int j = 0; j < D_NPARAMS; ++j) p[j] = d[j];
+    } else if (kind == PW_AEROSOL_INDIRECT) { /* parameters/aerosol.rs:98-117 */
+        static const double d[I_NPARAMS] = {-1.0, 50.0, 1.0, 0.3, 1.0, 10.0, 0.0, 2019.0, -0.89};
+        for (int j = 0; j < I_NPARAMS; ++j) p[j] = d[j];
+    }
+}
+
+/* forcing/ozone.rs:99-164; in = {EESC, CH4, NOx, CO, NMVOC, temperature}; out = {strat, trop, feedback} */
+static void ozone(const double* p, const double* in, double* out)
+{
+    const double delta_eesc = in[0] - p[O_EESC_REF];
+    out[0] = delta_eesc <= 0.0 ? 0.0 : p[O_STRAT_SCALE] * pow(delta_eesc / 100.0, p[O_STRAT_EXP]);
+    const double ch4 = in[1];
+    const double ch4_term = (ch4 > 0.0 && p[O_CH4_PI] > 0.0) ? p[O_TROP_CH4] * log(ch4 / p[O_CH4_PI]) : 0.0;
+    const double delta_nox = in[2] - p[O_NOX_PI], delta_co = in[3] - p[O_CO_PI], delta_nmvoc = in[4] - p[O_NMVOC_PI];
+    const double precursor = p[O_TROP_NOX] * delta_nox + p[O_TROP_CO] * delta_co + p[O_TROP_VOC] * delta_nmvoc;
+    out[1] = p[O_TROP_RADEFF] * (ch4_term + precursor);
+    out[2] = p[O_TEMP_FB] * in[5];
+}
+
+/* forcing/aerosol_direct.rs:86-158; in = {SOx, BC, OC, NOx}; out = FourBox {NO, NL, SO, SL} */
+static void aerosol_direct(const double* p, const double* in, double* out)
+{
+    const double sox = p[D_SOX_C] * (in[0] - p[D_SOX_PI]);
+    const double bc = p[D_BC_C] * (in[1] - p[D_BC_PI]);
+    const double oc = p[D_OC_C] * (in[2] - p[D_OC_PI]);
+    const double nit = p[D_NIT_C] * (in[3] - p[D_NOX_PI]);
+    const double total = sox + bc + oc + nit; /* SpeciesForcing::total: ((sox + bc) + oc) + nitrate */
+    if (fabs(total) < 1e-15) {
+        for (int i = 0; i < 4; ++i) out[i] = 0.0;
+        return;
+    }
+    const double total_abs = fabs(sox) + fabs(bc) + fabs(oc) + fabs(nit);
+    if (total_abs < 1e-15) {
+        for (int i = 0; i < 4; ++i) out[i] = total / 4.0;
+        return;
+    }
+    for (int i = 0; i < 4; ++i) {
+        const double weighted = (fabs(sox) * p[D_SOX_R + i] + fabs(bc) * p[D_BC_R + i] + fabs(oc) * p[D_OC_R + i] +
+                                 fabs(nit) * p[D_NIT_R + i]) / total_abs;
+        out[i] = total * weighted;
+    }
+}
+
+/* forcing/aerosol_indirect.rs:75-115; in = {SOx, OC}; out = {indirect ERF} */
+static void aerosol_indirect(const double* p, const double* in, double* out)
+{
+    const double burden = p[I_SOX_W] * in[0] + p[I_OC_W] * in[1];
+    const double burden_pi = p[I_SOX_W] * p[I_SOX_PI] + p[I_OC_W] * p[I_OC_PI];
+    const double delta = burden - burden_pi;
+    out[0] = delta <= 0.0 ? 0.0 : p[I_COEF] * log(1.0 + delta / p[I_REF_BURDEN]);
+}
+
+ORC_API int32_t orc_pointwise_eval(int32_t kind, const double* p, const double* in, double* out)
+{
+    if (kind == PW_OZONE) ozone(p, in, out);
+    else if (kind == PW_AEROSOL_DIRECT) aerosol_direct(p, in, out);
+    else if (kind == PW_AEROSOL_INDIRECT) aerosol_indirect(p, in, out);
+    else return 1;
+    return 0;
+}
+
+/*
+ * Ensemble run: params [P][N] (SoA), inputs [S][n_inputs][T], scen[N] or NULL,
+ * outputs [n_outputs][T][N] (row 0 NaN, rows 1..T-1 written), members [m0, m1).
+ */
+ORC_API int32_t orc_pointwise_run(int32_t kind, int64_t n_members, int32_t n_times, const double* params,
+                                  const double* inputs, const int32_t* scen, double* outputs, int64_t m0, int64_t m1)
+{
+    const int P = orc_pointwise_n_params(kind), NI = orc_pointwise_n_inputs(kind), NO = orc_pointwise_n_outputs(kind);
+    if (P < 0) return 1;
+    for (int64_t i = m0; i < m1; ++i) {
+        double p[32], in[8], out[4];
+        for (int j = 0; j < P; ++j) p[j] = params[(int64_t)j * n_members + i];
+        const double* c = inputs + (int64_t)(scen ? scen[i] : 0) * NI * n_times;
+        for (int o = 0; o < NO; ++o) outputs[(int64_t)o * n_times * n_members + i] = NAN;
+        for (int32_t n = 0; n + 1 < n_times; ++n) {
+            for (int k = 0; k < NI; ++k) in[k] = c[(int64_t)k * n_times + n];
+            orc_pointwise_eval(kind, p, in, out);
+            for (int o = 0; o < NO; ++o) outputs[((int64_t)o * n_times + (n + 1)) * n_members + i] = out[o];
+        }
+    }
+    return 0;
+}

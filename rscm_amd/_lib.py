@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librscm_gpu.so")
 
 OK, ERR_INVALID, ERR_STATE, ERR_TIME_AXIS, ERR_DEVICE, ERR_NOMEM = range(6)
 KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB, KIND_GHG_FORCING = 0, 1, 2, 3
+KIND_OZONE_FORCING, KIND_AEROSOL_DIRECT, KIND_AEROSOL_INDIRECT = 4, 5, 6
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -60,6 +61,41 @@ GH_METHODS = {"Ipcctar": 0.0, "Olbl": 1.0}
 # GhgForcingParameters::default() (crates/rscm-magicc/src/parameters/ghg_forcing.rs)
 GH_DEFAULTS = (1.0, 278.0, 722.0, 270.0, 3.71, 0.036, 0.12, -2.4785e-7, 7.5906e-4, -2.1492e-3, 5.2,
                -8.9603e-5, -1.2462e-4, 0.045, -3.4197e-4, 2.5455e-4, -2.4357e-4, 0.14, 1.05, 0.86, 1.0)
+
+# OzoneForcing / AerosolDirect / AerosolIndirect (crates/rscm-magicc/src/forcing/*.rs): variable 0
+# is the block of input rows, [S][n_inputs][T], in the order of the #[inputs(...)] declaration
+OZ_INPUTS = ("EESC", "Atmospheric Concentration|CH4", "Emissions|NOx", "Emissions|CO", "Emissions|NMVOC",
+             "Surface Temperature")
+OZ_VARS = {"Ozone inputs": 0, "Effective Radiative Forcing|O3|Stratospheric": 1,
+           "Effective Radiative Forcing|O3|Tropospheric": 2,
+           "Effective Radiative Forcing|O3|Temperature Feedback": 3}
+OZ_PARAM_NAMES = ("eesc_reference", "strat_o3_scale", "strat_cl_exponent", "trop_radeff", "trop_oz_ch4",
+                  "trop_oz_nox", "trop_oz_co", "trop_oz_voc", "ch4_pi", "nox_pi", "co_pi", "nmvoc_pi",
+                  "temp_feedback_scale")
+OZ_DEFAULTS = (1420.0, -0.0043, 1.7, 0.032, 5.7, 0.168, 0.00396, 0.01008, 700.0, 0.0, 0.0, 0.0, -0.037)
+FOURBOX_REGIONS = ("NorthernOcean", "NorthernLand", "SouthernOcean", "SouthernLand")
+AD_INPUTS = ("Emissions|SOx", "Emissions|BC", "Emissions|OC", "Emissions|NOx")
+AD_VARS = {"Aerosol direct inputs": 0,
+           **{f"Effective Radiative Forcing|Aerosol|Direct|{r}": k + 1 for k, r in enumerate(FOURBOX_REGIONS)}}
+AD_PARAM_NAMES = (("sox_coefficient", "bc_coefficient", "oc_coefficient", "nitrate_coefficient")
+                  + tuple(f"{s}_regional_{i}" for s in ("sox", "bc", "oc", "nitrate") for i in range(4))
+                  + ("sox_pi", "bc_pi", "oc_pi", "nox_pi", "harmonize", "harmonize_year", "harmonize_target"))
+AD_DEFAULTS = (-0.0035, 0.0077, -0.002, -0.001, 0.15, 0.55, 0.10, 0.20, 0.15, 0.50, 0.15, 0.20,
+               0.15, 0.45, 0.15, 0.25, 0.15, 0.50, 0.15, 0.20, 1.0, 2.5, 10.0, 10.0, 0.0, 2019.0, -0.22)
+AI_INPUTS = ("Emissions|SOx", "Emissions|OC")
+AI_VARS = {"Aerosol indirect inputs": 0, "Effective Radiative Forcing|Aerosol|Indirect": 1}
+AI_PARAM_NAMES = ("cloud_albedo_coefficient", "reference_burden", "sox_weight", "oc_weight", "sox_pi", "oc_pi",
+                  "harmonize", "harmonize_year", "harmonize_target")
+AI_DEFAULTS = (-1.0, 50.0, 1.0, 0.3, 1.0, 10.0, 0.0, 2019.0, -0.89)
+
+# per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
+KIND_TABLE = {
+    KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
+    KIND_GHG_FORCING: (GH_VARS, 21, GH_INPUTS), KIND_OZONE_FORCING: (OZ_VARS, 13, OZ_INPUTS),
+    KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS)}
+# FourBox variables stored as four scalar series: kind -> (name, first variable id)
+FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
+                KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1)}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -371,10 +371,14 @@ class ComponentBuilder:
 
 # ------------------------------------------------------------------------------------ builder
 SUPPORTED = ("[ClimateUDEB] with exogenous 'Effective Radiative Forcing'",
-             "[GhgForcing] with the three exogenous 'Atmospheric Concentration|CO2/CH4/N2O' series",
+             "[GhgForcing] | [OzoneForcing] | [AerosolDirect] | [AerosolIndirect] with their inputs as "
+             "exogenous series",
              "[TwoLayer] with exogenous or upstream 'Effective Radiative Forcing'",
              "[CarbonCycle, CO2ERF, TwoLayer] + Sum aggregate 'Effective Radiative Forcing' "
              "over ['Effective Radiative Forcing|CO2'] (registration order as listed)")
+
+STATELESS_KINDS = {"GhgForcing": L.KIND_GHG_FORCING, "OzoneForcing": L.KIND_OZONE_FORCING,
+                   "AerosolDirect": L.KIND_AEROSOL_DIRECT, "AerosolIndirect": L.KIND_AEROSOL_INDIRECT}
 
 TL_PARAM_ORDER = ("lambda0", "a", "efficacy", "eta", "heat_capacity_surface", "heat_capacity_deep")
 CP_PARAM_ORDER = TL_PARAM_ORDER + ("tau", "conc_pi", "alpha_temperature", "erf_2xco2")
@@ -510,9 +514,9 @@ class ModelBuilder:
             src = L.SRC_EXOGENOUS
             params = self._components[0].param_vector()
             h = {}
-        elif types == ["GhgForcing"] and not aggregates:
-            kind = L.KIND_GHG_FORCING
-            rows = [self._exogenous_on_axis(name, exo_names) for name in L.GH_INPUTS]
+        elif len(types) == 1 and types[0] in STATELESS_KINDS and not aggregates:
+            kind = STATELESS_KINDS[types[0]]
+            rows = [self._exogenous_on_axis(name, exo_names) for name in L.KIND_TABLE[kind][2]]
             forcing = np.stack([np.full(len(self._axis), NAN) if r is None else r for r in rows])
             src = L.SRC_EXOGENOUS
             params = self._components[0].param_vector()
@@ -536,7 +540,9 @@ class ModelBuilder:
                 # a FourBox state initialised with one scalar sets all four regions (builder.rs:797-804)
                 ens.set_initial(vid, self._initial[name.split("|")[0]])
         param_order = {L.KIND_TWO_LAYER: TL_PARAM_ORDER, L.KIND_COUPLED: CP_PARAM_ORDER,
-                       L.KIND_UDEB: L.UD_PARAM_NAMES, L.KIND_GHG_FORCING: L.GH_PARAM_NAMES}[kind]
+                       L.KIND_UDEB: L.UD_PARAM_NAMES, L.KIND_GHG_FORCING: L.GH_PARAM_NAMES,
+                       L.KIND_OZONE_FORCING: L.OZ_PARAM_NAMES, L.KIND_AEROSOL_DIRECT: L.AD_PARAM_NAMES,
+                       L.KIND_AEROSOL_INDIRECT: L.AI_PARAM_NAMES}[kind]
         return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
                      np.array(params, dtype=np.float64))
 
@@ -581,15 +587,19 @@ class Model:
     def timeseries(self, member: int = 0) -> TimeseriesCollection:
         coll = TimeseriesCollection()
         input_name = [n for n, v in self.ensemble.var_ids.items() if v == 0][0]
-        if self.ensemble.kind == L.KIND_UDEB:
+        fourbox = L.FOURBOX_VARS.get(self.ensemble.kind)
+        fb_ids = ()
+        if fourbox:  # a FourBox variable is stored as four scalar series
+            fb_ids = tuple(range(fourbox[1], fourbox[1] + 4))
             boxes = np.stack([self.ensemble.get_series(v, m_begin=member, m_end=member + 1)[:, 0]
-                              for v in (1, 2, 3, 4)], axis=1)
-            coll.add_fourbox_timeseries("Surface Temperature", FourBoxTimeseries(boxes, self._axis, "K"))
+                              for v in fb_ids], axis=1)
+            unit = "K" if self.ensemble.kind == L.KIND_UDEB else "W/m^2"
+            coll.add_fourbox_timeseries(fourbox[0], FourBoxTimeseries(boxes, self._axis, unit))
         for name, vid in self.ensemble.var_ids.items():
-            if self.ensemble.kind == L.KIND_UDEB and 1 <= vid <= 4:
+            if vid in fb_ids:
                 continue
-            if vid == 0 and self.ensemble.kind == L.KIND_GHG_FORCING:
-                for k, input_row in enumerate(L.GH_INPUTS):  # the input block holds three series
+            if vid == 0 and self.ensemble.input_rows:
+                for k, input_row in enumerate(self.ensemble.input_rows):  # the input block's series
                     coll.add_timeseries(input_row, Timeseries(self._forcing[k], self._axis, "",
                                                               InterpolationStrategy.Linear), VariableType.Exogenous)
                 continue

@@ -1,0 +1,124 @@
+// Stateless rscm-magicc forcing components as ensemble kernels for gfx950 (MI355X), one thread
+// per member: OzoneForcing, AerosolDirect, AerosolIndirect.
+//
+// What they replace, per model step n (reference file:line):
+//   OzoneForcing::solve / calculate_forcings      crates/rscm-magicc/src/forcing/ozone.rs:99-238
+//   AerosolDirect::solve / calculate_forcing      crates/rscm-magicc/src/forcing/aerosol_direct.rs:86-239
+//   AerosolIndirect::solve / calculate_forcing    crates/rscm-magicc/src/forcing/aerosol_indirect.rs:75-170
+// under the stepper conventions of crates/rscm-core/src/model/runtime.rs: inputs are exogenous
+// series shared per scenario (index n), outputs land at index n+1, index 0 stays NaN.
+//
+// The expressions are the reference's, operation for operation (no contraction: the build uses
+// -ffp-contract=off); pow and log come from the device math library, so agreement with the CPU
+// oracle is to their last-place error (tests/test_gpu_pointwise.py states 1e-12), exact where no
+// transcendental is involved (AerosolDirect, the ozone temperature feedback).
+// Rooflines: 8-32 B written per member-year; OzoneForcing carries one f64 pow and one log per
+// member-year and is VALU-bound, the two aerosol kernels are bound by the HBM write stream.
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+template <int KIND>
+struct Shape;
+template <>
+struct Shape<4> { static constexpr int P = 13, NI = 6, NO = 3; };
+template <>
+struct Shape<5> { static constexpr int P = 27, NI = 4, NO = 4; };
+template <>
+struct Shape<6> { static constexpr int P = 9, NI = 2, NO = 1; };
+
+// forcing/ozone.rs:99-164; in = {EESC, CH4, NOx, CO, NMVOC, temperature}
+__device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[6], double (&out)[3])
+{
+    const double delta_eesc = in[0] - p[0];
+    out[0] = delta_eesc <= 0.0 ? 0.0 : p[1] * pow(delta_eesc / 100.0, p[2]);
+    const double ch4 = in[1];
+    const double ch4_term = (ch4 > 0.0 && p[8] > 0.0) ? p[4] * log(ch4 / p[8]) : 0.0;
+    const double delta_nox = in[2] - p[9], delta_co = in[3] - p[10], delta_nmvoc = in[4] - p[11];
+    const double precursor = p[5] * delta_nox + p[6] * delta_co + p[7] * delta_nmvoc;
+    out[1] = p[3] * (ch4_term + precursor);
+    out[2] = p[12] * in[5];
+}
+
+// forcing/aerosol_direct.rs:86-158; in = {SOx, BC, OC, NOx}; out = FourBox {NO, NL, SO, SL}
+__device__ __forceinline__ void eval(const double (&p)[27], const double (&in)[4], double (&out)[4])
+{
+    const double sox = p[0] * (in[0] - p[20]);
+    const double bc = p[1] * (in[1] - p[21]);
+    const double oc = p[2] * (in[2] - p[22]);
+    const double nit = p[3] * (in[3] - p[23]);
+    const double total = sox + bc + oc + nit;
+    const double total_abs = fabs(sox) + fabs(bc) + fabs(oc) + fabs(nit);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double weighted = (fabs(sox) * p[4 + i] + fabs(bc) * p[8 + i] + fabs(oc) * p[12 + i] + fabs(nit) * p[16 + i]) / total_abs;
+        double r = total * weighted;
+        if (total_abs < 1e-15) r = total / 4.0;
+        if (fabs(total) < 1e-15) r = 0.0;
+        out[i] = r;
+    }
+}
+
+// forcing/aerosol_indirect.rs:75-115; in = {SOx, OC}
+__device__ __forceinline__ void eval(const double (&p)[9], const double (&in)[2], double (&out)[1])
+{
+    const double burden = p[2] * in[0] + p[3] * in[1];
+    const double burden_pi = p[2] * p[4] + p[3] * p[5];
+    const double delta = burden - burden_pi;
+    out[0] = delta <= 0.0 ? 0.0 : p[0] * log(1.0 + delta / p[1]);
+}
+
+template <int KIND, bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void pointwise_kernel(PointwiseArgs a)
+{
+    using S = Shape<KIND>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    double p[S::P];
+#pragma unroll
+    for (int j = 0; j < S::P; ++j) p[j] = a.params[(size_t)j * N + i];
+    const double* __restrict__ in_base = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * S::NI * T;
+    const size_t var_stride = (size_t)a.rows * N;
+    a.status[i] = 0;
+    if (a.step_begin == 0 && a.rows > 1) {  // index 0 is nobody's output
+#pragma unroll
+        for (int o = 0; o < S::NO; ++o) a.out[(size_t)o * var_stride + i] = __builtin_nan("");
+    }
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        double in[S::NI], out[S::NO];
+#pragma unroll
+        for (int k = 0; k < S::NI; ++k) in[k] = in_base[(size_t)k * T + n];
+        eval(p, in, out);
+        const size_t r = (a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i;
+#pragma unroll
+        for (int o = 0; o < S::NO; ++o) a.out[(size_t)o * var_stride + r] = out[o];
+    }
+}
+
+template <int KIND>
+hipError_t launch_kind(const PointwiseArgs& a, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
+    if (a.scen) hipLaunchKernelGGL((pointwise_kernel<KIND, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((pointwise_kernel<KIND, false>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s)
+{
+    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    switch (a.kind) {
+        case 4: return launch_kind<4>(a, s);
+        case 5: return launch_kind<5>(a, s);
+        case 6: return launch_kind<6>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rscm

@@ -109,6 +109,20 @@ struct GhgArgs {
     uint8_t* status;
 };
 
+// OzoneForcing / AerosolDirect / AerosolIndirect (csrc/pointwise.hip)
+struct PointwiseArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t rows;            // stored rows per series (T)
+    int32_t kind;            // RSCM_KIND_OZONE_FORCING / _AEROSOL_DIRECT / _AEROSOL_INDIRECT
+    const double* params;    // [P][N]
+    const double* inputs;    // [S][n_inputs][T]
+    const int32_t* scen;     // [N] or null
+    double* out;             // [n_outputs][rows][N]
+    uint8_t* status;
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -125,6 +139,7 @@ hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t 
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
+hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

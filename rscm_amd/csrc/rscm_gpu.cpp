@@ -158,7 +158,7 @@ struct rscm_ens {
     {
         if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
         if (kind == RSCM_KIND_UDEB) return var >= RSCM_UD_VAR_ST_NH_OCEAN && var <= RSCM_UD_VAR_ST_SH_LAND;
-        if (kind == RSCM_KIND_GHG_FORCING) return false;  // a stateless component
+        if (kind >= RSCM_KIND_GHG_FORCING) return false;  // stateless components
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
 };
@@ -313,8 +313,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind != RSCM_KIND_TWO_LAYER && kind != RSCM_KIND_COUPLED && kind != RSCM_KIND_UDEB &&
-        kind != RSCM_KIND_GHG_FORCING)
+    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_AEROSOL_INDIRECT)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -331,10 +330,13 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->T = n_times;
     h->rows = (flags & RSCM_FLAG_NO_SERIES) ? 1 : n_times;
     h->device = device_id;
-    h->P = kind == RSCM_KIND_TWO_LAYER ? RSCM_TL_NPARAMS : kind == RSCM_KIND_COUPLED ? RSCM_CP_NPARAMS
-         : kind == RSCM_KIND_UDEB ? RSCM_UD_NPARAMS : RSCM_GH_NPARAMS;
-    h->V = kind == RSCM_KIND_TWO_LAYER ? 3 : kind == RSCM_KIND_GHG_FORCING ? 4 : 8;
-    h->n_inputs = kind == RSCM_KIND_GHG_FORCING ? 3 : 1;
+    static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
+                                 RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS};
+    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2};  // variable ids incl. the input block 0
+    static const int32_t kInputs[] = {1, 1, 1, 3, RSCM_OZ_NINPUTS, RSCM_AD_NINPUTS, RSCM_AI_NINPUTS};
+    h->P = kP[kind];
+    h->V = kV[kind];
+    h->n_inputs = kInputs[kind];
     h->bounds.assign(time_bounds, time_bounds + n_times + 1);
     h->initial_set.assign(h->V, 0);
 
@@ -511,8 +513,8 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
         return fail(RSCM_ERR_INVALID, "emissions of the coupled chain are exogenous (no component produces them)");
     if (h->kind == RSCM_KIND_UDEB && source != RSCM_SRC_EXOGENOUS)
         return fail(RSCM_ERR_INVALID, "ClimateUDEB reads its forcing as an exogenous series (at_start / at_end)");
-    if (h->kind == RSCM_KIND_GHG_FORCING && source != RSCM_SRC_EXOGENOUS)
-        return fail(RSCM_ERR_INVALID, "GhgForcing on the device reads its concentrations as exogenous series");
+    if (h->kind >= RSCM_KIND_GHG_FORCING && source != RSCM_SRC_EXOGENOUS)
+        return fail(RSCM_ERR_INVALID, "the stateless forcing kinds read their inputs as exogenous series");
     if (scenario_of_member)
         for (int64_t i = 0; i < h->N; ++i)
             if (scenario_of_member[i] < 0 || scenario_of_member[i] >= n_scen)
@@ -664,6 +666,20 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ghg(a, h->stream));
+    } else if (h->kind >= RSCM_KIND_OZONE_FORCING) {
+        rscm::PointwiseArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.rows = h->rows;
+        a.kind = h->kind;
+        a.params = h->d_params;
+        a.inputs = h->d_forcing;
+        a.scen = h->d_scen;
+        a.out = h->series(1);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_pointwise(a, h->stream));
     } else if (h->kind == RSCM_KIND_UDEB) {
         if (!h->udeb_ready) return fail(RSCM_ERR_STATE, "ClimateUDEB parameters not configured");
         rscm::UdebArgs a{};

@@ -28,11 +28,10 @@ class Ensemble:
         self.n_times = len(b) - 1
         self.bounds = b
         self.device = device
-        self.var_ids: Dict[str, int] = dict({L.KIND_TWO_LAYER: L.TL_VARS, L.KIND_COUPLED: L.CP_VARS,
-                                             L.KIND_UDEB: L.UD_VARS, L.KIND_GHG_FORCING: L.GH_VARS}[kind])
-        self.n_params = {L.KIND_TWO_LAYER: 6, L.KIND_COUPLED: 10, L.KIND_UDEB: 37,
-                         L.KIND_GHG_FORCING: 21}[kind]
-        self.n_inputs = 3 if kind == L.KIND_GHG_FORCING else 1
+        var_ids, self.n_params, input_rows = L.KIND_TABLE[kind]
+        self.var_ids: Dict[str, int] = dict(var_ids)
+        self.input_rows = input_rows  # names of the rows of the input block, or None
+        self.n_inputs = len(input_rows) if input_rows else 1
         h = C.c_void_p()
         self.store_series = bool(store_series)
         L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
@@ -160,8 +159,8 @@ class Ensemble:
         if self.kind == L.KIND_UDEB:
             raise NotImplementedError("ClimateUDEB keeps internal ocean state on the device; "
                                       "host checkpoints are not available for this kind yet")
-        if self.kind == L.KIND_GHG_FORCING:
-            return {}  # a stateless component
+        if self.kind >= L.KIND_GHG_FORCING:
+            return {}  # stateless components
         return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}
 
     def checkpoint(self) -> Dict[str, object]:

@@ -1,6 +1,7 @@
-"""``ClimateUDEBBuilder`` and ``GhgForcingBuilder`` -- mirror of ``rscm.magicc`` for the climate
-core and the greenhouse-gas forcing (python/rscm/_lib/magicc.pyi;
-crates/rscm-magicc/src/climate/udeb/mod.rs, crates/rscm-magicc/src/forcing/ghg.rs and their
+"""``ClimateUDEBBuilder``, ``GhgForcingBuilder``, ``OzoneForcingBuilder``, ``AerosolDirectBuilder``
+and ``AerosolIndirectBuilder`` -- mirror of ``rscm.magicc`` for the climate core and the forcing
+components (python/rscm/_lib/magicc.pyi; crates/rscm-magicc/src/climate/udeb/mod.rs,
+crates/rscm-magicc/src/forcing/{ghg,ozone,aerosol_direct,aerosol_indirect}.rs and their
 parameter structs under crates/rscm-magicc/src/parameters/).  Unspecified parameters take the
 structs' ``Default`` (``#[serde(default)]``)."""
 from __future__ import annotations
@@ -69,3 +70,72 @@ class GhgForcingBuilder(ComponentBuilder):
             else:
                 p[k] = float(v)
         return cls(p)
+
+
+def _flat_parameters(names, defaults, parameters, arrays=()):
+    """serde(default) semantics over a flat name list; ``arrays`` are [f64; 4] fields stored as
+    name_0..name_3; booleans become 0/1."""
+    p = dict(zip(names, defaults))
+    for k, v in parameters.items():
+        if k in arrays:
+            if len(v) != 4:
+                raise ValueError(f"invalid length {len(v)}, expected an array of length 4")
+            for j, x in enumerate(v):
+                p[f"{k}_{j}"] = float(x)
+        elif k in p:
+            p[k] = float(v)
+        else:  # serde: unknown field
+            raise ValueError(f"unknown field `{k}`")
+    return p
+
+
+class OzoneForcing(Component):
+    type_name = "OzoneForcing"
+    definitions = ([(n, u, "Input") for n, u in zip(L.OZ_INPUTS, ("ppt", "ppb", "Mt N/yr", "Mt CO/yr", "Mt NMVOC/yr", "K"))]
+                   + [(n, "W/m^2", "Output") for n, v in L.OZ_VARS.items() if v > 0])
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.OZ_PARAM_NAMES]
+
+
+class OzoneForcingBuilder(ComponentBuilder):
+    component_cls = OzoneForcing
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        return cls(_flat_parameters(L.OZ_PARAM_NAMES, L.OZ_DEFAULTS, parameters))
+
+
+class AerosolDirect(Component):
+    type_name = "AerosolDirect"
+    definitions = ([(n, u, "Input") for n, u in zip(L.AD_INPUTS, ("Mt S/yr", "Mt BC/yr", "Mt OC/yr", "Mt N/yr"))]
+                   + [("Effective Radiative Forcing|Aerosol|Direct", "W/m^2", "Output")])  # FourBox grid
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.AD_PARAM_NAMES]
+
+
+class AerosolDirectBuilder(ComponentBuilder):
+    component_cls = AerosolDirect
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        return cls(_flat_parameters(L.AD_PARAM_NAMES, L.AD_DEFAULTS, parameters,
+                                    arrays=("sox_regional", "bc_regional", "oc_regional", "nitrate_regional")))
+
+
+class AerosolIndirect(Component):
+    type_name = "AerosolIndirect"
+    definitions = ([(n, u, "Input") for n, u in zip(L.AI_INPUTS, ("Mt S/yr", "Mt OC/yr"))]
+                   + [("Effective Radiative Forcing|Aerosol|Indirect", "W/m^2", "Output")])
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.AI_PARAM_NAMES]
+
+
+class AerosolIndirectBuilder(ComponentBuilder):
+    component_cls = AerosolIndirect
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        return cls(_flat_parameters(L.AI_PARAM_NAMES, L.AI_DEFAULTS, parameters))
