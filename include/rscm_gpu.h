@@ -76,6 +76,8 @@ extern "C" {
 #define RSCM_KIND_OZONE_FORCING 4    /* rscm-magicc OzoneForcing                                  */
 #define RSCM_KIND_AEROSOL_DIRECT 5   /* rscm-magicc AerosolDirect (FourBox output)                */
 #define RSCM_KIND_AEROSOL_INDIRECT 6 /* rscm-magicc AerosolIndirect                               */
+#define RSCM_KIND_CH4_CHEMISTRY 7    /* rscm-magicc CH4Chemistry (Prather iteration)              */
+#define RSCM_KIND_N2O_CHEMISTRY 8    /* rscm-magicc N2OChemistry (stratospheric delay)            */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -162,6 +164,23 @@ extern "C" {
  *           harmonize, harmonize_year, harmonize_target */
 #define RSCM_AI_NINPUTS 2
 #define RSCM_AI_NPARAMS 9
+/* CH4Chemistry (crates/rscm-magicc/src/chemistry/ch4.rs:50-66, parameters/ch4_chemistry.rs):
+ *   inputs  Emissions|CH4, Surface Temperature, Emissions|NOx, Emissions|CO, Emissions|NMVOC
+ *   state   1 Atmospheric Concentration|CH4 (needs an initial value);  output 2 Lifetime|CH4
+ *   params  ch4_pi, natural_emissions, tau_oh, tau_soil, tau_strat, tau_trop_cl,
+ *           ch4_self_feedback, oh_sensitivity_scale, oh_nox_sensitivity, oh_co_sensitivity,
+ *           oh_nmvoc_sensitivity, temp_sensitivity, include_temp_feedback,
+ *           include_emissions_feedback, ppb_to_tg, nox_reference, co_reference, nmvoc_reference */
+#define RSCM_CH4_NINPUTS 5
+#define RSCM_CH4_NPARAMS 18
+/* N2OChemistry (chemistry/n2o.rs:44-54, parameters/n2o_chemistry.rs):
+ *   input   Emissions|N2O;  state 1 Atmospheric Concentration|N2O;  output 2 Lifetime|N2O
+ *   params  n2o_pi, natural_emissions, tau_n2o, lifetime_feedback, strat_delay (an integer >= 0
+ *           held in a double), ppb_to_tg */
+#define RSCM_N2O_NINPUTS 1
+#define RSCM_N2O_NPARAMS 6
+#define RSCM_CHEM_VAR_CONC 1
+#define RSCM_CHEM_VAR_LIFETIME 2
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.

@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
@@ -74,6 +74,17 @@ def lib() -> C.CDLL:
         L.orc_pointwise_eval.restype = C.c_int32
         L.orc_pointwise_run.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, _dp, _ip, _dp, C.c_int64, C.c_int64]
         L.orc_pointwise_run.restype = C.c_int32
+        for f in ("n_params", "n_inputs"):
+            getattr(L, "orc_chem_" + f).argtypes = [C.c_int32]
+            getattr(L, "orc_chem_" + f).restype = C.c_int32
+        L.orc_chem_default_params.argtypes = [C.c_int32, _dp]
+        L.orc_chem_default_params.restype = None
+        L.orc_ch4_solve_concentration.argtypes = [_dp] + [C.c_double] * 7 + [_dp]
+        L.orc_ch4_solve_concentration.restype = None
+        L.orc_n2o_solve_concentration.argtypes = [_dp] + [C.c_double] * 5 + [_dp]
+        L.orc_n2o_solve_concentration.restype = None
+        L.orc_chem_run.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp, _dp, C.c_int64, C.c_int64]
+        L.orc_chem_run.restype = C.c_int32
         L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
         L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
@@ -382,3 +393,58 @@ def pointwise_run(kind, n_times, params, inputs, *, scen=None, threads=1) -> np.
     _pmap(lambda i0, i1: L.orc_pointwise_run(kind, N, n_times, _d(params), _d(inputs), _i(scen), _d(out), i0, i1),
           N, threads)
     return out
+
+
+# ------------------------------------------------------------ CH4Chemistry / N2OChemistry
+CHEM_CH4, CHEM_N2O = 7, 8
+CHEM_PARAM_NAMES = {
+    CHEM_CH4: ("ch4_pi", "natural_emissions", "tau_oh", "tau_soil", "tau_strat", "tau_trop_cl", "ch4_self_feedback",
+               "oh_sensitivity_scale", "oh_nox_sensitivity", "oh_co_sensitivity", "oh_nmvoc_sensitivity",
+               "temp_sensitivity", "include_temp_feedback", "include_emissions_feedback", "ppb_to_tg",
+               "nox_reference", "co_reference", "nmvoc_reference"),
+    CHEM_N2O: ("n2o_pi", "natural_emissions", "tau_n2o", "lifetime_feedback", "strat_delay", "ppb_to_tg"),
+}
+
+
+def chem_default_params(kind, **over) -> np.ndarray:
+    p = np.empty(lib().orc_chem_n_params(kind))
+    assert len(p) == len(CHEM_PARAM_NAMES[kind])
+    lib().orc_chem_default_params(kind, _d(p))
+    for k, v in over.items():
+        p[CHEM_PARAM_NAMES[kind].index(k)] = float(v)
+    return p
+
+
+def ch4_solve_concentration(params, prev, current, emissions, temperature, nox, co, nmvoc):
+    out = np.empty(2)
+    lib().orc_ch4_solve_concentration(_d(_f64(params)), prev, current, emissions, temperature, nox, co, nmvoc, _d(out))
+    return float(out[0]), float(out[1])
+
+
+def n2o_solve_concentration(params, prev, current, lagged, emissions, dt):
+    out = np.empty(2)
+    lib().orc_n2o_solve_concentration(_d(_f64(params)), prev, current, lagged, emissions, dt, _d(out))
+    return float(out[0]), float(out[1])
+
+
+def chem_run(kind, bounds, params, inputs, conc0, *, scen=None, threads=1):
+    """params [P][N]; inputs [S][n_inputs][T]; conc0 scalar or [N].  Returns (conc, lifetime), [T][N]."""
+    bounds = _f64(bounds)
+    T = len(bounds) - 1
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    inputs = _f64(inputs)
+    if inputs.ndim == 2:
+        inputs = inputs[None]
+    L = lib()
+    assert inputs.shape[1:] == (L.orc_chem_n_inputs(kind), T)
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    conc = np.full((T, N), np.nan)
+    conc[0] = conc0
+    life = np.full((T, N), np.nan)
+    _pmap(lambda i0, i1: L.orc_chem_run(kind, N, T, _d(bounds), _d(params), _d(inputs), _i(scen), _d(conc), _d(life),
+                                        i0, i1), N, threads)
+    return conc, life

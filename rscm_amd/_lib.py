@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librscm_gpu.so")
 OK, ERR_INVALID, ERR_STATE, ERR_TIME_AXIS, ERR_DEVICE, ERR_NOMEM = range(6)
 KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB, KIND_GHG_FORCING = 0, 1, 2, 3
 KIND_OZONE_FORCING, KIND_AEROSOL_DIRECT, KIND_AEROSOL_INDIRECT = 4, 5, 6
+KIND_CH4_CHEMISTRY, KIND_N2O_CHEMISTRY = 7, 8
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -88,11 +89,27 @@ AI_PARAM_NAMES = ("cloud_albedo_coefficient", "reference_burden", "sox_weight", 
                   "harmonize", "harmonize_year", "harmonize_target")
 AI_DEFAULTS = (-1.0, 50.0, 1.0, 0.3, 1.0, 10.0, 0.0, 2019.0, -0.89)
 
+# CH4Chemistry / N2OChemistry (crates/rscm-magicc/src/chemistry/{ch4,n2o}.rs): variable 1 is the
+# concentration state, variable 2 the lifetime output
+CH4_INPUTS = ("Emissions|CH4", "Surface Temperature", "Emissions|NOx", "Emissions|CO", "Emissions|NMVOC")
+CH4_VARS = {"CH4 chemistry inputs": 0, "Atmospheric Concentration|CH4": 1, "Lifetime|CH4": 2}
+CH4_PARAM_NAMES = ("ch4_pi", "natural_emissions", "tau_oh", "tau_soil", "tau_strat", "tau_trop_cl",
+                   "ch4_self_feedback", "oh_sensitivity_scale", "oh_nox_sensitivity", "oh_co_sensitivity",
+                   "oh_nmvoc_sensitivity", "temp_sensitivity", "include_temp_feedback",
+                   "include_emissions_feedback", "ppb_to_tg", "nox_reference", "co_reference", "nmvoc_reference")
+CH4_DEFAULTS = (722.0, 209.0, 9.3, 150.0, 120.0, 200.0, -0.32, 0.72, 0.0042, -0.000105, -0.000315, 0.0316,
+                1.0, 1.0, 2.75, 0.0, 0.0, 0.0)
+N2O_INPUTS = ("Emissions|N2O",)
+N2O_VARS = {"N2O chemistry inputs": 0, "Atmospheric Concentration|N2O": 1, "Lifetime|N2O": 2}
+N2O_PARAM_NAMES = ("n2o_pi", "natural_emissions", "tau_n2o", "lifetime_feedback", "strat_delay", "ppb_to_tg")
+N2O_DEFAULTS = (270.0, 11.0, 139.275, -0.04, 1.0, 4.79)
+
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {
     KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
     KIND_GHG_FORCING: (GH_VARS, 21, GH_INPUTS), KIND_OZONE_FORCING: (OZ_VARS, 13, OZ_INPUTS),
-    KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS)}
+    KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS),
+    KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS)}
 # FourBox variables stored as four scalar series: kind -> (name, first variable id)
 FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
                 KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1)}

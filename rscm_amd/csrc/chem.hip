@@ -1,0 +1,144 @@
+// CH4Chemistry and N2OChemistry ensemble kernels for gfx950 (MI355X), one thread per member.
+//
+// What they replace, per model step n (reference file:line):
+//   CH4Chemistry::solve / solve_concentration / prather_iteration
+//                                   crates/rscm-magicc/src/chemistry/ch4.rs:121-330
+//   N2OChemistry::solve / solve_concentration / iteration
+//                                   crates/rscm-magicc/src/chemistry/n2o.rs:96-260
+// under the stepper conventions of crates/rscm-core/src/model/runtime.rs: emissions and
+// temperature are exogenous series shared per scenario (index n); the concentration is the
+// component's own state -- at_start() is index n, previous() index n-1, at_offset(-k) index n-k,
+// with the reference's fall-backs when the history is shorter than the lag; concentration and
+// lifetime are written at index n+1.
+//
+// The last two concentrations travel in registers; N2O's stratospheric-delay lookups read this
+// thread's own earlier rows of the stored series (coalesced across the wavefront when the delay is
+// uniform).  The arithmetic is the reference's, operation for operation; pow and exp come from
+// the device math library (tests/test_gpu_chem.py states the tolerance).  Both kernels are
+// VALU-bound: four Prather passes per member-year, each with one f64 pow and several divisions,
+// against 16 B written.
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+constexpr int kPratherIterations = 4;
+
+template <bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    const double ch4_pi = P(0), natural = P(1), tau_oh0 = P(2);
+    const double tau_other = 1.0 / (1.0 / P(3) + 1.0 / P(4) + 1.0 / P(5));  // parameters/ch4_chemistry.rs tau_other
+    const double self_fb = P(6), gamma = P(7), s_nox = P(8), s_co = P(9), s_nmvoc = P(10), temp_sens = P(11);
+    const bool incl_temp = P(12) != 0.0, incl_emis = P(13) != 0.0;
+    const double ppb_to_tg = P(14), nox_ref = P(15), co_ref = P(16), nmvoc_ref = P(17);
+    const double burden_reference = ch4_pi * ppb_to_tg;
+    const double x = -gamma * self_fb;
+    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 5 * T;
+    a.status[i] = 0;
+    double cur = a.conc[(size_t)a.step_begin * N + i];
+    double prev = a.step_begin > 0 ? a.conc[(size_t)(a.step_begin - 1) * N + i] : cur;  // previous().unwrap_or(current)
+    if (a.step_begin == 0) a.lifetime[i] = __builtin_nan("");
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double emissions = in[n], temperature = in[(size_t)T + n];
+        const double delta_nox = in[(size_t)2 * T + n] - nox_ref, delta_co = in[(size_t)3 * T + n] - co_ref;
+        const double delta_nmvoc = in[(size_t)4 * T + n] - nmvoc_ref;
+        const double total_emissions = emissions + natural;
+        const double burden_prev = prev * ppb_to_tg;
+        double base = tau_oh0;
+        if (incl_emis) base = tau_oh0 * exp(-gamma * (s_nox * delta_nox + s_co * delta_co + s_nmvoc * delta_nmvoc));
+        double burden = cur * ppb_to_tg;
+        double delta_burden = 0.0, tau_oh = tau_oh0;
+#pragma unroll
+        for (int it = 0; it < kPratherIterations; ++it) {
+            const double burden_mean = (burden + burden_prev) / 2.0;
+            const double ratio = fmax(burden_mean / burden_reference, 1.0);
+            tau_oh = base * pow(ratio, x);
+            if (it > 0 && !(fabs(burden_prev) < 1e-10)) tau_oh = tau_oh * (1.0 - 0.5 * x * delta_burden / burden_prev);
+            if (incl_temp && !(fabs(temperature) < 1e-10)) {
+                const double delta_t = fmax(temperature, 0.0);
+                tau_oh = tau_oh0 / (tau_oh0 / tau_oh + temp_sens * delta_t);
+            }
+            delta_burden = total_emissions - burden_mean / tau_oh - burden_mean / tau_other;
+            burden = burden_prev + delta_burden;
+        }
+        const double next = burden / ppb_to_tg;
+        const size_t r = (size_t)(n + 1) * N + i;
+        a.conc[r] = next;
+        a.lifetime[r] = 1.0 / (1.0 / tau_oh + 1.0 / tau_other);
+        prev = cur;
+        cur = next;
+    }
+}
+
+template <bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    const double n2o_pi = P(0), natural = P(1), tau0 = P(2), lifetime_fb = P(3), ppb_to_tg = P(5);
+    int64_t delay = (int64_t)P(4);
+    if (delay < 1) delay = 1;  // strat_delay.max(1)
+    const double burden_reference = n2o_pi * ppb_to_tg;
+    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * T;
+    auto C = [&](int64_t k) -> double { return a.conc[(size_t)k * N + i]; };
+    a.status[i] = 0;
+    double cur = C(a.step_begin);
+    double prev = a.step_begin > 0 ? C(a.step_begin - 1) : cur;
+    if (a.step_begin == 0) a.lifetime[i] = __builtin_nan("");
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double dt = a.bounds[n + 1] - a.bounds[n];
+        // n2o.rs:203-218: at_offset(-delay) else previous; at_offset(-(delay+1)) else the former
+        double t_delay = prev;  // delay == 1: C(n-1) is `prev` already (and the fall-back for n == 0)
+        if (delay > 1 && (int64_t)n - delay >= 0) t_delay = C((int64_t)n - delay);
+        double t_delay_m1 = t_delay;
+        if ((int64_t)n - delay - 1 >= 0) t_delay_m1 = C((int64_t)n - delay - 1);
+        const double lagged = (t_delay + t_delay_m1) / 2.0;
+        const double total_emissions = in[n] + natural;
+        const double burden_prev = prev * ppb_to_tg, burden_lagged = lagged * ppb_to_tg;
+        double burden = cur * ppb_to_tg, tau_eff = tau0;
+#pragma unroll
+        for (int it = 0; it < kPratherIterations; ++it) {
+            const double burden_mid = (burden_prev + burden) / 2.0;
+            const double ratio = fmax(burden_mid / burden_reference, 1.0);
+            tau_eff = tau0 * pow(ratio, lifetime_fb);
+            const double rate = total_emissions - burden_lagged / tau_eff;
+            burden = burden_prev + rate * dt;
+        }
+        const double next = burden / ppb_to_tg;
+        const size_t r = (size_t)(n + 1) * N + i;
+        a.conc[r] = next;
+        a.lifetime[r] = tau_eff;
+        prev = cur;
+        cur = next;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_chem(const ChemArgs& a, hipStream_t s)
+{
+    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
+    if (a.kind == 7) {
+        if (a.scen) hipLaunchKernelGGL((ch4_kernel<true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((ch4_kernel<false>), grid, dim3(kBlock), 0, s, a);
+    } else if (a.kind == 8) {
+        if (a.scen) hipLaunchKernelGGL((n2o_kernel<true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((n2o_kernel<false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rscm

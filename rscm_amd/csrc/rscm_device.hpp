@@ -123,6 +123,21 @@ struct PointwiseArgs {
     uint8_t* status;
 };
 
+// CH4Chemistry / N2OChemistry (csrc/chem.hip)
+struct ChemArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t kind;            // RSCM_KIND_CH4_CHEMISTRY / RSCM_KIND_N2O_CHEMISTRY
+    const double* params;    // [P][N]
+    const double* inputs;    // [S][n_inputs][T]
+    const int32_t* scen;     // [N] or null
+    const double* bounds;    // [T+1]
+    double* conc;            // [T][N] state, row 0 = initial value
+    double* lifetime;        // [T][N]
+    uint8_t* status;
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -140,6 +155,7 @@ hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
+hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

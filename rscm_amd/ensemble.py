@@ -83,9 +83,12 @@ class Ensemble:
     def set_forcing(self, series, scenario_of_member=None, source: int = L.SRC_EXOGENOUS,
                     var=0) -> None:
         s = L.f64(series)
-        if self.n_inputs > 1:  # a block of rows per scenario: [S][n_inputs][T] or [n_inputs][T]
-            if s.ndim == 2:
-                s = s[None]
+        if self.input_rows:  # a block of rows per scenario: [S][n_inputs][T] or [n_inputs][T]
+            if s.ndim == 1 and self.n_inputs == 1:
+                s = s[None, None]
+            elif s.ndim == 2:
+                # one input row: [S][T]; several: one scenario's [n_inputs][T]
+                s = s[:, None] if self.n_inputs == 1 else s[None]
             if s.ndim != 3 or s.shape[1:] != (self.n_inputs, self.n_times):
                 raise ValueError(f"input block must be [S][{self.n_inputs}][{self.n_times}], got {s.shape}")
             s = np.ascontiguousarray(s)
@@ -159,6 +162,10 @@ class Ensemble:
         if self.kind == L.KIND_UDEB:
             raise NotImplementedError("ClimateUDEB keeps internal ocean state on the device; "
                                       "host checkpoints are not available for this kind yet")
+        if self.kind in (L.KIND_CH4_CHEMISTRY, L.KIND_N2O_CHEMISTRY):
+            # the update reads the two latest concentrations (previous() / at_start()) and, for
+            # N2O, rows further back: one row is not enough to resume from
+            raise NotImplementedError("host checkpoints of the chemistry kinds need the concentration history")
         if self.kind >= L.KIND_GHG_FORCING:
             return {}  # stateless components
         return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}

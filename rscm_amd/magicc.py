@@ -1,7 +1,9 @@
 """``ClimateUDEBBuilder``, ``GhgForcingBuilder``, ``OzoneForcingBuilder``, ``AerosolDirectBuilder``
-and ``AerosolIndirectBuilder`` -- mirror of ``rscm.magicc`` for the climate core and the forcing
-components (python/rscm/_lib/magicc.pyi; crates/rscm-magicc/src/climate/udeb/mod.rs,
-crates/rscm-magicc/src/forcing/{ghg,ozone,aerosol_direct,aerosol_indirect}.rs and their
+``AerosolIndirectBuilder``, ``CH4ChemistryBuilder`` and ``N2OChemistryBuilder`` -- mirror of
+``rscm.magicc`` for the climate core, the forcing components and the CH4 / N2O chemistry
+(python/rscm/_lib/magicc.pyi; crates/rscm-magicc/src/climate/udeb/mod.rs,
+crates/rscm-magicc/src/forcing/{ghg,ozone,aerosol_direct,aerosol_indirect}.rs,
+crates/rscm-magicc/src/chemistry/{ch4,n2o}.rs and their
 parameter structs under crates/rscm-magicc/src/parameters/).  Unspecified parameters take the
 structs' ``Default`` (``#[serde(default)]``)."""
 from __future__ import annotations
@@ -139,3 +141,40 @@ class AerosolIndirectBuilder(ComponentBuilder):
     @classmethod
     def from_parameters(cls, parameters: Dict[str, float]):
         return cls(_flat_parameters(L.AI_PARAM_NAMES, L.AI_DEFAULTS, parameters))
+
+
+class CH4Chemistry(Component):
+    type_name = "CH4Chemistry"
+    definitions = ([(n, u, "Input") for n, u in zip(L.CH4_INPUTS, ("Mt CH4/yr", "K", "Mt N/yr", "Mt CO/yr", "Mt NMVOC/yr"))]
+                   + [("Atmospheric Concentration|CH4", "ppb", "State"), ("Lifetime|CH4", "yr", "Output")])
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.CH4_PARAM_NAMES]
+
+
+class CH4ChemistryBuilder(ComponentBuilder):
+    component_cls = CH4Chemistry
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        return cls(_flat_parameters(L.CH4_PARAM_NAMES, L.CH4_DEFAULTS, parameters))
+
+
+class N2OChemistry(Component):
+    type_name = "N2OChemistry"
+    definitions = [("Emissions|N2O", "Mt N/yr", "Input"), ("Atmospheric Concentration|N2O", "ppb", "State"),
+                   ("Lifetime|N2O", "yr", "Output")]
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.N2O_PARAM_NAMES]
+
+
+class N2OChemistryBuilder(ComponentBuilder):
+    component_cls = N2OChemistry
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        p = _flat_parameters(L.N2O_PARAM_NAMES, L.N2O_DEFAULTS, parameters)
+        if p["strat_delay"] < 0 or p["strat_delay"] != int(p["strat_delay"]):  # serde: usize
+            raise ValueError("invalid type: strat_delay must be a non-negative integer")
+        return cls(p)
