@@ -78,6 +78,8 @@ extern "C" {
 #define RSCM_KIND_AEROSOL_INDIRECT 6 /* rscm-magicc AerosolIndirect                               */
 #define RSCM_KIND_CH4_CHEMISTRY 7    /* rscm-magicc CH4Chemistry (Prather iteration)              */
 #define RSCM_KIND_N2O_CHEMISTRY 8    /* rscm-magicc N2OChemistry (stratospheric delay)            */
+#define RSCM_KIND_CO2_BUDGET 9       /* rscm-magicc CO2Budget                                     */
+#define RSCM_KIND_TERRESTRIAL_CARBON 10 /* rscm-magicc TerrestrialCarbon (four pools)             */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -181,6 +183,22 @@ extern "C" {
 #define RSCM_N2O_NPARAMS 6
 #define RSCM_CHEM_VAR_CONC 1
 #define RSCM_CHEM_VAR_LIFETIME 2
+/* CO2Budget (crates/rscm-magicc/src/carbon/budget.rs:60-75, parameters/co2_budget.rs):
+ *   inputs  Emissions|CO2|Fossil, Emissions|CO2|Land Use, Carbon Flux|Terrestrial, Carbon Flux|Ocean
+ *   state   1 Atmospheric Concentration|CO2;  outputs 2 Emissions|CO2|Net, 3 Airborne Fraction|CO2
+ *   params  gtc_per_ppm, co2_pi */
+#define RSCM_CB_NINPUTS 4
+#define RSCM_CB_NPARAMS 2
+/* TerrestrialCarbon (carbon/terrestrial.rs:66-82, parameters/terrestrial_carbon.rs):
+ *   inputs  Atmospheric Concentration|CO2, Surface Temperature, Emissions|CO2|Land Use
+ *   states  1 Carbon Pool|Plant, 2 Carbon Pool|Detritus, 3 Carbon Pool|Soil, 4 Carbon Pool|Humus
+ *   output  5 Carbon Flux|Terrestrial
+ *   params  npp_pi, co2_pi, beta, npp/resp/detritus/soil/humus_temp_sensitivity,
+ *           plant/detritus/soil/humus_pool_pi, respiration_pi, frac_npp_to_plant,
+ *           frac_npp_to_detritus, frac_plant_to_detritus, frac_detritus_to_soil,
+ *           frac_soil_to_humus, enable_fertilization, enable_temp_feedback */
+#define RSCM_TC_NINPUTS 3
+#define RSCM_TC_NPARAMS 20
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.

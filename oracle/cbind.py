@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c", "carbon_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
@@ -85,6 +85,19 @@ def lib() -> C.CDLL:
         L.orc_n2o_solve_concentration.restype = None
         L.orc_chem_run.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp, _dp, C.c_int64, C.c_int64]
         L.orc_chem_run.restype = C.c_int32
+        for f in ("n_params", "n_inputs", "n_states", "n_outputs"):
+            getattr(L, "orc_carbon_" + f).argtypes = [C.c_int32]
+            getattr(L, "orc_carbon_" + f).restype = C.c_int32
+        L.orc_carbon_default_params.argtypes = [C.c_int32, _dp]
+        L.orc_carbon_default_params.restype = None
+        L.orc_co2_budget_solve.argtypes = [_dp, _dp, C.c_double, C.c_double, _dp]
+        L.orc_co2_budget_solve.restype = None
+        L.orc_terrestrial_taus.argtypes = [_dp, _dp]
+        L.orc_terrestrial_taus.restype = None
+        L.orc_terrestrial_solve_pools.argtypes = [_dp, _dp, _dp, C.c_double, _dp]
+        L.orc_terrestrial_solve_pools.restype = None
+        L.orc_carbon_run.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp, C.c_int64, C.c_int64]
+        L.orc_carbon_run.restype = C.c_int32
         L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
         L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
@@ -448,3 +461,67 @@ def chem_run(kind, bounds, params, inputs, conc0, *, scen=None, threads=1):
     _pmap(lambda i0, i1: L.orc_chem_run(kind, N, T, _d(bounds), _d(params), _d(inputs), _i(scen), _d(conc), _d(life),
                                         i0, i1), N, threads)
     return conc, life
+
+
+# ------------------------------------------------------------ CO2Budget / TerrestrialCarbon
+CARBON_BUDGET, CARBON_TERRESTRIAL = 9, 10
+CARBON_PARAM_NAMES = {
+    CARBON_BUDGET: ("gtc_per_ppm", "co2_pi"),
+    CARBON_TERRESTRIAL: ("npp_pi", "co2_pi", "beta", "npp_temp_sensitivity", "resp_temp_sensitivity",
+                         "detritus_temp_sensitivity", "soil_temp_sensitivity", "humus_temp_sensitivity",
+                         "plant_pool_pi", "detritus_pool_pi", "soil_pool_pi", "humus_pool_pi", "respiration_pi",
+                         "frac_npp_to_plant", "frac_npp_to_detritus", "frac_plant_to_detritus",
+                         "frac_detritus_to_soil", "frac_soil_to_humus", "enable_fertilization", "enable_temp_feedback"),
+}
+
+
+def carbon_default_params(kind, **over) -> np.ndarray:
+    p = np.empty(lib().orc_carbon_n_params(kind))
+    assert len(p) == len(CARBON_PARAM_NAMES[kind])
+    lib().orc_carbon_default_params(kind, _d(p))
+    for k, v in over.items():
+        p[CARBON_PARAM_NAMES[kind].index(k)] = float(v)
+    return p
+
+
+def co2_budget_solve(params, fossil, landuse, terrestrial, ocean, co2, dt):
+    out = np.empty(3)
+    lib().orc_co2_budget_solve(_d(_f64(params)), _d(_f64([fossil, landuse, terrestrial, ocean])), co2, dt, _d(out))
+    return tuple(float(x) for x in out)
+
+
+def terrestrial_taus(params):
+    out = np.empty(4)
+    lib().orc_terrestrial_taus(_d(_f64(params)), _d(out))
+    return out
+
+
+def terrestrial_solve_pools(params, co2, temperature, landuse, pools, dt):
+    out = np.empty(5)
+    lib().orc_terrestrial_solve_pools(_d(_f64(params)), _d(_f64([co2, temperature, landuse])), _d(_f64(pools)), dt, _d(out))
+    return out[:4].copy(), float(out[4])
+
+
+def carbon_run(kind, bounds, params, inputs, initial, *, scen=None, threads=1):
+    """params [P][N]; inputs [S][n_inputs][T]; initial [n_states] or [n_states][N].
+    Returns [n_states + n_outputs][T][N] (states first)."""
+    bounds = _f64(bounds)
+    T = len(bounds) - 1
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    inputs = _f64(inputs)
+    if inputs.ndim == 2:
+        inputs = inputs[None]
+    L = lib()
+    ns, no = L.orc_carbon_n_states(kind), L.orc_carbon_n_outputs(kind)
+    assert inputs.shape[1:] == (L.orc_carbon_n_inputs(kind), T)
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    series = np.full((ns + no, T, N), np.nan)
+    init = _f64(initial)
+    series[:ns, 0] = init.reshape(ns, -1)
+    _pmap(lambda i0, i1: L.orc_carbon_run(kind, N, T, _d(bounds), _d(params), _d(inputs), _i(scen), _d(series), i0, i1),
+          N, threads)
+    return series

@@ -18,6 +18,7 @@ OK, ERR_INVALID, ERR_STATE, ERR_TIME_AXIS, ERR_DEVICE, ERR_NOMEM = range(6)
 KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB, KIND_GHG_FORCING = 0, 1, 2, 3
 KIND_OZONE_FORCING, KIND_AEROSOL_DIRECT, KIND_AEROSOL_INDIRECT = 4, 5, 6
 KIND_CH4_CHEMISTRY, KIND_N2O_CHEMISTRY = 7, 8
+KIND_CO2_BUDGET, KIND_TERRESTRIAL_CARBON = 9, 10
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -104,12 +105,30 @@ N2O_VARS = {"N2O chemistry inputs": 0, "Atmospheric Concentration|N2O": 1, "Life
 N2O_PARAM_NAMES = ("n2o_pi", "natural_emissions", "tau_n2o", "lifetime_feedback", "strat_delay", "ppb_to_tg")
 N2O_DEFAULTS = (270.0, 11.0, 139.275, -0.04, 1.0, 4.79)
 
+# CO2Budget / TerrestrialCarbon (crates/rscm-magicc/src/carbon/{budget,terrestrial}.rs)
+CB_INPUTS = ("Emissions|CO2|Fossil", "Emissions|CO2|Land Use", "Carbon Flux|Terrestrial", "Carbon Flux|Ocean")
+CB_VARS = {"CO2 budget inputs": 0, "Atmospheric Concentration|CO2": 1, "Emissions|CO2|Net": 2,
+           "Airborne Fraction|CO2": 3}
+CB_PARAM_NAMES = ("gtc_per_ppm", "co2_pi")
+CB_DEFAULTS = (2.123, 278.0)
+TC_INPUTS = ("Atmospheric Concentration|CO2", "Surface Temperature", "Emissions|CO2|Land Use")
+TC_VARS = {"Terrestrial carbon inputs": 0, "Carbon Pool|Plant": 1, "Carbon Pool|Detritus": 2,
+           "Carbon Pool|Soil": 3, "Carbon Pool|Humus": 4, "Carbon Flux|Terrestrial": 5}
+TC_PARAM_NAMES = ("npp_pi", "co2_pi", "beta", "npp_temp_sensitivity", "resp_temp_sensitivity",
+                  "detritus_temp_sensitivity", "soil_temp_sensitivity", "humus_temp_sensitivity",
+                  "plant_pool_pi", "detritus_pool_pi", "soil_pool_pi", "humus_pool_pi", "respiration_pi",
+                  "frac_npp_to_plant", "frac_npp_to_detritus", "frac_plant_to_detritus",
+                  "frac_detritus_to_soil", "frac_soil_to_humus", "enable_fertilization", "enable_temp_feedback")
+TC_DEFAULTS = (66.27, 278.0, 0.6486, 0.0107, 0.0685, 0.1358, 0.1541, 0.05, 884.86, 92.77, 1681.53, 836.0,
+               12.26, 0.4483, 0.3998, 0.9989, 0.3, 0.1, 1.0, 1.0)
+
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {
     KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
     KIND_GHG_FORCING: (GH_VARS, 21, GH_INPUTS), KIND_OZONE_FORCING: (OZ_VARS, 13, OZ_INPUTS),
     KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS),
-    KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS)}
+    KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS),
+    KIND_CO2_BUDGET: (CB_VARS, 2, CB_INPUTS), KIND_TERRESTRIAL_CARBON: (TC_VARS, 20, TC_INPUTS)}
 # FourBox variables stored as four scalar series: kind -> (name, first variable id)
 FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
                 KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1)}

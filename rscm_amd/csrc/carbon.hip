@@ -1,0 +1,138 @@
+// CO2Budget and TerrestrialCarbon ensemble kernels for gfx950 (MI355X), one thread per member.
+//
+// What they replace, per model step n (reference file:line):
+//   CO2Budget::solve / solve_budget            crates/rscm-magicc/src/carbon/budget.rs:96-190
+//   TerrestrialCarbon::solve / solve_pools     crates/rscm-magicc/src/carbon/terrestrial.rs:103-330
+//   derived turnover times                     crates/rscm-magicc/src/parameters/terrestrial_carbon.rs:103-168
+// under the stepper conventions of crates/rscm-core/src/model/runtime.rs: inputs are exogenous
+// series shared per scenario (index n), the concentration / the four pools are the component's
+// own state (index n, carried in registers across the launch), everything is written at index
+// n+1, dt = bounds[n+1] - bounds[n].
+//
+// CO2Budget has no transcendental: its results carry the same bits as the CPU oracle's.
+// TerrestrialCarbon evaluates one log and up to five exp per member-year from the device math
+// library (tests/test_gpu_carbon.py states the tolerance).  Both stream their state rows to HBM
+// (24 / 40 B per member-year); CO2Budget is bound by that write stream, TerrestrialCarbon by
+// the transcendental VALU work.
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+template <bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void co2_budget_kernel(CarbonArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    const double gtc_per_ppm = a.params[i];
+    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 4 * T;
+    const size_t vs = (size_t)T * N;
+    a.status[i] = 0;
+    double co2 = a.series[(size_t)a.step_begin * N + i];
+    if (a.step_begin == 0) {
+        a.series[vs + i] = __builtin_nan("");
+        a.series[2 * vs + i] = __builtin_nan("");
+    }
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double dt = a.bounds[n + 1] - a.bounds[n];
+        const double total_emissions = in[n] + in[(size_t)T + n];
+        const double total_uptake = in[(size_t)2 * T + n] + in[(size_t)3 * T + n];
+        const double net_to_atm = total_emissions - total_uptake;
+        co2 = co2 + (net_to_atm * dt) / gtc_per_ppm;
+        const size_t r = (size_t)(n + 1) * N + i;
+        a.series[r] = co2;
+        a.series[vs + r] = net_to_atm;
+        a.series[2 * vs + r] = total_emissions > 0.0 ? net_to_atm / total_emissions : 0.0;
+    }
+}
+
+// carbon/terrestrial.rs:82-100
+__device__ __forceinline__ void implicit_pool_step(double pool, double tau, double flux_in, double temp_factor, double dt,
+                                                   double& new_pool, double& turnover)
+{
+    const double k_eff = temp_factor / tau;
+    const double half_k = 0.5 * k_eff * dt;
+    double np = ((1.0 - half_k) * pool + flux_in * dt) / (1.0 + half_k);
+    np = fmax(np, 0.0);
+    new_pool = np;
+    turnover = 0.5 * k_eff * (pool + np);
+}
+
+template <bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    const double npp_pi = P(0), co2_pi = P(1), beta = P(2), npp_ts = P(3), resp_ts = P(4), det_ts = P(5), soil_ts = P(6),
+                 hum_ts = P(7), plant_pi = P(8), det_pi = P(9), soil_pi = P(10), hum_pi = P(11), resp_pi = P(12),
+                 f_npp_plant = P(13), f_npp_det = P(14), f_plant_det = P(15), f_det_soil = P(16), f_soil_hum = P(17);
+    const bool fert_on = P(18) != 0.0, temp_on = P(19) != 0.0;
+    // parameters/terrestrial_carbon.rs:103-168, once per member
+    const double f_npp_soil = fmax(1.0 - f_npp_plant - f_npp_det, 0.0);
+    const double net_plant = f_npp_plant * npp_pi - resp_pi;
+    const double tau_plant = net_plant > 1e-10 ? plant_pi / net_plant : 100.0;
+    const double flux_det = f_npp_det * npp_pi + f_plant_det * net_plant;
+    const double tau_det = flux_det > 1e-10 ? det_pi / flux_det : 3.0;
+    const double flux_soil = f_npp_soil * npp_pi + (1.0 - f_plant_det) * net_plant + f_det_soil * (det_pi / tau_det);
+    const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
+    const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
+    const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
+    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 3 * T;
+    const size_t vs = (size_t)T * N;
+    a.status[i] = 0;
+    const size_t r0 = (size_t)a.step_begin * N + i;
+    double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];
+    if (a.step_begin == 0) a.series[4 * vs + i] = __builtin_nan("");
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double dt = a.bounds[n + 1] - a.bounds[n];
+        const double co2 = in[n], temperature = in[(size_t)T + n], landuse = in[(size_t)2 * T + n];
+        const double fert = (!fert_on || co2 <= 0.0) ? 1.0 : fmax(1.0 + beta * log(co2 / co2_pi), 0.1);
+        auto tf = [&](double sens) -> double { return temp_on ? exp(sens * temperature) : 1.0; };
+        const double npp = npp_pi * fert * tf(npp_ts);
+        const double respiration = resp_pi * fert * tf(resp_ts);
+        const double tf_det = tf(det_ts), tf_soil = tf(soil_ts), tf_hum = tf(hum_ts);
+        double n_plant, to_plant, n_det, to_det, n_soil, to_soil, n_hum, to_hum;
+        implicit_pool_step(plant, tau_plant, npp * f_npp_plant - respiration - landuse, 1.0, dt, n_plant, to_plant);
+        implicit_pool_step(det, tau_det, npp * f_npp_det + f_plant_det * to_plant, tf_det, dt, n_det, to_det);
+        const double npp_to_soil = npp * f_npp_soil;
+        const double plant_to_soil = (1.0 - f_plant_det) * to_plant;
+        const double det_to_soil = f_det_soil * to_det;
+        implicit_pool_step(soil, tau_soil, npp_to_soil + plant_to_soil + det_to_soil, tf_soil, dt, n_soil, to_soil);
+        implicit_pool_step(hum, tau_hum, f_soil_hum * to_soil, tf_hum, dt, n_hum, to_hum);
+        const double det_to_atm = (1.0 - f_det_soil) * to_det;
+        const double soil_to_atm = (1.0 - f_soil_hum) * to_soil;
+        const double total_resp = respiration + det_to_atm + soil_to_atm + to_hum;
+        const size_t r = (size_t)(n + 1) * N + i;
+        a.series[r] = plant = n_plant;
+        a.series[vs + r] = det = n_det;
+        a.series[2 * vs + r] = soil = n_soil;
+        a.series[3 * vs + r] = hum = n_hum;
+        a.series[4 * vs + r] = npp - total_resp - landuse;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s)
+{
+    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
+    if (a.kind == 9) {
+        if (a.scen) hipLaunchKernelGGL((co2_budget_kernel<true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((co2_budget_kernel<false>), grid, dim3(kBlock), 0, s, a);
+    } else if (a.kind == 10) {
+        if (a.scen) hipLaunchKernelGGL((terrestrial_kernel<true>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((terrestrial_kernel<false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rscm

@@ -138,6 +138,20 @@ struct ChemArgs {
     uint8_t* status;
 };
 
+// CO2Budget / TerrestrialCarbon (csrc/carbon.hip)
+struct CarbonArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t kind;            // RSCM_KIND_CO2_BUDGET / RSCM_KIND_TERRESTRIAL_CARBON
+    const double* params;    // [P][N]
+    const double* inputs;    // [S][n_inputs][T]
+    const int32_t* scen;     // [N] or null
+    const double* bounds;    // [T+1]
+    double* series;          // [n_states + n_outputs][T][N], states first
+    uint8_t* status;
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -156,6 +170,7 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
+hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

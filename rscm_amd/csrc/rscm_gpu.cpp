@@ -159,6 +159,8 @@ struct rscm_ens {
         if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
         if (kind == RSCM_KIND_UDEB) return var >= RSCM_UD_VAR_ST_NH_OCEAN && var <= RSCM_UD_VAR_ST_SH_LAND;
         if (kind == RSCM_KIND_CH4_CHEMISTRY || kind == RSCM_KIND_N2O_CHEMISTRY) return var == RSCM_CHEM_VAR_CONC;
+        if (kind == RSCM_KIND_CO2_BUDGET) return var == 1;
+        if (kind == RSCM_KIND_TERRESTRIAL_CARBON) return var >= 1 && var <= 4;
         if (kind >= RSCM_KIND_GHG_FORCING) return false;  // stateless components
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
@@ -314,7 +316,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_N2O_CHEMISTRY)
+    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_TERRESTRIAL_CARBON)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -333,10 +335,10 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->device = device_id;
     static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
                                  RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS, RSCM_CH4_NPARAMS,
-                                 RSCM_N2O_NPARAMS};
-    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3};  // variable ids incl. the input block 0
+                                 RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS};
+    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6};  // variable ids incl. the input block 0
     static const int32_t kInputs[] = {1, 1, 1, 3, RSCM_OZ_NINPUTS, RSCM_AD_NINPUTS, RSCM_AI_NINPUTS,
-                                      RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS};
+                                      RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS, RSCM_CB_NINPUTS, RSCM_TC_NINPUTS};
     h->P = kP[kind];
     h->V = kV[kind];
     h->n_inputs = kInputs[kind];
@@ -375,7 +377,8 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         CK(hipMalloc(&h->d_scal, (size_t)rscm::kUdebScalars * h->N * sizeof(double)));
         CK(hipMalloc(&h->d_hist, (size_t)h->T * h->N * sizeof(double)));
     }
-    if (kind == RSCM_KIND_UDEB || kind == RSCM_KIND_N2O_CHEMISTRY) {  // kinds that use the step length
+    if (kind == RSCM_KIND_UDEB || kind == RSCM_KIND_N2O_CHEMISTRY || kind == RSCM_KIND_CO2_BUDGET ||
+        kind == RSCM_KIND_TERRESTRIAL_CARBON) {  // kinds that use the step length
         CK(hipMalloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
         CK(hipMemcpyAsync(h->d_bounds, h->bounds.data(), (size_t)(h->T + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
@@ -671,6 +674,20 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ghg(a, h->stream));
+    } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON) {
+        rscm::CarbonArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.kind = h->kind;
+        a.params = h->d_params;
+        a.inputs = h->d_forcing;
+        a.scen = h->d_scen;
+        a.bounds = h->d_bounds;
+        a.series = h->series(1);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_carbon(a, h->stream));
     } else if (h->kind == RSCM_KIND_CH4_CHEMISTRY || h->kind == RSCM_KIND_N2O_CHEMISTRY) {
         rscm::ChemArgs a{};
         a.n_members = h->N;
@@ -686,7 +703,7 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.lifetime = h->series(RSCM_CHEM_VAR_LIFETIME);
         a.status = h->d_status;
         HIPCHK(rscm::launch_chem(a, h->stream));
-    } else if (h->kind >= RSCM_KIND_OZONE_FORCING) {
+    } else if (h->kind >= RSCM_KIND_OZONE_FORCING && h->kind <= RSCM_KIND_AEROSOL_INDIRECT) {
         rscm::PointwiseArgs a{};
         a.n_members = h->N;
         a.n_times = h->T;

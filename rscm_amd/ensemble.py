@@ -166,6 +166,10 @@ class Ensemble:
             # the update reads the two latest concentrations (previous() / at_start()) and, for
             # N2O, rows further back: one row is not enough to resume from
             raise NotImplementedError("host checkpoints of the chemistry kinds need the concentration history")
+        if self.kind == L.KIND_CO2_BUDGET:
+            return {k: v for k, v in self.var_ids.items() if v == 1}
+        if self.kind == L.KIND_TERRESTRIAL_CARBON:
+            return {k: v for k, v in self.var_ids.items() if 1 <= v <= 4}
         if self.kind >= L.KIND_GHG_FORCING:
             return {}  # stateless components
         return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}

@@ -1,9 +1,11 @@
 """``ClimateUDEBBuilder``, ``GhgForcingBuilder``, ``OzoneForcingBuilder``, ``AerosolDirectBuilder``
-``AerosolIndirectBuilder``, ``CH4ChemistryBuilder`` and ``N2OChemistryBuilder`` -- mirror of
-``rscm.magicc`` for the climate core, the forcing components and the CH4 / N2O chemistry
+``AerosolIndirectBuilder``, ``CH4ChemistryBuilder``, ``N2OChemistryBuilder``, ``CO2BudgetBuilder`` and
+``TerrestrialCarbonBuilder`` -- mirror of ``rscm.magicc`` for the climate core, the forcing
+components, the CH4 / N2O chemistry, the CO2 budget and the terrestrial carbon pools
 (python/rscm/_lib/magicc.pyi; crates/rscm-magicc/src/climate/udeb/mod.rs,
 crates/rscm-magicc/src/forcing/{ghg,ozone,aerosol_direct,aerosol_indirect}.rs,
-crates/rscm-magicc/src/chemistry/{ch4,n2o}.rs and their
+crates/rscm-magicc/src/chemistry/{ch4,n2o}.rs, crates/rscm-magicc/src/carbon/{budget,terrestrial}.rs
+and their
 parameter structs under crates/rscm-magicc/src/parameters/).  Unspecified parameters take the
 structs' ``Default`` (``#[serde(default)]``)."""
 from __future__ import annotations
@@ -178,3 +180,39 @@ class N2OChemistryBuilder(ComponentBuilder):
         if p["strat_delay"] < 0 or p["strat_delay"] != int(p["strat_delay"]):  # serde: usize
             raise ValueError("invalid type: strat_delay must be a non-negative integer")
         return cls(p)
+
+
+class CO2Budget(Component):
+    type_name = "CO2Budget"
+    definitions = ([(n, "GtC/yr", "Input") for n in L.CB_INPUTS]
+                   + [("Atmospheric Concentration|CO2", "ppm", "State"), ("Emissions|CO2|Net", "GtC/yr", "Output"),
+                      ("Airborne Fraction|CO2", "1", "Output")])
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.CB_PARAM_NAMES]
+
+
+class CO2BudgetBuilder(ComponentBuilder):
+    component_cls = CO2Budget
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        return cls(_flat_parameters(L.CB_PARAM_NAMES, L.CB_DEFAULTS, parameters))
+
+
+class TerrestrialCarbon(Component):
+    type_name = "TerrestrialCarbon"
+    definitions = ([(n, u, "Input") for n, u in zip(L.TC_INPUTS, ("ppm", "K", "GtC/yr"))]
+                   + [(n, "GtC", "State") for n, v in L.TC_VARS.items() if 1 <= v <= 4]
+                   + [("Carbon Flux|Terrestrial", "GtC/yr", "Output")])
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.TC_PARAM_NAMES]
+
+
+class TerrestrialCarbonBuilder(ComponentBuilder):
+    component_cls = TerrestrialCarbon
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        return cls(_flat_parameters(L.TC_PARAM_NAMES, L.TC_DEFAULTS, parameters))
