@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c", "carbon_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c", "carbon_oracle.c", "ocean_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
@@ -98,6 +98,19 @@ def lib() -> C.CDLL:
         L.orc_terrestrial_solve_pools.restype = None
         L.orc_carbon_run.argtypes = [C.c_int32, C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp, C.c_int64, C.c_int64]
         L.orc_carbon_run.restype = C.c_int32
+        L.orc_ocean_n_params.restype = C.c_int32
+        L.orc_ocean_default_params.argtypes = [C.c_int32, _dp]
+        L.orc_ocean_default_params.restype = None
+        L.orc_ocean_irf.argtypes = [_dp, C.c_double]
+        L.orc_ocean_irf.restype = C.c_double
+        L.orc_ocean_delta_pco2_from_dic.argtypes = [_dp, C.c_double]
+        L.orc_ocean_delta_pco2_from_dic.restype = C.c_double
+        L.orc_ocean_pco2.argtypes = [_dp, C.c_double, C.c_double]
+        L.orc_ocean_pco2.restype = C.c_double
+        L.orc_ocean_run.argtypes = [C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp, C.c_int64, C.c_int64]
+        L.orc_ocean_run.restype = C.c_int32
+        L.orc_ocean_solve_repeated.argtypes = [_dp] + [C.c_double] * 5 + [C.c_int32, _dp]
+        L.orc_ocean_solve_repeated.restype = C.c_int32
         L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
         L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
@@ -524,4 +537,66 @@ def carbon_run(kind, bounds, params, inputs, initial, *, scen=None, threads=1):
     series[:ns, 0] = init.reshape(ns, -1)
     _pmap(lambda i0, i1: L.orc_carbon_run(kind, N, T, _d(bounds), _d(params), _d(inputs), _i(scen), _d(series), i0, i1),
           N, threads)
+    return series
+
+
+# ------------------------------------------------------------------------------ OceanCarbon
+OCEAN_MODELS = {"3D-GFDL": 0, "2D-BERN": 1, "HILDA": 2}
+OCEAN_PARAM_NAMES = (("model", "co2_pi", "pco2_pi", "gas_exchange_scale", "gas_exchange_tau", "temp_sensitivity",
+                      "irf_scale", "mixed_layer_depth", "ocean_surface_area", "sst_pi", "steps_per_year",
+                      "max_history_months", "irf_switch_time")
+                     + tuple(f"delta_ospp_offsets_{i}" for i in range(5))
+                     + tuple(f"delta_ospp_coefficients_{i}" for i in range(5)) + ("enable_temp_feedback",))
+
+
+def ocean_default_params(model="3D-GFDL", **over) -> np.ndarray:
+    p = np.empty(lib().orc_ocean_n_params())
+    assert len(p) == len(OCEAN_PARAM_NAMES)
+    lib().orc_ocean_default_params(OCEAN_MODELS[model], _d(p))
+    for k, v in over.items():
+        p[OCEAN_PARAM_NAMES.index(k)] = float(v)
+    return p
+
+
+def ocean_irf(params, t):
+    return lib().orc_ocean_irf(_d(_f64(params)), float(t))
+
+
+def ocean_delta_pco2_from_dic(params, d):
+    return lib().orc_ocean_delta_pco2_from_dic(_d(_f64(params)), float(d))
+
+
+def ocean_pco2(params, delta_pco2_dic, delta_sst):
+    return lib().orc_ocean_pco2(_d(_f64(params)), float(delta_pco2_dic), float(delta_sst))
+
+
+def ocean_solve_repeated(params, co2, delta_sst, pco2, cumulative, dt, n_calls):
+    """n_calls x (pco2, cumulative, flux) of consecutive solve_ocean calls from an empty history."""
+    out = np.empty((n_calls, 3))
+    assert lib().orc_ocean_solve_repeated(_d(_f64(params)), co2, delta_sst, pco2, cumulative, dt, n_calls, _d(out)) == 0
+    return out
+
+
+def ocean_run(bounds, params, inputs, pco2_0, cumulative_0=0.0, *, scen=None, threads=1):
+    """params [P][N]; inputs [S][2][T] (CO2, SST anomaly).  Returns [3][T][N]: pCO2, cumulative, flux."""
+    bounds = _f64(bounds)
+    T = len(bounds) - 1
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    inputs = _f64(inputs)
+    if inputs.ndim == 2:
+        inputs = inputs[None]
+    assert inputs.shape[1:] == (2, T)
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    series = np.full((3, T, N), np.nan)
+    series[0, 0] = pco2_0
+    series[1, 0] = cumulative_0
+    L = lib()
+    rc = []
+    _pmap(lambda i0, i1: rc.append(L.orc_ocean_run(N, T, _d(bounds), _d(params), _d(inputs), _i(scen), _d(series), i0, i1)),
+          N, threads)
+    assert not any(rc)
     return series
