@@ -80,6 +80,7 @@ extern "C" {
 #define RSCM_KIND_N2O_CHEMISTRY 8    /* rscm-magicc N2OChemistry (stratospheric delay)            */
 #define RSCM_KIND_CO2_BUDGET 9       /* rscm-magicc CO2Budget                                     */
 #define RSCM_KIND_TERRESTRIAL_CARBON 10 /* rscm-magicc TerrestrialCarbon (four pools)             */
+#define RSCM_KIND_OCEAN_CARBON 11    /* rscm-magicc OceanCarbon (impulse-response mixed layer)    */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -199,6 +200,23 @@ extern "C" {
  *           frac_soil_to_humus, enable_fertilization, enable_temp_feedback */
 #define RSCM_TC_NINPUTS 3
 #define RSCM_TC_NPARAMS 20
+/* OceanCarbon (crates/rscm-magicc/src/carbon/ocean.rs:46-62, parameters/ocean_carbon.rs:73-196):
+ *   inputs  Atmospheric Concentration|CO2, Sea Surface Temperature (the anomaly the component
+ *           uses as delta_sst)
+ *   states  1 Ocean Surface pCO2, 2 Cumulative Ocean Uptake;  output 3 Carbon Flux|Ocean
+ *   params  model [u] (0 = 3D-GFDL, 1 = 2D-BERN, 2 = HILDA: selects the two IrfForm coefficient
+ *           sets of the reference's presets; other IrfForm contents are not supported), co2_pi,
+ *           pco2_pi, gas_exchange_scale, gas_exchange_tau, temp_sensitivity, irf_scale [u],
+ *           mixed_layer_depth, ocean_surface_area, sst_pi, steps_per_year [u] (12),
+ *           max_history_months [u], irf_switch_time [u], delta_ospp_offsets[5],
+ *           delta_ospp_coefficients[5], enable_temp_feedback.  [u] rows are uniform. */
+#define RSCM_OC_NINPUTS 2
+#define RSCM_OC_NPARAMS 24
+#define RSCM_OC_P_MODEL 0
+#define RSCM_OC_P_IRF_SCALE 6
+#define RSCM_OC_P_STEPS_PER_YEAR 10
+#define RSCM_OC_P_MAX_HISTORY_MONTHS 11
+#define RSCM_OC_P_IRF_SWITCH_TIME 12
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.

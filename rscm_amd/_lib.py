@@ -19,6 +19,7 @@ KIND_TWO_LAYER, KIND_COUPLED, KIND_UDEB, KIND_GHG_FORCING = 0, 1, 2, 3
 KIND_OZONE_FORCING, KIND_AEROSOL_DIRECT, KIND_AEROSOL_INDIRECT = 4, 5, 6
 KIND_CH4_CHEMISTRY, KIND_N2O_CHEMISTRY = 7, 8
 KIND_CO2_BUDGET, KIND_TERRESTRIAL_CARBON = 9, 10
+KIND_OCEAN_CARBON = 11
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -122,13 +123,31 @@ TC_PARAM_NAMES = ("npp_pi", "co2_pi", "beta", "npp_temp_sensitivity", "resp_temp
 TC_DEFAULTS = (66.27, 278.0, 0.6486, 0.0107, 0.0685, 0.1358, 0.1541, 0.05, 884.86, 92.77, 1681.53, 836.0,
                12.26, 0.4483, 0.3998, 0.9989, 0.3, 0.1, 1.0, 1.0)
 
+# OceanCarbon (crates/rscm-magicc/src/carbon/ocean.rs, parameters/ocean_carbon.rs presets)
+OC_INPUTS = ("Atmospheric Concentration|CO2", "Sea Surface Temperature")
+OC_VARS = {"Ocean carbon inputs": 0, "Ocean Surface pCO2": 1, "Cumulative Ocean Uptake": 2, "Carbon Flux|Ocean": 3}
+OC_MODELS = {"3D-GFDL": 0.0, "2D-BERN": 1.0, "HILDA": 2.0}
+OC_PARAM_NAMES = (("model", "co2_pi", "pco2_pi", "gas_exchange_scale", "gas_exchange_tau", "temp_sensitivity",
+                   "irf_scale", "mixed_layer_depth", "ocean_surface_area", "sst_pi", "steps_per_year",
+                   "max_history_months", "irf_switch_time")
+                  + tuple(f"delta_ospp_offsets_{i}" for i in range(5))
+                  + tuple(f"delta_ospp_coefficients_{i}" for i in range(5)) + ("enable_temp_feedback",))
+_OC_OSPP = (1.5568, 7.4706, 1.2748, 2.4491, 1.5468, -0.013993, -0.20207, -0.12015, -0.12639, -0.15326, 1.0)
+# gfdl_3d(), bern_2d(), hilda() (parameters/ocean_carbon.rs:88-196)
+OC_PRESETS = {
+    "3D-GFDL": (0.0, 278.0, 278.0, 1.833492, 7.66, 0.03717879, 0.9492864, 50.9, 3.55e14, 17.7, 12.0, 6000.0, 1.0) + _OC_OSPP,
+    "2D-BERN": (1.0, 278.0, 278.0, 1.833492, 7.46, 0.03717879, 0.9492864, 50.0, 3.5375e14, 18.2997, 12.0, 6000.0, 9.9) + _OC_OSPP,
+    "HILDA": (2.0, 278.0, 278.0, 1.833492, 9.06, 0.03717879, 0.9492864, 75.0, 3.62e14, 18.1716, 12.0, 6000.0, 2.0) + _OC_OSPP,
+}
+
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {
     KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
     KIND_GHG_FORCING: (GH_VARS, 21, GH_INPUTS), KIND_OZONE_FORCING: (OZ_VARS, 13, OZ_INPUTS),
     KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS),
     KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS),
-    KIND_CO2_BUDGET: (CB_VARS, 2, CB_INPUTS), KIND_TERRESTRIAL_CARBON: (TC_VARS, 20, TC_INPUTS)}
+    KIND_CO2_BUDGET: (CB_VARS, 2, CB_INPUTS), KIND_TERRESTRIAL_CARBON: (TC_VARS, 20, TC_INPUTS),
+    KIND_OCEAN_CARBON: (OC_VARS, 24, OC_INPUTS)}
 # FourBox variables stored as four scalar series: kind -> (name, first variable id)
 FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
                 KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1)}

@@ -1,0 +1,160 @@
+// OceanCarbon ensemble kernel for gfx950 (MI355X), one thread per member.
+//
+// What it replaces, per model step n (reference file:line):
+//   OceanCarbon::solve_impl / solve_ocean / calculate_delta_dic / calculate_flux
+//                                    crates/rscm-magicc/src/carbon/ocean.rs:73-215
+//   OceanCarbonParameters::{irf, scale_irf, delta_pco2_from_dic, ocean_pco2, ...}
+//                                    crates/rscm-magicc/src/parameters/ocean_carbon.rs:198-250
+// under the stepper conventions of crates/rscm-core/src/model/runtime.rs: CO2 and the SST anomaly
+// are exogenous series shared per scenario (index n), pCO2 and the cumulative uptake are the
+// component's own state (index n), the flux history is its internal state; outputs at n+1.
+//
+// The reference convolves, at every monthly sub-step, the whole flux history (up to
+// max_history_months = 6000 pulses) with the mixed-layer impulse response, evaluating the response
+// function for every pair.  Here:
+//   * the scaled response depends only on the lag and on uniform parameters: the host tabulates it
+//     once (rscm_gpu.cpp, ocean_irf_table -- same expressions, so the same bits as per-call
+//     evaluation), and the kernel reads it with wave-uniform indices (scalar loads);
+//   * the flux history lives in HBM as hist[month][N], member fastest;
+//   * the twelve convolutions of a year share their old pulses: each old pulse is loaded ONCE per
+//     year and multiplied into twelve running sums (one per sub-step), so a year costs one pass
+//     over the history instead of twelve.  Every sum still adds its terms oldest-to-newest, one
+//     rounded multiply and one rounded add per term like the reference (the build uses
+//     -ffp-contract=off), so the sums carry the same bits;
+//   * this year's own pulses stay in registers.
+// Per member-year: one coalesced pass over the history (8 B per pulse) and 24 f64 operations per
+// pulse: with the full 6000-month window 48 KB and 144 k operations -- the kernel sits between
+// the HBM and the FP64 roofs.  exp() of the temperature factor comes from the device
+// math library: results agree with the CPU oracle to its last-place error, and bit for bit when
+// the temperature feedback is off (tests/test_gpu_ocean.py).
+#include "rscm_device.hpp"
+
+namespace rscm {
+
+namespace {
+
+constexpr double kPpmToGtc = 2.124;                 // carbon/ocean.rs:26
+constexpr double kMicromolPerPpmM3PerKg = 1.72e17;  // parameters/ocean_carbon.rs:4
+
+struct OceanMember {
+    double pco2_pi, k_gas, temp_sens, dic_conv, coef[5];
+    bool temp_on;
+};
+
+// delta_pco2_from_dic + ocean_pco2 (parameters/ocean_carbon.rs:218-245); powi(k) as LLVM expands it
+__device__ __forceinline__ double pco2_from_dic(const OceanMember& m, double d, double temp_factor)
+{
+    const double d2 = d * d, d3 = d * d2, d4 = d2 * d2, d5 = d * d4;
+    const double g[5] = {d, d2 * 1e-3, -d3 * 1e-5, d4 * 1e-7, -d5 * 1e-10};
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s += m.coef[q] * g[q];
+    return (m.pco2_pi + s) * temp_factor;
+}
+
+template <int STEPS, bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    const int64_t H = a.max_hist;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    OceanMember m;
+    m.pco2_pi = P(2);
+    m.k_gas = P(3) / (P(4) * 12.0);  // gas_exchange_rate()
+    m.temp_sens = P(5);
+    m.dic_conv = kMicromolPerPpmM3PerKg / (P(7) * P(8));  // dic_conversion_factor()
+    const double sst_pi = P(9);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
+    m.temp_on = P(23) != 0.0;
+    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 2 * T;
+    const double* __restrict__ irf = a.irf;   // [H], wave-uniform indices
+    double* __restrict__ hist = a.hist + i;   // [months][N]
+    const size_t vs = (size_t)T * N;
+    a.status[i] = 0;
+    if (a.step_begin == 0) a.series[2 * vs + i] = __builtin_nan("");
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const size_t r0 = (size_t)n * N + i;
+        const double co2 = in[n], delta_sst = in[(size_t)T + n];
+        const double dt = a.bounds[n + 1] - a.bounds[n];
+        const double dt_month = dt / (double)STEPS;
+        const double temp_factor = m.temp_on ? exp(m.temp_sens * delta_sst) : 1.0;
+        double pco2 = a.series[r0], cumulative = a.series[vs + r0], total = 0.0;
+        const int64_t m0 = (int64_t)n * STEPS;  // months already in the history
+        // sub-step k convolves the pulses j in [lo(k), m0 + k]
+        auto lo = [&](int k) -> int64_t { const int64_t v = m0 + k + 1 - H; return v > 0 ? v : 0; };
+        double A[STEPS];
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k) A[k] = 0.0;
+        // ---- the old pulses, oldest first.  Head: the first STEPS-1 of them are still outside
+        // the window of the later sub-steps (bounded history), so each term is predicated.
+        int64_t j = lo(0);
+        const int64_t head_end = (j + STEPS - 1 < m0) ? j + STEPS - 1 : m0;
+        for (; j < head_end; ++j) {
+            const double f = hist[(size_t)j * N];
+#pragma unroll
+            for (int k = 0; k < STEPS; ++k) {
+                const int64_t lag = m0 + k - j;
+                const double term = f * irf[lag < H ? lag : 0];
+                if (j >= lo(k)) A[k] = A[k] + term;
+            }
+        }
+        // Bulk: groups of STEPS pulses share a 2*STEPS-1 entry window of the response table
+        for (; j + STEPS <= m0; j += STEPS) {
+            const int64_t base = m0 - j - (STEPS - 1);  // lag of (last pulse of the group, k = 0), >= 1
+            double w[2 * STEPS - 1], f[STEPS];
+#pragma unroll
+            for (int t = 0; t < 2 * STEPS - 1; ++t) w[t] = irf[base + t];
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) f[u] = hist[(size_t)(j + u) * N];
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) {
+#pragma unroll
+                for (int k = 0; k < STEPS; ++k) A[k] = A[k] + f[u] * w[STEPS - 1 - u + k];
+            }
+        }
+        for (; j < m0; ++j) {  // tail
+            const double f = hist[(size_t)j * N];
+#pragma unroll
+            for (int k = 0; k < STEPS; ++k) A[k] = A[k] + f * irf[m0 + k - j];
+        }
+        // ---- this year's sub-steps (solve_ocean, carbon/ocean.rs:116-160)
+        double fy[STEPS];
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k) {
+            const double flux_ppm = m.k_gas * (co2 - pco2);
+            fy[k] = flux_ppm;
+            hist[(size_t)(m0 + k) * N] = flux_ppm;
+            const double flux_gtc_yr = flux_ppm * 12.0 * kPpmToGtc;
+            total += flux_gtc_yr / (double)STEPS;
+            cumulative += flux_gtc_yr * dt_month;
+            double integral = A[k];
+#pragma unroll
+            for (int q = 0; q <= k; ++q)
+                if (m0 + q >= lo(k)) integral = integral + fy[q] * irf[k - q < H ? k - q : 0];
+            const double delta_dic = H > 0 ? integral * m.dic_conv : 0.0;
+            pco2 = pco2_from_dic(m, delta_dic, temp_factor);
+        }
+        const size_t r1 = r0 + (size_t)N;
+        a.series[r1] = pco2;
+        a.series[vs + r1] = cumulative;
+        a.series[2 * vs + r1] = total;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_ocean(const OceanArgs& a, hipStream_t s)
+{
+    if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    if (a.steps != 12) return hipErrorInvalidValue;  // the sub-step loop is unrolled for monthly steps
+    const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
+    if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((ocean_kernel<12, false>), grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace rscm

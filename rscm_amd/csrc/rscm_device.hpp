@@ -152,6 +152,23 @@ struct CarbonArgs {
     uint8_t* status;
 };
 
+// OceanCarbon (csrc/ocean.hip)
+struct OceanArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    int32_t steps;           // sub-steps per model step (12)
+    int64_t max_hist;        // max_history_months
+    const double* params;    // [24][N]
+    const double* inputs;    // [S][2][T]: CO2, SST anomaly
+    const int32_t* scen;     // [N] or null
+    const double* bounds;    // [T+1]
+    const double* irf;       // [max(max_hist, 1)] scaled impulse response at lag k/12 yr
+    double* hist;            // [(T-1)*steps][N] flux history, ppm/month
+    double* series;          // [3][T][N]: pCO2, cumulative uptake, flux
+    uint8_t* status;
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -171,6 +188,7 @@ hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
 hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s);
+hipError_t launch_ocean(const OceanArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

@@ -102,6 +102,45 @@ static std::vector<double> ghg_tables(const double* conc, int32_t n_scen, int32_
     return t;
 }
 
+// OceanCarbon: the scaled mixed-layer impulse response at lag k/12 years, k = 0 .. n-1
+// (OceanCarbonParameters::irf + scale_irf, parameters/ocean_carbon.rs:202-216, with the IrfForm
+// coefficient sets of the gfdl_3d / bern_2d / hilda presets, :88-196).  The expressions are the
+// reference's, evaluated once per lag instead of once per (pulse, sub-step) pair.
+static std::vector<double> ocean_irf_table(int model, double irf_scale, double switch_time, int64_t n)
+{
+    struct Form { bool poly; int n; double c[8]; double tau[8]; };
+    static const Form gfdl_e = {true, 7, {1.0, -2.2617, 14.002, -48.770, 82.986, -67.527, 21.037}, {0}};
+    static const Form gfdl_l = {false, 6, {0.01481, 0.019439, 0.038344, 0.066485, 0.24966, 0.70367},
+                                {1.0e10, 347.55, 65.359, 15.281, 2.3488, 0.70177}};
+    static const Form bern_e = {false, 6, {0.058648, 0.07515, 0.079338, 0.41413, 0.24845, 0.12429},
+                                {1.0e10, 9.6218, 9.2364, 0.7603, 0.16294, 0.0032825}};
+    static const Form bern_l = {false, 6, {0.01369, 0.012456, 0.026933, 0.026994, 0.036608, 0.06738},
+                                {1.0e10, 331.54, 107.57, 38.946, 11.677, 10.515}};
+    static const Form hilda_e = {false, 5, {0.12935, 0.24093, 0.24071, 0.17003, 0.21898},
+                                 {1.0e10, 4.9792, 0.96083, 0.26936, 0.034569}};
+    static const Form hilda_l = {false, 6, {0.022936, 0.035549, 0.037820, 0.089318, 0.13963, 0.24278},
+                                 {1.0e10, 232.30, 68.736, 18.601, 5.2528, 1.2679}};
+    const Form& early = model == 1 ? bern_e : model == 2 ? hilda_e : gfdl_e;
+    const Form& late = model == 1 ? bern_l : model == 2 ? hilda_l : gfdl_l;
+    auto eval = [](const Form& f, double t) {
+        if (f.poly) {
+            double r = 0.0;
+            for (int i = f.n - 1; i >= 0; --i) r = r * t + f.c[i];
+            return r;
+        }
+        double s = 0.0;
+        for (int i = 0; i < f.n; ++i) s += f.c[i] * std::exp(-t / f.tau[i]);
+        return s;
+    };
+    std::vector<double> tab((size_t)std::max<int64_t>(n, 1), 0.0);
+    for (int64_t k = 0; k < n; ++k) {
+        const double t = (double)k * (1.0 / 12.0);
+        const double raw = t < switch_time ? eval(early, t) : eval(late, t);
+        tab[(size_t)k] = (raw * irf_scale) / (raw * irf_scale + 1.0 - raw);
+    }
+    return tab;
+}
+
 struct rscm_ens {
     int32_t kind = 0;
     int64_t N = 0;
@@ -123,6 +162,12 @@ struct rscm_ens {
     int32_t n_inputs = 1;        // rows per scenario of the shared input block
     double* d_ghg_tables = nullptr;  // GhgForcing: [S][kGhgRows][T] derived scenario rows
     int32_t ghg_method = 1;
+    // OceanCarbon: flux history (internal state) and the tabulated impulse response
+    double* d_ocean_hist = nullptr;  // [(T-1)*steps][N]
+    double* d_ocean_irf = nullptr;   // [max(max_hist, 1)]
+    int32_t ocean_steps = 0;
+    int64_t ocean_max_hist = 0;
+    bool ocean_ready = false;
     int32_t* d_scen = nullptr;   // [N] or null
     int32_t n_scen = 0;
     int32_t source = RSCM_SRC_EXOGENOUS;
@@ -161,6 +206,7 @@ struct rscm_ens {
         if (kind == RSCM_KIND_CH4_CHEMISTRY || kind == RSCM_KIND_N2O_CHEMISTRY) return var == RSCM_CHEM_VAR_CONC;
         if (kind == RSCM_KIND_CO2_BUDGET) return var == 1;
         if (kind == RSCM_KIND_TERRESTRIAL_CARBON) return var >= 1 && var <= 4;
+        if (kind == RSCM_KIND_OCEAN_CARBON) return var == 1 || var == 2;
         if (kind >= RSCM_KIND_GHG_FORCING) return false;  // stateless components
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
@@ -199,6 +245,42 @@ int refresh_schedule(rscm_ens* h)
     }
     HIPCHK(hipStreamSynchronize(h->stream));  // host vectors may be rebuilt afterwards
     h->schedule_dirty = false;
+    return RSCM_OK;
+}
+
+// OceanCarbon: the rows that select the response table and the loop bounds must be uniform.
+template <typename Row>
+int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
+{
+    static const int structural[] = {RSCM_OC_P_MODEL, RSCM_OC_P_IRF_SCALE, RSCM_OC_P_STEPS_PER_YEAR,
+                                     RSCM_OC_P_MAX_HISTORY_MONTHS, RSCM_OC_P_IRF_SWITCH_TIME};
+    for (int j : structural)
+        for (int64_t i = 1; i < n_check; ++i)
+            if (row(j, i) != row(j, 0))
+                return fail(RSCM_ERR_INVALID, "OceanCarbon parameter row %d must be the same for every member", j);
+    const double model = row(RSCM_OC_P_MODEL, 0), steps = row(RSCM_OC_P_STEPS_PER_YEAR, 0);
+    const double max_hist = row(RSCM_OC_P_MAX_HISTORY_MONTHS, 0);
+    if (model != 0.0 && model != 1.0 && model != 2.0)
+        return fail(RSCM_ERR_INVALID, "OceanCarbon model must be 0 (3D-GFDL), 1 (2D-BERN) or 2 (HILDA), got %g", model);
+    if (steps != 12.0) return fail(RSCM_ERR_INVALID, "OceanCarbon on the device supports steps_per_year = 12, got %g", steps);
+    if (!(max_hist >= 0.0) || max_hist > 1e7 || max_hist != std::floor(max_hist))
+        return fail(RSCM_ERR_INVALID, "max_history_months must be a non-negative integer, got %g", max_hist);
+    const std::vector<double> tab = ocean_irf_table((int)model, row(RSCM_OC_P_IRF_SCALE, 0),
+                                                    row(RSCM_OC_P_IRF_SWITCH_TIME, 0), (int64_t)max_hist);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(h->d_ocean_irf));
+    h->d_ocean_irf = nullptr;
+    HIPCHK(hipMalloc(&h->d_ocean_irf, tab.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(h->d_ocean_irf, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!h->d_ocean_hist) {
+        const hipError_t e = hipMalloc(&h->d_ocean_hist, (size_t)(h->T - 1) * 12 * h->N * sizeof(double));
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,
+                        "flux history of %lld members x %d months: %s", (long long)h->N, (h->T - 1) * 12, hipGetErrorString(e));
+    }
+    h->ocean_steps = 12;
+    h->ocean_max_hist = (int64_t)max_hist;
+    h->ocean_ready = true;
     return RSCM_OK;
 }
 
@@ -316,7 +398,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_TERRESTRIAL_CARBON)
+    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_OCEAN_CARBON)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -335,10 +417,11 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->device = device_id;
     static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
                                  RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS, RSCM_CH4_NPARAMS,
-                                 RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS};
-    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6};  // variable ids incl. the input block 0
+                                 RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS, RSCM_OC_NPARAMS};
+    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4};  // variable ids incl. the input block 0
     static const int32_t kInputs[] = {1, 1, 1, 3, RSCM_OZ_NINPUTS, RSCM_AD_NINPUTS, RSCM_AI_NINPUTS,
-                                      RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS, RSCM_CB_NINPUTS, RSCM_TC_NINPUTS};
+                                      RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS, RSCM_CB_NINPUTS, RSCM_TC_NINPUTS,
+                                      RSCM_OC_NINPUTS};
     h->P = kP[kind];
     h->V = kV[kind];
     h->n_inputs = kInputs[kind];
@@ -378,7 +461,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         CK(hipMalloc(&h->d_hist, (size_t)h->T * h->N * sizeof(double)));
     }
     if (kind == RSCM_KIND_UDEB || kind == RSCM_KIND_N2O_CHEMISTRY || kind == RSCM_KIND_CO2_BUDGET ||
-        kind == RSCM_KIND_TERRESTRIAL_CARBON) {  // kinds that use the step length
+        kind == RSCM_KIND_TERRESTRIAL_CARBON || kind == RSCM_KIND_OCEAN_CARBON) {  // kinds that use the step length
         CK(hipMalloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
         CK(hipMemcpyAsync(h->d_bounds, h->bounds.data(), (size_t)(h->T + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
@@ -406,6 +489,8 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_nsub_tl);
     (void)hipFree(h->d_nsub_cc);
     (void)hipFree(h->d_ghg_tables);
+    (void)hipFree(h->d_ocean_hist);
+    (void)hipFree(h->d_ocean_irf);
     (void)hipFree(h->d_ocean);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
@@ -482,6 +567,8 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
     if (int rc = set_device(h)) return rc;
     if (h->kind == RSCM_KIND_UDEB)
         if (int rc = configure_udeb(h, h->N, [&](int j, int64_t i) { return soa[(size_t)j * h->N + i]; })) return rc;
+    if (h->kind == RSCM_KIND_OCEAN_CARBON)
+        if (int rc = configure_ocean(h, h->N, [&](int j, int64_t i) { return soa[(size_t)j * h->N + i]; })) return rc;
     if (h->kind == RSCM_KIND_GHG_FORCING) {  // one forcing method per ensemble (one kernel instance)
         const double m = soa[(size_t)RSCM_GH_P_METHOD * h->N];
         if (m != 0.0 && m != 1.0) return fail(RSCM_ERR_INVALID, "GhgForcing method must be 0 (Ipcctar) or 1 (Olbl), got %g", m);
@@ -674,6 +761,24 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ghg(a, h->stream));
+    } else if (h->kind == RSCM_KIND_OCEAN_CARBON) {
+        if (!h->ocean_ready) return fail(RSCM_ERR_STATE, "OceanCarbon parameters not configured");
+        rscm::OceanArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.steps = h->ocean_steps;
+        a.max_hist = h->ocean_max_hist;
+        a.params = h->d_params;
+        a.inputs = h->d_forcing;
+        a.scen = h->d_scen;
+        a.bounds = h->d_bounds;
+        a.irf = h->d_ocean_irf;
+        a.hist = h->d_ocean_hist;
+        a.series = h->series(1);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_ocean(a, h->stream));
     } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON) {
         rscm::CarbonArgs a{};
         a.n_members = h->N;
@@ -1055,6 +1160,14 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
             if (low[j] != high[j])
                 return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d is structural: low must equal high", j);
         if (int rc = configure_udeb(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
+    }
+    if (h->kind == RSCM_KIND_OCEAN_CARBON) {
+        static const int structural[] = {RSCM_OC_P_MODEL, RSCM_OC_P_IRF_SCALE, RSCM_OC_P_STEPS_PER_YEAR,
+                                         RSCM_OC_P_MAX_HISTORY_MONTHS, RSCM_OC_P_IRF_SWITCH_TIME};
+        for (int j : structural)
+            if (low[j] != high[j])
+                return fail(RSCM_ERR_INVALID, "OceanCarbon parameter row %d is structural: low must equal high", j);
+        if (int rc = configure_ocean(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
     }
     if (h->kind == RSCM_KIND_GHG_FORCING) {
         const double m = low[RSCM_GH_P_METHOD];

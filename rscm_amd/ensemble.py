@@ -166,6 +166,9 @@ class Ensemble:
             # the update reads the two latest concentrations (previous() / at_start()) and, for
             # N2O, rows further back: one row is not enough to resume from
             raise NotImplementedError("host checkpoints of the chemistry kinds need the concentration history")
+        if self.kind == L.KIND_OCEAN_CARBON:
+            raise NotImplementedError("OceanCarbon keeps its flux history on the device; "
+                                      "host checkpoints are not available for this kind yet")
         if self.kind == L.KIND_CO2_BUDGET:
             return {k: v for k, v in self.var_ids.items() if v == 1}
         if self.kind == L.KIND_TERRESTRIAL_CARBON:

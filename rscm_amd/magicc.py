@@ -1,10 +1,10 @@
 """``ClimateUDEBBuilder``, ``GhgForcingBuilder``, ``OzoneForcingBuilder``, ``AerosolDirectBuilder``
-``AerosolIndirectBuilder``, ``CH4ChemistryBuilder``, ``N2OChemistryBuilder``, ``CO2BudgetBuilder`` and
-``TerrestrialCarbonBuilder`` -- mirror of ``rscm.magicc`` for the climate core, the forcing
+``AerosolIndirectBuilder``, ``CH4ChemistryBuilder``, ``N2OChemistryBuilder``, ``CO2BudgetBuilder``,
+``TerrestrialCarbonBuilder`` and ``OceanCarbonBuilder`` -- mirror of ``rscm.magicc`` for the climate core, the forcing
 components, the CH4 / N2O chemistry, the CO2 budget and the terrestrial carbon pools
 (python/rscm/_lib/magicc.pyi; crates/rscm-magicc/src/climate/udeb/mod.rs,
 crates/rscm-magicc/src/forcing/{ghg,ozone,aerosol_direct,aerosol_indirect}.rs,
-crates/rscm-magicc/src/chemistry/{ch4,n2o}.rs, crates/rscm-magicc/src/carbon/{budget,terrestrial}.rs
+crates/rscm-magicc/src/chemistry/{ch4,n2o}.rs, crates/rscm-magicc/src/carbon/{budget,terrestrial,ocean}.rs
 and their
 parameter structs under crates/rscm-magicc/src/parameters/).  Unspecified parameters take the
 structs' ``Default`` (``#[serde(default)]``)."""
@@ -82,8 +82,9 @@ def _flat_parameters(names, defaults, parameters, arrays=()):
     p = dict(zip(names, defaults))
     for k, v in parameters.items():
         if k in arrays:
-            if len(v) != 4:
-                raise ValueError(f"invalid length {len(v)}, expected an array of length 4")
+            n_expected = sum(1 for name in names if name.startswith(k + "_") and name[len(k) + 1:].isdigit())
+            if len(v) != n_expected:
+                raise ValueError(f"invalid length {len(v)}, expected an array of length {n_expected}")
             for j, x in enumerate(v):
                 p[f"{k}_{j}"] = float(x)
         elif k in p:
@@ -216,3 +217,33 @@ class TerrestrialCarbonBuilder(ComponentBuilder):
     @classmethod
     def from_parameters(cls, parameters: Dict[str, float]):
         return cls(_flat_parameters(L.TC_PARAM_NAMES, L.TC_DEFAULTS, parameters))
+
+
+class OceanCarbon(Component):
+    type_name = "OceanCarbon"
+    definitions = [("Atmospheric Concentration|CO2", "ppm", "Input"), ("Sea Surface Temperature", "K", "Input"),
+                   ("Ocean Surface pCO2", "ppm", "State"), ("Cumulative Ocean Uptake", "GtC", "State"),
+                   ("Carbon Flux|Ocean", "GtC/yr", "Output")]
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.OC_PARAM_NAMES]
+
+
+class OceanCarbonBuilder(ComponentBuilder):
+    """``model`` picks the preset the unspecified fields default to and the impulse-response
+    coefficient sets (the reference's ``OceanCarbonParameters::{gfdl_3d, bern_2d, hilda}``; its
+    serde default is 3D-GFDL).  Custom ``irf_early`` / ``irf_late`` forms are not supported on the
+    device."""
+    component_cls = OceanCarbon
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, float]):
+        parameters = dict(parameters)
+        model = parameters.pop("model", "3D-GFDL")
+        if model not in L.OC_PRESETS:  # serde: unknown variant
+            raise ValueError(f"unknown variant `{model}`, expected one of `3D-GFDL`, `2D-BERN`, `HILDA`")
+        for k in ("irf_early", "irf_late"):
+            if k in parameters:
+                raise NotImplementedError(f"custom {k} forms are not supported by the device kernel; choose a model preset")
+        return cls(_flat_parameters(L.OC_PARAM_NAMES, L.OC_PRESETS[model], parameters,
+                                    arrays=("delta_ospp_offsets", "delta_ospp_coefficients")))
