@@ -16,15 +16,15 @@
 //     once (rscm_gpu.cpp, ocean_irf_table -- same expressions, so the same bits as per-call
 //     evaluation), and the kernel reads it with wave-uniform indices (scalar loads);
 //   * the flux history lives in HBM as hist[month][N], member fastest;
-//   * the twelve convolutions of a year share their old pulses: each old pulse is loaded ONCE per
-//     year and multiplied into twelve running sums (one per sub-step), so a year costs one pass
-//     over the history instead of twelve.  Every sum still adds its terms oldest-to-newest, one
+//   * the convolutions of two consecutive years share their old pulses: each old pulse is loaded
+//     ONCE per two years and multiplied into 24 running sums (one per sub-step), so two years cost
+//     one pass over the history instead of 24.  Every sum still adds its terms oldest-to-newest, one
 //     rounded multiply and one rounded add per term like the reference (the build uses
 //     -ffp-contract=off), so the sums carry the same bits;
 //   * this year's own pulses stay in registers.
-// Per member-year: one coalesced pass over the history (8 B per pulse) and 24 f64 operations per
-// pulse: with the full 6000-month window 48 KB and 144 k operations -- the kernel sits between
-// the HBM and the FP64 roofs.  exp() of the temperature factor comes from the device
+// Per member-year: half a coalesced pass over the history (4 B per pulse) and 24 f64 operations
+// per pulse: with the full 6000-month window 24 KB and 144 k operations (DESIGN.md has the
+// roofline).  exp() of the temperature factor comes from the device
 // math library: results agree with the CPU oracle to its last-place error, and bit for bit when
 // the temperature feedback is off (tests/test_gpu_ocean.py).
 #include "rscm_device.hpp"
@@ -52,79 +52,69 @@ __device__ __forceinline__ double pco2_from_dic(const OceanMember& m, double d, 
     return (m.pco2_pi + s) * temp_factor;
 }
 
-template <int STEPS, bool HAS_SCEN>
-__global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a)
+// YEARS consecutive model steps starting at n: one pass over the old pulses feeds the
+// STEPS*YEARS running sums of all their sub-steps.
+template <int STEPS, int YEARS>
+__device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember& m, const double* __restrict__ in,
+                                           const double* __restrict__ irf, double* __restrict__ hist, int64_t i, int32_t n)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.n_members) return;
+    constexpr int K = STEPS * YEARS;
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     const int64_t H = a.max_hist;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
-    OceanMember m;
-    m.pco2_pi = P(2);
-    m.k_gas = P(3) / (P(4) * 12.0);  // gas_exchange_rate()
-    m.temp_sens = P(5);
-    m.dic_conv = kMicromolPerPpmM3PerKg / (P(7) * P(8));  // dic_conversion_factor()
-    const double sst_pi = P(9);
-#pragma unroll
-    for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
-    m.temp_on = P(23) != 0.0;
-    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 2 * T;
-    const double* __restrict__ irf = a.irf;   // [H], wave-uniform indices
-    double* __restrict__ hist = a.hist + i;   // [months][N]
     const size_t vs = (size_t)T * N;
-    a.status[i] = 0;
-    if (a.step_begin == 0) a.series[2 * vs + i] = __builtin_nan("");
-    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-        const size_t r0 = (size_t)n * N + i;
-        const double co2 = in[n], delta_sst = in[(size_t)T + n];
-        const double dt = a.bounds[n + 1] - a.bounds[n];
+    const int64_t m0 = (int64_t)n * STEPS;  // months already in the history
+    // sub-step k of the tile convolves the pulses j in [lo(k), m0 + k]
+    auto lo = [&](int k) -> int64_t { const int64_t v = m0 + k + 1 - H; return v > 0 ? v : 0; };
+    double A[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) A[k] = 0.0;
+    // ---- the old pulses, oldest first.  Head: the first K-1 of them are still outside the
+    // window of the later sub-steps (bounded history), so each term is predicated.
+    int64_t j = lo(0);
+    const int64_t head_end = (j + K - 1 < m0) ? j + K - 1 : m0;
+    for (; j < head_end; ++j) {
+        const double f = hist[(size_t)j * N];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t lag = m0 + k - j;
+            const double term = f * irf[lag < H ? lag : 0];
+            if (j >= lo(k)) A[k] = A[k] + term;
+        }
+    }
+    // Bulk: groups of STEPS pulses share a K+STEPS-1 entry window of the response table
+    for (; j + STEPS <= m0; j += STEPS) {
+        const int64_t base = m0 - j - (STEPS - 1);  // lag of (last pulse of the group, k = 0), >= 1
+        double w[K + STEPS - 1], f[STEPS];
+#pragma unroll
+        for (int t = 0; t < K + STEPS - 1; ++t) w[t] = irf[base + t];
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) f[u] = hist[(size_t)(j + u) * N];
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) A[k] = A[k] + f[u] * w[STEPS - 1 - u + k];
+        }
+    }
+    for (; j < m0; ++j) {  // tail
+        const double f = hist[(size_t)j * N];
+#pragma unroll
+        for (int k = 0; k < K; ++k) A[k] = A[k] + f * irf[m0 + k - j];
+    }
+    // ---- the tile's own sub-steps (solve_ocean, carbon/ocean.rs:116-160), its pulses in registers
+    double fy[K];
+    const size_t r0 = (size_t)n * N + i;
+    double pco2 = a.series[r0], cumulative = a.series[vs + r0];
+#pragma unroll
+    for (int y = 0; y < YEARS; ++y) {
+        const double co2 = in[n + y], delta_sst = in[(size_t)T + n + y];
+        const double dt = a.bounds[n + y + 1] - a.bounds[n + y];
         const double dt_month = dt / (double)STEPS;
         const double temp_factor = m.temp_on ? exp(m.temp_sens * delta_sst) : 1.0;
-        double pco2 = a.series[r0], cumulative = a.series[vs + r0], total = 0.0;
-        const int64_t m0 = (int64_t)n * STEPS;  // months already in the history
-        // sub-step k convolves the pulses j in [lo(k), m0 + k]
-        auto lo = [&](int k) -> int64_t { const int64_t v = m0 + k + 1 - H; return v > 0 ? v : 0; };
-        double A[STEPS];
+        double total = 0.0;
 #pragma unroll
-        for (int k = 0; k < STEPS; ++k) A[k] = 0.0;
-        // ---- the old pulses, oldest first.  Head: the first STEPS-1 of them are still outside
-        // the window of the later sub-steps (bounded history), so each term is predicated.
-        int64_t j = lo(0);
-        const int64_t head_end = (j + STEPS - 1 < m0) ? j + STEPS - 1 : m0;
-        for (; j < head_end; ++j) {
-            const double f = hist[(size_t)j * N];
-#pragma unroll
-            for (int k = 0; k < STEPS; ++k) {
-                const int64_t lag = m0 + k - j;
-                const double term = f * irf[lag < H ? lag : 0];
-                if (j >= lo(k)) A[k] = A[k] + term;
-            }
-        }
-        // Bulk: groups of STEPS pulses share a 2*STEPS-1 entry window of the response table
-        for (; j + STEPS <= m0; j += STEPS) {
-            const int64_t base = m0 - j - (STEPS - 1);  // lag of (last pulse of the group, k = 0), >= 1
-            double w[2 * STEPS - 1], f[STEPS];
-#pragma unroll
-            for (int t = 0; t < 2 * STEPS - 1; ++t) w[t] = irf[base + t];
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) f[u] = hist[(size_t)(j + u) * N];
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) {
-#pragma unroll
-                for (int k = 0; k < STEPS; ++k) A[k] = A[k] + f[u] * w[STEPS - 1 - u + k];
-            }
-        }
-        for (; j < m0; ++j) {  // tail
-            const double f = hist[(size_t)j * N];
-#pragma unroll
-            for (int k = 0; k < STEPS; ++k) A[k] = A[k] + f * irf[m0 + k - j];
-        }
-        // ---- this year's sub-steps (solve_ocean, carbon/ocean.rs:116-160)
-        double fy[STEPS];
-#pragma unroll
-        for (int k = 0; k < STEPS; ++k) {
+        for (int s = 0; s < STEPS; ++s) {
+            const int k = y * STEPS + s;
             const double flux_ppm = m.k_gas * (co2 - pco2);
             fy[k] = flux_ppm;
             hist[(size_t)(m0 + k) * N] = flux_ppm;
@@ -138,11 +128,40 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a)
             const double delta_dic = H > 0 ? integral * m.dic_conv : 0.0;
             pco2 = pco2_from_dic(m, delta_dic, temp_factor);
         }
-        const size_t r1 = r0 + (size_t)N;
+        const size_t r1 = r0 + (size_t)(y + 1) * N;
         a.series[r1] = pco2;
         a.series[vs + r1] = cumulative;
         a.series[2 * vs + r1] = total;
     }
+}
+
+template <int STEPS, bool HAS_SCEN>
+__global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    OceanMember m;
+    m.pco2_pi = P(2);
+    m.k_gas = P(3) / (P(4) * 12.0);  // gas_exchange_rate()
+    m.temp_sens = P(5);
+    m.dic_conv = kMicromolPerPpmM3PerKg / (P(7) * P(8));  // dic_conversion_factor()
+    const double sst_pi = P(9);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
+    m.temp_on = P(23) != 0.0;
+    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 2 * T;
+    const double* __restrict__ irf = a.irf;   // [H], wave-uniform indices
+    double* __restrict__ hist = a.hist + i;   // [months][N]
+    a.status[i] = 0;
+    if (a.step_begin == 0) a.series[2 * (size_t)T * N + i] = __builtin_nan("");
+    int32_t n = a.step_begin;
+    // two model steps per pass over the history while two remain: half the HBM traffic, the same
+    // sums in the same order
+    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2>(a, m, in, irf, hist, i, n);
+    if (n < a.step_end) ocean_tile<STEPS, 1>(a, m, in, irf, hist, i, n);
 }
 
 }  // namespace

@@ -41,9 +41,17 @@ if kind == 3:  # GhgForcing: pre-industrial values, CO2 sensitivity and adjustme
                                adjust_co2=(0.95, 1.1), adjust_ch4=(0.8, 0.95), adjust_n2o=(0.9, 1.05)).items():
         j = _lib.GH_PARAM_NAMES.index(name)
         lo[j], hi[j] = a_, b_
-P = {0: 6, 1: 10, 2: 37, 3: 21}[kind]
+if kind == 11:  # OceanCarbon (3D-GFDL preset): gas exchange, temperature sensitivity, mixed layer varied
+    from rscm_amd import _lib
+    lo = np.array(_lib.OC_PRESETS["3D-GFDL"], dtype=float)
+    hi = lo.copy()
+    for name, (a_, b_) in dict(gas_exchange_tau=(6.0, 10.0), temp_sensitivity=(0.03, 0.045), mixed_layer_depth=(45.0, 60.0),
+                               sst_pi=(16.0, 19.0)).items():
+        j = _lib.OC_PARAM_NAMES.index(name)
+        lo[j], hi[j] = a_, b_
+P = {0: 6, 1: 10, 2: 37, 3: 21, 11: 24}[kind]
 with rscm_amd.Ensemble(kind, members, b) as e:
-    if kind != 3:
+    if kind not in (3, 11):
         e.set_mode(mode)
     e.sample_lhs(20260327, lo[:P], hi[:P])
     if kind == 0:
@@ -54,6 +62,11 @@ with rscm_amd.Ensemble(kind, members, b) as e:
         e.set_forcing(F)
         for v in (1, 2, 3, 4):
             e.set_initial(v, 0.0)
+    elif kind == 11:
+        yr = t - 1750.0
+        e.set_forcing(np.stack([np.minimum(278.0 * 1.003 ** yr, 1100.0), np.minimum(0.006 * yr, 4.0)]))
+        e.set_initial(1, 278.0)
+        e.set_initial(2, 0.0)
     elif kind == 3:
         yr = t - 1750.0
         e.set_forcing(np.stack([278.0 * 1.0015 ** yr, 722.0 + 2.0 * yr, 270.0 + 0.1 * yr]))
