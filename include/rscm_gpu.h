@@ -81,6 +81,7 @@ extern "C" {
 #define RSCM_KIND_CO2_BUDGET 9       /* rscm-magicc CO2Budget                                     */
 #define RSCM_KIND_TERRESTRIAL_CARBON 10 /* rscm-magicc TerrestrialCarbon (four pools)             */
 #define RSCM_KIND_OCEAN_CARBON 11    /* rscm-magicc OceanCarbon (impulse-response mixed layer)    */
+#define RSCM_KIND_HALOCARBON 12      /* rscm-magicc HalocarbonChemistry (41 species)              */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -217,6 +218,20 @@ extern "C" {
 #define RSCM_OC_P_STEPS_PER_YEAR 10
 #define RSCM_OC_P_MAX_HISTORY_MONTHS 11
 #define RSCM_OC_P_IRF_SWITCH_TIME 12
+/* HalocarbonChemistry (crates/rscm-magicc/src/chemistry/halocarbon.rs:262-300,
+ * parameters/halocarbon.rs:46-160) with the species list of HalocarbonParameters::default():
+ * 23 F-gases then 18 Montreal gases, in that order (41 species; other list lengths are not
+ * supported on the device).
+ *   inputs  Emissions|<species> x 41 (kt/yr), in species order
+ *   states  1..41 Atmospheric Concentration|<species> (ppt)
+ *   outputs 42 Forcing|Halocarbons, 43 Forcing|F-gases, 44 Forcing|Montreal Gases, 45 EESC
+ *   params  br_multiplier, cfc11_release_normalisation, eesc_delay, air_molar_mass,
+ *           atmospheric_mass_tg, mixing_box_fraction, then per species: lifetime,
+ *           radiative_efficiency, concentration_pi, molecular_weight, n_cl, n_br,
+ *           fractional_release */
+#define RSCM_HC_NSPECIES 41
+#define RSCM_HC_NINPUTS 41
+#define RSCM_HC_NPARAMS (6 + 41 * 7)
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.

@@ -21,7 +21,7 @@ _ip = C.POINTER(C.c_int32)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "librscm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c", "carbon_oracle.c", "ocean_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rscm_oracle.c", "udeb_oracle.c", "ghg_oracle.c", "forcing_oracle.c", "chem_oracle.c", "carbon_oracle.c", "ocean_oracle.c", "halocarbon_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B", "librscm_oracle.so"], check=True,
                        capture_output=True)
@@ -111,6 +111,16 @@ def lib() -> C.CDLL:
         L.orc_ocean_run.restype = C.c_int32
         L.orc_ocean_solve_repeated.argtypes = [_dp] + [C.c_double] * 5 + [C.c_int32, _dp]
         L.orc_ocean_solve_repeated.restype = C.c_int32
+        for f in ("n_params", "n_species", "n_fgases"):
+            getattr(L, "orc_halo_" + f).restype = C.c_int32
+        L.orc_halo_default_params.argtypes = [_dp]
+        L.orc_halo_default_params.restype = None
+        L.orc_halo_decay_species.argtypes = [_dp, C.c_int32, C.c_double, C.c_double, C.c_double]
+        L.orc_halo_decay_species.restype = C.c_double
+        L.orc_halo_aggregates.argtypes = [_dp, _dp, _dp]
+        L.orc_halo_aggregates.restype = None
+        L.orc_halo_run.argtypes = [C.c_int64, C.c_int32, _dp, _dp, _dp, _ip, _dp, C.c_int64, C.c_int64]
+        L.orc_halo_run.restype = C.c_int32
         L.orc_udeb_lamcalc.argtypes = [_dp, C.c_double, _dp]
         L.orc_udeb_area_factors.argtypes = [_dp, _dp, _dp, _dp]
         L.orc_udeb_sst_to_air.argtypes = [_dp, C.c_double]
@@ -599,4 +609,70 @@ def ocean_run(bounds, params, inputs, pco2_0, cumulative_0=0.0, *, scen=None, th
     _pmap(lambda i0, i1: rc.append(L.orc_ocean_run(N, T, _d(bounds), _d(params), _d(inputs), _i(scen), _d(series), i0, i1)),
           N, threads)
     assert not any(rc)
+    return series
+
+
+# ------------------------------------------------------------------------- HalocarbonChemistry
+HALO_SPECIES = ("CF4", "C2F6", "C3F8", "C4F10", "C5F12", "C6F14", "C7F16", "C8F18", "c-C4F8", "HFC-23", "HFC-32",
+                "HFC-43-10mee", "HFC-125", "HFC-134a", "HFC-143a", "HFC-152a", "HFC-227ea", "HFC-236fa", "HFC-245fa",
+                "HFC-365mfc", "NF3", "SF6", "SO2F2",
+                "CFC-11", "CFC-12", "CFC-113", "CFC-114", "CFC-115", "HCFC-22", "HCFC-141b", "HCFC-142b", "CH3CCl3",
+                "CCl4", "CH3Cl", "CH2Cl2", "CHCl3", "CH3Br", "Halon-1211", "Halon-1301", "Halon-2402", "Halon-1202")
+HALO_GLOBALS = ("br_multiplier", "cfc11_release_normalisation", "eesc_delay", "air_molar_mass", "atmospheric_mass_tg",
+                "mixing_box_fraction")
+HALO_FIELDS = ("lifetime", "radiative_efficiency", "concentration_pi", "molecular_weight", "n_cl", "n_br",
+               "fractional_release")
+
+
+def halo_index(species, field):
+    return len(HALO_GLOBALS) + HALO_SPECIES.index(species) * len(HALO_FIELDS) + HALO_FIELDS.index(field)
+
+
+def halo_default_params(**over) -> np.ndarray:
+    """Overrides: a global by name, or ``{"CFC-11.lifetime": 45.0}``-style species fields via ``species=``."""
+    p = np.empty(lib().orc_halo_n_params())
+    assert lib().orc_halo_n_species() == len(HALO_SPECIES)
+    lib().orc_halo_default_params(_d(p))
+    for k, v in over.pop("species", {}).items():
+        sp, field = k.rsplit(".", 1)
+        p[halo_index(sp, field)] = v
+    for k, v in over.items():
+        p[HALO_GLOBALS.index(k)] = v
+    return p
+
+
+def halo_decay_species(params, species, concentration, emissions, dt):
+    return lib().orc_halo_decay_species(_d(_f64(params)), HALO_SPECIES.index(species), concentration, emissions, dt)
+
+
+def halo_aggregates(params, conc):
+    """conc: dict species -> ppt (missing species sit at their pre-industrial value).  Returns
+    (total, fgas, montreal, eesc)."""
+    p = _f64(params)
+    c = np.array([conc.get(s, p[halo_index(s, "concentration_pi")]) for s in HALO_SPECIES], dtype=np.float64)
+    out = np.empty(4)
+    lib().orc_halo_aggregates(_d(p), _d(c), _d(out))
+    return tuple(float(x) for x in out)
+
+
+def halo_run(bounds, params, emissions, conc0, *, scen=None, threads=1):
+    """params [P][N]; emissions [S][41][T]; conc0 [41] or [41][N].  Returns [45][T][N]."""
+    bounds = _f64(bounds)
+    T = len(bounds) - 1
+    params = _f64(params)
+    if params.ndim == 1:
+        params = params.reshape(-1, 1).copy()
+    N = params.shape[1]
+    emissions = _f64(emissions)
+    if emissions.ndim == 2:
+        emissions = emissions[None]
+    ns = len(HALO_SPECIES)
+    assert emissions.shape[1:] == (ns, T)
+    if scen is not None:
+        scen = np.ascontiguousarray(scen, dtype=np.int32)
+    series = np.full((ns + 4, T, N), np.nan)
+    series[:ns, 0] = _f64(conc0).reshape(ns, -1)
+    L = lib()
+    _pmap(lambda i0, i1: L.orc_halo_run(N, T, _d(bounds), _d(params), _d(emissions), _i(scen), _d(series), i0, i1),
+          N, threads)
     return series

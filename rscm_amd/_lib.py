@@ -20,6 +20,7 @@ KIND_OZONE_FORCING, KIND_AEROSOL_DIRECT, KIND_AEROSOL_INDIRECT = 4, 5, 6
 KIND_CH4_CHEMISTRY, KIND_N2O_CHEMISTRY = 7, 8
 KIND_CO2_BUDGET, KIND_TERRESTRIAL_CARBON = 9, 10
 KIND_OCEAN_CARBON = 11
+KIND_HALOCARBON = 12
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -140,6 +141,43 @@ OC_PRESETS = {
     "HILDA": (2.0, 278.0, 278.0, 1.833492, 9.06, 0.03717879, 0.9492864, 75.0, 3.62e14, 18.1716, 12.0, 6000.0, 2.0) + _OC_OSPP,
 }
 
+# HalocarbonChemistry (crates/rscm-magicc/src/chemistry/halocarbon.rs, parameters/halocarbon.rs:95-160):
+# name, lifetime, radiative_efficiency, concentration_pi, molecular_weight, n_cl, n_br, fractional_release
+HC_FGASES = (
+    ("CF4", 50000.0, 0.09, 0.0, 88.0, 0, 0, 0.0), ("C2F6", 10000.0, 0.25, 0.0, 138.0, 0, 0, 0.0),
+    ("C3F8", 2600.0, 0.28, 0.0, 188.0, 0, 0, 0.0), ("C4F10", 2600.0, 0.36, 0.0, 238.0, 0, 0, 0.0),
+    ("C5F12", 4100.0, 0.41, 0.0, 288.0, 0, 0, 0.0), ("C6F14", 3100.0, 0.44, 0.0, 338.0, 0, 0, 0.0),
+    ("C7F16", 3000.0, 0.50, 0.0, 388.0, 0, 0, 0.0), ("C8F18", 3000.0, 0.55, 0.0, 438.0, 0, 0, 0.0),
+    ("c-C4F8", 3200.0, 0.32, 0.0, 200.0, 0, 0, 0.0), ("HFC-23", 228.0, 0.18, 0.0, 70.0, 0, 0, 0.0),
+    ("HFC-32", 5.4, 0.11, 0.0, 52.0, 0, 0, 0.0), ("HFC-43-10mee", 17.0, 0.359, 0.0, 252.0, 0, 0, 0.0),
+    ("HFC-125", 31.0, 0.23, 0.0, 120.0, 0, 0, 0.0), ("HFC-134a", 14.0, 0.16, 0.0, 102.0, 0, 0, 0.0),
+    ("HFC-143a", 51.0, 0.16, 0.0, 84.0, 0, 0, 0.0), ("HFC-152a", 1.6, 0.10, 0.0, 66.0, 0, 0, 0.0),
+    ("HFC-227ea", 36.0, 0.26, 0.0, 170.0, 0, 0, 0.0), ("HFC-236fa", 213.0, 0.24, 0.0, 152.0, 0, 0, 0.0),
+    ("HFC-245fa", 7.9, 0.24, 0.0, 134.0, 0, 0, 0.0), ("HFC-365mfc", 8.9, 0.22, 0.0, 148.0, 0, 0, 0.0),
+    ("NF3", 569.0, 0.20, 0.0, 71.0, 0, 0, 0.0), ("SF6", 850.0, 0.57, 0.0, 146.0, 0, 0, 0.0),
+    ("SO2F2", 36.0, 0.20, 0.0, 102.0, 0, 0, 0.0))
+HC_MONTREAL = (
+    ("CFC-11", 52.0, 0.295, 0.0, 137.4, 3, 0, 0.47), ("CFC-12", 102.0, 0.364, 0.0, 120.9, 2, 0, 0.23),
+    ("CFC-113", 93.0, 0.30, 0.0, 187.4, 3, 0, 0.29), ("CFC-114", 189.0, 0.31, 0.0, 170.9, 2, 0, 0.12),
+    ("CFC-115", 540.0, 0.20, 0.0, 154.5, 1, 0, 0.04), ("HCFC-22", 11.9, 0.21, 0.0, 86.5, 1, 0, 0.13),
+    ("HCFC-141b", 9.4, 0.16, 0.0, 116.9, 2, 0, 0.34), ("HCFC-142b", 18.0, 0.19, 0.0, 100.5, 1, 0, 0.17),
+    ("CH3CCl3", 5.0, 0.07, 0.0, 133.4, 3, 0, 0.67), ("CCl4", 32.0, 0.174, 0.0, 153.8, 4, 0, 0.56),
+    ("CH3Cl", 0.9, 0.004, 500.0, 50.5, 1, 0, 0.44), ("CH2Cl2", 0.5, 0.028, 0.0, 84.9, 2, 0, 0.0),
+    ("CHCl3", 0.5, 0.07, 0.0, 119.4, 3, 0, 0.0), ("CH3Br", 0.8, 0.004, 5.0, 94.9, 0, 1, 0.60),
+    ("Halon-1211", 16.0, 0.29, 0.0, 165.4, 1, 1, 0.62), ("Halon-1301", 72.0, 0.30, 0.0, 148.9, 0, 1, 0.28),
+    ("Halon-2402", 28.0, 0.31, 0.0, 259.8, 0, 2, 0.65), ("Halon-1202", 2.5, 0.27, 0.0, 209.8, 0, 2, 0.62))
+HC_SPECIES = tuple(s[0] for s in HC_FGASES + HC_MONTREAL)
+HC_FIELDS = ("lifetime", "radiative_efficiency", "concentration_pi", "molecular_weight", "n_cl", "n_br",
+             "fractional_release")
+HC_GLOBALS = ("br_multiplier", "cfc11_release_normalisation", "eesc_delay", "air_molar_mass",
+              "atmospheric_mass_tg", "mixing_box_fraction")
+HC_GLOBAL_DEFAULTS = (60.0, 0.47, 3.0, 28.97, 5.133e9, 0.949)
+HC_PARAM_NAMES = HC_GLOBALS + tuple(f"{s}.{f}" for s in HC_SPECIES for f in HC_FIELDS)
+HC_DEFAULTS = HC_GLOBAL_DEFAULTS + tuple(float(x) for s in HC_FGASES + HC_MONTREAL for x in s[1:])
+HC_INPUTS = tuple(f"Emissions|{s}" for s in HC_SPECIES)
+HC_VARS = {"Halocarbon emissions": 0, **{f"Atmospheric Concentration|{s}": k + 1 for k, s in enumerate(HC_SPECIES)},
+           "Forcing|Halocarbons": 42, "Forcing|F-gases": 43, "Forcing|Montreal Gases": 44, "EESC": 45}
+
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {
     KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
@@ -147,7 +185,7 @@ KIND_TABLE = {
     KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS),
     KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS),
     KIND_CO2_BUDGET: (CB_VARS, 2, CB_INPUTS), KIND_TERRESTRIAL_CARBON: (TC_VARS, 20, TC_INPUTS),
-    KIND_OCEAN_CARBON: (OC_VARS, 24, OC_INPUTS)}
+    KIND_OCEAN_CARBON: (OC_VARS, 24, OC_INPUTS), KIND_HALOCARBON: (HC_VARS, len(HC_PARAM_NAMES), HC_INPUTS)}
 # FourBox variables stored as four scalar series: kind -> (name, first variable id)
 FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
                 KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1)}

@@ -169,6 +169,19 @@ struct OceanArgs {
     uint8_t* status;
 };
 
+// HalocarbonChemistry (csrc/halocarbon.hip)
+struct HaloArgs {
+    int64_t n_members;
+    int32_t n_times;
+    int32_t step_begin, step_end;
+    const double* params;     // [293][N]
+    const double* emissions;  // [S][41][T]
+    const int32_t* scen;      // [N] or null
+    const double* bounds;     // [T+1]
+    double* series;           // [41 + 4][T][N]: concentrations, then total / F-gas / Montreal forcing, EESC
+    uint8_t* status;
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -189,6 +202,7 @@ hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
 hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s);
 hipError_t launch_ocean(const OceanArgs& a, hipStream_t s);
+hipError_t launch_halocarbon(const HaloArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

@@ -207,6 +207,7 @@ struct rscm_ens {
         if (kind == RSCM_KIND_CO2_BUDGET) return var == 1;
         if (kind == RSCM_KIND_TERRESTRIAL_CARBON) return var >= 1 && var <= 4;
         if (kind == RSCM_KIND_OCEAN_CARBON) return var == 1 || var == 2;
+        if (kind == RSCM_KIND_HALOCARBON) return var >= 1 && var <= RSCM_HC_NSPECIES;
         if (kind >= RSCM_KIND_GHG_FORCING) return false;  // stateless components
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
@@ -398,7 +399,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_OCEAN_CARBON)
+    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_HALOCARBON)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -417,11 +418,12 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->device = device_id;
     static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
                                  RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS, RSCM_CH4_NPARAMS,
-                                 RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS, RSCM_OC_NPARAMS};
-    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4};  // variable ids incl. the input block 0
+                                 RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS, RSCM_OC_NPARAMS,
+                                 RSCM_HC_NPARAMS};
+    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4, RSCM_HC_NSPECIES + 5};  // variable ids incl. the input block 0
     static const int32_t kInputs[] = {1, 1, 1, 3, RSCM_OZ_NINPUTS, RSCM_AD_NINPUTS, RSCM_AI_NINPUTS,
                                       RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS, RSCM_CB_NINPUTS, RSCM_TC_NINPUTS,
-                                      RSCM_OC_NINPUTS};
+                                      RSCM_OC_NINPUTS, RSCM_HC_NINPUTS};
     h->P = kP[kind];
     h->V = kV[kind];
     h->n_inputs = kInputs[kind];
@@ -461,7 +463,8 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         CK(hipMalloc(&h->d_hist, (size_t)h->T * h->N * sizeof(double)));
     }
     if (kind == RSCM_KIND_UDEB || kind == RSCM_KIND_N2O_CHEMISTRY || kind == RSCM_KIND_CO2_BUDGET ||
-        kind == RSCM_KIND_TERRESTRIAL_CARBON || kind == RSCM_KIND_OCEAN_CARBON) {  // kinds that use the step length
+        kind == RSCM_KIND_TERRESTRIAL_CARBON || kind == RSCM_KIND_OCEAN_CARBON ||
+        kind == RSCM_KIND_HALOCARBON) {  // kinds that use the step length
         CK(hipMalloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
         CK(hipMemcpyAsync(h->d_bounds, h->bounds.data(), (size_t)(h->T + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
@@ -761,6 +764,19 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ghg(a, h->stream));
+    } else if (h->kind == RSCM_KIND_HALOCARBON) {
+        rscm::HaloArgs a{};
+        a.n_members = h->N;
+        a.n_times = h->T;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.params = h->d_params;
+        a.emissions = h->d_forcing;
+        a.scen = h->d_scen;
+        a.bounds = h->d_bounds;
+        a.series = h->series(1);
+        a.status = h->d_status;
+        HIPCHK(rscm::launch_halocarbon(a, h->stream));
     } else if (h->kind == RSCM_KIND_OCEAN_CARBON) {
         if (!h->ocean_ready) return fail(RSCM_ERR_STATE, "OceanCarbon parameters not configured");
         rscm::OceanArgs a{};

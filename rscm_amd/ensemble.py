@@ -169,6 +169,8 @@ class Ensemble:
         if self.kind == L.KIND_OCEAN_CARBON:
             raise NotImplementedError("OceanCarbon keeps its flux history on the device; "
                                       "host checkpoints are not available for this kind yet")
+        if self.kind == L.KIND_HALOCARBON:
+            return {k: v for k, v in self.var_ids.items() if 1 <= v <= len(L.HC_SPECIES)}
         if self.kind == L.KIND_CO2_BUDGET:
             return {k: v for k, v in self.var_ids.items() if v == 1}
         if self.kind == L.KIND_TERRESTRIAL_CARBON:

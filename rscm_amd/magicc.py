@@ -1,6 +1,6 @@
 """``ClimateUDEBBuilder``, ``GhgForcingBuilder``, ``OzoneForcingBuilder``, ``AerosolDirectBuilder``
 ``AerosolIndirectBuilder``, ``CH4ChemistryBuilder``, ``N2OChemistryBuilder``, ``CO2BudgetBuilder``,
-``TerrestrialCarbonBuilder`` and ``OceanCarbonBuilder`` -- mirror of ``rscm.magicc`` for the climate core, the forcing
+``TerrestrialCarbonBuilder``, ``OceanCarbonBuilder`` and ``HalocarbonChemistryBuilder`` -- mirror of ``rscm.magicc`` for the climate core, the forcing
 components, the CH4 / N2O chemistry, the CO2 budget and the terrestrial carbon pools
 (python/rscm/_lib/magicc.pyi; crates/rscm-magicc/src/climate/udeb/mod.rs,
 crates/rscm-magicc/src/forcing/{ghg,ozone,aerosol_direct,aerosol_indirect}.rs,
@@ -247,3 +247,43 @@ class OceanCarbonBuilder(ComponentBuilder):
                 raise NotImplementedError(f"custom {k} forms are not supported by the device kernel; choose a model preset")
         return cls(_flat_parameters(L.OC_PARAM_NAMES, L.OC_PRESETS[model], parameters,
                                     arrays=("delta_ospp_offsets", "delta_ospp_coefficients")))
+
+
+class HalocarbonChemistry(Component):
+    type_name = "HalocarbonChemistry"
+    definitions = ([(n, "kt/yr", "Input") for n in L.HC_INPUTS]
+                   + [(f"Atmospheric Concentration|{s}", "ppt", "State") for s in L.HC_SPECIES]
+                   + [("Forcing|Halocarbons", "W/m^2", "Output"), ("Forcing|F-gases", "W/m^2", "Output"),
+                      ("Forcing|Montreal Gases", "W/m^2", "Output"), ("EESC", "ppt", "Output")])
+
+    def param_vector(self):
+        return [float(self.parameters[k]) for k in L.HC_PARAM_NAMES]
+
+
+class HalocarbonChemistryBuilder(ComponentBuilder):
+    """``fgases`` / ``montreal_gases`` take the reference's list-of-species form
+    (``[{"name": "CF4", "lifetime": ..., ...}, ...]``); the device kernel is laid out for the 23 + 18
+    species of ``HalocarbonParameters::default()`` in their default order, so the lists may change
+    species properties but not the species set."""
+    component_cls = HalocarbonChemistry
+
+    @classmethod
+    def from_parameters(cls, parameters: Dict[str, object]):
+        p = dict(zip(L.HC_PARAM_NAMES, L.HC_DEFAULTS))
+        for k, v in parameters.items():
+            if k in ("fgases", "montreal_gases"):
+                expected = [s[0] for s in (L.HC_FGASES if k == "fgases" else L.HC_MONTREAL)]
+                if [sp.get("name") for sp in v] != expected:
+                    raise NotImplementedError(f"{k}: the device kernel supports the default species set {expected}")
+                for sp in v:
+                    for f, x in sp.items():
+                        if f == "name":
+                            continue
+                        if f not in L.HC_FIELDS:  # serde: unknown field
+                            raise ValueError(f"unknown field `{f}`")
+                        p[f"{sp['name']}.{f}"] = float(x)
+            elif k in L.HC_GLOBALS:
+                p[k] = float(v)
+            else:
+                raise ValueError(f"unknown field `{k}`")
+        return cls(p)
