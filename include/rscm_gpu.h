@@ -82,6 +82,8 @@ extern "C" {
 #define RSCM_KIND_TERRESTRIAL_CARBON 10 /* rscm-magicc TerrestrialCarbon (four pools)             */
 #define RSCM_KIND_OCEAN_CARBON 11    /* rscm-magicc OceanCarbon (impulse-response mixed layer)    */
 #define RSCM_KIND_HALOCARBON 12      /* rscm-magicc HalocarbonChemistry (41 species)              */
+#define RSCM_KIND_FOURBOX_OHU 13     /* rscm-components FourBoxOceanHeatUptake                    */
+#define RSCM_KIND_OSPP 14            /* rscm-components OceanSurfacePartialPressure               */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -232,6 +234,20 @@ extern "C" {
 #define RSCM_HC_NSPECIES 41
 #define RSCM_HC_NINPUTS 41
 #define RSCM_HC_NPARAMS (6 + 41 * 7)
+/* FourBoxOceanHeatUptake (crates/rscm-components/src/components/four_box_ocean_heat_uptake.rs):
+ *   input   Effective Radiative Forcing|Aggregated;  outputs 1-4 Heat Uptake|Ocean in
+ *   NorthernOcean, NorthernLand, SouthernOcean, SouthernLand
+ *   params  northern_ocean_ratio, northern_land_ratio, southern_ocean_ratio, southern_land_ratio
+ *           (from_parameters asserts they average to 1 within 0.01; the front-end mirrors that) */
+#define RSCM_FB_NINPUTS 1
+#define RSCM_FB_NPARAMS 4
+/* OceanSurfacePartialPressure (.../ocean_carbon_cycle/ocean_surface_partial_pressure.rs):
+ *   inputs  Sea Surface Temperature, Dissolved Inorganic Carbon (both anomalies)
+ *   output  1 Ocean Surface Partial Pressure|CO2
+ *   params  ospp_preindustrial, sensitivity_ospp_to_temperature,
+ *           sea_surface_temperature_preindustrial, delta_ospp_offsets[5], delta_ospp_coefficients[5] */
+#define RSCM_SP_NINPUTS 2
+#define RSCM_SP_NPARAMS 13
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.

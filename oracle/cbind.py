@@ -383,6 +383,7 @@ def ghg_run(n_times, params, conc, *, scen=None, threads=1):
 
 # ------------------------------------------------- OzoneForcing / AerosolDirect / AerosolIndirect
 PW_OZONE, PW_AEROSOL_DIRECT, PW_AEROSOL_INDIRECT = 4, 5, 6
+PW_FOURBOX_OHU, PW_OSPP = 13, 14  # rscm-components: FourBoxOceanHeatUptake, OceanSurfacePartialPressure
 PW_PARAM_NAMES = {
     PW_OZONE: ("eesc_reference", "strat_o3_scale", "strat_cl_exponent", "trop_radeff", "trop_oz_ch4",
                "trop_oz_nox", "trop_oz_co", "trop_oz_voc", "ch4_pi", "nox_pi", "co_pi", "nmvoc_pi",
@@ -392,6 +393,9 @@ PW_PARAM_NAMES = {
     + ("sox_pi", "bc_pi", "oc_pi", "nox_pi", "harmonize", "harmonize_year", "harmonize_target"),
     PW_AEROSOL_INDIRECT: ("cloud_albedo_coefficient", "reference_burden", "sox_weight", "oc_weight",
                           "sox_pi", "oc_pi", "harmonize", "harmonize_year", "harmonize_target"),
+    PW_FOURBOX_OHU: ("northern_ocean_ratio", "northern_land_ratio", "southern_ocean_ratio", "southern_land_ratio"),
+    PW_OSPP: ("ospp_preindustrial", "sensitivity_ospp_to_temperature", "sea_surface_temperature_preindustrial")
+    + tuple(f"delta_ospp_offsets_{i}" for i in range(5)) + tuple(f"delta_ospp_coefficients_{i}" for i in range(5)),
 }
 
 

@@ -1,19 +1,24 @@
 /*
- * CPU ORACLE for rscm-magicc's stateless forcing components OzoneForcing, AerosolDirect and
- * AerosolIndirect -- TEST INFRASTRUCTURE ONLY.
+ * CPU ORACLE for the stateless pointwise components: rscm-magicc's OzoneForcing, AerosolDirect and
+ * AerosolIndirect, rscm-components' FourBoxOceanHeatUptake and OceanSurfacePartialPressure --
+ * TEST INFRASTRUCTURE ONLY.
  *
  * A plain-C restatement of
  *   OzoneForcing::calculate_forcings / solve      crates/rscm-magicc/src/forcing/ozone.rs:99-238
  *   AerosolDirect::calculate_forcing / solve      crates/rscm-magicc/src/forcing/aerosol_direct.rs:86-239
  *   AerosolIndirect::calculate_forcing / solve    crates/rscm-magicc/src/forcing/aerosol_indirect.rs:75-170
  *   their parameter structs (+ Default)           crates/rscm-magicc/src/parameters/{ozone_forcing,aerosol}.rs
+ *   FourBoxOceanHeatUptake::solve                 crates/rscm-components/src/components/four_box_ocean_heat_uptake.rs:85-112
+ *   OceanSurfacePartialPressure::solve / calculate_ospp
+ *                                                 crates/rscm-components/src/components/ocean_carbon_cycle/ocean_surface_partial_pressure.rs:57-122
  * under the stepper conventions of crates/rscm-core/src/model/runtime.rs: every input is read as
  * an exogenous series (index n), outputs are written at index n+1, index 0 stays NaN.
  *
- * Parity pin: the reference holds no golden vectors for these three components (its only
- * full-chain regression scenario is marked xfail upstream); the restatement is checked against
- * the known answers of the components' in-file unit tests (tests/test_oracle_forcing.py).
- * Numeric agreement with the Rust binary is therefore "parity unpinned" beyond those.
+ * Parity pin: OceanSurfacePartialPressure is pinned by the two known answers of the reference's
+ * own test (339.089 and 381.003 ppm at rel 1e-4, ocean_surface_partial_pressure.rs:219-259);
+ * the reference holds no golden vectors for the other four (its only full-chain regression
+ * scenario is marked xfail upstream), which are checked against the known answers of their
+ * in-file unit tests (tests/test_oracle_forcing.py).  "Parity unpinned" beyond those.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
  */
@@ -23,7 +28,7 @@
 #define ORC_API __attribute__((visibility("default")))
 
 /* kinds, matching include/rscm_gpu.h */
-enum { PW_OZONE = 4, PW_AEROSOL_DIRECT = 5, PW_AEROSOL_INDIRECT = 6 };
+enum { PW_OZONE = 4, PW_AEROSOL_DIRECT = 5, PW_AEROSOL_INDIRECT = 6, PW_FOURBOX_OHU = 13, PW_OSPP = 14 };
 
 /* OzoneForcingParameters field order */
 enum { O_EESC_REF = 0, O_STRAT_SCALE, O_STRAT_EXP, O_TROP_RADEFF, O_TROP_CH4, O_TROP_NOX, O_TROP_CO,
@@ -35,17 +40,25 @@ enum { D_SOX_C = 0, D_BC_C, D_OC_C, D_NIT_C, D_SOX_R = 4, D_BC_R = 8, D_OC_R = 1
 enum { I_COEF = 0, I_REF_BURDEN, I_SOX_W, I_OC_W, I_SOX_PI, I_OC_PI, I_HARMONIZE, I_HARM_YEAR,
        I_HARM_TARGET, I_NPARAMS };
 
+/* FourBoxOceanHeatUptakeParameters: the four regional ratios (NO, NL, SO, SL) */
+enum { F_NPARAMS = 4 };
+/* OceanSurfacePartialPressureParameters field order */
+enum { P_OSPP_PI = 0, P_SENS, P_SST_PI, P_OFF0, P_COEF0 = P_OFF0 + 5, P_NPARAMS = P_COEF0 + 5 };
+
 ORC_API int32_t orc_pointwise_n_params(int32_t kind)
 {
-    return kind == PW_OZONE ? O_NPARAMS : kind == PW_AEROSOL_DIRECT ? D_NPARAMS : kind == PW_AEROSOL_INDIRECT ? I_NPARAMS : -1;
+    return kind == PW_OZONE ? O_NPARAMS : kind == PW_AEROSOL_DIRECT ? D_NPARAMS : kind == PW_AEROSOL_INDIRECT ? I_NPARAMS
+         : kind == PW_FOURBOX_OHU ? F_NPARAMS : kind == PW_OSPP ? P_NPARAMS : -1;
 }
 ORC_API int32_t orc_pointwise_n_inputs(int32_t kind)
 {
-    return kind == PW_OZONE ? 6 : kind == PW_AEROSOL_DIRECT ? 4 : kind == PW_AEROSOL_INDIRECT ? 2 : -1;
+    return kind == PW_OZONE ? 6 : kind == PW_AEROSOL_DIRECT ? 4 : kind == PW_AEROSOL_INDIRECT ? 2
+         : kind == PW_FOURBOX_OHU ? 1 : kind == PW_OSPP ? 2 : -1;
 }
 ORC_API int32_t orc_pointwise_n_outputs(int32_t kind)
 {
-    return kind == PW_OZONE ? 3 : kind == PW_AEROSOL_DIRECT ? 4 : kind == PW_AEROSOL_INDIRECT ? 1 : -1;
+    return kind == PW_OZONE ? 3 : kind == PW_AEROSOL_DIRECT ? 4 : kind == PW_AEROSOL_INDIRECT ? 1
+         : kind == PW_FOURBOX_OHU ? 4 : kind == PW_OSPP ? 1 : -1;
 }
 
 ORC_API void orc_pointwise_default_params(int32_t kind, double* p)
@@ -64,6 +77,12 @@ ORC_API void orc_pointwise_default_params(int32_t kind, double* p)
     } else if (kind == PW_AEROSOL_INDIRECT) { /* parameters/aerosol.rs:98-117 */
         static const double d[I_NPARAMS] = {-1.0, 50.0, 1.0, 0.3, 1.0, 10.0, 0.0, 2019.0, -0.89};
         for (int j = 0; j < I_NPARAMS; ++j) p[j] = d[j];
+    } else if (kind == PW_FOURBOX_OHU) { /* four_box_ocean_heat_uptake.rs:36-50 */
+        p[0] = 1.2; p[1] = 0.6; p[2] = 1.6; p[3] = 0.6;
+    } else if (kind == PW_OSPP) { /* no Default upstream: the first case of its test, :200-209 */
+        static const double d[P_NPARAMS] = {278.0, 0.043, 17.9, 1.5568, 7.4706, 1.2748, 2.4491, 1.5468,
+                                            -0.013993, -0.20207, -0.12015, -0.12639, -0.15326};
+        for (int j = 0; j < P_NPARAMS; ++j) p[j] = d[j];
     }
 }
 
@@ -113,11 +132,32 @@ static void aerosol_indirect(const double* p, const double* in, double* out)
     out[0] = delta <= 0.0 ? 0.0 : p[I_COEF] * log(1.0 + delta / p[I_REF_BURDEN]);
 }
 
+/* four_box_ocean_heat_uptake.rs:85-112; in = {ERF|Aggregated}; out = FourBox {NO, NL, SO, SL} */
+static void fourbox_ohu(const double* p, const double* in, double* out)
+{
+    for (int i = 0; i < 4; ++i) out[i] = in[0] * p[i];
+}
+
+/* ocean_surface_partial_pressure.rs:57-122; in = {delta SST, delta DIC}.  As upstream: the
+ * factors are written 10e-3, 10e-5, 10e-7, 10e-10 and the fifth term uses the FOURTH power; the
+ * five products are summed in order (ndarray's dot on five elements). */
+static void ospp(const double* p, const double* in, double* out)
+{
+    const double d = in[1];
+    const double d2 = d * d, d3 = d * d2, d4 = d2 * d2;
+    const double bits[5] = {d, d2 * 10e-3, -d3 * 10e-5, d4 * 10e-7, -d4 * 10e-10};
+    double delta = 0.0;
+    for (int i = 0; i < 5; ++i) delta = delta + (p[P_OFF0 + i] + p[P_COEF0 + i] * p[P_SST_PI]) * bits[i];
+    out[0] = (p[P_OSPP_PI] + delta) * exp(p[P_SENS] * in[0]);
+}
+
 ORC_API int32_t orc_pointwise_eval(int32_t kind, const double* p, const double* in, double* out)
 {
     if (kind == PW_OZONE) ozone(p, in, out);
     else if (kind == PW_AEROSOL_DIRECT) aerosol_direct(p, in, out);
     else if (kind == PW_AEROSOL_INDIRECT) aerosol_indirect(p, in, out);
+    else if (kind == PW_FOURBOX_OHU) fourbox_ohu(p, in, out);
+    else if (kind == PW_OSPP) ospp(p, in, out);
     else return 1;
     return 0;
 }

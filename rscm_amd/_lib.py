@@ -21,6 +21,7 @@ KIND_CH4_CHEMISTRY, KIND_N2O_CHEMISTRY = 7, 8
 KIND_CO2_BUDGET, KIND_TERRESTRIAL_CARBON = 9, 10
 KIND_OCEAN_CARBON = 11
 KIND_HALOCARBON = 12
+KIND_FOURBOX_OHU, KIND_OSPP = 13, 14
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -178,6 +179,17 @@ HC_INPUTS = tuple(f"Emissions|{s}" for s in HC_SPECIES)
 HC_VARS = {"Halocarbon emissions": 0, **{f"Atmospheric Concentration|{s}": k + 1 for k, s in enumerate(HC_SPECIES)},
            "Forcing|Halocarbons": 42, "Forcing|F-gases": 43, "Forcing|Montreal Gases": 44, "EESC": 45}
 
+# rscm-components: FourBoxOceanHeatUptake, OceanSurfacePartialPressure
+FB_INPUTS = ("Effective Radiative Forcing|Aggregated",)
+FB_VARS = {"Heat uptake input": 0, **{f"Heat Uptake|Ocean|{r}": k + 1 for k, r in enumerate(FOURBOX_REGIONS)}}
+FB_PARAM_NAMES = ("northern_ocean_ratio", "northern_land_ratio", "southern_ocean_ratio", "southern_land_ratio")
+FB_DEFAULTS = (1.2, 0.6, 1.6, 0.6)
+SP_INPUTS = ("Sea Surface Temperature", "Dissolved Inorganic Carbon")
+SP_VARS = {"OSPP inputs": 0, "Ocean Surface Partial Pressure|CO2": 1}
+SP_PARAM_NAMES = (("ospp_preindustrial", "sensitivity_ospp_to_temperature", "sea_surface_temperature_preindustrial")
+                  + tuple(f"delta_ospp_offsets_{i}" for i in range(5))
+                  + tuple(f"delta_ospp_coefficients_{i}" for i in range(5)))
+
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {
     KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
@@ -185,10 +197,12 @@ KIND_TABLE = {
     KIND_AEROSOL_DIRECT: (AD_VARS, 27, AD_INPUTS), KIND_AEROSOL_INDIRECT: (AI_VARS, 9, AI_INPUTS),
     KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS),
     KIND_CO2_BUDGET: (CB_VARS, 2, CB_INPUTS), KIND_TERRESTRIAL_CARBON: (TC_VARS, 20, TC_INPUTS),
-    KIND_OCEAN_CARBON: (OC_VARS, 24, OC_INPUTS), KIND_HALOCARBON: (HC_VARS, len(HC_PARAM_NAMES), HC_INPUTS)}
+    KIND_OCEAN_CARBON: (OC_VARS, 24, OC_INPUTS), KIND_HALOCARBON: (HC_VARS, len(HC_PARAM_NAMES), HC_INPUTS),
+    KIND_FOURBOX_OHU: (FB_VARS, 4, FB_INPUTS), KIND_OSPP: (SP_VARS, 13, SP_INPUTS)}
 # FourBox variables stored as four scalar series: kind -> (name, first variable id)
 FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
-                KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1)}
+                KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1),
+                KIND_FOURBOX_OHU: ("Heat Uptake|Ocean", 1)}
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

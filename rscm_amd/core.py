@@ -372,7 +372,8 @@ class ComponentBuilder:
 # ------------------------------------------------------------------------------------ builder
 SUPPORTED = ("[ClimateUDEB] with exogenous 'Effective Radiative Forcing'",
              "[GhgForcing] | [OzoneForcing] | [AerosolDirect] | [AerosolIndirect] | [CH4Chemistry] | "
-             "[N2OChemistry] | [CO2Budget] | [TerrestrialCarbon] | [OceanCarbon] | [HalocarbonChemistry] with their inputs as "
+             "[N2OChemistry] | [CO2Budget] | [TerrestrialCarbon] | [OceanCarbon] | [HalocarbonChemistry] | "
+             "[FourBoxOceanHeatUptake] | [OceanSurfacePartialPressure] with their inputs as "
              "exogenous series",
              "[TwoLayer] with exogenous or upstream 'Effective Radiative Forcing'",
              "[CarbonCycle, CO2ERF, TwoLayer] + Sum aggregate 'Effective Radiative Forcing' "
@@ -383,7 +384,8 @@ STATELESS_KINDS = {"GhgForcing": L.KIND_GHG_FORCING, "OzoneForcing": L.KIND_OZON
                    "AerosolDirect": L.KIND_AEROSOL_DIRECT, "AerosolIndirect": L.KIND_AEROSOL_INDIRECT,
                    "CH4Chemistry": L.KIND_CH4_CHEMISTRY, "N2OChemistry": L.KIND_N2O_CHEMISTRY,
                    "CO2Budget": L.KIND_CO2_BUDGET, "TerrestrialCarbon": L.KIND_TERRESTRIAL_CARBON,
-                   "OceanCarbon": L.KIND_OCEAN_CARBON, "HalocarbonChemistry": L.KIND_HALOCARBON}
+                   "OceanCarbon": L.KIND_OCEAN_CARBON, "HalocarbonChemistry": L.KIND_HALOCARBON,
+                   "FourBoxOceanHeatUptake": L.KIND_FOURBOX_OHU, "OceanSurfacePartialPressure": L.KIND_OSPP}
 
 TL_PARAM_ORDER = ("lambda0", "a", "efficacy", "eta", "heat_capacity_surface", "heat_capacity_deep")
 CP_PARAM_ORDER = TL_PARAM_ORDER + ("tau", "conc_pi", "alpha_temperature", "erf_2xco2")
@@ -550,7 +552,8 @@ class ModelBuilder:
                        L.KIND_AEROSOL_INDIRECT: L.AI_PARAM_NAMES, L.KIND_CH4_CHEMISTRY: L.CH4_PARAM_NAMES,
                        L.KIND_N2O_CHEMISTRY: L.N2O_PARAM_NAMES, L.KIND_CO2_BUDGET: L.CB_PARAM_NAMES,
                        L.KIND_TERRESTRIAL_CARBON: L.TC_PARAM_NAMES, L.KIND_OCEAN_CARBON: L.OC_PARAM_NAMES,
-                       L.KIND_HALOCARBON: L.HC_PARAM_NAMES}[kind]
+                       L.KIND_HALOCARBON: L.HC_PARAM_NAMES, L.KIND_FOURBOX_OHU: L.FB_PARAM_NAMES,
+                       L.KIND_OSPP: L.SP_PARAM_NAMES}[kind]
         return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
                      np.array(params, dtype=np.float64))
 

@@ -1,17 +1,21 @@
-// Stateless rscm-magicc forcing components as ensemble kernels for gfx950 (MI355X), one thread
-// per member: OzoneForcing, AerosolDirect, AerosolIndirect.
+// Stateless pointwise components as ensemble kernels for gfx950 (MI355X), one thread per member:
+// rscm-magicc's OzoneForcing, AerosolDirect, AerosolIndirect and rscm-components'
+// FourBoxOceanHeatUptake, OceanSurfacePartialPressure.
 //
 // What they replace, per model step n (reference file:line):
 //   OzoneForcing::solve / calculate_forcings      crates/rscm-magicc/src/forcing/ozone.rs:99-238
 //   AerosolDirect::solve / calculate_forcing      crates/rscm-magicc/src/forcing/aerosol_direct.rs:86-239
 //   AerosolIndirect::solve / calculate_forcing    crates/rscm-magicc/src/forcing/aerosol_indirect.rs:75-170
+//   FourBoxOceanHeatUptake::solve                 crates/rscm-components/src/components/four_box_ocean_heat_uptake.rs:85-112
+//   OceanSurfacePartialPressure::solve            crates/rscm-components/src/components/ocean_carbon_cycle/ocean_surface_partial_pressure.rs:57-122
 // under the stepper conventions of crates/rscm-core/src/model/runtime.rs: inputs are exogenous
 // series shared per scenario (index n), outputs land at index n+1, index 0 stays NaN.
 //
 // The expressions are the reference's, operation for operation (no contraction: the build uses
 // -ffp-contract=off); pow and log come from the device math library, so agreement with the CPU
 // oracle is to their last-place error (tests/test_gpu_pointwise.py states 1e-12), exact where no
-// transcendental is involved (AerosolDirect, the ozone temperature feedback).
+// transcendental is involved (AerosolDirect, FourBoxOceanHeatUptake, the ozone temperature
+// feedback).
 // Rooflines: 8-32 B written per member-year; OzoneForcing carries one f64 pow and one log per
 // member-year and is VALU-bound, the two aerosol kernels are bound by the HBM write stream.
 #include "rscm_device.hpp"
@@ -28,6 +32,10 @@ template <>
 struct Shape<5> { static constexpr int P = 27, NI = 4, NO = 4; };
 template <>
 struct Shape<6> { static constexpr int P = 9, NI = 2, NO = 1; };
+template <>
+struct Shape<13> { static constexpr int P = 4, NI = 1, NO = 4; };
+template <>
+struct Shape<14> { static constexpr int P = 13, NI = 2, NO = 1; };
 
 // forcing/ozone.rs:99-164; in = {EESC, CH4, NOx, CO, NMVOC, temperature}
 __device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[6], double (&out)[3])
@@ -68,6 +76,26 @@ __device__ __forceinline__ void eval(const double (&p)[9], const double (&in)[2]
     const double burden_pi = p[2] * p[4] + p[3] * p[5];
     const double delta = burden - burden_pi;
     out[0] = delta <= 0.0 ? 0.0 : p[0] * log(1.0 + delta / p[1]);
+}
+
+// four_box_ocean_heat_uptake.rs:85-112; in = {ERF|Aggregated}; out = FourBox {NO, NL, SO, SL}
+__device__ __forceinline__ void eval(const double (&p)[4], const double (&in)[1], double (&out)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = in[0] * p[i];
+}
+
+// ocean_surface_partial_pressure.rs:57-122; in = {delta SST, delta DIC}.  As upstream: the factors
+// are written 10e-3 .. 10e-10 and the fifth term carries the fourth power.
+__device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[2], double (&out)[1])
+{
+    const double d = in[1];
+    const double d2 = d * d, d3 = d * d2, d4 = d2 * d2;
+    const double bits[5] = {d, d2 * 10e-3, -d3 * 10e-5, d4 * 10e-7, -d4 * 10e-10};
+    double delta = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) delta = delta + (p[3 + i] + p[8 + i] * p[2]) * bits[i];
+    out[0] = (p[0] + delta) * exp(p[1] * in[0]);
 }
 
 template <int KIND, bool HAS_SCEN>
@@ -117,6 +145,8 @@ hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s)
         case 4: return launch_kind<4>(a, s);
         case 5: return launch_kind<5>(a, s);
         case 6: return launch_kind<6>(a, s);
+        case 13: return launch_kind<13>(a, s);
+        case 14: return launch_kind<14>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -399,7 +399,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_HALOCARBON)
+    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_OSPP)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -419,11 +419,11 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
                                  RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS, RSCM_CH4_NPARAMS,
                                  RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS, RSCM_OC_NPARAMS,
-                                 RSCM_HC_NPARAMS};
-    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4, RSCM_HC_NSPECIES + 5};  // variable ids incl. the input block 0
+                                 RSCM_HC_NPARAMS, RSCM_FB_NPARAMS, RSCM_SP_NPARAMS};
+    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4, RSCM_HC_NSPECIES + 5, 5, 2};  // variable ids incl. the input block 0
     static const int32_t kInputs[] = {1, 1, 1, 3, RSCM_OZ_NINPUTS, RSCM_AD_NINPUTS, RSCM_AI_NINPUTS,
                                       RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS, RSCM_CB_NINPUTS, RSCM_TC_NINPUTS,
-                                      RSCM_OC_NINPUTS, RSCM_HC_NINPUTS};
+                                      RSCM_OC_NINPUTS, RSCM_HC_NINPUTS, RSCM_FB_NINPUTS, RSCM_SP_NINPUTS};
     h->P = kP[kind];
     h->V = kV[kind];
     h->n_inputs = kInputs[kind];
@@ -824,7 +824,8 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.lifetime = h->series(RSCM_CHEM_VAR_LIFETIME);
         a.status = h->d_status;
         HIPCHK(rscm::launch_chem(a, h->stream));
-    } else if (h->kind >= RSCM_KIND_OZONE_FORCING && h->kind <= RSCM_KIND_AEROSOL_INDIRECT) {
+    } else if ((h->kind >= RSCM_KIND_OZONE_FORCING && h->kind <= RSCM_KIND_AEROSOL_INDIRECT) ||
+               h->kind == RSCM_KIND_FOURBOX_OHU || h->kind == RSCM_KIND_OSPP) {
         rscm::PointwiseArgs a{};
         a.n_members = h->N;
         a.n_times = h->T;

@@ -66,7 +66,7 @@ def test_aerosol_indirect_unit_test_answers():
     assert c < b < a < 0 and b / a < 2.0 and c / b < b / a
 
 
-@pytest.mark.parametrize("kind", [OZ, AD, AI])
+@pytest.mark.parametrize("kind", [OZ, AD, AI, orc.PW_FOURBOX_OHU, orc.PW_OSPP])
 def test_pointwise_run_layout(kind):
     rng = np.random.default_rng(kind)
     L = orc.lib()
@@ -81,3 +81,28 @@ def test_pointwise_run_layout(kind):
     for i in (0, 8, 16):
         for n in (0, 13, T - 2):
             assert np.array_equal(out[:, n + 1, i], orc.pointwise_eval(kind, P[:, i].copy(), inputs[scen[i], :, n]))
+
+
+def test_ospp_reference_known_answers():
+    """ocean_surface_partial_pressure.rs:196-259: delta SST = 4 K, delta DIC = 5 umol/kg give
+    339.089 and 381.003 ppm (max_relative 10e-5) for the two parameter sets of the test."""
+    K = orc.PW_OSPP
+    p1 = orc.pointwise_default_params(K)
+    assert orc.pointwise_eval(K, p1, (4.0, 5.0))[0] == pytest.approx(339.089, rel=10e-5)
+    names = orc.PW_PARAM_NAMES[K]
+    over = dict(ospp_preindustrial=315.0, sensitivity_ospp_to_temperature=0.0423)
+    over.update({f"delta_ospp_offsets_{i}": v for i, v in enumerate((1.5, 7.5, 1.3, 2.5, 1.6))})
+    over.update({f"delta_ospp_coefficients_{i}": v for i, v in enumerate((-0.02, -0.2, -0.1, -0.14, -0.2))})
+    assert set(over) <= set(names)
+    assert orc.pointwise_eval(K, orc.pointwise_default_params(K, **over), (4.0, 5.0))[0] == pytest.approx(381.003, rel=10e-5)
+    # no anomaly: the pre-industrial pressure
+    assert orc.pointwise_eval(K, p1, (0.0, 0.0))[0] == 278.0
+
+
+def test_fourbox_ocean_heat_uptake_answers():
+    """four_box_ocean_heat_uptake.rs:115-260: regional = ERF x ratio; the default ratios average to one."""
+    K = orc.PW_FOURBOX_OHU
+    p = orc.pointwise_default_params(K)
+    assert abs(p.mean() - 1.0) < 0.01
+    out = orc.pointwise_eval(K, p, (2.0,))
+    assert np.array_equal(out, 2.0 * np.array([1.2, 0.6, 1.6, 0.6])) and out.mean() == pytest.approx(2.0)
