@@ -136,7 +136,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
 }
 
 template <int STEPS, bool HAS_SCEN>
-__global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a)
+__global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double* __restrict__ irf_table)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a)
     for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
     m.temp_on = P(23) != 0.0;
     const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 2 * T;
-    const double* __restrict__ irf = a.irf;   // [H], wave-uniform indices
+    const double* __restrict__ irf = irf_table;  // [H], wave-uniform indices: a read-only kernel argument -> scalar loads
     double* __restrict__ hist = a.hist + i;   // [months][N]
     a.status[i] = 0;
     if (a.step_begin == 0) a.series[2 * (size_t)T * N + i] = __builtin_nan("");
@@ -171,8 +171,8 @@ hipError_t launch_ocean(const OceanArgs& a, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     if (a.steps != 12) return hipErrorInvalidValue;  // the sub-step loop is unrolled for monthly steps
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true>), grid, dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((ocean_kernel<12, false>), grid, dim3(kBlock), 0, s, a);
+    if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true>), grid, dim3(kBlock), 0, s, a, a.irf);
+    else hipLaunchKernelGGL((ocean_kernel<12, false>), grid, dim3(kBlock), 0, s, a, a.irf);
     return hipGetLastError();
 }
 
