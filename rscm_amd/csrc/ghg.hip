@@ -31,7 +31,7 @@ __device__ __forceinline__ double overlap_split(double m75, double n75, double m
 }
 
 template <int METHOD, bool HAS_SCEN>
-__global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a)
+__global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a, const double* __restrict__ tables)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
@@ -42,7 +42,9 @@ __global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a)
     const double adj_co2 = P(18), adj_ch4 = P(19), adj_n2o = P(20);
     const double ln_c0 = log(co2_pi), sq_m0 = sqrt(ch4_pi), sq_n0 = sqrt(n2o_pi);
     // scenario table of this member: rows [kGhgRows][T]
-    const double* __restrict__ tab = a.tables + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * kGhgRows * T;
+    // read-only __restrict__ kernel argument: without a scenario map the row addresses are
+    // wave-uniform and become scalar loads
+    const double* __restrict__ tab = tables + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * kGhgRows * T;
     auto row = [&](int r, int32_t n) -> double { return tab[(size_t)r * T + n]; };
 
     // member constants
@@ -107,11 +109,11 @@ hipError_t launch_ghg(const GhgArgs& a, hipStream_t s)
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     const bool scen = a.scen != nullptr;
     if (a.method == 0) {
-        if (scen) hipLaunchKernelGGL((ghg_kernel<0, true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((ghg_kernel<0, false>), grid, dim3(kBlock), 0, s, a);
+        if (scen) hipLaunchKernelGGL((ghg_kernel<0, true>), grid, dim3(kBlock), 0, s, a, a.tables);
+        else hipLaunchKernelGGL((ghg_kernel<0, false>), grid, dim3(kBlock), 0, s, a, a.tables);
     } else {
-        if (scen) hipLaunchKernelGGL((ghg_kernel<1, true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((ghg_kernel<1, false>), grid, dim3(kBlock), 0, s, a);
+        if (scen) hipLaunchKernelGGL((ghg_kernel<1, true>), grid, dim3(kBlock), 0, s, a, a.tables);
+        else hipLaunchKernelGGL((ghg_kernel<1, false>), grid, dim3(kBlock), 0, s, a, a.tables);
     }
     return hipGetLastError();
 }
