@@ -339,6 +339,8 @@ RSCM_API int rscm_ens_destroy(rscm_ens* h);
 
 RSCM_API int rscm_ens_n_params(const rscm_ens* h, int32_t* out);
 RSCM_API int rscm_ens_n_vars(const rscm_ens* h, int32_t* out);
+/* Rows per scenario of the shared input block (variable 0): 1 for the first three kinds. */
+RSCM_API int rscm_ens_n_inputs(const rscm_ens* h, int32_t* out);
 RSCM_API int rscm_ens_n_members(const rscm_ens* h, int64_t* out);
 RSCM_API int rscm_ens_n_times(const rscm_ens* h, int32_t* out);
 

@@ -221,6 +221,7 @@ SIGNATURES = {
     "rscm_ens_destroy": (C.c_int, [_h]),
     "rscm_ens_n_params": (C.c_int, [_h, _ip]),
     "rscm_ens_n_vars": (C.c_int, [_h, _ip]),
+    "rscm_ens_n_inputs": (C.c_int, [_h, _ip]),
     "rscm_ens_n_members": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "rscm_ens_n_times": (C.c_int, [_h, _ip]),
     "rscm_ens_set_mode": (C.c_int, [_h, C.c_int32]),

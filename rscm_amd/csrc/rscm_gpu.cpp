@@ -516,6 +516,7 @@ int rscm_ens_destroy(rscm_ens* h)
 
 int rscm_ens_n_params(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->P; return RSCM_OK; }
 int rscm_ens_n_vars(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->V; return RSCM_OK; }
+int rscm_ens_n_inputs(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->n_inputs; return RSCM_OK; }
 int rscm_ens_n_members(const rscm_ens* h, int64_t* out) { NEED(h); *out = h->N; return RSCM_OK; }
 int rscm_ens_n_times(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->T; return RSCM_OK; }
 int rscm_ens_time_index(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->time_index; return RSCM_OK; }

@@ -37,6 +37,15 @@ class Ensemble:
         L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
                                              0 if store_series else L.FLAG_NO_SERIES, C.byref(h)))
         self._h = h
+        # the library and the tables of this package must agree on the shape of the kind
+        got = [C.c_int32() for _ in range(3)]
+        for fn, x in zip((self._lib.rscm_ens_n_params, self._lib.rscm_ens_n_vars, self._lib.rscm_ens_n_inputs), got):
+            L.check(fn(self._h, C.byref(x)))
+        want = (self.n_params, max(self.var_ids.values()) + 1, self.n_inputs)
+        if tuple(x.value for x in got) != want:
+            self.close()
+            raise RuntimeError(f"kind {kind}: library reports (params, vars, inputs) = {tuple(x.value for x in got)}, "
+                               f"package tables say {want}")
 
     # -- lifecycle --------------------------------------------------------------------------
     def close(self) -> None:
