@@ -27,6 +27,108 @@ int orc_udeb_run(int64_t, int32_t, const double*, const double*, int32_t, const 
                  const double*, double*, double*, double*, double*, double*, double*, double*, int32_t*,
                  int64_t, int64_t);
 
+/* rscm-magicc / rscm-components restatements */
+int32_t orc_ghg_n_params(void);
+void orc_ghg_default_params(double*);
+void orc_ghg_run(int64_t, int32_t, const double*, int32_t, const double*, const int32_t*, double*, double*, double*,
+                 int64_t, int64_t);
+int32_t orc_pointwise_n_params(int32_t), orc_pointwise_n_inputs(int32_t), orc_pointwise_n_outputs(int32_t);
+void orc_pointwise_default_params(int32_t, double*);
+int32_t orc_pointwise_run(int32_t, int64_t, int32_t, const double*, const double*, const int32_t*, double*, int64_t, int64_t);
+int32_t orc_chem_n_params(int32_t), orc_chem_n_inputs(int32_t);
+void orc_chem_default_params(int32_t, double*);
+int32_t orc_chem_run(int32_t, int64_t, int32_t, const double*, const double*, const double*, const int32_t*, double*,
+                     double*, int64_t, int64_t);
+int32_t orc_carbon_n_params(int32_t), orc_carbon_n_inputs(int32_t), orc_carbon_n_states(int32_t), orc_carbon_n_outputs(int32_t);
+void orc_carbon_default_params(int32_t, double*);
+int32_t orc_carbon_run(int32_t, int64_t, int32_t, const double*, const double*, const double*, const int32_t*, double*,
+                       int64_t, int64_t);
+int32_t orc_ocean_n_params(void);
+void orc_ocean_default_params(int32_t, double*);
+int32_t orc_ocean_run(int64_t, int32_t, const double*, const double*, const double*, const int32_t*, double*, int64_t, int64_t);
+int32_t orc_halo_n_params(void), orc_halo_n_species(void);
+void orc_halo_default_params(double*);
+int32_t orc_halo_run(int64_t, int32_t, const double*, const double*, const double*, const int32_t*, double*, int64_t, int64_t);
+
+/* params [P][n] from one default vector, member i scaled by (1 + 0.01 i) in row `vary` */
+static double* spread(const double* d, int P, int n, int vary)
+{
+    double* p = malloc(sizeof(double) * P * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < P; ++j) p[j * n + i] = d[j] * (j == vary ? 1.0 + 0.01 * i : 1.0);
+    return p;
+}
+
+static int magicc_kinds(void)
+{
+    enum { NM = 5, TM = 16 };
+    double b[TM + 1], d[320];
+    int32_t scen[NM];
+    for (int i = 0; i <= TM; ++i) b[i] = 1900.0 + i;
+    for (int i = 0; i < NM; ++i) scen[i] = i % 2;
+    double* in = malloc(sizeof(double) * 2 * 41 * TM);  /* the widest input block: 2 scenarios x 41 rows */
+    for (int i = 0; i < 2 * 41 * TM; ++i) in[i] = 300.0 + (i % 97);
+    double* out = malloc(sizeof(double) * 45 * TM * NM);  /* the widest series block */
+    double* p;
+    /* GhgForcing, both methods */
+    for (int method = 0; method < 2; ++method) {
+        orc_ghg_default_params(d);
+        d[0] = method;
+        p = spread(d, orc_ghg_n_params(), NM, 1);
+        orc_ghg_run(NM, TM, p, 2, in, scen, out, out + TM * NM, out + 2 * TM * NM, 0, NM);
+        if (!isnan(out[0]) || !isfinite(out[(TM - 1) * NM + NM - 1])) return 20 + method;
+        free(p);
+    }
+    /* the five pointwise kinds */
+    const int pw[5] = {4, 5, 6, 13, 14};
+    for (int k = 0; k < 5; ++k) {
+        orc_pointwise_default_params(pw[k], d);
+        p = spread(d, orc_pointwise_n_params(pw[k]), NM, 0);
+        if (orc_pointwise_run(pw[k], NM, TM, p, in, scen, out, 0, NM)) return 30 + k;
+        free(p);
+    }
+    /* chemistry: concentration state in out, lifetime behind it */
+    for (int kind = 7; kind <= 8; ++kind) {
+        orc_chem_default_params(kind, d);
+        p = spread(d, orc_chem_n_params(kind), NM, 2);
+        for (int i = 0; i < NM; ++i) out[i] = kind == 7 ? 800.0 : 275.0;
+        if (orc_chem_run(kind, NM, TM, b, p, in, scen, out, out + TM * NM, 0, NM)) return 40 + kind;
+        free(p);
+    }
+    /* carbon: states then outputs */
+    for (int kind = 9; kind <= 10; ++kind) {
+        orc_carbon_default_params(kind, d);
+        p = spread(d, orc_carbon_n_params(kind), NM, 0);
+        for (int s_ = 0; s_ < orc_carbon_n_states(kind); ++s_)
+            for (int i = 0; i < NM; ++i) out[s_ * TM * NM + i] = 300.0 + 100.0 * s_;
+        if (orc_carbon_run(kind, NM, TM, b, p, in, scen, out, 0, NM)) return 50 + kind;
+        free(p);
+    }
+    /* ocean: the history ring at its bound (max_history_months = 30 < 15 x 12 months) and unbounded */
+    for (int sc = 0; sc < 2; ++sc)  /* the second input row is an SST anomaly in K */
+        for (int t_ = 0; t_ < TM; ++t_) in[(sc * 2 + 1) * TM + t_] = 0.05 * t_;
+    for (int bounded = 0; bounded < 2; ++bounded) {
+        orc_ocean_default_params(bounded ? 2 : 0, d);
+        if (bounded) d[11] = 30.0;
+        p = spread(d, orc_ocean_n_params(), NM, 4);
+        for (int i = 0; i < NM; ++i) { out[i] = 290.0; out[TM * NM + i] = 0.0; }
+        if (orc_ocean_run(NM, TM, b, p, in, scen, out, 0, NM)) return 60 + bounded;
+        if (!isfinite(out[(TM - 1) * NM])) return 62;
+        free(p);
+    }
+    /* halocarbon: 41 concentration states then four aggregates */
+    orc_halo_default_params(d);
+    p = spread(d, orc_halo_n_params(), NM, 6);
+    for (int s_ = 0; s_ < orc_halo_n_species(); ++s_)
+        for (int i = 0; i < NM; ++i) out[s_ * TM * NM + i] = 5.0;
+    if (orc_halo_run(NM, TM, b, p, in, scen, out, 0, NM)) return 70;
+    if (!isfinite(out[44 * TM * NM + (TM - 1) * NM])) return 71;
+    free(p);
+    free(in);
+    free(out);
+    return 0;
+}
+
 #define N 37
 #define T 41
 int main(void)
@@ -78,6 +180,10 @@ int main(void)
         if (ust[0] || !(uo[0][(TU - 1) * NU + 2] > uo[0][(TU - 1) * NU + 0])) return 10;
         for (int k = 0; k < 7; ++k) free(uo[k]);
         free(up);
+    }
+    {
+        const int rc = magicc_kinds();
+        if (rc) return rc;
     }
     printf("oracle selftest ok: Ts=%.17g lnL[0]=%.17g conc=%.17g\n", ts, ll[0], y[0]);
     for (int k = 0; k < 7; ++k) free(s[k]);
