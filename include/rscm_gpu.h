@@ -366,6 +366,8 @@ RSCM_API int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* val
  * series (1 value = broadcast, or N values); rscm_ens_set_time_index moves the stepper there. */
 RSCM_API int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* values,
                                 int64_t n_values);
+/* RSCM_KIND_UDEB and RSCM_KIND_OCEAN_CARBON keep the reference's internal ComponentState (ocean
+ * columns, flux history) on the device: for them tidx must be 0 or the current index. */
 RSCM_API int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx);
 /* Use an existing hipStream_t (as void*) for all launches and copies; NULL = own stream. */
 RSCM_API int rscm_ens_set_stream(rscm_ens* h, void* hip_stream);

@@ -695,6 +695,11 @@ int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
 {
     NEED(h);
     if (tidx < 0 || tidx > h->rows - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    // kinds whose components keep internal state in the reference (ComponentState: the UDEB ocean
+    // columns, the OceanCarbon flux history) can only continue from where that state stands
+    if ((h->kind == RSCM_KIND_UDEB || h->kind == RSCM_KIND_OCEAN_CARBON) && tidx != 0 && tidx != h->time_index)
+        return fail(RSCM_ERR_STATE, "this kind carries internal component state on the device: the time index can "
+                                    "only be rewound to 0 or left at %d", h->time_index);
     if (tidx > 0)
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;  // a restored checkpoint carries its own state rows

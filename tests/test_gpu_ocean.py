@@ -173,3 +173,24 @@ def test_ocean_full_window_properties(ra, orc):
     want = orc.ocean_run(b, P[:, :2].copy(), inputs, 278.0, 0.0, threads=2)
     assert np.array_equal(pco2[:, :2], want[0]) and np.array_equal(cum[:2], want[1, T - 1])
     print(f"ocean 4096 x 750 yr: {ms:.1f} ms")
+
+
+def test_internal_state_kinds_refuse_time_jumps(ra, orc):
+    """ClimateUDEB and OceanCarbon carry the reference's ComponentState on the device: their time
+    index can be rewound or left alone, not moved somewhere the state has not been."""
+    b = np.arange(11, dtype=float)
+    with ra.Ensemble(ra.KIND_OCEAN_CARBON, 2, b) as e:
+        e.set_params(np.repeat(orc.ocean_default_params().reshape(-1, 1), 2, axis=1))
+        e.set_forcing(np.stack([np.full(10, 400.0), np.zeros(10)]))
+        e.set_initial(1, 278.0)
+        e.set_initial(2, 0.0)
+        e.run(4)
+        from rscm_amd import _lib
+        with pytest.raises(ra.RscmGpuError, match="internal component state"):
+            _lib.check(e._lib.rscm_ens_set_time_index(e._h, 2))
+        _lib.check(e._lib.rscm_ens_set_time_index(e._h, 4))
+        e.run()
+        first = e.get_series(1)
+        e.rewind()
+        e.run()
+        assert np.array_equal(e.get_series(1), first)
