@@ -25,6 +25,11 @@ namespace {
 
 constexpr int kPratherIterations = 4;
 
+// x^y for x >= 1 as exp(y ln x): the lifetime ratios are in [1, ~10] and |y| < 1, so the product
+// y ln x is O(1) and carries ~1 ulp of ln's error into an exponent of that size -- a relative
+// error of ~1e-16 in the power, at a third of the instructions of the general pow().
+__device__ __forceinline__ double pow_ratio(double x, double y) { return exp(y * log(x)); }
+
 template <bool HAS_SCEN>
 __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
 {
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
         for (int it = 0; it < kPratherIterations; ++it) {
             const double burden_mean = (burden + burden_prev) / 2.0;
             const double ratio = fmax(burden_mean / burden_reference, 1.0);
-            tau_oh = base * pow(ratio, x);
+            tau_oh = base * pow_ratio(ratio, x);
             if (it > 0 && !(fabs(burden_prev) < 1e-10)) tau_oh = tau_oh * (1.0 - 0.5 * x * delta_burden / burden_prev);
             if (incl_temp && !(fabs(temperature) < 1e-10)) {
                 const double delta_t = fmax(temperature, 0.0);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
         for (int it = 0; it < kPratherIterations; ++it) {
             const double burden_mid = (burden_prev + burden) / 2.0;
             const double ratio = fmax(burden_mid / burden_reference, 1.0);
-            tau_eff = tau0 * pow(ratio, lifetime_fb);
+            tau_eff = tau0 * pow_ratio(ratio, lifetime_fb);
             const double rate = total_emissions - burden_lagged / tau_eff;
             burden = burden_prev + rate * dt;
         }

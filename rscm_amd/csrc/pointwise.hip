@@ -41,7 +41,9 @@ struct Shape<14> { static constexpr int P = 13, NI = 2, NO = 1; };
 __device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[6], double (&out)[3])
 {
     const double delta_eesc = in[0] - p[0];
-    out[0] = delta_eesc <= 0.0 ? 0.0 : p[1] * pow(delta_eesc / 100.0, p[2]);
+    // x^y for x > 0 as exp(y ln x): |y ln x| is O(1..10) here, so the power keeps ~1e-15 relative
+    // accuracy at a third of the instructions of the general pow()
+    out[0] = delta_eesc <= 0.0 ? 0.0 : p[1] * exp(p[2] * log(delta_eesc / 100.0));
     const double ch4 = in[1];
     const double ch4_term = (ch4 > 0.0 && p[8] > 0.0) ? p[4] * log(ch4 / p[8]) : 0.0;
     const double delta_nox = in[2] - p[9], delta_co = in[3] - p[10], delta_nmvoc = in[4] - p[11];
