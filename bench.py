@@ -305,6 +305,8 @@ def main():
                 # (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/r1_exact_1e5_v2.txt.
                 # The traffic is input-independent (params + forcing in, Ts/Td out).
                 "traffic": 1.2067e9 if (args.members == 100_000 and args.mode == "exact") else None,
+                "traffic_source": "profiles/r1_exact_1e5_v2.txt: separate rocprofv3 --pmc passes of this launch "
+                                  "(FETCH_SIZE x2 + WRITE_SIZE, KiB); not re-measured inside bench.py",
                 "kernel": "two_layer_kernel",
                 "kernel_ms": kernel_ms,
                 "note": "algorithmic 16 B/member-year x members x 750 / launch duration; the "
