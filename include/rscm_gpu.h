@@ -310,7 +310,9 @@ extern "C" {
 #define RSCM_MODE_EXACT 0 /* op-for-op the reference's f64 expression order, no FMA contraction:
                              bit-identical to the CPU oracle for the two-layer kind            */
 #define RSCM_MODE_FAST 1  /* FMA + reciprocal heat capacities; |rel diff| <= 1e-11 on bounded
-                             trajectories (tests/test_gpu_parity.py states the tolerance)      */
+                             trajectories (tests/test_gpu_parity.py states the tolerance).
+                             RSCM_KIND_OCEAN_CARBON: fused multiply-add in the history convolution
+                             (tests/test_gpu_ocean.py).  The other kinds have one arithmetic.  */
 
 typedef struct rscm_ens rscm_ens;
 

@@ -52,9 +52,17 @@ __device__ __forceinline__ double pco2_from_dic(const OceanMember& m, double d, 
     return (m.pco2_pi + s) * temp_factor;
 }
 
+// acc + f*r: one rounded multiply and one rounded add like the reference (EXACT), or fused
+// (RSCM_MODE_FAST: half the instructions, results differ by rounding only)
+template <bool FUSED>
+__device__ __forceinline__ double mac(double acc, double f, double r)
+{
+    return FUSED ? __builtin_fma(f, r, acc) : acc + f * r;
+}
+
 // YEARS consecutive model steps starting at n: one pass over the old pulses feeds the
 // STEPS*YEARS running sums of all their sub-steps.
-template <int STEPS, int YEARS>
+template <int STEPS, int YEARS, bool FUSED>
 __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember& m, const double* __restrict__ in,
                                            const double* __restrict__ irf, double* __restrict__ hist, int64_t i, int32_t n)
 {
@@ -78,8 +86,8 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int64_t lag = m0 + k - j;
-            const double term = f * irf[lag < H ? lag : 0];
-            if (j >= lo(k)) A[k] = A[k] + term;
+            const double next = mac<FUSED>(A[k], f, irf[lag < H ? lag : 0]);
+            if (j >= lo(k)) A[k] = next;
         }
     }
     // Bulk: groups of STEPS pulses share a K+STEPS-1 entry window of the response table
@@ -93,13 +101,13 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) A[k] = A[k] + f[u] * w[STEPS - 1 - u + k];
+            for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f[u], w[STEPS - 1 - u + k]);
         }
     }
     for (; j < m0; ++j) {  // tail
         const double f = hist[(size_t)j * N];
 #pragma unroll
-        for (int k = 0; k < K; ++k) A[k] = A[k] + f * irf[m0 + k - j];
+        for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f, irf[m0 + k - j]);
     }
     // ---- the tile's own sub-steps (solve_ocean, carbon/ocean.rs:116-160), its pulses in registers
     double fy[K];
@@ -124,7 +132,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
             double integral = A[k];
 #pragma unroll
             for (int q = 0; q <= k; ++q)
-                if (m0 + q >= lo(k)) integral = integral + fy[q] * irf[k - q < H ? k - q : 0];
+                if (m0 + q >= lo(k)) integral = mac<FUSED>(integral, fy[q], irf[k - q < H ? k - q : 0]);
             const double delta_dic = H > 0 ? integral * m.dic_conv : 0.0;
             pco2 = pco2_from_dic(m, delta_dic, temp_factor);
         }
@@ -135,7 +143,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     }
 }
 
-template <int STEPS, bool HAS_SCEN>
+template <int STEPS, bool HAS_SCEN, bool FUSED>
 __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double* __restrict__ irf_table)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -160,8 +168,8 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
     int32_t n = a.step_begin;
     // two model steps per pass over the history while two remain: half the HBM traffic, the same
     // sums in the same order
-    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2>(a, m, in, irf, hist, i, n);
-    if (n < a.step_end) ocean_tile<STEPS, 1>(a, m, in, irf, hist, i, n);
+    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2, FUSED>(a, m, in, irf, hist, i, n);
+    if (n < a.step_end) ocean_tile<STEPS, 1, FUSED>(a, m, in, irf, hist, i, n);
 }
 
 }  // namespace
@@ -171,8 +179,13 @@ hipError_t launch_ocean(const OceanArgs& a, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     if (a.steps != 12) return hipErrorInvalidValue;  // the sub-step loop is unrolled for monthly steps
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true>), grid, dim3(kBlock), 0, s, a, a.irf);
-    else hipLaunchKernelGGL((ocean_kernel<12, false>), grid, dim3(kBlock), 0, s, a, a.irf);
+    if (a.fused) {
+        if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true, true>), grid, dim3(kBlock), 0, s, a, a.irf);
+        else hipLaunchKernelGGL((ocean_kernel<12, false, true>), grid, dim3(kBlock), 0, s, a, a.irf);
+    } else {
+        if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true, false>), grid, dim3(kBlock), 0, s, a, a.irf);
+        else hipLaunchKernelGGL((ocean_kernel<12, false, false>), grid, dim3(kBlock), 0, s, a, a.irf);
+    }
     return hipGetLastError();
 }
 

@@ -158,6 +158,7 @@ struct OceanArgs {
     int32_t n_times;
     int32_t step_begin, step_end;
     int32_t steps;           // sub-steps per model step (12)
+    int32_t fused;           // RSCM_MODE_FAST: fused multiply-add in the convolution
     int64_t max_hist;        // max_history_months
     const double* params;    // [24][N]
     const double* inputs;    // [S][2][T]: CO2, SST anomaly

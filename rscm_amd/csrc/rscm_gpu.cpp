@@ -791,6 +791,7 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.step_begin = step_begin;
         a.step_end = step_end;
         a.steps = h->ocean_steps;
+        a.fused = h->mode == RSCM_MODE_FAST ? 1 : 0;
         a.max_hist = h->ocean_max_hist;
         a.params = h->d_params;
         a.inputs = h->d_forcing;

@@ -51,7 +51,7 @@ if kind == 11:  # OceanCarbon (3D-GFDL preset): gas exchange, temperature sensit
         lo[j], hi[j] = a_, b_
 P = {0: 6, 1: 10, 2: 37, 3: 21, 11: 24}[kind]
 with rscm_amd.Ensemble(kind, members, b) as e:
-    if kind not in (3, 11):
+    if kind != 3:
         e.set_mode(mode)
     e.sample_lhs(20260327, lo[:P], hi[:P])
     if kind == 0:

@@ -194,3 +194,31 @@ def test_internal_state_kinds_refuse_time_jumps(ra, orc):
         e.rewind()
         e.run()
         assert np.array_equal(e.get_series(1), first)
+
+
+def test_ocean_fast_mode_tolerance(ra, orc):
+    """RSCM_MODE_FAST fuses the multiply-adds of the convolution (half the VALU work): the sums
+    of up to 6000 terms then differ from the reference's by rounding only."""
+    rng = np.random.default_rng(12)
+    n, T = 64, 601
+    b = np.arange(T + 1, dtype=float) + 1750.0
+    P, _ = _case(orc, "3D-GFDL", n, T, rng, enable_temp_feedback=0.0)
+    # a bounded pathway: beyond ~1500 ppm the fifth-order Joos polynomial leaves its fitted range
+    # and amplifies any rounding difference
+    inputs = np.stack([np.minimum(278.0 + 0.9 * np.arange(T), 700.0), np.zeros(T)])[None]
+    with ra.Ensemble(ra.KIND_OCEAN_CARBON, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(inputs[:1])
+        e.set_initial(1, 278.0)
+        e.set_initial(2, 0.0)
+        e.run()
+        exact = np.stack([e.get_series(v) for v in (1, 2, 3)])
+        e.set_mode(ra.MODE_FAST)
+        e.rewind()
+        e.run()
+        fast = np.stack([e.get_series(v) for v in (1, 2, 3)])
+    want = orc.ocean_run(b, P[:, :2].copy(), inputs[:1], 278.0, 0.0, threads=2)
+    assert np.array_equal(exact[:, :, :2], want, equal_nan=True)
+    ok = ~np.isnan(exact)
+    err = np.abs(fast[ok] - exact[ok]) / np.maximum(1.0, np.abs(exact[ok]))
+    assert 0.0 < err.max() <= 1e-12, err.max()
