@@ -419,6 +419,38 @@ RSCM_API int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var,
 RSCM_API int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var,
                                  const int32_t* obs_tidx, const double* obs_value,
                                  const double* obs_sigma, int32_t normalize, double* out);
+/* ---- device stretch-move sampler ------------------------------------------------------------
+ * EnsembleSampler::run (crates/rscm-calibrate/src/sampler/ensemble.rs:496-547) with StretchMove
+ * (sampler/moves.rs:40-125) and the ParameterSet prior kept on the GPU: per half-ensemble update
+ * a proposal kernel writes y = c + z (x - c), z = ((a-1)u + 1)^2 / a, straight into the evaluating
+ * ensemble's parameter block, the fused run+likelihood kernel scores it and an accept kernel
+ * applies q = z^(d-1) p(y)/p(x).  Random numbers are counter-based (Philox, keyed by `seed`), so a
+ * run is reproducible; the reference draws from thread_rng, so only distributions compare.
+ *
+ * `evaluator`: a two-layer ensemble of n_walkers/2 members with forcing and initial values set
+ * (RSCM_FLAG_NO_SERIES is enough); it must outlive the sampler and is used exclusively by it while
+ * iterating.  Sampled dimension d drives parameter row param_rows[d]; the other rows hold
+ * base_params[P].  prior_kind: 0 = Uniform(low = a, high = b), 1 = Normal(mean = a, std = b)
+ * (distribution.rs).  Observations as for rscm_ens_run_loglik. */
+typedef struct rscm_sampler rscm_sampler;
+RSCM_API int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims,
+                                 const int32_t* param_rows, const double* base_params,
+                                 const int32_t* prior_kind, const double* prior_a, const double* prior_b,
+                                 int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                                 const double* obs_value, const double* obs_sigma, int32_t normalize,
+                                 double stretch_a, uint64_t seed, rscm_sampler** out);
+RSCM_API int rscm_sampler_destroy(rscm_sampler* s);
+/* positions[n_walkers][n_dims] row-major (the Chain layout); scores every walker and zeroes the
+ * acceptance counters. */
+RSCM_API int rscm_sampler_set_positions(rscm_sampler* s, const double* positions);
+/* n_iterations full sweeps (first half against the second, then the second against the updated
+ * first); synchronous.  rscm_ens_last_run_ms(evaluator) reports the device time of the call. */
+RSCM_API int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations);
+/* Any output may be NULL.  positions[n_walkers][n_dims], log_prob[n_walkers] (log prior + log
+ * likelihood, -inf for failed members), per-walker acceptance counters. */
+RSCM_API int rscm_sampler_get(rscm_sampler* s, double* positions, double* log_prob, int64_t* n_accepted,
+                              int64_t* n_proposed);
+
 /* Ensemble summary of one variable at one time index over finite members:
  * out[0]=count_finite, out[1]=sum, out[2]=min, out[3]=max (wavefront + block reductions). */
 RSCM_API int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4]);

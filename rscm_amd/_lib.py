@@ -246,6 +246,12 @@ SIGNATURES = {
     "rscm_ens_status": (C.c_int, [_h, _bp]),
     "rscm_ens_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
     "rscm_ens_run_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
+    "rscm_sampler_create": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, C.c_int32, _ip, _ip,
+                                      _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.POINTER(_h)]),
+    "rscm_sampler_destroy": (C.c_int, [_h]),
+    "rscm_sampler_set_positions": (C.c_int, [_h, _dp]),
+    "rscm_sampler_iterate": (C.c_int, [_h, C.c_int32]),
+    "rscm_sampler_get": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_ens_summary": (C.c_int, [_h, C.c_int32, C.c_int32, _dp]),
     "rscm_ens_get_params": (C.c_int, [_h, _dp]),
     "rscm_ens_sample_lhs": (C.c_int, [_h, C.c_uint64, _dp, _dp, C.c_int64, C.c_int64]),

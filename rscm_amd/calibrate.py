@@ -105,6 +105,9 @@ class ParameterSet:
     def param_names(self) -> List[str]:
         return list(self._names)
 
+    def distributions(self) -> List[object]:
+        return list(self._dists)
+
     def bounds(self) -> Tuple[List[float], List[float]]:
         lo, hi = [], []
         for d in self._dists:
@@ -521,6 +524,104 @@ class EnsembleSampler:
             if progress:
                 progress(it, float(self.n_accepted.sum() / max(1, self.n_proposed.sum())),
                          float(logp.mean()))
+        return chain
+
+    def acceptance_rate(self) -> float:
+        return float(self.n_accepted.sum() / max(1, self.n_proposed.sum()))
+
+
+class DeviceEnsembleSampler:
+    """``EnsembleSampler`` with the whole stretch-move loop on the GPU (``rscm_sampler_*`` of the C
+    ABI, csrc/sampler.hip): proposals, priors, the fused run+likelihood of every half-ensemble and
+    the accept step never leave the device, the host only fetches the walker positions it wants
+    to keep.  Same interface as ``EnsembleSampler``; priors must be ``Uniform`` or ``Normal`` and
+    the model a stand-alone two-layer one.  Random numbers are counter-based from ``seed``."""
+
+    def __init__(self, params: ParameterSet, runner: ModelRunner, likelihood: GaussianLikelihood,
+                 target: Target, stretch_a: float = 2.0):
+        if stretch_a <= 1.0:
+            raise ValueError(f"Stretch move scale parameter must be > 1.0, got {stretch_a}")
+        if list(params.param_names) != runner.param_names:
+            raise ValueError("the parameter set must name the runner's parameters, in its order")
+        self.params, self.runner, self.likelihood, self.target = params, runner, likelihood, target
+        self.a = float(stretch_a)
+        self.default_n_walkers = max(2 * len(params), 32)
+        self.n_accepted = None
+        self.n_proposed = None
+        self.device_ms = 0.0
+        kinds, pa, pb = [], [], []
+        for d in params.distributions():
+            if isinstance(d, Uniform):
+                kinds.append(0), pa.append(d.low), pb.append(d.high)
+            elif isinstance(d, Normal):
+                kinds.append(1), pa.append(d.mean), pb.append(d.std_dev)
+            else:
+                raise NotImplementedError(f"prior {type(d).__name__} has no device form (Uniform and Normal do)")
+        self._prior = (np.array(kinds, dtype=np.int32), L.f64(pa), L.f64(pb))
+
+    def _observations(self, model: Model):
+        ov, ot, val, sig = [], [], [], []
+        for name, vt in self.target.variables():
+            if name not in model.ensemble.var_ids or model.ensemble.var_ids[name] == 0:
+                raise KeyError(f"Model output missing variable: {name}")
+            for obs in vt.observations:
+                idx = model._axis.index_of(obs.time)
+                if idx is None:
+                    raise KeyError(f"Model output missing time: {obs.time}")
+                ov.append(model.ensemble.var_ids[name]), ot.append(idx), val.append(obs.value), sig.append(obs.uncertainty)
+        return np.array(ov, dtype=np.int32), np.array(ot, dtype=np.int32), L.f64(val), L.f64(sig)
+
+    def run(self, n_iterations: int, init: "WalkerInit", thin: int = 1, n_walkers: Optional[int] = None,
+            rng: Optional[np.random.Generator] = None, seed: int = 0) -> "Chain":
+        import ctypes as C
+        n_walkers = n_walkers or self.default_n_walkers
+        if n_walkers < 2:
+            raise ValueError("Must have at least 2 walkers")
+        if n_walkers % 2:
+            raise ValueError("Number of walkers must be even")
+        rng = rng or np.random.default_rng(seed)
+        pos = L.f64(init.initialize(n_walkers, self.params, rng))
+        model = self.runner._lik_model(n_walkers // 2)
+        if model.ensemble.kind != L.KIND_TWO_LAYER:
+            raise NotImplementedError("the device sampler drives the stand-alone two-layer kind")
+        ens, lib = model.ensemble, model.ensemble._lib
+        ens.rewind()
+        ov, ot, val, sig = self._observations(model)
+        rows = np.array(self.runner._rows, dtype=np.int32)
+        kinds, pa, pb = self._prior
+        base = L.f64(model.base_params)
+        h = C.c_void_p()
+        L.check(lib.rscm_sampler_create(ens._h, n_walkers, len(rows), L.iptr(rows), L.dptr(base), L.iptr(kinds),
+                                        L.dptr(pa), L.dptr(pb), len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
+                                        L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
+                                        C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.byref(h)))
+        try:
+            L.check(lib.rscm_sampler_set_positions(h, L.dptr(pos)))
+            chain = Chain(self.params.param_names, thin)
+            logp = np.empty(n_walkers)
+            self.device_ms = 0.0
+            kept = lambda k: (k - 1) % chain.thin == 0  # noqa: E731  (Chain.push keeps 1, 1+thin, ...)
+            it = 0
+            while it < n_iterations:  # iterate on the device up to the next sweep the chain keeps
+                nxt = it + 1
+                while not kept(nxt):
+                    nxt += 1
+                step = min(nxt, n_iterations) - it
+                L.check(lib.rscm_sampler_iterate(h, step))
+                self.device_ms += ens.last_run_ms()
+                it += step
+                if kept(it):
+                    L.check(lib.rscm_sampler_get(h, L.dptr(pos), L.dptr(logp), None, None))
+                    chain._samples.append(pos.copy())
+                    chain._log_probs.append(logp.copy())
+            chain.total_iterations = n_iterations
+            acc = np.empty(n_walkers, dtype=np.int64)
+            prop = np.empty(n_walkers, dtype=np.int64)
+            L.check(lib.rscm_sampler_get(h, None, None, acc.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         prop.ctypes.data_as(C.POINTER(C.c_int64))))
+            self.n_accepted, self.n_proposed = acc, prop
+        finally:
+            lib.rscm_sampler_destroy(h)
         return chain
 
     def acceptance_rate(self) -> float:

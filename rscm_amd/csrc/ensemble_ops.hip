@@ -4,6 +4,7 @@
 //   * counter-based Latin hypercube          crates/rscm-calibrate/src/parameter_set.rs:207-233
 //   * fills / row broadcast for collection initialisation (builder.rs:772-780)
 //   * the division self-test behind rscm_gpu_selftest_div
+#include "philox.hpp"
 #include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
@@ -129,23 +130,7 @@ __global__ __launch_bounds__(kBlock) void summary_final_kernel(const double* par
 }
 
 // ---- counter-based Latin hypercube ----------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011) keyed by (seed, dimension), counter = global member id.
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
+// Philox4x32-10 (philox.hpp) keyed by (seed, dimension), counter = global member id.
 // Keyed bijection of [0, n): 4-round Feistel network on the next even-bit power-of-two domain,
 // cycle-walked back into range (expected < 4 walks).  Replaces the serial Fisher-Yates shuffle
 // of parameter_set.rs:224-226 with something every member can evaluate independently.
@@ -185,9 +170,7 @@ __global__ __launch_bounds__(kBlock) void lhs_kernel(double* params, int32_t n_p
         const uint64_t stratum = feistel_perm(g, (uint64_t)n_total, half_bits, k0, k1);
         uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), 0xA5A5u, (uint32_t)j};
         philox4x32_10(c, k0, ~k1);
-        // 53-bit uniform in [0,1), like rand's Standard f64 (rng.gen::<f64>())
-        const uint64_t bits53 = (((uint64_t)c[1] << 32) | c[0]) >> 11;
-        const double u01 = (double)bits53 * (1.0 / 9007199254740992.0);
+        const double u01 = u01_from_bits(c[0], c[1]);
         // interval_start + U*interval_size (parameter_set.rs:217-218), then the inverse CDF of a
         // bounded constant-pdf prior, low + u*(high-low) (:331-334)
         const double u = (double)stratum * interval_size + u01 * interval_size;

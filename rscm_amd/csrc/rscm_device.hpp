@@ -183,6 +183,30 @@ struct HaloArgs {
     uint8_t* status;
 };
 
+// device stretch-move sampler (csrc/sampler.hip); pos is [D][W], the per-half buffers [.][W/2]
+struct SamplerArgs {
+    int32_t n_walkers, n_dims, n_params;
+    int32_t half;        // 0 / 1: the half being updated
+    int32_t iteration;
+    int32_t identity;    // score the walkers where they stand (initialisation)
+    uint64_t seed;
+    double stretch_a;
+    const int32_t* param_rows;   // [D] evaluator parameter row of each sampled dimension
+    const double* base_params;   // [P] values of the rows that are not sampled
+    const int32_t* prior_kind;   // [D] 0 = Uniform(a, b), 1 = Normal(mean a, std b)
+    const double* prior_a;
+    const double* prior_b;
+    double* pos;         // [D][W]
+    double* logp;        // [W]
+    double* proposal;    // [D][W/2]
+    double* z;           // [W/2]
+    double* lp;          // [W/2] log prior of the proposals
+    const double* loglik;  // [W/2] written by the evaluator's fused run+likelihood launch
+    double* eval_params;   // [P][W/2] the evaluator's parameter block
+    int64_t* n_accepted;   // [W]
+    int64_t* n_proposed;   // [W]
+};
+
 struct LoglikArgs {
     int64_t n_members;
     int32_t n_obs;
@@ -204,6 +228,8 @@ hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
 hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s);
 hipError_t launch_ocean(const OceanArgs& a, hipStream_t s);
 hipError_t launch_halocarbon(const HaloArgs& a, hipStream_t s);
+hipError_t launch_sampler_propose(const SamplerArgs& a, hipStream_t s);
+hipError_t launch_sampler_accept(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

@@ -188,6 +188,10 @@ struct rscm_ens {
     double* d_partial = nullptr;  // summary scratch
     double* d_out4 = nullptr;
     double* d_loglik = nullptr;   // [N]
+    // observations prepared for the fused run+likelihood kernel (prepare_obs)
+    void* d_obs = nullptr;
+    size_t obs_capacity = 0;
+    int32_t obs_n = 0, obs_normalize = 0, obs_first_is_deep = 0;
 
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -504,6 +508,7 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_partial);
     (void)hipFree(h->d_out4);
     (void)hipFree(h->d_loglik);
+    (void)hipFree(h->d_obs);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1057,22 +1062,17 @@ int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const in
     GUARD_END
 }
 
-int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
-                        const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
+namespace {
+
+// Validate a set of observations for the fused run+likelihood kernel and keep it on the device
+// (h->d_obs): groups of one variable each, ascending time indices inside a group.
+int prepare_obs(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                const double* obs_value, const double* obs_sigma, int32_t normalize)
 {
-    GUARD_BEGIN
-    NEED(h);
     if (h->kind != RSCM_KIND_TWO_LAYER) return fail(RSCM_ERR_INVALID, "run_loglik supports the two-layer kind");
-    if (n_obs < 0 || !out || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
+    if (n_obs < 0 || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
         return fail(RSCM_ERR_INVALID, "bad observation arrays");
-    if (h->time_index != 0) return fail(RSCM_ERR_STATE, "run_loglik starts from time index 0 (call rscm_ens_rewind)");
-    if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
-    if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
-    for (int32_t v = 1; v < h->V; ++v)
-        if (h->is_state(v) && !h->initial_set[v])
-            return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
-    // groups: each variable contiguous, ascending time index inside a group
-    int32_t first_var = n_obs > 0 ? obs_var[0] : RSCM_TL_VAR_TS;
+    const int32_t first_var = n_obs > 0 ? obs_var[0] : RSCM_TL_VAR_TS;
     for (int32_t j = 0; j < n_obs; ++j) {
         if (obs_var[j] != RSCM_TL_VAR_TS && obs_var[j] != RSCM_TL_VAR_TD)
             return fail(RSCM_ERR_INVALID, "observation %d: variable %d has no stored series", j, obs_var[j]);
@@ -1084,8 +1084,7 @@ int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, cons
                                           "(use rscm_ens_run + rscm_ens_loglik for arbitrary order)");
     }
     if (int rc = set_device(h)) return rc;
-    if (int rc = refresh_schedule(h)) return rc;
-    // merge the (at most two) groups by time index; ties keep Surface Temperature first
+    // merge the (at most two) groups by time index; ties keep the first group's variable first
     std::vector<int32_t> order(n_obs);
     for (int32_t j = 0; j < n_obs; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return obs_tidx[x] < obs_tidx[y]; });
@@ -1102,10 +1101,38 @@ int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, cons
         bt[k] = obs_tidx[j];
         bd[k] = obs_var[j] == RSCM_TL_VAR_TD ? 1 : 0;
     }
+    HIPCHK(hipStreamSynchronize(h->stream));  // a launch may still be reading the previous plan
+    if (blob.size() > h->obs_capacity) {
+        HIPCHK(hipFree(h->d_obs));
+        h->d_obs = nullptr;
+        h->obs_capacity = 0;
+        HIPCHK(hipMalloc(&h->d_obs, blob.size()));
+        h->obs_capacity = blob.size();
+    }
+    HIPCHK(hipMemcpy(h->d_obs, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    h->obs_n = n_obs;
+    h->obs_normalize = normalize ? 1 : 0;
+    h->obs_first_is_deep = first_var == RSCM_TL_VAR_TD ? 1 : 0;
     if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
-    void* d_blob = nullptr;
-    HIPCHK(hipMalloc(&d_blob, blob.size()));
-    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, h->stream);
+    return RSCM_OK;
+}
+
+// Everything rscm_ens_run_loglik needs of the handle besides the observations.
+int check_loglik_ready(rscm_ens* h)
+{
+    if (h->time_index != 0) return fail(RSCM_ERR_STATE, "run_loglik starts from time index 0 (call rscm_ens_rewind)");
+    if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
+    if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
+    for (int32_t v = 1; v < h->V; ++v)
+        if (h->is_state(v) && !h->initial_set[v])
+            return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
+    if (int rc = set_device(h)) return rc;
+    return refresh_schedule(h);
+}
+
+// Asynchronous fused run+likelihood launch with the prepared observations; fills h->d_loglik.
+hipError_t launch_loglik(rscm_ens* h)
+{
     const int32_t len = h->T - 1;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
     rscm::TwoLayerArgs a{};
@@ -1124,22 +1151,247 @@ int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, cons
     a.ts = h->series(RSCM_TL_VAR_TS);
     a.td = h->series(RSCM_TL_VAR_TD);
     a.status = h->d_status;
-    a.n_obs = n_obs;
-    a.normalize = normalize ? 1 : 0;
-    a.first_is_deep = first_var == RSCM_TL_VAR_TD ? 1 : 0;
-    a.obs_value = (const double*)d_blob;
-    a.obs_sigma = a.obs_value + n_obs;
-    a.obs_tidx = (const int32_t*)(a.obs_sigma + n_obs);
-    a.obs_is_deep = a.obs_tidx + n_obs;
+    a.n_obs = h->obs_n;
+    a.normalize = h->obs_normalize;
+    a.first_is_deep = h->obs_first_is_deep;
+    a.obs_value = (const double*)h->d_obs;
+    a.obs_sigma = a.obs_value + h->obs_n;
+    a.obs_tidx = (const int32_t*)(a.obs_sigma + h->obs_n);
+    a.obs_is_deep = a.obs_tidx + h->obs_n;
     a.loglik = h->d_loglik;
-    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
-    if (e == hipSuccess) e = rscm::launch_two_layer_loglik(a, h->mode, h->stream);
+    return rscm::launch_two_layer_loglik(a, h->mode, h->stream);
+}
+
+}  // namespace
+
+int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                        const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    if (int rc = check_loglik_ready(h)) return rc;
+    hipError_t e = hipEventRecord(h->ev0, h->stream);
+    if (e == hipSuccess) e = launch_loglik(h);
     if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_blob);
     if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "run_loglik: %s", hipGetErrorString(e));
     h->timed = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device stretch-move sampler (csrc/sampler.hip)
+// ---------------------------------------------------------------------------------------------
+struct rscm_sampler {
+    rscm_ens* ev = nullptr;  // evaluates one half-ensemble per launch; not owned
+    int32_t W = 0, D = 0;
+    double stretch_a = 2.0;
+    uint64_t seed = 0;
+    int32_t iteration = 0;
+    bool positions_set = false;
+    int32_t* d_rows = nullptr;
+    int32_t* d_kind = nullptr;
+    double* d_base = nullptr;
+    double* d_pa = nullptr;
+    double* d_pb = nullptr;
+    double* d_pos = nullptr;
+    double* d_logp = nullptr;
+    double* d_prop = nullptr;
+    double* d_z = nullptr;
+    double* d_lp = nullptr;
+    int64_t* d_nacc = nullptr;
+    int64_t* d_nprop = nullptr;
+};
+
+namespace {
+
+rscm::SamplerArgs sampler_args(const rscm_sampler* s, int32_t half, int32_t identity)
+{
+    rscm::SamplerArgs a{};
+    a.n_walkers = s->W;
+    a.n_dims = s->D;
+    a.n_params = s->ev->P;
+    a.half = half;
+    a.iteration = s->iteration;
+    a.identity = identity;
+    a.seed = s->seed;
+    a.stretch_a = s->stretch_a;
+    a.param_rows = s->d_rows;
+    a.base_params = s->d_base;
+    a.prior_kind = s->d_kind;
+    a.prior_a = s->d_pa;
+    a.prior_b = s->d_pb;
+    a.pos = s->d_pos;
+    a.logp = s->d_logp;
+    a.proposal = s->d_prop;
+    a.z = s->d_z;
+    a.lp = s->d_lp;
+    a.loglik = s->ev->d_loglik;
+    a.eval_params = s->ev->d_params;
+    a.n_accepted = s->d_nacc;
+    a.n_proposed = s->d_nprop;
+    return a;
+}
+
+// propose (or re-score) one half, evaluate it, accept: three launches on the evaluator's stream
+hipError_t sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
+{
+    const rscm::SamplerArgs a = sampler_args(s, half, identity);
+    hipError_t e = rscm::launch_sampler_propose(a, s->ev->stream);
+    if (e == hipSuccess) e = launch_loglik(s->ev);
+    if (e == hipSuccess) e = rscm::launch_sampler_accept(a, s->ev->stream);
+    return e;
+}
+
+}  // namespace
+
+int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, const int32_t* param_rows,
+                        const double* base_params, const int32_t* prior_kind, const double* prior_a,
+                        const double* prior_b, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                        const double* obs_value, const double* obs_sigma, int32_t normalize, double stretch_a,
+                        uint64_t seed, rscm_sampler** out)
+{
+    GUARD_BEGIN
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    rscm_ens* h = evaluator;
+    NEED(h);
+    if (n_walkers < 2) return fail(RSCM_ERR_INVALID, "Must have at least 2 walkers");          // ensemble.rs:120-127
+    if (n_walkers % 2) return fail(RSCM_ERR_INVALID, "Number of walkers must be even");
+    if (h->N != n_walkers / 2)
+        return fail(RSCM_ERR_INVALID, "the evaluating ensemble must have n_walkers/2 = %d members, it has %lld",
+                    n_walkers / 2, (long long)h->N);
+    if (!(stretch_a > 1.0)) return fail(RSCM_ERR_INVALID, "Stretch move scale parameter must be > 1.0, got %g", stretch_a);  // moves.rs:40-48
+    if (n_dims < 1 || n_dims > h->P || !param_rows || !base_params || !prior_kind || !prior_a || !prior_b)
+        return fail(RSCM_ERR_INVALID, "bad parameter description");
+    for (int32_t d = 0; d < n_dims; ++d) {
+        if (param_rows[d] < 0 || param_rows[d] >= h->P) return fail(RSCM_ERR_INVALID, "dimension %d: parameter row %d out of range", d, param_rows[d]);
+        for (int32_t e2 = 0; e2 < d; ++e2)
+            if (param_rows[e2] == param_rows[d]) return fail(RSCM_ERR_INVALID, "parameter row %d sampled twice", param_rows[d]);
+        if (prior_kind[d] != 0 && prior_kind[d] != 1) return fail(RSCM_ERR_INVALID, "dimension %d: unknown prior kind %d", d, prior_kind[d]);
+        if (prior_kind[d] == 0 && !(prior_b[d] > prior_a[d])) return fail(RSCM_ERR_INVALID, "dimension %d: Uniform needs high > low", d);
+        if (prior_kind[d] == 1 && !(prior_b[d] > 0.0)) return fail(RSCM_ERR_INVALID, "dimension %d: Normal needs std > 0", d);
+    }
+    if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    rscm_sampler* s = new rscm_sampler();
+    s->ev = h;
+    s->W = n_walkers;
+    s->D = n_dims;
+    s->stretch_a = stretch_a;
+    s->seed = seed;
+    auto cleanup = [&](int rc) {
+        rscm_sampler_destroy(s);
+        return rc;
+    };
+    const size_t W = (size_t)n_walkers, H = W / 2, D = (size_t)n_dims;
+#define CK(expr)                                                                               \
+    do {                                                                                       \
+        hipError_t e2_ = (expr);                                                               \
+        if (e2_ != hipSuccess)                                                                 \
+            return cleanup(fail(e2_ == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, \
+                                "%s failed: %s", #expr, hipGetErrorString(e2_)));              \
+    } while (0)
+    CK(hipMalloc(&s->d_rows, D * sizeof(int32_t)));
+    CK(hipMalloc(&s->d_kind, D * sizeof(int32_t)));
+    CK(hipMalloc(&s->d_base, (size_t)h->P * sizeof(double)));
+    CK(hipMalloc(&s->d_pa, D * sizeof(double)));
+    CK(hipMalloc(&s->d_pb, D * sizeof(double)));
+    CK(hipMalloc(&s->d_pos, D * W * sizeof(double)));
+    CK(hipMalloc(&s->d_logp, W * sizeof(double)));
+    CK(hipMalloc(&s->d_prop, D * H * sizeof(double)));
+    CK(hipMalloc(&s->d_z, H * sizeof(double)));
+    CK(hipMalloc(&s->d_lp, H * sizeof(double)));
+    CK(hipMalloc(&s->d_nacc, W * sizeof(int64_t)));
+    CK(hipMalloc(&s->d_nprop, W * sizeof(int64_t)));
+    CK(hipMemcpy(s->d_rows, param_rows, D * sizeof(int32_t), hipMemcpyHostToDevice));
+    CK(hipMemcpy(s->d_kind, prior_kind, D * sizeof(int32_t), hipMemcpyHostToDevice));
+    CK(hipMemcpy(s->d_base, base_params, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemcpy(s->d_pa, prior_a, D * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemcpy(s->d_pb, prior_b, D * sizeof(double), hipMemcpyHostToDevice));
+    CK(hipMemset(s->d_nacc, 0, W * sizeof(int64_t)));
+    CK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
+#undef CK
+    *out = s;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_sampler_destroy(rscm_sampler* s)
+{
+    if (!s) return RSCM_OK;
+    if (s->ev) (void)hipStreamSynchronize(s->ev->stream);
+    (void)hipFree(s->d_rows); (void)hipFree(s->d_kind); (void)hipFree(s->d_base); (void)hipFree(s->d_pa);
+    (void)hipFree(s->d_pb); (void)hipFree(s->d_pos); (void)hipFree(s->d_logp); (void)hipFree(s->d_prop);
+    (void)hipFree(s->d_z); (void)hipFree(s->d_lp); (void)hipFree(s->d_nacc); (void)hipFree(s->d_nprop);
+    delete s;
+    return RSCM_OK;
+}
+
+int rscm_sampler_set_positions(rscm_sampler* s, const double* positions)
+{
+    GUARD_BEGIN
+    if (!s || !positions) return fail(RSCM_ERR_INVALID, "sampler or positions is NULL");
+    rscm_ens* h = s->ev;
+    h->params_set = true;  // the proposals are written into the evaluator's parameter block
+    if (int rc = check_loglik_ready(h)) return rc;
+    const size_t W = (size_t)s->W, D = (size_t)s->D;
+    std::vector<double> soa(D * W);  // [W][D] row-major in, [D][W] on the device
+    for (size_t w = 0; w < W; ++w)
+        for (size_t d = 0; d < D; ++d) soa[d * W + w] = positions[w * D + d];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(s->d_pos, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(s->d_nacc, 0, W * sizeof(int64_t)));
+    HIPCHK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
+    s->iteration = 0;
+    for (int32_t half = 0; half < 2; ++half) HIPCHK(sampler_half_step(s, half, 1));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    s->positions_set = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations)
+{
+    GUARD_BEGIN
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
+    if (n_iterations < 0) return fail(RSCM_ERR_INVALID, "n_iterations must be >= 0");
+    rscm_ens* h = s->ev;
+    if (int rc = check_loglik_ready(h)) return rc;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int32_t it = 0; it < n_iterations; ++it) {
+        s->iteration += 1;
+        // first half against the second, then the second against the updated first (ensemble.rs:509-515)
+        HIPCHK(sampler_half_step(s, 0, 0));
+        HIPCHK(sampler_half_step(s, 1, 0));
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->timed = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_sampler_get(rscm_sampler* s, double* positions, double* log_prob, int64_t* n_accepted, int64_t* n_proposed)
+{
+    GUARD_BEGIN
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
+    const size_t W = (size_t)s->W, D = (size_t)s->D;
+    HIPCHK(hipStreamSynchronize(s->ev->stream));
+    if (positions) {
+        std::vector<double> soa(D * W);
+        HIPCHK(hipMemcpy(soa.data(), s->d_pos, soa.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t w = 0; w < W; ++w)
+            for (size_t d = 0; d < D; ++d) positions[w * D + d] = soa[d * W + w];
+    }
+    if (log_prob) HIPCHK(hipMemcpy(log_prob, s->d_logp, W * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_accepted) HIPCHK(hipMemcpy(n_accepted, s->d_nacc, W * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (n_proposed) HIPCHK(hipMemcpy(n_proposed, s->d_nprop, W * sizeof(int64_t), hipMemcpyDeviceToHost));
     return RSCM_OK;
     GUARD_END
 }
