@@ -479,6 +479,12 @@ class EnsembleSampler:
     def log_posterior_batch(self, positions: np.ndarray) -> np.ndarray:
         """log prior + device log-likelihood; anything failing is -inf (ensemble.rs:143-177)."""
         lp = self.params.log_prior_batch(positions)
+        outside = ~np.isfinite(lp)
+        if outside.any() and not outside.all():
+            # rejected whatever the model says: evaluate a valid walker in their place, so that
+            # garbage parameters do not push wavefronts onto the kernel's slow replay path
+            positions = np.array(positions, dtype=np.float64)
+            positions[outside] = positions[np.flatnonzero(~outside)[0]]
         ll = self.runner.log_likelihood_batch(positions, self.target, self.likelihood)
         with np.errstate(invalid="ignore"):
             out = lp + ll

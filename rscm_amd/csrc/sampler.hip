@@ -56,9 +56,16 @@ __global__ __launch_bounds__(kBlock) void propose_kernel(SamplerArgs a)
         const double cval = a.pos[(size_t)d * W + comp];
         const double y = a.identity ? x : cval + z * (x - cval);  // y = c + z (x - c)
         a.proposal[(size_t)d * H + k] = y;
-        a.eval_params[(size_t)a.param_rows[d] * H + k] = y;
         lp += ln_prior(a.prior_kind[d], a.prior_a[d], a.prior_b[d], y);
     }
+    // A proposal outside the prior's support is rejected whatever the model says
+    // (ensemble.rs:143-177), so the model is not asked: the lane evaluates the walker's current,
+    // valid position instead and the result is discarded.  Garbage parameters (negative heat
+    // capacities ...) would push whole wavefronts onto the kernel's slow replay path.
+    const bool in_support = lp > -__builtin_inf();
+    for (int32_t d = 0; d < a.n_dims; ++d)
+        a.eval_params[(size_t)a.param_rows[d] * H + k] =
+            (in_support || a.identity) ? a.proposal[(size_t)d * H + k] : a.pos[(size_t)d * W + active];
     a.z[k] = z;
     a.lp[k] = lp;
 }

@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--walkers", type=int, default=100_000)
     ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--device-sampler", action="store_true",
+                    help="keep proposals, priors and the accept step on the GPU (rscm_sampler_*); single rank")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,7 +56,12 @@ def main():
     params = cal.ParameterSet()
     for k, (lo, hi) in zip(names, [(0.8, 1.5), (0.0, 0.1), (1.0, 1.8), (0.5, 1.0), (5.0, 15.0), (50.0, 200.0)]):
         params.add(k, cal.Uniform(lo, hi))
-    sampler = cal.EnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    if args.device_sampler:
+        if world > 1:
+            raise SystemExit("--device-sampler runs one ensemble of walkers per process")
+        sampler = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    else:
+        sampler = cal.EnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
     rng = np.random.default_rng(20260327)  # same on every rank
     sampler.run(2, cal.WalkerInit.from_prior(), n_walkers=args.walkers, rng=rng)  # warm-up
     start = cal.WalkerInit.explicit(params.sample_random(args.walkers, rng))
@@ -62,7 +69,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    chain = sampler.run(args.iterations, start, n_walkers=args.walkers, rng=rng)
+    kw = dict(thin=args.iterations) if args.device_sampler else {}  # device: fetch the first sweep only
+    chain = sampler.run(args.iterations, start, n_walkers=args.walkers, rng=rng, **kw)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -74,7 +82,9 @@ def main():
             "value": evals / dt, "unit": "member-runs/s", "n_gpus": world, "walkers": args.walkers,
             "iterations": args.iterations, "s_per_iteration": dt / args.iterations,
             "member_years_per_s": evals * 750 / dt, "acceptance_rate": sampler.acceptance_rate(),
-            "mean_log_prob_last": float(chain.flat_log_probs(args.iterations - 1).mean())}))
+            "sampler": "device" if args.device_sampler else "host",
+            "device_ms_per_iteration": (sampler.device_ms / args.iterations) if args.device_sampler else None,
+            "mean_log_prob_last": float(chain.flat_log_probs(len(chain) - 1).mean())}))
     runner.close()
     if world > 1:
         dist.destroy_process_group()
