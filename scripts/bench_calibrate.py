@@ -57,8 +57,8 @@ def main():
     for k, (lo, hi) in zip(names, [(0.8, 1.5), (0.0, 0.1), (1.0, 1.8), (0.5, 1.0), (5.0, 15.0), (50.0, 200.0)]):
         params.add(k, cal.Uniform(lo, hi))
     if args.device_sampler:
-        if world > 1:
-            raise SystemExit("--device-sampler runs one ensemble of walkers per process")
+        # one independent ensemble of walkers per GPU (seed = rank): nothing is exchanged while
+        # sampling, the chains are pooled afterwards
         sampler = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
     else:
         sampler = cal.EnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
@@ -69,14 +69,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kw = dict(thin=args.iterations) if args.device_sampler else {}  # device: fetch the first sweep only
+    kw = dict(thin=args.iterations, seed=rank) if args.device_sampler else {}  # device: fetch the first sweep only
     chain = sampler.run(args.iterations, start, n_walkers=args.walkers, rng=rng, **kw)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
-        evals = args.walkers * (args.iterations + 1)
+        evals = args.walkers * (args.iterations + 1) * (world if args.device_sampler else 1)
         print(json.dumps({
             "metric": "calibration loop, model evaluations/s (751-point two-layer runs incl. likelihood)",
             "value": evals / dt, "unit": "member-runs/s", "n_gpus": world, "walkers": args.walkers,
