@@ -427,9 +427,12 @@ RSCM_API int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_
  * applies q = z^(d-1) p(y)/p(x).  Random numbers are counter-based (Philox, keyed by `seed`), so a
  * run is reproducible; the reference draws from thread_rng, so only distributions compare.
  *
- * `evaluator`: a two-layer ensemble of n_walkers/2 members with forcing and initial values set
- * (RSCM_FLAG_NO_SERIES is enough); it must outlive the sampler and is used exclusively by it while
- * iterating.  Sampled dimension d drives parameter row param_rows[d]; the other rows hold
+ * `evaluator`: an ensemble of n_walkers/2 members with parameters (rscm_ens_set_params, once: it
+ * configures the structural rows of kinds that have them), forcing and initial values set; it must
+ * outlive the sampler and is used exclusively by it while iterating.  A two-layer evaluator whose
+ * observations have ascending time indices inside each variable group is scored by the fused
+ * run+likelihood kernel (RSCM_FLAG_NO_SERIES is enough); any other kind, or observation order,
+ * is run through rscm_ens_run_async and scored from its stored series.  Sampled dimension d drives parameter row param_rows[d]; the other rows hold
  * base_params[P].  prior_kind: 0 = Uniform(low = a, high = b), 1 = Normal(mean = a, std = b)
  * (distribution.rs).  Observations as for rscm_ens_run_loglik. */
 typedef struct rscm_sampler rscm_sampler;
@@ -444,8 +447,9 @@ RSCM_API int rscm_sampler_destroy(rscm_sampler* s);
  * acceptance counters. */
 RSCM_API int rscm_sampler_set_positions(rscm_sampler* s, const double* positions);
 /* n_iterations full sweeps (first half against the second, then the second against the updated
- * first); synchronous.  rscm_ens_last_run_ms(evaluator) reports the device time of the call. */
+ * first); synchronous.  rscm_sampler_last_ms reports the device time of the last call. */
 RSCM_API int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations);
+RSCM_API int rscm_sampler_last_ms(const rscm_sampler* s, float* out);
 /* Any output may be NULL.  positions[n_walkers][n_dims], log_prob[n_walkers] (log prior + log
  * likelihood, -inf for failed members), per-walker acceptance counters. */
 RSCM_API int rscm_sampler_get(rscm_sampler* s, double* positions, double* log_prob, int64_t* n_accepted,

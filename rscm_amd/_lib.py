@@ -251,6 +251,7 @@ SIGNATURES = {
     "rscm_sampler_destroy": (C.c_int, [_h]),
     "rscm_sampler_set_positions": (C.c_int, [_h, _dp]),
     "rscm_sampler_iterate": (C.c_int, [_h, C.c_int32]),
+    "rscm_sampler_last_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "rscm_sampler_get": (C.c_int, [_h, _dp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_ens_summary": (C.c_int, [_h, C.c_int32, C.c_int32, _dp]),
     "rscm_ens_get_params": (C.c_int, [_h, _dp]),

@@ -540,8 +540,10 @@ class DeviceEnsembleSampler:
     """``EnsembleSampler`` with the whole stretch-move loop on the GPU (``rscm_sampler_*`` of the C
     ABI, csrc/sampler.hip): proposals, priors, the fused run+likelihood of every half-ensemble and
     the accept step never leave the device, the host only fetches the walker positions it wants
-    to keep.  Same interface as ``EnsembleSampler``; priors must be ``Uniform`` or ``Normal`` and
-    the model a stand-alone two-layer one.  Random numbers are counter-based from ``seed``."""
+    to keep.  Same interface as ``EnsembleSampler``; priors must be ``Uniform`` or ``Normal``.  A
+    two-layer model is scored by the fused run+likelihood kernel, any other kind (the coupled
+    chain, ClimateUDEB, ...) is run and scored from its stored series, still on the device.
+    Random numbers are counter-based from ``seed``."""
 
     def __init__(self, params: ParameterSet, runner: ModelRunner, likelihood: GaussianLikelihood,
                  target: Target, stretch_a: float = 2.0):
@@ -587,9 +589,8 @@ class DeviceEnsembleSampler:
             raise ValueError("Number of walkers must be even")
         rng = rng or np.random.default_rng(seed)
         pos = L.f64(init.initialize(n_walkers, self.params, rng))
-        model = self.runner._lik_model(n_walkers // 2)
-        if model.ensemble.kind != L.KIND_TWO_LAYER:
-            raise NotImplementedError("the device sampler drives the stand-alone two-layer kind")
+        two_layer = self.runner._model(1).ensemble.kind == L.KIND_TWO_LAYER
+        model = self.runner._lik_model(n_walkers // 2) if two_layer else self.runner._model(n_walkers // 2)
         ens, lib = model.ensemble, model.ensemble._lib
         ens.rewind()
         ov, ot, val, sig = self._observations(model)
@@ -614,7 +615,9 @@ class DeviceEnsembleSampler:
                     nxt += 1
                 step = min(nxt, n_iterations) - it
                 L.check(lib.rscm_sampler_iterate(h, step))
-                self.device_ms += ens.last_run_ms()
+                ms = C.c_float()
+                L.check(lib.rscm_sampler_last_ms(h, C.byref(ms)))
+                self.device_ms += ms.value
                 it += step
                 if kept(it):
                     L.check(lib.rscm_sampler_get(h, L.dptr(pos), L.dptr(logp), None, None))

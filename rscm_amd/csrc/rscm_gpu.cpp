@@ -1205,6 +1205,12 @@ struct rscm_sampler {
     double* d_lp = nullptr;
     int64_t* d_nacc = nullptr;
     int64_t* d_nprop = nullptr;
+    // fused: the two-layer run+likelihood kernel scores a half; otherwise the half is run through
+    // rscm_ens_run_async (any kind, stored series) and scored by the likelihood kernel
+    bool fused = true;
+    void* d_sobs = nullptr;          // stored path: observation rows, values, sigmas, groups
+    rscm::LoglikArgs lik{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace {
@@ -1237,14 +1243,21 @@ rscm::SamplerArgs sampler_args(const rscm_sampler* s, int32_t half, int32_t iden
     return a;
 }
 
-// propose (or re-score) one half, evaluate it, accept: three launches on the evaluator's stream
-hipError_t sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
+// propose (or re-score) one half, evaluate it, accept: all on the evaluator's stream
+int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
 {
     const rscm::SamplerArgs a = sampler_args(s, half, identity);
-    hipError_t e = rscm::launch_sampler_propose(a, s->ev->stream);
-    if (e == hipSuccess) e = launch_loglik(s->ev);
-    if (e == hipSuccess) e = rscm::launch_sampler_accept(a, s->ev->stream);
-    return e;
+    HIPCHK(rscm::launch_sampler_propose(a, s->ev->stream));
+    if (s->fused) {
+        HIPCHK(launch_loglik(s->ev));
+    } else {
+        s->ev->time_index = 0;  // every evaluation is a fresh Model::run of the half
+        if (int rc = rscm_ens_run_async(s->ev, 0, s->ev->T - 1)) return rc;
+        s->ev->time_index = 0;
+        HIPCHK(rscm::launch_loglik(s->lik, s->ev->stream));
+    }
+    HIPCHK(rscm::launch_sampler_accept(a, s->ev->stream));
+    return RSCM_OK;
 }
 
 }  // namespace
@@ -1276,9 +1289,33 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
         if (prior_kind[d] == 0 && !(prior_b[d] > prior_a[d])) return fail(RSCM_ERR_INVALID, "dimension %d: Uniform needs high > low", d);
         if (prior_kind[d] == 1 && !(prior_b[d] > 0.0)) return fail(RSCM_ERR_INVALID, "dimension %d: Normal needs std > 0", d);
     }
-    if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    // the fused kernel takes two-layer observations with ascending time indices inside a group
+    bool fused = h->kind == RSCM_KIND_TWO_LAYER;
+    for (int32_t j = 0; j < n_obs && fused; ++j) {
+        if (!obs_var || !obs_tidx) return fail(RSCM_ERR_INVALID, "bad observation arrays");
+        if (j > 0 && obs_var[j] == obs_var[j - 1] && obs_tidx[j] < obs_tidx[j - 1]) fused = false;
+    }
+    if (fused) {
+        if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    } else {
+        if (h->rows != h->T)
+            return fail(RSCM_ERR_INVALID, "this evaluator stores no series: only the fused two-layer likelihood "
+                                          "(ascending observation times) is available for it");
+        if (n_obs < 0 || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
+            return fail(RSCM_ERR_INVALID, "bad observation arrays");
+        for (int32_t j = 0; j < n_obs; ++j) {
+            if (obs_var[j] < 1 || obs_var[j] >= h->V) return fail(RSCM_ERR_INVALID, "observation %d: variable %d has no stored series", j, obs_var[j]);
+            if (obs_tidx[j] < 0 || obs_tidx[j] >= h->T) return fail(RSCM_ERR_INVALID, "observation %d: time index %d out of range", j, obs_tidx[j]);
+            if (j > 0 && obs_var[j] != obs_var[j - 1])
+                for (int32_t k = 0; k < j; ++k)
+                    if (obs_var[k] == obs_var[j]) return fail(RSCM_ERR_INVALID, "observations must be grouped by variable");
+        }
+        if (int rc = set_device(h)) return rc;
+        if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+    }
     rscm_sampler* s = new rscm_sampler();
     s->ev = h;
+    s->fused = fused;
     s->W = n_walkers;
     s->D = n_dims;
     s->stretch_a = stretch_a;
@@ -1314,6 +1351,32 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
     CK(hipMemcpy(s->d_pb, prior_b, D * sizeof(double), hipMemcpyHostToDevice));
     CK(hipMemset(s->d_nacc, 0, W * sizeof(int64_t)));
     CK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
+    CK(hipEventCreate(&s->ev0));
+    CK(hipEventCreate(&s->ev1));
+    if (!fused) {  // the observation rows of the stored series, once
+        const size_t sz_ptr = (size_t)n_obs * sizeof(double*), sz_i = (size_t)n_obs * sizeof(int32_t),
+                     sz_d = (size_t)n_obs * sizeof(double);
+        const size_t off_val = sz_ptr, off_sig = off_val + sz_d, off_grp = off_sig + sz_d;
+        std::vector<unsigned char> blob(off_grp + sz_i + 8);
+        std::vector<const double*> ptrs(n_obs);
+        for (int32_t j = 0; j < n_obs; ++j) ptrs[j] = h->series(obs_var[j]) + (size_t)obs_tidx[j] * h->N;
+        if (n_obs > 0) {
+            memcpy(blob.data(), ptrs.data(), sz_ptr);
+            memcpy(blob.data() + off_val, obs_value, sz_d);
+            memcpy(blob.data() + off_sig, obs_sigma, sz_d);
+            memcpy(blob.data() + off_grp, obs_var, sz_i);
+        }
+        CK(hipMalloc(&s->d_sobs, blob.size()));
+        CK(hipMemcpy(s->d_sobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        s->lik.n_members = h->N;
+        s->lik.n_obs = n_obs;
+        s->lik.normalize = normalize ? 1 : 0;
+        s->lik.obs_series = (const double* const*)s->d_sobs;
+        s->lik.obs_value = (const double*)((char*)s->d_sobs + off_val);
+        s->lik.obs_sigma = (const double*)((char*)s->d_sobs + off_sig);
+        s->lik.obs_group = (const int32_t*)((char*)s->d_sobs + off_grp);
+        s->lik.out = h->d_loglik;
+    }
 #undef CK
     *out = s;
     return RSCM_OK;
@@ -1327,6 +1390,9 @@ int rscm_sampler_destroy(rscm_sampler* s)
     (void)hipFree(s->d_rows); (void)hipFree(s->d_kind); (void)hipFree(s->d_base); (void)hipFree(s->d_pa);
     (void)hipFree(s->d_pb); (void)hipFree(s->d_pos); (void)hipFree(s->d_logp); (void)hipFree(s->d_prop);
     (void)hipFree(s->d_z); (void)hipFree(s->d_lp); (void)hipFree(s->d_nacc); (void)hipFree(s->d_nprop);
+    (void)hipFree(s->d_sobs);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
     return RSCM_OK;
 }
@@ -1336,7 +1402,9 @@ int rscm_sampler_set_positions(rscm_sampler* s, const double* positions)
     GUARD_BEGIN
     if (!s || !positions) return fail(RSCM_ERR_INVALID, "sampler or positions is NULL");
     rscm_ens* h = s->ev;
-    h->params_set = true;  // the proposals are written into the evaluator's parameter block
+    if (!h->params_set)  // kinds with structural rows (ClimateUDEB) are configured by rscm_ens_set_params
+        return fail(RSCM_ERR_STATE, "set the evaluator's parameters once (rscm_ens_set_params) before sampling");
+    h->time_index = 0;
     if (int rc = check_loglik_ready(h)) return rc;
     const size_t W = (size_t)s->W, D = (size_t)s->D;
     std::vector<double> soa(D * W);  // [W][D] row-major in, [D][W] on the device
@@ -1347,7 +1415,8 @@ int rscm_sampler_set_positions(rscm_sampler* s, const double* positions)
     HIPCHK(hipMemset(s->d_nacc, 0, W * sizeof(int64_t)));
     HIPCHK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
     s->iteration = 0;
-    for (int32_t half = 0; half < 2; ++half) HIPCHK(sampler_half_step(s, half, 1));
+    for (int32_t half = 0; half < 2; ++half)
+        if (int rc = sampler_half_step(s, half, 1)) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     s->positions_set = true;
     return RSCM_OK;
@@ -1361,17 +1430,26 @@ int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations)
     if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
     if (n_iterations < 0) return fail(RSCM_ERR_INVALID, "n_iterations must be >= 0");
     rscm_ens* h = s->ev;
+    h->time_index = 0;
     if (int rc = check_loglik_ready(h)) return rc;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(hipEventRecord(s->ev0, h->stream));
     for (int32_t it = 0; it < n_iterations; ++it) {
         s->iteration += 1;
         // first half against the second, then the second against the updated first (ensemble.rs:509-515)
-        HIPCHK(sampler_half_step(s, 0, 0));
-        HIPCHK(sampler_half_step(s, 1, 0));
+        if (int rc = sampler_half_step(s, 0, 0)) return rc;
+        if (int rc = sampler_half_step(s, 1, 0)) return rc;
     }
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventRecord(s->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->timed = true;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_sampler_last_ms(const rscm_sampler* s, float* out)
+{
+    GUARD_BEGIN
+    if (!s || !out) return fail(RSCM_ERR_INVALID, "sampler or out is NULL");
+    HIPCHK(hipEventElapsedTime(out, s->ev0, s->ev1));
     return RSCM_OK;
     GUARD_END
 }

@@ -136,3 +136,38 @@ def test_device_sampler_error_conventions(setup):
     chain = dev.run(40, cal.WalkerInit.from_prior(), n_walkers=256, seed=2)
     assert abs(chain.flat_samples(discard=39)[:, 0].mean() - 1.1) < 0.05
     runner.close()
+
+
+def test_device_sampler_on_climate_udeb(setup):
+    """The stored-series path: calibrating ECS and the vertical diffusivity of ClimateUDEB (the
+    MAGICC climate core) against its own sea-surface temperatures, proposals and scoring on the
+    device.  Initial scores equal the host's; the posterior concentrates on the truth."""
+    cal, _ = setup
+    from rscm_amd import core
+    from rscm_amd.magicc import ClimateUDEBBuilder
+    years = np.arange(1850.0, 1911.0)
+    axis = core.TimeAxis.from_values(years)
+    erf = 3.71 * np.minimum((years - 1850.0) / 40.0, 1.0)
+    b = (core.ModelBuilder().with_time_axis(axis)
+         .with_rust_component(ClimateUDEBBuilder.from_parameters({"ecs": 3.2, "kappa": 0.9}).build())
+         .with_exogenous_variable("Effective Radiative Forcing", core.Timeseries(erf, axis, "W/m^2", core.InterpolationStrategy.Previous))
+         .with_initial_values({"Surface Temperature": 0.0}))
+    runner = cal.ModelRunner(b, ["ecs", "kappa"], ["Sea Surface Temperature"])
+    truth = runner.run([3.2, 0.9])["Sea Surface Temperature"]
+    target = cal.Target()
+    for yr in range(1860, 1911, 5):
+        target.add_observation("Sea Surface Temperature", float(yr), truth[float(yr)], 0.02)
+    params = cal.ParameterSet().add("ecs", cal.Uniform(1.5, 6.0)).add("kappa", cal.Uniform(0.3, 2.0))
+    lik = cal.GaussianLikelihood()
+    dev = cal.DeviceEnsembleSampler(params, runner, lik, target)
+    pos = params.sample_random(128, np.random.default_rng(9))
+    chain = dev.run(1, cal.WalkerInit.explicit(pos), n_walkers=128, seed=1)
+    got_pos, got_lp = chain.flat_samples(), chain.flat_log_probs()
+    host = cal.EnsembleSampler(params, runner, lik, target)
+    assert np.allclose(got_lp, host.log_posterior_batch(got_pos), rtol=1e-9, atol=1e-9)
+    chain = dev.run(150, cal.WalkerInit.from_prior(), n_walkers=128, seed=2, rng=np.random.default_rng(3))
+    x = chain.flat_samples(discard=100)
+    assert abs(x[:, 0].mean() - 3.2) < 3 * x[:, 0].std() + 0.05 and x[:, 0].std() < 0.5
+    assert abs(x[:, 1].mean() - 0.9) < 3 * x[:, 1].std() + 0.05
+    assert 0.05 < dev.acceptance_rate() < 0.9 and dev.device_ms > 0
+    runner.close()
