@@ -701,3 +701,48 @@ def test_handle_churn_does_not_leak(ra):
             cycle(kind)
     free1, _ = _lib.mem_info()
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_two_handles_from_two_threads(ra, orc):
+    """One handle per thread (include/rscm_gpu.h: a handle is not thread-safe, the library is): two
+    threads drive their own ensembles on their own streams at the same time and get the results of
+    a serial run, bit for bit; error text stays with the thread that caused it."""
+    import threading
+    t = axis_values(1750, 1900)
+    b = np.append(t, t[-1] + 1.0)
+    F = f_syn(t)
+    P = [two_layer_params(20000, seed=s) for s in (1, 2)]
+
+    def serial(p):
+        with ra.Ensemble(ra.KIND_TWO_LAYER, p.shape[1], b) as e:
+            e.set_params(p)
+            e.set_forcing(F)
+            e.set_initial(1, 0.0)
+            e.set_initial(2, 0.0)
+            e.run()
+            return e.get_series(1)
+
+    want = [serial(p) for p in P]
+    got, errors = [None, None], [None, None]
+
+    def worker(k):
+        try:
+            for _ in range(5):
+                got[k] = serial(P[k])
+            if k == 1:  # provoke an error on this thread only
+                with ra.Ensemble(ra.KIND_TWO_LAYER, 4, b) as e:
+                    try:
+                        e.run()
+                    except ra.RscmGpuError as exc:
+                        errors[k] = str(exc)
+        except Exception as exc:  # pragma: no cover
+            errors[k] = f"unexpected: {exc!r}"
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert errors[0] is None and errors[1] is not None and "parameters not set" in errors[1]
+    for k in (0, 1):
+        assert_bit_equal(got[k], want[k])
