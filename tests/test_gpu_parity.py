@@ -746,3 +746,41 @@ def test_two_handles_from_two_threads(ra, orc):
     assert errors[0] is None and errors[1] is not None and "parameters not set" in errors[1]
     for k in (0, 1):
         assert_bit_equal(got[k], want[k])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_two_layer_exact_fuzz(ra, orc, seed):
+    """Seeded random configurations -- axis length and irregular step lengths, RK4 step size,
+    number of scenarios (LDS and L2 paths), scenario map or none, variable source, member-wise
+    initial values, launch chunking -- each bit-compared with the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(2, 400))
+    n = int(rng.choice([1, 2, 63, 64, 65, 300, 1025]))
+    # step lengths that RK4 steps of h land on (get_last_step asserts |t_last - t1| < 5e-3):
+    # binary fractions keep (t1 - t0) / h an exact integer whatever the offset
+    h = float(rng.choice([0.0625, 0.125, 0.25, 0.5]))
+    lengths = rng.integers(1, 9, T) * h * int(rng.choice([1, 2, 4]))
+    b = np.concatenate([[1750.0], 1750.0 + np.cumsum(lengths)])
+    S = int(rng.choice([1, 1, 2, 5, 40]))
+    if S == 40 and T > 300:  # 40 scenarios x 300+ years exceed the LDS budget: the L2 path
+        pass
+    F = rng.normal(1.5, 1.5, (S, T))
+    scen = rng.integers(0, S, n).astype(np.int32) if (S > 1 or rng.random() < 0.3) else None
+    source = int(rng.integers(0, 2))
+    P = two_layer_params(n, seed=seed)
+    ts0 = rng.normal(0.0, 0.3, n) if rng.random() < 0.5 else 0.0
+    td0 = rng.normal(0.0, 0.1, n) if rng.random() < 0.5 else 0.0
+    want_ts, want_td = orc.two_layer_run(b, P, F, ts0, td0, scen=scen, source=source, h=h, threads=8)
+    cuts = sorted(set(int(x) for x in rng.integers(0, T, int(rng.integers(0, 4)))))
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        e.set_step_size(0, h)
+        e.set_params(P)
+        e.set_forcing(F, scen, source)
+        e.set_initial(1, ts0)
+        e.set_initial(2, td0)
+        for c in cuts:
+            if c > e.time_index:
+                e.run(c)
+        e.run()
+        assert_bit_equal(e.get_series(1), want_ts, f"seed {seed} Ts (T={T}, n={n}, S={S}, h={h}, source={source}, cuts={cuts})")
+        assert_bit_equal(e.get_series(2), want_td, f"seed {seed} Td")
