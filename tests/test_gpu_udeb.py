@@ -217,3 +217,31 @@ def test_udeb_model_runner_and_device_likelihood(ra, orc):
     host = np.array([lik.ln_likelihood(o, target) for o in outs])
     assert np.allclose(dev, host, rtol=1e-12, atol=1e-12) and dev[4] == 0.0 and np.argmax(dev) == 4
     runner.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_udeb_fuzz(ra, orc, seed):
+    """Seeded random ClimateUDEB configurations: structural switches (land heat capacity,
+    efficacy mode, sub-steps per year, depth-dependent area, feedback window length), an irregular
+    time axis, random launch chunking -- the running feedback window, the structured LAMCALC and the
+    regrouped column algebra against the oracle's plain forms."""
+    rng = np.random.default_rng(500 + seed)
+    T = int(rng.integers(3, 90))
+    n = int(rng.choice([1, 63, 130]))
+    b = np.concatenate([[1850.0], 1850.0 + np.cumsum(rng.choice([0.5, 1.0, 1.0, 2.0], T))])
+    fixed = dict(land_heat_capacity_enabled=float(rng.integers(0, 2)), efficacy_apply=float(rng.integers(0, 3)),
+                 steps_per_year=float(rng.choice([1, 4, 12])), depth_dependent_area=float(rng.choice([0.0, 0.5, 1.0])),
+                 feedback_cumt_period=float(rng.choice([3.0, 17.5, 300.0])), prescribed_efficacy_co2=float(rng.choice([1.0, 1.1])))
+    P = _ensemble_params(orc, n, seed=seed, **fixed)
+    if rng.random() < 0.3:
+        P[orc.UDEB_PARAM_NAMES.index("feedback_cumt_sensitivity")] = 0.0
+    if rng.random() < 0.3:
+        P[orc.UDEB_PARAM_NAMES.index("kappa_dkdt")] = 0.0
+    S = int(rng.choice([1, 3]))
+    F = np.cumsum(rng.normal(0.05, 0.3, (S, T)), axis=1)
+    scen = rng.integers(0, S, n).astype(np.int32) if S > 1 else None
+    want, wst = orc.udeb_run(b, P, F, scen=scen, threads=8)
+    cuts = tuple(sorted(set(int(x) for x in rng.integers(1, T, int(rng.integers(0, 3))))))
+    got, st = _gpu(ra, b, P, F, scen=scen, chunks=cuts)
+    assert (st == wst).all()
+    _assert_close(got, want, f"fuzz seed {seed} ({fixed}, T={T}, n={n}, cuts={cuts})")
