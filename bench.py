@@ -109,6 +109,41 @@ def make_ghg_ensemble(members, device, method, stream=None):
     return ens
 
 
+def calibration_extra(device, walkers=100_000, iterations=20):
+    """two-layer, 6 parameters, Surface Temperature observations 1850..2020 step 10
+    (sigma 0.1 K) from the default-parameter run; one iteration = two half-ensemble evaluations."""
+    from rscm_amd import calibrate as cal
+    from rscm_amd import core
+    from rscm_amd.two_layer import TwoLayerBuilder
+    t = np.arange(T0, T1 + 1, dtype=np.float64)
+    axis = core.TimeAxis.from_values(t)
+    fixed = dict(lambda0=1.1, a=0.05, efficacy=1.3, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    b = (core.ModelBuilder().with_device(device).with_time_axis(axis)
+         .with_rust_component(TwoLayerBuilder.from_parameters(fixed).build())
+         .with_exogenous_variable("Effective Radiative Forcing",
+                                  core.Timeseries(f_syn(t), axis, "W/m^2", core.InterpolationStrategy.Linear))
+         .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    names = list(fixed)
+    runner = cal.ModelRunner(b, names, ["Surface Temperature"])
+    truth = runner.run([fixed[k] for k in names])["Surface Temperature"]
+    target = cal.Target()
+    for yr in range(1850, 2021, 10):
+        target.add_observation("Surface Temperature", float(yr), truth[float(yr)], 0.1)
+    params = cal.ParameterSet()
+    for k, lo, hi in zip(names, TL_LOW, TL_HIGH):
+        params.add(k, cal.Uniform(float(lo), float(hi)))
+    sampler = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    rng = np.random.default_rng(SEED)
+    sampler.run(2, cal.WalkerInit.from_prior(), n_walkers=walkers, rng=rng, seed=1)  # warm-up
+    t0 = time.perf_counter()
+    sampler.run(iterations, cal.WalkerInit.from_prior(), thin=iterations, n_walkers=walkers, rng=rng, seed=2)
+    dt = time.perf_counter() - t0
+    runner.close()
+    return {"model_evaluations_per_s": walkers * iterations / (sampler.device_ms * 1e-3),
+            "device_ms_per_iteration": sampler.device_ms / iterations, "wall_s_per_iteration": dt / iterations,
+            "walkers": walkers, "acceptance_rate": sampler.acceptance_rate()}
+
+
 def one_pass(ens):
     ens.rewind()
     ens.run(sync=False)
@@ -265,6 +300,10 @@ def main():
             e4.close()
             extra[label] = {"member_years_per_s": 1_000_000 * years * 5 / w4, "kernel_ms": k4,
                             "hbm_frac": 24.0 * 1_000_000 * years / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        # BASELINE.json configs[4]: the calibration loop, 1e5 walkers per iteration, stretch move
+        # and likelihood on the device (rscm_sampler_*)
+        extra["calibrate_device_1e5"] = calibration_extra(local_rank)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
