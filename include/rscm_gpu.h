@@ -433,12 +433,15 @@ RSCM_API int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_
  * observations have ascending time indices inside each variable group is scored by the fused
  * run+likelihood kernel (RSCM_FLAG_NO_SERIES is enough); any other kind, or observation order,
  * is run through rscm_ens_run_async and scored from its stored series.  Sampled dimension d drives parameter row param_rows[d]; the other rows hold
- * base_params[P].  prior_kind: 0 = Uniform(low = a, high = b), 1 = Normal(mean = a, std = b)
+ * base_params[P].  prior_kind: 0 = Uniform(low = a, high = b), 1 = Normal(mean = a, std = b),
+ * 2 = LogNormal(mu = a, sigma = b); prior_low / prior_high truncate dimension d to [low, high]
+ * like the reference's Bound wrapper (both NULL, or -inf / +inf entries: no truncation)
  * (distribution.rs).  Observations as for rscm_ens_run_loglik. */
 typedef struct rscm_sampler rscm_sampler;
 RSCM_API int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims,
                                  const int32_t* param_rows, const double* base_params,
                                  const int32_t* prior_kind, const double* prior_a, const double* prior_b,
+                                 const double* prior_low, const double* prior_high,
                                  int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
                                  const double* obs_value, const double* obs_sigma, int32_t normalize,
                                  double stretch_a, uint64_t seed, rscm_sampler** out);

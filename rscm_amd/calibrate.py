@@ -15,6 +15,7 @@ draws from ``thread_rng`` (not reproducible); here every random draw takes a ``n
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -84,6 +85,90 @@ class Normal:
     def ln_pdf_n(self, x):
         z = (np.asarray(x) - self.mean) / self.std_dev
         return -0.5 * z * z - math.log(self.std_dev) - 0.5 * math.log(2.0 * math.pi)
+
+
+class LogNormal:
+    """distribution.rs:281-415: ``ln(X) ~ Normal(mu, sigma)``."""
+
+    def __init__(self, mu: float, sigma: float):
+        if not sigma > 0:
+            raise ValueError(f"LogNormal: sigma ({sigma}) must be positive")
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def sample(self, rng):
+        return rng.lognormal(self.mu, self.sigma)
+
+    def ln_pdf(self, x):
+        if x <= 0.0:
+            return -math.inf
+        ln_x = math.log(x)
+        z = (ln_x - self.mu) / self.sigma
+        return -0.5 * z * z - ln_x - math.log(self.sigma) - 0.5 * math.log(2.0 * math.pi)
+
+    def bounds(self):
+        return 0.0, math.inf
+
+    def quantile(self, u):
+        from scipy.special import ndtri
+        return np.exp(self.mu + self.sigma * ndtri(u))
+
+    def sample_n(self, rng, n):
+        return rng.lognormal(self.mu, self.sigma, n)
+
+    def ln_pdf_n(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            ln_x = np.log(x)
+            z = (ln_x - self.mu) / self.sigma
+            out = -0.5 * z * z - ln_x - math.log(self.sigma) - 0.5 * math.log(2.0 * math.pi)
+        return np.where(x <= 0.0, -np.inf, out)
+
+
+class Bound:
+    """distribution.rs:417-530: another distribution truncated to ``[low, high]`` (rejection
+    sampling; the log-density is the inner one, unnormalised, inside the bounds)."""
+
+    def __init__(self, distribution, low: float, high: float):
+        if low >= high:
+            raise ValueError(f"Bound: low ({low}) must be less than high ({high})")
+        self.distribution, self._low, self._high = distribution, float(low), float(high)
+
+    low = property(lambda self: self._low)
+    high = property(lambda self: self._high)
+
+    def inner(self):
+        return self.distribution
+
+    def sample(self, rng):
+        while True:
+            x = self.distribution.sample(rng)
+            if self._low <= x <= self._high:
+                return x
+
+    def ln_pdf(self, x):
+        if x < self._low or x > self._high:
+            return -math.inf
+        return self.distribution.ln_pdf(x)
+
+    def bounds(self):
+        return self._low, self._high
+
+    def quantile(self, u):
+        raise NotImplementedError("Bound has no closed-form quantile (the reference samples it)")
+
+    def sample_n(self, rng, n):
+        out = np.empty(n)
+        filled = 0
+        while filled < n:
+            x = self.distribution.sample_n(rng, max(16, 2 * (n - filled)))
+            x = x[(x >= self._low) & (x <= self._high)][: n - filled]
+            out[filled:filled + len(x)] = x
+            filled += len(x)
+        return out
+
+    def ln_pdf_n(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.where((x < self._low) | (x > self._high), -np.inf, self.distribution.ln_pdf_n(x))
 
 
 class ParameterSet:
@@ -458,9 +543,122 @@ class Chain:
             r = np.sqrt(var_plus / w)
         return {n: float(r[j]) for j, n in enumerate(self.param_names)}
 
+    def _autocorr_sums(self, discard: int) -> Dict[str, float]:
+        """Per parameter: the sum of the walker-averaged autocorrelations at lags 1, 2, ... up to the
+        first non-positive one (diagnostics.rs:164-252, compute_autocorrelation :302-335)."""
+        if not self._samples or discard >= len(self) or len(self) - discard < 10:
+            return {}
+        x = np.stack(self._samples[discard:])  # [keep][walkers][params]
+        n = x.shape[0]
+        max_lag = min(n // 2, 100)
+        out = {}
+        for j, name in enumerate(self.param_names):
+            c = x[:, :, j]
+            d = c - c.mean(axis=0)
+            var = (d * d).sum(axis=0) / n
+            avg = np.zeros(max_lag)
+            for lag in range(1, max_lag + 1):
+                cov = (d[: n - lag] * d[lag:]).sum(axis=0) / (n - lag)
+                with np.errstate(all="ignore"):
+                    ac = np.where(var == 0.0, 0.0, cov / var)
+                avg[lag - 1] = ac.mean()  # each walker weighs 1 / n_walkers
+            total = 0.0
+            for ac in avg:
+                if ac <= 0.0:
+                    break
+                total += ac
+            out[name] = total
+        return out
+
+    def ess(self, discard: int = 0) -> Dict[str, float]:
+        """Effective sample size, ``n_total / (1 + 2 sum rho_k)`` (diagnostics.rs:164-221)."""
+        sums = self._autocorr_sums(discard)
+        if not sums:
+            return {}
+        n_total = (len(self) - discard) * self._samples[0].shape[0]
+        return {k: n_total / (1.0 + 2.0 * s) for k, s in sums.items()}
+
+    def autocorr_time(self, discard: int = 0) -> Dict[str, float]:
+        """Integrated autocorrelation time ``1 + 2 sum rho_k`` (diagnostics.rs:254-300)."""
+        return {k: 1.0 + 2.0 * s for k, s in self._autocorr_sums(discard).items()}
+
+    def save(self, path) -> None:
+        """chain.rs:190-203.  The reference writes postcard; this writes a NumPy archive."""
+        with open(path, "wb") as fh:
+            np.savez(fh, param_names=np.array(self.param_names), thin=self.thin, total_iterations=self.total_iterations,
+                     samples=np.stack(self._samples) if self._samples else np.zeros((0, 0, len(self.param_names))),
+                     log_probs=np.stack(self._log_probs) if self._log_probs else np.zeros((0, 0)))
+
+    @staticmethod
+    def load(path) -> "Chain":
+        if os.path.getsize(path) > 1 << 30:  # chain.rs:218-231 MAX_CHAIN_FILE_SIZE
+            raise ValueError(f"Chain file too large: {os.path.getsize(path)} bytes (max {1 << 30} bytes)")
+        with np.load(path, allow_pickle=False) as z:
+            c = Chain([str(s) for s in z["param_names"]], int(z["thin"]))
+            c.total_iterations = int(z["total_iterations"])
+            c._samples = [a.copy() for a in z["samples"]]
+            c._log_probs = [a.copy() for a in z["log_probs"]]
+        return c
+
+    def merge(self, other: "Chain") -> None:
+        """chain.rs:256-277."""
+        if self.param_names != other.param_names:
+            raise ValueError(f"Cannot merge chains with different parameter names: {self.param_names} vs {other.param_names}")
+        if self.thin != other.thin:
+            raise ValueError(f"Cannot merge chains with different thinning intervals: {self.thin} vs {other.thin}")
+        self._samples += [s.copy() for s in other._samples]
+        self._log_probs += [s.copy() for s in other._log_probs]
+        self.total_iterations += other.total_iterations
+
     def is_converged(self, discard: int = 0, threshold: float = 1.1) -> bool:
         r = self.r_hat(discard)
         return bool(r) and all(math.isfinite(v) and v < threshold for v in r.values())
+
+
+class SamplerState:
+    """sampler/state.rs: walker positions, their log-probabilities and acceptance counters."""
+
+    def __init__(self, positions, param_names: Sequence[str]):
+        positions = np.array(positions, dtype=np.float64)
+        if positions.ndim != 2 or len(param_names) != positions.shape[1]:
+            raise ValueError(f"Number of parameter names ({len(param_names)}) does not match positions dimension "
+                             f"({positions.shape[1] if positions.ndim == 2 else positions.shape})")
+        if positions.shape[0] < 2:
+            raise ValueError("Must have at least 2 walkers for ensemble sampling")
+        self.positions = positions
+        self.log_probs = np.full(positions.shape[0], -np.inf)
+        self.n_accepted = np.zeros(positions.shape[0], dtype=np.int64)
+        self.n_proposed = np.zeros(positions.shape[0], dtype=np.int64)
+        self.param_names = list(param_names)
+
+    def n_walkers(self) -> int:
+        return self.positions.shape[0]
+
+    def n_params(self) -> int:
+        return self.positions.shape[1]
+
+    def acceptance_fraction(self) -> np.ndarray:
+        with np.errstate(all="ignore"):
+            return np.where(self.n_proposed > 0, self.n_accepted / np.maximum(self.n_proposed, 1), 0.0)
+
+    def mean_acceptance_rate(self) -> float:
+        return float(self.n_accepted.sum() / self.n_proposed.sum()) if self.n_proposed.sum() > 0 else 0.0
+
+    def save_checkpoint(self, path) -> None:
+        with open(path, "wb") as fh:
+            np.savez(fh, positions=self.positions, log_probs=self.log_probs, n_accepted=self.n_accepted,
+                     n_proposed=self.n_proposed, param_names=np.array(self.param_names))
+
+    @staticmethod
+    def load_checkpoint(path) -> "SamplerState":
+        if os.path.getsize(path) > 1 << 30:
+            raise ValueError(f"Checkpoint file too large: {os.path.getsize(path)} bytes (max {1 << 30} bytes)")
+        with np.load(path, allow_pickle=False) as z:
+            s = SamplerState(z["positions"], [str(n) for n in z["param_names"]])
+            s.log_probs = z["log_probs"].copy()
+            s.n_accepted = z["n_accepted"].copy()
+            s.n_proposed = z["n_proposed"].copy()
+        return s
 
 
 class EnsembleSampler:
@@ -535,6 +733,49 @@ class EnsembleSampler:
     def acceptance_rate(self) -> float:
         return float(self.n_accepted.sum() / max(1, self.n_proposed.sum()))
 
+    # -- checkpointed runs (ensemble.rs:272-410, 548-660) -----------------------------------------
+    def run_with_checkpoint(self, n_iterations: int, init: WalkerInit, thin: int, checkpoint_every: int,
+                            checkpoint_path, progress=None, n_walkers: Optional[int] = None,
+                            rng: Optional[np.random.Generator] = None) -> Chain:
+        n_walkers = n_walkers or self.default_n_walkers
+        if n_walkers < 2:
+            raise ValueError("Must have at least 2 walkers")
+        if n_walkers % 2:
+            raise ValueError("Number of walkers must be even")
+        rng = rng or np.random.default_rng()
+        state = SamplerState(init.initialize(n_walkers, self.params, rng), self.params.param_names)
+        return self._run_from_state(state, Chain(self.params.param_names, thin), n_iterations, checkpoint_every,
+                                    checkpoint_path, progress, rng)
+
+    def resume_from_checkpoint(self, n_iterations: int, thin: int, checkpoint_every: int, checkpoint_path,
+                               progress=None, rng: Optional[np.random.Generator] = None) -> Chain:
+        """``n_iterations`` is the total wanted: what the saved chain already holds is not repeated."""
+        state = SamplerState.load_checkpoint(f"{checkpoint_path}.state")
+        chain = Chain.load(f"{checkpoint_path}.chain")
+        remaining = max(0, n_iterations - chain.total_iterations)
+        if remaining == 0:
+            return chain
+        return self._run_from_state(state, chain, remaining, checkpoint_every, checkpoint_path, progress,
+                                    rng or np.random.default_rng())
+
+    def _run_from_state(self, state: SamplerState, chain: Chain, n_iterations: int, checkpoint_every: int,
+                        checkpoint_path, progress, rng) -> Chain:
+        if not np.isfinite(state.log_probs).any():  # not computed yet
+            state.log_probs = self.log_posterior_batch(state.positions)
+        self.n_accepted, self.n_proposed = state.n_accepted, state.n_proposed
+        half = state.n_walkers() // 2
+        first, second = np.arange(half), np.arange(half, state.n_walkers())
+        for it in range(n_iterations):
+            self._update_group(state.positions, state.log_probs, first, second, rng)
+            self._update_group(state.positions, state.log_probs, second, first, rng)
+            chain.push(state.positions, state.log_probs)
+            if checkpoint_every > 0 and (it + 1) % checkpoint_every == 0:
+                state.save_checkpoint(f"{checkpoint_path}.state")
+                chain.save(f"{checkpoint_path}.chain")
+            if progress:
+                progress(it, state.mean_acceptance_rate(), float(state.log_probs.mean()))
+        return chain
+
 
 class DeviceEnsembleSampler:
     """``EnsembleSampler`` with the whole stretch-move loop on the GPU (``rscm_sampler_*`` of the C
@@ -557,15 +798,21 @@ class DeviceEnsembleSampler:
         self.n_accepted = None
         self.n_proposed = None
         self.device_ms = 0.0
-        kinds, pa, pb = [], [], []
+        kinds, pa, pb, plo, phi = [], [], [], [], []
         for d in params.distributions():
+            lo, hi = -math.inf, math.inf
+            if isinstance(d, Bound):
+                lo, hi, d = d.low, d.high, d.inner()
             if isinstance(d, Uniform):
                 kinds.append(0), pa.append(d.low), pb.append(d.high)
             elif isinstance(d, Normal):
                 kinds.append(1), pa.append(d.mean), pb.append(d.std_dev)
+            elif isinstance(d, LogNormal):
+                kinds.append(2), pa.append(d.mu), pb.append(d.sigma)
             else:
-                raise NotImplementedError(f"prior {type(d).__name__} has no device form (Uniform and Normal do)")
-        self._prior = (np.array(kinds, dtype=np.int32), L.f64(pa), L.f64(pb))
+                raise NotImplementedError(f"prior {type(d).__name__} has no device form")
+            plo.append(lo), phi.append(hi)
+        self._prior = (np.array(kinds, dtype=np.int32), L.f64(pa), L.f64(pb), L.f64(plo), L.f64(phi))
 
     def _observations(self, model: Model):
         ov, ot, val, sig = [], [], [], []
@@ -595,11 +842,11 @@ class DeviceEnsembleSampler:
         ens.rewind()
         ov, ot, val, sig = self._observations(model)
         rows = np.array(self.runner._rows, dtype=np.int32)
-        kinds, pa, pb = self._prior
+        kinds, pa, pb, plo, phi = self._prior
         base = L.f64(model.base_params)
         h = C.c_void_p()
         L.check(lib.rscm_sampler_create(ens._h, n_walkers, len(rows), L.iptr(rows), L.dptr(base), L.iptr(kinds),
-                                        L.dptr(pa), L.dptr(pb), len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
+                                        L.dptr(pa), L.dptr(pb), L.dptr(plo), L.dptr(phi), len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
                                         L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
                                         C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.byref(h)))
         try:

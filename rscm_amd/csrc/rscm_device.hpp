@@ -193,9 +193,11 @@ struct SamplerArgs {
     double stretch_a;
     const int32_t* param_rows;   // [D] evaluator parameter row of each sampled dimension
     const double* base_params;   // [P] values of the rows that are not sampled
-    const int32_t* prior_kind;   // [D] 0 = Uniform(a, b), 1 = Normal(mean a, std b)
+    const int32_t* prior_kind;   // [D] 0 = Uniform(a, b), 1 = Normal(mean a, std b), 2 = LogNormal(mu a, sigma b)
     const double* prior_a;
     const double* prior_b;
+    const double* prior_lo;      // [D] truncation (Bound), -inf / +inf when there is none
+    const double* prior_hi;
     double* pos;         // [D][W]
     double* logp;        // [W]
     double* proposal;    // [D][W/2]

@@ -1198,6 +1198,8 @@ struct rscm_sampler {
     double* d_base = nullptr;
     double* d_pa = nullptr;
     double* d_pb = nullptr;
+    double* d_plo = nullptr;
+    double* d_phi = nullptr;
     double* d_pos = nullptr;
     double* d_logp = nullptr;
     double* d_prop = nullptr;
@@ -1231,6 +1233,8 @@ rscm::SamplerArgs sampler_args(const rscm_sampler* s, int32_t half, int32_t iden
     a.prior_kind = s->d_kind;
     a.prior_a = s->d_pa;
     a.prior_b = s->d_pb;
+    a.prior_lo = s->d_plo;
+    a.prior_hi = s->d_phi;
     a.pos = s->d_pos;
     a.logp = s->d_logp;
     a.proposal = s->d_prop;
@@ -1264,7 +1268,8 @@ int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
 
 int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, const int32_t* param_rows,
                         const double* base_params, const int32_t* prior_kind, const double* prior_a,
-                        const double* prior_b, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                        const double* prior_b, const double* prior_low, const double* prior_high,
+                        int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
                         const double* obs_value, const double* obs_sigma, int32_t normalize, double stretch_a,
                         uint64_t seed, rscm_sampler** out)
 {
@@ -1285,9 +1290,10 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
         if (param_rows[d] < 0 || param_rows[d] >= h->P) return fail(RSCM_ERR_INVALID, "dimension %d: parameter row %d out of range", d, param_rows[d]);
         for (int32_t e2 = 0; e2 < d; ++e2)
             if (param_rows[e2] == param_rows[d]) return fail(RSCM_ERR_INVALID, "parameter row %d sampled twice", param_rows[d]);
-        if (prior_kind[d] != 0 && prior_kind[d] != 1) return fail(RSCM_ERR_INVALID, "dimension %d: unknown prior kind %d", d, prior_kind[d]);
+        if (prior_kind[d] < 0 || prior_kind[d] > 2) return fail(RSCM_ERR_INVALID, "dimension %d: unknown prior kind %d", d, prior_kind[d]);
         if (prior_kind[d] == 0 && !(prior_b[d] > prior_a[d])) return fail(RSCM_ERR_INVALID, "dimension %d: Uniform needs high > low", d);
-        if (prior_kind[d] == 1 && !(prior_b[d] > 0.0)) return fail(RSCM_ERR_INVALID, "dimension %d: Normal needs std > 0", d);
+        if (prior_kind[d] != 0 && !(prior_b[d] > 0.0)) return fail(RSCM_ERR_INVALID, "dimension %d: the scale parameter must be > 0", d);
+        if ((prior_low && prior_high) && !(prior_low[d] < prior_high[d])) return fail(RSCM_ERR_INVALID, "dimension %d: Bound needs low < high", d);
     }
     // the fused kernel takes two-layer observations with ascending time indices inside a group
     bool fused = h->kind == RSCM_KIND_TWO_LAYER;
@@ -1337,6 +1343,8 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
     CK(hipMalloc(&s->d_base, (size_t)h->P * sizeof(double)));
     CK(hipMalloc(&s->d_pa, D * sizeof(double)));
     CK(hipMalloc(&s->d_pb, D * sizeof(double)));
+    CK(hipMalloc(&s->d_plo, D * sizeof(double)));
+    CK(hipMalloc(&s->d_phi, D * sizeof(double)));
     CK(hipMalloc(&s->d_pos, D * W * sizeof(double)));
     CK(hipMalloc(&s->d_logp, W * sizeof(double)));
     CK(hipMalloc(&s->d_prop, D * H * sizeof(double)));
@@ -1349,6 +1357,13 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
     CK(hipMemcpy(s->d_base, base_params, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice));
     CK(hipMemcpy(s->d_pa, prior_a, D * sizeof(double), hipMemcpyHostToDevice));
     CK(hipMemcpy(s->d_pb, prior_b, D * sizeof(double), hipMemcpyHostToDevice));
+    {
+        std::vector<double> lo(D, -std::numeric_limits<double>::infinity()), hi(D, std::numeric_limits<double>::infinity());
+        if (prior_low && prior_high)
+            for (size_t d = 0; d < D; ++d) { lo[d] = prior_low[d]; hi[d] = prior_high[d]; }
+        CK(hipMemcpy(s->d_plo, lo.data(), D * sizeof(double), hipMemcpyHostToDevice));
+        CK(hipMemcpy(s->d_phi, hi.data(), D * sizeof(double), hipMemcpyHostToDevice));
+    }
     CK(hipMemset(s->d_nacc, 0, W * sizeof(int64_t)));
     CK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
     CK(hipEventCreate(&s->ev0));
@@ -1388,7 +1403,7 @@ int rscm_sampler_destroy(rscm_sampler* s)
     if (!s) return RSCM_OK;
     if (s->ev) (void)hipStreamSynchronize(s->ev->stream);
     (void)hipFree(s->d_rows); (void)hipFree(s->d_kind); (void)hipFree(s->d_base); (void)hipFree(s->d_pa);
-    (void)hipFree(s->d_pb); (void)hipFree(s->d_pos); (void)hipFree(s->d_logp); (void)hipFree(s->d_prop);
+    (void)hipFree(s->d_pb); (void)hipFree(s->d_plo); (void)hipFree(s->d_phi); (void)hipFree(s->d_pos); (void)hipFree(s->d_logp); (void)hipFree(s->d_prop);
     (void)hipFree(s->d_z); (void)hipFree(s->d_lp); (void)hipFree(s->d_nacc); (void)hipFree(s->d_nprop);
     (void)hipFree(s->d_sobs);
     if (s->ev0) (void)hipEventDestroy(s->ev0);

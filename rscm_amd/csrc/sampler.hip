@@ -18,11 +18,20 @@ namespace rscm {
 
 namespace {
 
-__device__ __forceinline__ double ln_prior(int32_t kind, double a, double b, double x)
+// distribution.rs: Uniform :152-175, Normal :249-262, LogNormal :346-356, Bound :479-490 (the inner
+// density, unnormalised, inside [lo, hi]; lo = -inf, hi = +inf when the prior is not truncated)
+__device__ __forceinline__ double ln_prior(int32_t kind, double a, double b, double lo, double hi, double x)
 {
-    if (kind == 0) {  // Uniform(low = a, high = b): distribution.rs:114-175
+    if (!(x >= lo && x <= hi)) return -__builtin_inf();
+    if (kind == 0) {  // Uniform(low = a, high = b)
         if (!(x >= a && x <= b)) return -__builtin_inf();
         return -log(b - a);
+    }
+    if (kind == 2) {  // LogNormal(mu = a, sigma = b)
+        if (x <= 0.0) return -__builtin_inf();
+        const double ln_x = log(x);
+        const double z = (ln_x - a) / b;
+        return -0.5 * z * z - ln_x - log(b) - 0.5 * log(2.0 * 3.14159265358979323846);
     }
     // Normal(mean = a, std = b)
     const double z = (x - a) / b;
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void propose_kernel(SamplerArgs a)
         const double cval = a.pos[(size_t)d * W + comp];
         const double y = a.identity ? x : cval + z * (x - cval);  // y = c + z (x - c)
         a.proposal[(size_t)d * H + k] = y;
-        lp += ln_prior(a.prior_kind[d], a.prior_a[d], a.prior_b[d], y);
+        lp += ln_prior(a.prior_kind[d], a.prior_a[d], a.prior_b[d], a.prior_lo[d], a.prior_hi[d], y);
     }
     // A proposal outside the prior's support is rejected whatever the model says
     // (ensemble.rs:143-177), so the model is not asked: the lane evaluates the walker's current,

@@ -171,3 +171,24 @@ def test_device_sampler_on_climate_udeb(setup):
     assert abs(x[:, 1].mean() - 0.9) < 3 * x[:, 1].std() + 0.05
     assert 0.05 < dev.acceptance_rate() < 0.9 and dev.device_ms > 0
     runner.close()
+
+
+def test_device_sampler_lognormal_and_bound_priors(setup):
+    """No observations: the device sampler must reproduce a LogNormal prior and a Normal truncated
+    by Bound; its initial scores are the host prior's."""
+    cal, b = setup
+    runner = cal.ModelRunner(b, ["heat_capacity_surface", "eta"], ["Surface Temperature"])
+    params = (cal.ParameterSet().add("heat_capacity_surface", cal.LogNormal(2.0, 0.25))
+              .add("eta", cal.Bound(cal.Normal(0.7, 0.2), 0.5, 1.0)))
+    dev = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), cal.Target())
+    pos = params.sample_random(4096, np.random.default_rng(1))
+    first = dev.run(1, cal.WalkerInit.explicit(pos), n_walkers=4096, seed=5)
+    moved = (first.flat_samples() != pos).any(axis=1)
+    assert np.allclose(first.flat_log_probs()[~moved], params.log_prior_batch(pos[~moved]), rtol=1e-13, atol=1e-13)
+    chain = dev.run(80, cal.WalkerInit.explicit(pos), n_walkers=4096, seed=6)
+    x = chain.flat_samples(discard=79)
+    assert abs(np.log(x[:, 0]).mean() - 2.0) < 0.02 and abs(np.log(x[:, 0]).std() - 0.25) < 0.02
+    assert x[:, 1].min() >= 0.5 and x[:, 1].max() <= 1.0
+    ref = params.distributions()[1].sample_n(np.random.default_rng(2), 200_000)  # truncated normal by rejection
+    assert abs(x[:, 1].mean() - ref.mean()) < 0.01 and abs(x[:, 1].std() - ref.std()) < 0.01
+    runner.close()
