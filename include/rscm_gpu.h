@@ -461,6 +461,9 @@ RSCM_API int rscm_sampler_get(rscm_sampler* s, double* positions, double* log_pr
 /* Ensemble summary of one variable at one time index over finite members:
  * out[0]=count_finite, out[1]=sum, out[2]=min, out[3]=max (wavefront + block reductions). */
 RSCM_API int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4]);
+/* The same four numbers for every time index in [t_begin, t_end) in two launches:
+ * out[(t_end - t_begin)][4].  Each row carries the bits rscm_ens_summary returns for it. */
+RSCM_API int rscm_ens_summary_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end, double* out);
 
 /* Copy the parameter matrix back to the host as [P][N] (e.g. after rscm_ens_sample_lhs). */
 RSCM_API int rscm_ens_get_params(rscm_ens* h, double* out_soa);

@@ -129,6 +129,37 @@ __global__ __launch_bounds__(kBlock) void summary_final_kernel(const double* par
     }
 }
 
+// The same reduction for many time rows in one launch: blockIdx.y selects the row, the block
+// layout along x is the one launch_summary uses, so every row gets the bits a single-row call gives.
+__global__ __launch_bounds__(kBlock) void summary_rows_partial_kernel(const double* rows, int64_t n, double* partial)
+{
+    const double* row = rows + (size_t)blockIdx.y * n;
+    Stat4 v = {0.0, 0.0, __builtin_inf(), -__builtin_inf()};
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double x = row[i];
+        if (is_finite(x)) v = stat_merge(v, {1.0, x, x, x});
+    }
+    v = block_reduce(v);
+    if (threadIdx.x == 0) {
+        double* p = partial + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        p[0] = v.cnt; p[1] = v.sum; p[2] = v.mn; p[3] = v.mx;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void summary_rows_final_kernel(const double* partial, int32_t n_blocks, double* out)
+{
+    const double* part = partial + 4 * (size_t)blockIdx.x * n_blocks;
+    Stat4 v = {0.0, 0.0, __builtin_inf(), -__builtin_inf()};
+    for (int32_t b = threadIdx.x; b < n_blocks; b += kBlock)
+        v = stat_merge(v, {part[4 * b], part[4 * b + 1], part[4 * b + 2], part[4 * b + 3]});
+    v = block_reduce(v);
+    if (threadIdx.x == 0) {
+        double* o = out + 4 * (size_t)blockIdx.x;
+        o[0] = v.cnt; o[1] = v.sum; o[2] = v.mn; o[3] = v.mx;
+    }
+}
+
 // ---- counter-based Latin hypercube ----------------------------------------------------------
 // Philox4x32-10 (philox.hpp) keyed by (seed, dimension), counter = global member id.
 // Keyed bijection of [0, n): 4-round Feistel network on the next even-bit power-of-two domain,
@@ -232,6 +263,18 @@ hipError_t launch_summary(const double* row, int64_t n, double* partial, int32_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(summary_final_kernel, dim3(1), dim3(kBlock), 0, s, partial, n_blocks, out);
+    return hipGetLastError();
+}
+
+// rows: n_rows consecutive [n] rows; partial: [n_rows][n_blocks][4]; out: [n_rows][4]
+hipError_t launch_summary_rows(const double* rows, int64_t n, int32_t n_rows, double* partial, int32_t n_blocks,
+                               double* out, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(summary_rows_partial_kernel, dim3(n_blocks, n_rows), dim3(kBlock), 0, s, rows, n, partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(summary_rows_final_kernel, dim3(n_rows), dim3(kBlock), 0, s, partial, n_blocks, out);
     return hipGetLastError();
 }
 

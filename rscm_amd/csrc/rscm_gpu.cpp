@@ -1489,6 +1489,39 @@ int rscm_sampler_get(rscm_sampler* s, double* positions, double* log_prob, int64
     GUARD_END
 }
 
+int rscm_ens_summary_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id < 1 || var_id >= h->V || t_begin < 0 || t_end > h->T || t_begin > t_end || !out)
+        return fail(RSCM_ERR_INVALID, "bad variable / time range");
+    if (h->rows != h->T) return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES)");
+    const int32_t n_rows = t_end - t_begin;
+    // rows beyond the current time index have not been computed: empty summaries, as rscm_ens_summary
+    const int32_t computed = std::max(0, std::min(t_end, h->time_index + 1) - t_begin);
+    for (int32_t r = computed; r < n_rows; ++r) {
+        out[4 * r + 0] = 0.0; out[4 * r + 1] = 0.0;
+        out[4 * r + 2] = std::numeric_limits<double>::infinity();
+        out[4 * r + 3] = -std::numeric_limits<double>::infinity();
+    }
+    if (computed == 0) return RSCM_OK;
+    if (int rc = set_device(h)) return rc;
+    const int32_t nb = rscm::summary_blocks(h->N);
+    double* d_partial = nullptr;
+    double* d_out = nullptr;
+    HIPCHK(hipMalloc(&d_partial, (size_t)computed * nb * 4 * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, (size_t)computed * 4 * sizeof(double));
+    if (e == hipSuccess)
+        e = rscm::launch_summary_rows(h->series(var_id) + (size_t)t_begin * h->N, h->N, computed, d_partial, nb, d_out, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)computed * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_partial);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "summary_series: %s", hipGetErrorString(e));
+    return RSCM_OK;
+    GUARD_END
+}
+
 int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4])
 {
     GUARD_BEGIN

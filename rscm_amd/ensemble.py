@@ -265,6 +265,17 @@ class Ensemble:
         return {"count": int(cnt), "mean": out[1] / cnt if cnt else float("nan"),
                 "min": out[2], "max": out[3]}
 
+    def summary_series(self, var, t_begin: int = 0, t_end: Optional[int] = None) -> Dict[str, np.ndarray]:
+        """Ensemble count / mean / min / max over the finite members at every time index of
+        ``[t_begin, t_end)`` -- the plume of a variable -- reduced on the device in two launches."""
+        t_end = self.n_times if t_end is None else t_end
+        out = np.empty((max(0, t_end - t_begin), 4))
+        L.check(self._lib.rscm_ens_summary_series(self._h, self._var(var), t_begin, t_end, L.dptr(out)))
+        cnt = out[:, 0]
+        with np.errstate(all="ignore"):
+            mean = np.where(cnt > 0, out[:, 1] / np.where(cnt > 0, cnt, 1.0), np.nan)
+        return {"count": cnt.astype(np.int64), "mean": mean, "min": out[:, 2].copy(), "max": out[:, 3].copy()}
+
 
 class _PinnedOwner:
     def __init__(self, ptr):

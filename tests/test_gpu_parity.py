@@ -784,3 +784,31 @@ def test_two_layer_exact_fuzz(ra, orc, seed):
         e.run()
         assert_bit_equal(e.get_series(1), want_ts, f"seed {seed} Ts (T={T}, n={n}, S={S}, h={h}, source={source}, cuts={cuts})")
         assert_bit_equal(e.get_series(2), want_td, f"seed {seed} Td")
+
+
+def test_summary_series_equals_row_summaries(ra, orc):
+    """rscm_ens_summary_series: the plume of a variable in two launches, each row with the bits
+    of the single-row summary; NaN members are left out; rows not yet computed are empty."""
+    t = axis_values(1750, 1850)
+    b = np.append(t, t[-1] + 1.0)
+    n = 70_000
+    P = two_layer_params(n)
+    P[4, ::1000] = np.nan  # members whose series is NaN from the first step on
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(f_syn(t))
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run(60)
+        s = e.summary_series("Surface Temperature")
+        assert s["count"].shape == (len(t),) and s["count"][0] == n and (s["count"][61:] == 0).all()
+        assert (s["count"][1:61] == n - 70).all() and np.isnan(s["mean"][61:]).all()
+        for tidx in (0, 1, 30, 60, 61, 100):
+            one = e.summary("Surface Temperature", tidx)
+            for k in ("count", "min", "max"):
+                assert s[k][tidx] == one[k], (k, tidx)
+            assert (s["mean"][tidx] == one["mean"]) or (np.isnan(s["mean"][tidx]) and np.isnan(one["mean"]))
+        e.run()
+        part = e.summary_series("Deep Ocean Temperature", 10, 20)
+        row = e.get_series(2, 10, 20)
+        assert np.allclose(part["mean"], np.nanmean(row, axis=1), rtol=1e-12) and np.array_equal(part["max"], np.nanmax(row, axis=1))
