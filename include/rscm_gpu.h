@@ -446,6 +446,12 @@ RSCM_API int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t
                                  const double* obs_value, const double* obs_sigma, int32_t normalize,
                                  double stretch_a, uint64_t seed, rscm_sampler** out);
 RSCM_API int rscm_sampler_destroy(rscm_sampler* s);
+/* Split the walkers into n_groups independent ensembles of n_walkers / n_groups walkers each
+ * (consecutive blocks of the walker index): every group is a sampler of its own -- its own two
+ * halves, complementary walkers drawn from itself only -- and all groups advance in the same
+ * launches.  This is how ensembles of the reference's usual size (tens of walkers) fill a GPU:
+ * thousands of them side by side, e.g. for an R-hat across independent runs.  Default 1. */
+RSCM_API int rscm_sampler_set_groups(rscm_sampler* s, int32_t n_groups);
 /* positions[n_walkers][n_dims] row-major (the Chain layout); scores every walker and zeroes the
  * acceptance counters. */
 RSCM_API int rscm_sampler_set_positions(rscm_sampler* s, const double* positions);

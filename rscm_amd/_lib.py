@@ -250,6 +250,7 @@ SIGNATURES = {
     "rscm_sampler_create": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp, _dp, C.c_int32, _ip, _ip,
                                       _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.POINTER(_h)]),
     "rscm_sampler_destroy": (C.c_int, [_h]),
+    "rscm_sampler_set_groups": (C.c_int, [_h, C.c_int32]),
     "rscm_sampler_set_positions": (C.c_int, [_h, _dp]),
     "rscm_sampler_iterate": (C.c_int, [_h, C.c_int32]),
     "rscm_sampler_last_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),

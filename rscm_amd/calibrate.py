@@ -827,9 +827,11 @@ class DeviceEnsembleSampler:
         return np.array(ov, dtype=np.int32), np.array(ot, dtype=np.int32), L.f64(val), L.f64(sig)
 
     def run(self, n_iterations: int, init: "WalkerInit", thin: int = 1, n_walkers: Optional[int] = None,
-            rng: Optional[np.random.Generator] = None, seed: int = 0) -> "Chain":
+            rng: Optional[np.random.Generator] = None, seed: int = 0, n_groups: int = 1) -> "Chain":
+        """``n_groups`` > 1 runs that many independent ensembles of ``n_walkers / n_groups`` walkers
+        side by side (consecutive blocks of the walker index), each a sampler of its own."""
         import ctypes as C
-        n_walkers = n_walkers or self.default_n_walkers
+        n_walkers = n_walkers or self.default_n_walkers * n_groups
         if n_walkers < 2:
             raise ValueError("Must have at least 2 walkers")
         if n_walkers % 2:
@@ -850,6 +852,8 @@ class DeviceEnsembleSampler:
                                         L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
                                         C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.byref(h)))
         try:
+            if n_groups != 1:
+                L.check(lib.rscm_sampler_set_groups(h, n_groups))
             L.check(lib.rscm_sampler_set_positions(h, L.dptr(pos)))
             chain = Chain(self.params.param_names, thin)
             logp = np.empty(n_walkers)

@@ -186,7 +186,8 @@ struct HaloArgs {
 // device stretch-move sampler (csrc/sampler.hip); pos is [D][W], the per-half buffers [.][W/2]
 struct SamplerArgs {
     int32_t n_walkers, n_dims, n_params;
-    int32_t half;        // 0 / 1: the half being updated
+    int32_t n_groups;    // independent ensembles of n_walkers / n_groups walkers each
+    int32_t half;        // 0 / 1: the half (of every group) being updated
     int32_t iteration;
     int32_t identity;    // score the walkers where they stand (initialisation)
     uint64_t seed;

@@ -1188,7 +1188,7 @@ int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, cons
 // ---------------------------------------------------------------------------------------------
 struct rscm_sampler {
     rscm_ens* ev = nullptr;  // evaluates one half-ensemble per launch; not owned
-    int32_t W = 0, D = 0;
+    int32_t W = 0, D = 0, groups = 1;
     double stretch_a = 2.0;
     uint64_t seed = 0;
     int32_t iteration = 0;
@@ -1223,6 +1223,7 @@ rscm::SamplerArgs sampler_args(const rscm_sampler* s, int32_t half, int32_t iden
     a.n_walkers = s->W;
     a.n_dims = s->D;
     a.n_params = s->ev->P;
+    a.n_groups = s->groups;
     a.half = half;
     a.iteration = s->iteration;
     a.identity = identity;
@@ -1410,6 +1411,18 @@ int rscm_sampler_destroy(rscm_sampler* s)
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
     return RSCM_OK;
+}
+
+int rscm_sampler_set_groups(rscm_sampler* s, int32_t n_groups)
+{
+    GUARD_BEGIN
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    if (n_groups < 1 || s->W % n_groups != 0 || (s->W / n_groups) % 2 != 0 || s->W / n_groups < 2)
+        return fail(RSCM_ERR_INVALID, "%d walkers do not split into %d groups of an even number (>= 2) of walkers", s->W, n_groups);
+    s->groups = n_groups;
+    s->positions_set = false;  // positions are scored per group layout: set them again
+    return RSCM_OK;
+    GUARD_END
 }
 
 int rscm_sampler_set_positions(rscm_sampler* s, const double* positions)

@@ -44,7 +44,11 @@ __global__ __launch_bounds__(kBlock) void propose_kernel(SamplerArgs a)
     const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     const int32_t H = a.n_walkers / 2;
     if (k >= H) return;
-    const int32_t active = a.half * H + k;
+    // independent ensembles ("groups") of Wg walkers each, laid out one after the other; each is
+    // split into its own two halves and draws complementary walkers from itself only
+    const int32_t Wg = a.n_walkers / a.n_groups, Hg = Wg / 2;
+    const int32_t g = k / Hg, jg = k % Hg;
+    const int32_t active = g * Wg + a.half * Hg + jg;
     double z = 1.0;
     int32_t comp = active;  // identity proposal: scores the walker where it stands
     if (!a.identity) {
@@ -54,8 +58,8 @@ __global__ __launch_bounds__(kBlock) void propose_kernel(SamplerArgs a)
         const double s = (a.stretch_a - 1.0) * u + 1.0;  // moves.rs:55-59: z = ((a-1) u + 1)^2 / a
         z = s * s / a.stretch_a;
         // a uniformly chosen walker of the complementary half (moves.rs:118-121)
-        const uint32_t j = (uint32_t)((((uint64_t)c[2] << 32) | c[3]) % (uint64_t)H);
-        comp = (1 - a.half) * H + (int32_t)j;
+        const uint32_t j = (uint32_t)((((uint64_t)c[2] << 32) | c[3]) % (uint64_t)Hg);
+        comp = g * Wg + (1 - a.half) * Hg + (int32_t)j;
     }
     const int64_t W = a.n_walkers;
     double lp = 0.0;
@@ -84,7 +88,8 @@ __global__ __launch_bounds__(kBlock) void accept_kernel(SamplerArgs a)
     const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     const int32_t H = a.n_walkers / 2;
     if (k >= H) return;
-    const int32_t active = a.half * H + k;
+    const int32_t Wg = a.n_walkers / a.n_groups, Hg = Wg / 2;
+    const int32_t active = (k / Hg) * Wg + a.half * Hg + (k % Hg);
     const int64_t W = a.n_walkers;
     // log prior + log likelihood; anything failing is -inf (ensemble.rs:143-177)
     const double lp = a.lp[k];

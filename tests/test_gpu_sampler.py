@@ -192,3 +192,28 @@ def test_device_sampler_lognormal_and_bound_priors(setup):
     ref = params.distributions()[1].sample_n(np.random.default_rng(2), 200_000)  # truncated normal by rejection
     assert abs(x[:, 1].mean() - ref.mean()) < 0.01 and abs(x[:, 1].std() - ref.std()) < 0.01
     runner.close()
+
+
+def test_device_sampler_groups_are_independent(setup):
+    """n_groups independent ensembles side by side: a group's trajectory does not depend on what
+    the other groups hold, and every group converges to the same posterior."""
+    cal, b = setup
+    names, ranges = ["lambda0", "efficacy"], [(0.8, 1.5), (1.0, 1.8)]
+    runner, target, params = _problem(cal, b, names, ranges)
+    dev = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    G, Wg = 64, 32
+    pos = params.sample_random(G * Wg, np.random.default_rng(11))
+    a = dev.run(40, cal.WalkerInit.explicit(pos), n_walkers=G * Wg, seed=8, n_groups=G)
+    other = pos.copy()
+    other[Wg:] = params.sample_random((G - 1) * Wg, np.random.default_rng(12))  # every group but the first
+    c = dev.run(40, cal.WalkerInit.explicit(other), n_walkers=G * Wg, seed=8, n_groups=G)
+    xa = np.stack(a._samples)  # [sweeps][walkers][dims]
+    xc = np.stack(c._samples)
+    assert np.array_equal(xa[:, :Wg], xc[:, :Wg]) and not np.array_equal(xa[:, Wg:], xc[:, Wg:])
+    one = dev.run(40, cal.WalkerInit.explicit(pos), n_walkers=G * Wg, seed=8)  # a single big ensemble differs
+    assert not np.array_equal(np.stack(one._samples)[:, :Wg], xa[:, :Wg])
+    last = xa[-1].reshape(G, Wg, 2).mean(axis=1)  # per-group posterior means
+    assert np.abs(last.mean(axis=0) - [1.1, 1.3]).max() < 0.1 and last.std(axis=0).max() < 0.15
+    with pytest.raises(Exception, match="do not split"):
+        dev.run(1, cal.WalkerInit.explicit(pos), n_walkers=G * Wg, seed=8, n_groups=3)
+    runner.close()
