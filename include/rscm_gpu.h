@@ -84,6 +84,10 @@ extern "C" {
 #define RSCM_KIND_HALOCARBON 12      /* rscm-magicc HalocarbonChemistry (41 species)              */
 #define RSCM_KIND_FOURBOX_OHU 13     /* rscm-components FourBoxOceanHeatUptake                    */
 #define RSCM_KIND_OSPP 14            /* rscm-components OceanSurfacePartialPressure               */
+/* the members of the coupled chain on their own, for graphs assembled with rscm_ens_link_input */
+#define RSCM_KIND_CARBON_CYCLE 15    /* rscm-components CarbonCycle (RK4, three states)           */
+#define RSCM_KIND_CO2_ERF 16         /* rscm-components CO2ERF                                    */
+#define RSCM_KIND_AGGREGATE 17       /* rscm-core schema aggregate (Sum / Mean / Weighted)        */
 
 /* variable ids, kind TWO_LAYER (V = 3) */
 #define RSCM_TL_VAR_ERF 0 /* "Effective Radiative Forcing"  (input, [S][T] shared)              */
@@ -248,6 +252,25 @@ extern "C" {
  *           sea_surface_temperature_preindustrial, delta_ospp_offsets[5], delta_ospp_coefficients[5] */
 #define RSCM_SP_NINPUTS 2
 #define RSCM_SP_NPARAMS 13
+/* CarbonCycle (crates/rscm-components/src/components/carbon_cycle.rs:102-159):
+ *   inputs  Emissions|CO2|Anthropogenic, Surface Temperature
+ *   states  1 Atmospheric Concentration|CO2, 2 Cumulative Land Uptake, 3 Cumulative Emissions|CO2
+ *   params  tau, conc_pi, alpha_temperature; RK4 step via rscm_ens_set_step_size(RSCM_COMP_CARBON_CYCLE)
+ *   Same arithmetic as inside RSCM_KIND_COUPLED: the linked graph reproduces the fused kind's bits. */
+#define RSCM_CC_NINPUTS 2
+#define RSCM_CC_NPARAMS 3
+/* CO2ERF (co2_erf.rs:57-80): input Atmospheric Concentration|CO2; output 1 Effective Radiative
+ *   Forcing|CO2; params erf_2xco2, conc_pi */
+#define RSCM_CE_NINPUTS 1
+#define RSCM_CE_NPARAMS 2
+/* Schema aggregate (AggregatorComponent / compute_aggregate, crates/rscm-core/src/schema.rs:760-802,
+ * 886-901): up to eight contributors, every one read at index n+1 (at_end(), whatever `source` is
+ * passed), NaN contributors skipped, all-NaN -> NaN.  The input block starts out all-NaN, so only the
+ * rows that are linked or set take part.  output 1 the aggregate.
+ *   params  operation (0 Sum, 1 Mean, 2 Weighted = sum of value * weight, no renormalisation),
+ *           weights[8] */
+#define RSCM_AG_NINPUTS 8
+#define RSCM_AG_NPARAMS 9
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
@@ -361,6 +384,24 @@ RSCM_API int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, c
                          const int32_t* scenario_of_member, int32_t source);
 /* Initial value(s) at time index 0 of a state variable: n_values == 1 (broadcast) or N.
  * Also rewinds the time index to 0. */
+/* Linked input: row `input_row` of h's input block is read, member by member, from the stored series
+ * `src_var` of another ensemble `src` (same n_members, n_times and device) instead of the shared
+ * scenario table -- the edge of a component graph (ModelBuilder::build, builder.rs:487-518) kept on
+ * the device.  `source` is the consumer's VariableSource for that variable: RSCM_SRC_EXOGENOUS reads
+ * index n (also the reference's choice for a producer registered *after* the consumer: lagged
+ * feedback), RSCM_SRC_UPSTREAM index n+1.  ClimateUDEB reads at_start / at_end (n and n+1) and the
+ * aggregate kind always n+1; both ignore `source`.
+ * Rows that are not linked keep coming from rscm_ens_set_forcing's block (which is only required if
+ * such rows exist).  Both ensembles must run on the same stream (rscm_ens_set_stream), and a run
+ * of h over [b, e) needs src to have been stepped to e - 1 + source first: for a chain without
+ * feedback run the producers over the whole axis and then the consumers; with feedback step every
+ * ensemble one step at a time in graph order (what Model::step does).  `src` must outlive the link:
+ * rscm_ens_destroy(src) fails while links to it exist.  Not available for RSCM_KIND_COUPLED and
+ * RSCM_KIND_HALOCARBON inputs, nor with RSCM_FLAG_NO_SERIES on either side. */
+RSCM_API int rscm_ens_link_input(rscm_ens* h, int32_t input_row, rscm_ens* src, int32_t src_var, int32_t source);
+/* Row `input_row` reads the scenario table again. */
+RSCM_API int rscm_ens_unlink_input(rscm_ens* h, int32_t input_row);
+
 RSCM_API int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int64_t n_values);
 /* Checkpoint / resume (the reference serialises time_index + the whole collection,
  * crates/rscm-core/src/model/runtime.rs:270-282): a run can be resumed from
@@ -373,6 +414,10 @@ RSCM_API int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const
 RSCM_API int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx);
 /* Use an existing hipStream_t (as void*) for all launches and copies; NULL = own stream. */
 RSCM_API int rscm_ens_set_stream(rscm_ens* h, void* hip_stream);
+/* A non-blocking hipStream_t on `device_id` for callers without a HIP runtime of their own (linked
+ * ensembles must share one stream); destroy it after the ensembles that use it. */
+RSCM_API int rscm_gpu_stream_create(int32_t device_id, void** out_stream);
+RSCM_API int rscm_gpu_stream_destroy(int32_t device_id, void* hip_stream);
 
 /* ---- stepping (Model::step / run) --------------------------------------------------------- */
 /* Execute steps n = step_begin .. step_end-1 (0 <= step_begin <= step_end <= n_times-1).

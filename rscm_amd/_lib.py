@@ -22,6 +22,7 @@ KIND_CO2_BUDGET, KIND_TERRESTRIAL_CARBON = 9, 10
 KIND_OCEAN_CARBON = 11
 KIND_HALOCARBON = 12
 KIND_FOURBOX_OHU, KIND_OSPP = 13, 14
+KIND_CARBON_CYCLE, KIND_CO2_ERF, KIND_AGGREGATE = 15, 16, 17
 SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
@@ -190,6 +191,19 @@ SP_PARAM_NAMES = (("ospp_preindustrial", "sensitivity_ospp_to_temperature", "sea
                   + tuple(f"delta_ospp_offsets_{i}" for i in range(5))
                   + tuple(f"delta_ospp_coefficients_{i}" for i in range(5)))
 
+CC_INPUTS = ("Emissions|CO2|Anthropogenic", "Surface Temperature")
+CC_VARS = {"CarbonCycle inputs": 0, "Atmospheric Concentration|CO2": 1, "Cumulative Land Uptake": 2,
+           "Cumulative Emissions|CO2": 3}
+CC_PARAM_NAMES = ("tau", "conc_pi", "alpha_temperature")
+CE_INPUTS = ("Atmospheric Concentration|CO2",)
+CE_VARS = {"CO2ERF input": 0, "Effective Radiative Forcing|CO2": 1}
+CE_PARAM_NAMES = ("erf_2xco2", "conc_pi")
+AG_NINPUTS = 8
+AG_INPUTS = tuple(f"contributor_{k}" for k in range(AG_NINPUTS))
+AG_VARS = {"contributors": 0, "aggregate": 1}
+AG_PARAM_NAMES = ("operation",) + tuple(f"weight_{k}" for k in range(AG_NINPUTS))
+AG_OPERATIONS = {"Sum": 0.0, "Mean": 1.0, "Weighted": 2.0}
+
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {
     KIND_TWO_LAYER: (TL_VARS, 6, None), KIND_COUPLED: (CP_VARS, 10, None), KIND_UDEB: (UD_VARS, 37, None),
@@ -198,7 +212,9 @@ KIND_TABLE = {
     KIND_CH4_CHEMISTRY: (CH4_VARS, 18, CH4_INPUTS), KIND_N2O_CHEMISTRY: (N2O_VARS, 6, N2O_INPUTS),
     KIND_CO2_BUDGET: (CB_VARS, 2, CB_INPUTS), KIND_TERRESTRIAL_CARBON: (TC_VARS, 20, TC_INPUTS),
     KIND_OCEAN_CARBON: (OC_VARS, 24, OC_INPUTS), KIND_HALOCARBON: (HC_VARS, len(HC_PARAM_NAMES), HC_INPUTS),
-    KIND_FOURBOX_OHU: (FB_VARS, 4, FB_INPUTS), KIND_OSPP: (SP_VARS, 13, SP_INPUTS)}
+    KIND_FOURBOX_OHU: (FB_VARS, 4, FB_INPUTS), KIND_OSPP: (SP_VARS, 13, SP_INPUTS),
+    KIND_CARBON_CYCLE: (CC_VARS, 3, CC_INPUTS), KIND_CO2_ERF: (CE_VARS, 2, CE_INPUTS),
+    KIND_AGGREGATE: (AG_VARS, 9, AG_INPUTS)}
 # FourBox variables stored as four scalar series: kind -> (name, first variable id)
 FOURBOX_VARS = {KIND_UDEB: ("Surface Temperature", 1),
                 KIND_AEROSOL_DIRECT: ("Effective Radiative Forcing|Aerosol|Direct", 1),
@@ -229,9 +245,13 @@ SIGNATURES = {
     "rscm_ens_set_params": (C.c_int, [_h, _dp]),
     "rscm_ens_set_params_aos": (C.c_int, [_h, _dp]),
     "rscm_ens_set_forcing": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, _ip, C.c_int32]),
+    "rscm_ens_link_input": (C.c_int, [_h, C.c_int32, _h, C.c_int32, C.c_int32]),
+    "rscm_ens_unlink_input": (C.c_int, [_h, C.c_int32]),
     "rscm_ens_set_initial": (C.c_int, [_h, C.c_int32, _dp, C.c_int64]),
     "rscm_ens_set_state": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.c_int64]),
     "rscm_ens_set_time_index": (C.c_int, [_h, C.c_int32]),
+    "rscm_gpu_stream_create": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "rscm_gpu_stream_destroy": (C.c_int, [C.c_int32, C.c_void_p]),
     "rscm_ens_set_stream": (C.c_int, [_h, C.c_void_p]),
     "rscm_ens_run": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "rscm_ens_run_async": (C.c_int, [_h, C.c_int32, C.c_int32]),

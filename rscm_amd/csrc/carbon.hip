@@ -14,13 +14,60 @@
 // library (tests/test_gpu_carbon.py states the tolerance).  Both stream their state rows to HBM
 // (24 / 40 B per member-year); CO2Budget is bound by that write stream, TerrestrialCarbon by
 // the transcendental VALU work.
+#include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
 namespace rscm {
 
 namespace {
 
-template <bool HAS_SCEN>
+constexpr double kGtcPerPpm = 2.13;  // crates/rscm-components/src/constants.rs:37
+
+// rscm-components' CarbonCycle on its own (carbon_cycle.rs:102-159): y = (C, cumulative uptake,
+// cumulative emissions) integrated with RK4 over the model step, emissions and temperature
+// constant over it (get() ignores t).  The arithmetic is that of the fused coupled chain
+// (csrc/coupled.hip, year<false>), so a graph assembled from linked ensembles reproduces the
+// fused kind bit for bit.  in = {Emissions|CO2|Anthropogenic, Surface Temperature}.
+template <int SRC>
+__global__ __launch_bounds__(kBlock) void carbon_cycle_kernel(CarbonArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    const double tau = a.params[i], conc_pi = a.params[(size_t)N + i], alpha = a.params[(size_t)2 * N + i];
+    const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
+    const size_t vs = (size_t)T * N;
+    const size_t r0 = (size_t)a.step_begin * N + i;
+    double conc = a.series[r0], cum_u = a.series[vs + r0], cum_e = a.series[2 * vs + r0];
+    const double hc = a.h, half_c = hc / 2.0, sixth_c = hc / 6.0;
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double emis = in.at(0, n), temperature = in.at(1, n);
+        const double lifetime = tau * exp(alpha * temperature);
+        const double e_ppm = emis / kGtcPerPpm;
+        const int32_t m = a.nsub[n];
+        for (int32_t s = 0; s < m; ++s) {
+            const double up1 = (conc - conc_pi) / lifetime;
+            const double k1c = e_ppm - up1, k1u = up1 * kGtcPerPpm;
+            const double up2 = ((conc + k1c * half_c) - conc_pi) / lifetime;
+            const double k2c = e_ppm - up2, k2u = up2 * kGtcPerPpm;
+            const double up3 = ((conc + k2c * half_c) - conc_pi) / lifetime;
+            const double k3c = e_ppm - up3, k3u = up3 * kGtcPerPpm;
+            const double up4 = ((conc + k3c * hc) - conc_pi) / lifetime;
+            const double k4c = e_ppm - up4, k4u = up4 * kGtcPerPpm;
+            conc = rk4_combine(conc, k1c, k2c, k3c, k4c, sixth_c);
+            cum_u = rk4_combine(cum_u, k1u, k2u, k3u, k4u, sixth_c);
+            cum_e = rk4_combine(cum_e, emis, emis, emis, emis, sixth_c);
+        }
+        const size_t r = (size_t)(n + 1) * N + i;
+        a.series[r] = conc;
+        a.series[vs + r] = cum_u;
+        a.series[2 * vs + r] = cum_e;
+    }
+    a.status[i] = (is_finite(conc) && is_finite(cum_u) && is_finite(cum_e)) ? 0 : 1;
+}
+
+template <int SRC>
 __global__ __launch_bounds__(kBlock) void co2_budget_kernel(CarbonArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -28,18 +75,14 @@ __global__ __launch_bounds__(kBlock) void co2_budget_kernel(CarbonArgs a)
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     const double gtc_per_ppm = a.params[i];
-    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 4 * T;
+    const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)T * N;
     a.status[i] = 0;
     double co2 = a.series[(size_t)a.step_begin * N + i];
-    if (a.step_begin == 0) {
-        a.series[vs + i] = __builtin_nan("");
-        a.series[2 * vs + i] = __builtin_nan("");
-    }
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double total_emissions = in[n] + in[(size_t)T + n];
-        const double total_uptake = in[(size_t)2 * T + n] + in[(size_t)3 * T + n];
+        const double total_emissions = in.at(0, n) + in.at(1, n);
+        const double total_uptake = in.at(2, n) + in.at(3, n);
         const double net_to_atm = total_emissions - total_uptake;
         co2 = co2 + (net_to_atm * dt) / gtc_per_ppm;
         const size_t r = (size_t)(n + 1) * N + i;
@@ -61,7 +104,7 @@ __device__ __forceinline__ void implicit_pool_step(double pool, double tau, doub
     turnover = 0.5 * k_eff * (pool + np);
 }
 
-template <bool HAS_SCEN>
+template <int SRC>
 __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -83,15 +126,14 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
     const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
     const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
     const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
-    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 3 * T;
+    const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)T * N;
     a.status[i] = 0;
     const size_t r0 = (size_t)a.step_begin * N + i;
     double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];
-    if (a.step_begin == 0) a.series[4 * vs + i] = __builtin_nan("");
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double co2 = in[n], temperature = in[(size_t)T + n], landuse = in[(size_t)2 * T + n];
+        const double co2 = in.at(0, n), temperature = in.at(1, n), landuse = in.at(2, n);
         const double fert = (!fert_on || co2 <= 0.0) ? 1.0 : fmax(1.0 + beta * log(co2 / co2_pi), 0.1);
         auto tf = [&](double sens) -> double { return temp_on ? exp(sens * temperature) : 1.0; };
         const double npp = npp_pi * fert * tf(npp_ts);
@@ -124,11 +166,11 @@ hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     if (a.kind == 9) {
-        if (a.scen) hipLaunchKernelGGL((co2_budget_kernel<true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((co2_budget_kernel<false>), grid, dim3(kBlock), 0, s, a);
+        RSCM_LAUNCH_BY_SOURCE(co2_budget_kernel, a, grid, dim3(kBlock), s, a);
     } else if (a.kind == 10) {
-        if (a.scen) hipLaunchKernelGGL((terrestrial_kernel<true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((terrestrial_kernel<false>), grid, dim3(kBlock), 0, s, a);
+        RSCM_LAUNCH_BY_SOURCE(terrestrial_kernel, a, grid, dim3(kBlock), s, a);
+    } else if (a.kind == 15) {
+        RSCM_LAUNCH_BY_SOURCE(carbon_cycle_kernel, a, grid, dim3(kBlock), s, a);
     } else {
         return hipErrorInvalidValue;
     }

@@ -30,7 +30,7 @@ constexpr int kPratherIterations = 4;
 // error of ~1e-16 in the power, at a third of the instructions of the general pow().
 __device__ __forceinline__ double pow_ratio(double x, double y) { return exp(y * log(x)); }
 
-template <bool HAS_SCEN>
+template <int SRC>
 __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -45,15 +45,14 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
     const double ppb_to_tg = P(14), nox_ref = P(15), co_ref = P(16), nmvoc_ref = P(17);
     const double burden_reference = ch4_pi * ppb_to_tg;
     const double x = -gamma * self_fb;
-    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 5 * T;
+    const MemberInputs<SRC, 5> in(a.inputs, a.scen, a.links, T, N, i);
     a.status[i] = 0;
     double cur = a.conc[(size_t)a.step_begin * N + i];
     double prev = a.step_begin > 0 ? a.conc[(size_t)(a.step_begin - 1) * N + i] : cur;  // previous().unwrap_or(current)
-    if (a.step_begin == 0) a.lifetime[i] = __builtin_nan("");
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-        const double emissions = in[n], temperature = in[(size_t)T + n];
-        const double delta_nox = in[(size_t)2 * T + n] - nox_ref, delta_co = in[(size_t)3 * T + n] - co_ref;
-        const double delta_nmvoc = in[(size_t)4 * T + n] - nmvoc_ref;
+        const double emissions = in.at(0, n), temperature = in.at(1, n);
+        const double delta_nox = in.at(2, n) - nox_ref, delta_co = in.at(3, n) - co_ref;
+        const double delta_nmvoc = in.at(4, n) - nmvoc_ref;
         const double total_emissions = emissions + natural;
         const double burden_prev = prev * ppb_to_tg;
         double base = tau_oh0;
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
     }
 }
 
-template <bool HAS_SCEN>
+template <int SRC>
 __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -94,12 +93,11 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
     int64_t delay = (int64_t)P(4);
     if (delay < 1) delay = 1;  // strat_delay.max(1)
     const double burden_reference = n2o_pi * ppb_to_tg;
-    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * T;
+    const MemberInputs<SRC, 1> in(a.inputs, a.scen, a.links, T, N, i);
     auto C = [&](int64_t k) -> double { return a.conc[(size_t)k * N + i]; };
     a.status[i] = 0;
     double cur = C(a.step_begin);
     double prev = a.step_begin > 0 ? C(a.step_begin - 1) : cur;
-    if (a.step_begin == 0) a.lifetime[i] = __builtin_nan("");
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
         // n2o.rs:203-218: at_offset(-delay) else previous; at_offset(-(delay+1)) else the former
@@ -108,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
         double t_delay_m1 = t_delay;
         if ((int64_t)n - delay - 1 >= 0) t_delay_m1 = C((int64_t)n - delay - 1);
         const double lagged = (t_delay + t_delay_m1) / 2.0;
-        const double total_emissions = in[n] + natural;
+        const double total_emissions = in.at(0, n) + natural;
         const double burden_prev = prev * ppb_to_tg, burden_lagged = lagged * ppb_to_tg;
         double burden = cur * ppb_to_tg, tau_eff = tau0;
 #pragma unroll
@@ -135,11 +133,9 @@ hipError_t launch_chem(const ChemArgs& a, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     if (a.kind == 7) {
-        if (a.scen) hipLaunchKernelGGL((ch4_kernel<true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((ch4_kernel<false>), grid, dim3(kBlock), 0, s, a);
+        RSCM_LAUNCH_BY_SOURCE(ch4_kernel, a, grid, dim3(kBlock), s, a);
     } else if (a.kind == 8) {
-        if (a.scen) hipLaunchKernelGGL((n2o_kernel<true>), grid, dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((n2o_kernel<false>), grid, dim3(kBlock), 0, s, a);
+        RSCM_LAUNCH_BY_SOURCE(n2o_kernel, a, grid, dim3(kBlock), s, a);
     } else {
         return hipErrorInvalidValue;
     }

@@ -5,7 +5,7 @@
 //   GhgForcing::solve / calculate_forcings     crates/rscm-magicc/src/forcing/ghg.rs:272-345
 //   IPCCTAR (Myhre et al. 1998) and OLBL forms  forcing/ghg.rs:119-269
 // under the stepper conventions of crates/rscm-core/src/model/runtime.rs: the concentrations are
-// exogenous (index n), the three ERFs land at index n+1, index 0 stays NaN.
+// exogenous (index n), the three ERFs land at index n+1; index 0 keeps what rscm_ens_set_initial put there (NaN otherwise, builder.rs:772-790).
 //
 // A stateless pointwise component: the concentrations are shared by every member of a scenario,
 // only the 21 parameters are per member.  Everything that depends on the concentrations alone --
@@ -30,7 +30,11 @@ __device__ __forceinline__ double overlap_split(double m75, double n75, double m
     return 0.47 * log(1.0 + 2.01e-5 * (m75 * n75) + 5.31e-15 * (m_m152 * n152));
 }
 
-template <int METHOD, bool HAS_SCEN>
+// LINKED: concentrations come per member from other ensembles' series (rscm_ens_link_input) mixed
+// with rows of the raw scenario block, and the table rows are evaluated on the fly with the device
+// math library -- the same factorisation, so both paths agree to the last-place error of sqrt /
+// log / pow.
+template <int METHOD, bool HAS_SCEN, bool LINKED>
 __global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a, const double* __restrict__ tables)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -45,7 +49,12 @@ __global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a, const double* __
     // read-only __restrict__ kernel argument: without a scenario map the row addresses are
     // wave-uniform and become scalar loads
     const double* __restrict__ tab = tables + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * kGhgRows * T;
-    auto row = [&](int r, int32_t n) -> double { return tab[(size_t)r * T + n]; };
+    const MemberInputs<LINKED ? 2 : 0, 3> conc(a.conc, a.scen, a.links, T, N, i);
+    double live[kGhgRows];  // LINKED: this year's rows
+    auto row = [&](int r, int32_t n) -> double {
+        if constexpr (LINKED) return live[r];
+        else return tab[(size_t)r * T + n];
+    };
 
     // member constants
     double alpha_tar = 0.0, radeff_m = 0.0, radeff_n = 0.0, n0_75 = 0.0, n0_152 = 0.0, m0_75 = 0.0, m0_m152 = 0.0, ovl00 = 0.0;
@@ -68,12 +77,22 @@ __global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a, const double* __
         alpha_sat = -b1 * b1 / (4.0 * a1) + d1;
     }
     a.status[i] = 0;
-    if (a.step_begin == 0 && a.rows > 1) {  // index 0 is nobody's output
-        const double nan = __builtin_nan("");
-        a.erf_co2[i] = nan; a.erf_ch4[i] = nan; a.erf_n2o[i] = nan;
-    }
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         double f_co2, f_ch4, f_n2o;
+        if constexpr (LINKED) {
+            const double c = conc.at(0, n), m = conc.at(1, n), nn = conc.at(2, n);
+            live[kGhgCo2] = c;
+            live[kGhgLnCo2] = log(c);
+            live[kGhgSqrtCo2] = sqrt(c);
+            live[kGhgSqrtCh4] = sqrt(m);
+            live[kGhgSqrtN2o] = sqrt(nn);
+            if (METHOD == 0) {
+                live[kGhgCh4P75] = pow(m, 0.75);
+                live[kGhgCh4TimesP152] = m * pow(m, 1.52);
+                live[kGhgN2oP75] = pow(nn, 0.75);
+                live[kGhgN2oP152] = pow(nn, 1.52);
+            }
+        }
         const double ln_ratio = row(kGhgLnCo2, n) - ln_c0;
         const double sq_m = row(kGhgSqrtCh4, n), sq_n = row(kGhgSqrtN2o, n);
         if (METHOD == 0) {
@@ -108,12 +127,15 @@ hipError_t launch_ghg(const GhgArgs& a, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     const bool scen = a.scen != nullptr;
-    if (a.method == 0) {
-        if (scen) hipLaunchKernelGGL((ghg_kernel<0, true>), grid, dim3(kBlock), 0, s, a, a.tables);
-        else hipLaunchKernelGGL((ghg_kernel<0, false>), grid, dim3(kBlock), 0, s, a, a.tables);
+    if (a.linked) {
+        if (a.method == 0) hipLaunchKernelGGL((ghg_kernel<0, false, true>), grid, dim3(kBlock), 0, s, a, a.tables);
+        else hipLaunchKernelGGL((ghg_kernel<1, false, true>), grid, dim3(kBlock), 0, s, a, a.tables);
+    } else if (a.method == 0) {
+        if (scen) hipLaunchKernelGGL((ghg_kernel<0, true, false>), grid, dim3(kBlock), 0, s, a, a.tables);
+        else hipLaunchKernelGGL((ghg_kernel<0, false, false>), grid, dim3(kBlock), 0, s, a, a.tables);
     } else {
-        if (scen) hipLaunchKernelGGL((ghg_kernel<1, true>), grid, dim3(kBlock), 0, s, a, a.tables);
-        else hipLaunchKernelGGL((ghg_kernel<1, false>), grid, dim3(kBlock), 0, s, a, a.tables);
+        if (scen) hipLaunchKernelGGL((ghg_kernel<1, true, false>), grid, dim3(kBlock), 0, s, a, a.tables);
+        else hipLaunchKernelGGL((ghg_kernel<1, false, false>), grid, dim3(kBlock), 0, s, a, a.tables);
     }
     return hipGetLastError();
 }

@@ -62,8 +62,8 @@ __device__ __forceinline__ double mac(double acc, double f, double r)
 
 // YEARS consecutive model steps starting at n: one pass over the old pulses feeds the
 // STEPS*YEARS running sums of all their sub-steps.
-template <int STEPS, int YEARS, bool FUSED>
-__device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember& m, const double* __restrict__ in,
+template <int STEPS, int YEARS, bool FUSED, class Inputs>
+__device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember& m, const Inputs& in,
                                            const double* __restrict__ irf, double* __restrict__ hist, int64_t i, int32_t n)
 {
     constexpr int K = STEPS * YEARS;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     double pco2 = a.series[r0], cumulative = a.series[vs + r0];
 #pragma unroll
     for (int y = 0; y < YEARS; ++y) {
-        const double co2 = in[n + y], delta_sst = in[(size_t)T + n + y];
+        const double co2 = in.at(0, n + y), delta_sst = in.at(1, n + y);
         const double dt = a.bounds[n + y + 1] - a.bounds[n + y];
         const double dt_month = dt / (double)STEPS;
         const double temp_factor = m.temp_on ? exp(m.temp_sens * delta_sst) : 1.0;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     }
 }
 
-template <int STEPS, bool HAS_SCEN, bool FUSED>
+template <int STEPS, int SRC, bool FUSED>
 __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double* __restrict__ irf_table)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -160,11 +160,10 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
 #pragma unroll
     for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
     m.temp_on = P(23) != 0.0;
-    const double* __restrict__ in = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * 2 * T;
+    const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
     const double* __restrict__ irf = irf_table;  // [H], wave-uniform indices: a read-only kernel argument -> scalar loads
     double* __restrict__ hist = a.hist + i;   // [months][N]
     a.status[i] = 0;
-    if (a.step_begin == 0) a.series[2 * (size_t)T * N + i] = __builtin_nan("");
     int32_t n = a.step_begin;
     // two model steps per pass over the history while two remain: half the HBM traffic, the same
     // sums in the same order
@@ -179,13 +178,11 @@ hipError_t launch_ocean(const OceanArgs& a, hipStream_t s)
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     if (a.steps != 12) return hipErrorInvalidValue;  // the sub-step loop is unrolled for monthly steps
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    if (a.fused) {
-        if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true, true>), grid, dim3(kBlock), 0, s, a, a.irf);
-        else hipLaunchKernelGGL((ocean_kernel<12, false, true>), grid, dim3(kBlock), 0, s, a, a.irf);
-    } else {
-        if (a.scen) hipLaunchKernelGGL((ocean_kernel<12, true, false>), grid, dim3(kBlock), 0, s, a, a.irf);
-        else hipLaunchKernelGGL((ocean_kernel<12, false, false>), grid, dim3(kBlock), 0, s, a, a.irf);
-    }
+    const int src = a.linked ? 2 : a.scen ? 1 : 0;
+    void (*kern)(OceanArgs, const double*) =
+        a.fused ? (src == 2 ? ocean_kernel<12, 2, true> : src == 1 ? ocean_kernel<12, 1, true> : ocean_kernel<12, 0, true>)
+                : (src == 2 ? ocean_kernel<12, 2, false> : src == 1 ? ocean_kernel<12, 1, false> : ocean_kernel<12, 0, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, a, a.irf);
     return hipGetLastError();
 }
 

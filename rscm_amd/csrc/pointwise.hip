@@ -9,7 +9,7 @@
 //   FourBoxOceanHeatUptake::solve                 crates/rscm-components/src/components/four_box_ocean_heat_uptake.rs:85-112
 //   OceanSurfacePartialPressure::solve            crates/rscm-components/src/components/ocean_carbon_cycle/ocean_surface_partial_pressure.rs:57-122
 // under the stepper conventions of crates/rscm-core/src/model/runtime.rs: inputs are exogenous
-// series shared per scenario (index n), outputs land at index n+1, index 0 stays NaN.
+// series shared per scenario (index n), outputs land at index n+1; index 0 keeps what rscm_ens_set_initial put there (NaN otherwise, builder.rs:772-790).
 //
 // The expressions are the reference's, operation for operation (no contraction: the build uses
 // -ffp-contract=off); pow and log come from the device math library, so agreement with the CPU
@@ -36,6 +36,12 @@ template <>
 struct Shape<13> { static constexpr int P = 4, NI = 1, NO = 4; };
 template <>
 struct Shape<14> { static constexpr int P = 13, NI = 2, NO = 1; };
+template <>
+struct Shape<16> { static constexpr int P = 2, NI = 1, NO = 1; };   // CO2ERF
+template <>
+struct Shape<17> { static constexpr int P = 9, NI = 8, NO = 1; };   // schema aggregate
+
+constexpr double kLn2 = 0.693147180559945309417;  // 2.0_f64.ln()
 
 // forcing/ozone.rs:99-164; in = {EESC, CH4, NOx, CO, NMVOC, temperature}
 __device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[6], double (&out)[3])
@@ -100,7 +106,32 @@ __device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[2
     out[0] = (p[0] + delta) * exp(p[1] * in[0]);
 }
 
-template <int KIND, bool HAS_SCEN>
+// co2_erf.rs:57-60; p = {erf_2xco2, conc_pi}; in = {Atmospheric Concentration|CO2}
+__device__ __forceinline__ void eval(const double (&p)[2], const double (&in)[1], double (&out)[1])
+{
+    out[0] = (p[0] / kLn2) * log(1.0 + (in[0] - p[1]) / p[1]);
+}
+
+// compute_aggregate, schema.rs:760-802; p = {operation (0 Sum, 1 Mean, 2 Weighted), weights[8]};
+// in = up to eight contributors.  NaN contributors are skipped and all-NaN gives NaN, so an unused
+// row is simply a NaN row (the input block of this kind starts out as all NaN).
+__device__ __forceinline__ void eval(const double (&p)[9], const double (&in)[8], double (&out)[1])
+{
+    const int op = (int)p[0];
+    double s = 0.0;
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (in[j] == in[j]) {
+            s = s + (op == 2 ? in[j] * p[1 + j] : in[j]);
+            ++n;
+        }
+    }
+    if (op == 1) s = s / (double)n;
+    out[0] = n ? s : __builtin_nan("");
+}
+
+template <int KIND, int SRC>
 __global__ __launch_bounds__(kBlock) void pointwise_kernel(PointwiseArgs a)
 {
     using S = Shape<KIND>;
@@ -111,17 +142,13 @@ __global__ __launch_bounds__(kBlock) void pointwise_kernel(PointwiseArgs a)
     double p[S::P];
 #pragma unroll
     for (int j = 0; j < S::P; ++j) p[j] = a.params[(size_t)j * N + i];
-    const double* __restrict__ in_base = a.inputs + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * S::NI * T;
+    const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
     a.status[i] = 0;
-    if (a.step_begin == 0 && a.rows > 1) {  // index 0 is nobody's output
-#pragma unroll
-        for (int o = 0; o < S::NO; ++o) a.out[(size_t)o * var_stride + i] = __builtin_nan("");
-    }
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         double in[S::NI], out[S::NO];
 #pragma unroll
-        for (int k = 0; k < S::NI; ++k) in[k] = in_base[(size_t)k * T + n];
+        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, KIND == 17 ? n + 1 : n);  // AggregatorComponent reads at_end() (schema.rs:886-901)
         eval(p, in, out);
         const size_t r = (a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i;
 #pragma unroll
@@ -133,8 +160,9 @@ template <int KIND>
 hipError_t launch_kind(const PointwiseArgs& a, hipStream_t s)
 {
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    if (a.scen) hipLaunchKernelGGL((pointwise_kernel<KIND, true>), grid, dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((pointwise_kernel<KIND, false>), grid, dim3(kBlock), 0, s, a);
+    if (a.linked) hipLaunchKernelGGL((pointwise_kernel<KIND, 2>), grid, dim3(kBlock), 0, s, a);
+    else if (a.scen) hipLaunchKernelGGL((pointwise_kernel<KIND, 1>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((pointwise_kernel<KIND, 0>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -149,6 +177,8 @@ hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s)
         case 6: return launch_kind<6>(a, s);
         case 13: return launch_kind<13>(a, s);
         case 14: return launch_kind<14>(a, s);
+        case 16: return launch_kind<16>(a, s);
+        case 17: return launch_kind<17>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

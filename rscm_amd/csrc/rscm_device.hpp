@@ -14,6 +14,63 @@ constexpr int kBlock = RSCM_BLOCK;           // 256 = 4 wavefronts of 64: one pe
 constexpr int kMaxStaticLds = 64 * 1024;     // above this the launcher raises the dynamic limit
 constexpr int kMaxLds = 160 * 1024;          // CDNA4: 160 KiB per CU
 
+// Linked inputs (rscm_ens_link_input): input row k of a member is read from the stored series of
+// another ensemble of the same shape -- row[k] is that series, [T][N], off[k] the index offset of
+// the reference's VariableSource (0: Exogenous / OwnState -> index n, 1: UpstreamOutput -> n+1).
+// A null row[k] leaves row k with the scenario table.  Passed by value: the kernels read it from
+// the kernarg segment with scalar loads.
+constexpr int kMaxLinks = 8;
+struct InputLinks {
+    const double* row[kMaxLinks];
+    int32_t off[kMaxLinks];
+};
+
+#ifdef __HIPCC__
+// The NI input rows of member i.  SRC 0: one shared table [NI][T]; 1: per-member scenario of a
+// table [S][NI][T]; 2: linked rows (coalesced [T][N] reads) mixed with table rows.  SRC < 2
+// compiles to the plain table indexing the kernels had before links existed.
+template <int SRC, int NI>
+struct MemberInputs {
+    const double* base;
+    int32_t T;
+    const double* p[SRC == 2 ? NI : 1];
+    size_t stride[SRC == 2 ? NI : 1];
+    __device__ __forceinline__ MemberInputs(const double* table, const int32_t* scen, const InputLinks& links,
+                                            int32_t n_times, int64_t N, int64_t i)
+        : T(n_times)
+    {
+        static_assert(SRC != 2 || NI <= kMaxLinks, "more input rows than InputLinks holds");
+        const size_t s = SRC == 0 ? (size_t)0 : (scen ? (size_t)scen[i] : (size_t)0);
+        base = table + s * NI * n_times;
+        if constexpr (SRC == 2) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                if (links.row[k]) {
+                    p[k] = links.row[k] + (size_t)links.off[k] * N + i;
+                    stride[k] = (size_t)N;
+                } else {
+                    p[k] = base + (size_t)k * n_times;
+                    stride[k] = 1;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ double at(int k, int32_t n) const
+    {
+        if constexpr (SRC == 2) return p[k][(size_t)n * stride[k]];
+        else return base[(size_t)k * T + n];
+    }
+};
+
+// kernel<0> / kernel<1> / kernel<2> by where the inputs come from
+#define RSCM_LAUNCH_BY_SOURCE(KERNEL, args, grid, block, stream, ...)                                        \
+    do {                                                                                                     \
+        if ((args).linked) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, stream, __VA_ARGS__);             \
+        else if ((args).scen) hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, stream, __VA_ARGS__);          \
+        else hipLaunchKernelGGL((KERNEL<0>), grid, block, 0, stream, __VA_ARGS__);                           \
+    } while (0)
+#endif
+
 // Stand-alone two-layer run over steps [step_begin, step_end).
 struct TwoLayerArgs {
     int64_t n_members;
@@ -24,6 +81,7 @@ struct TwoLayerArgs {
     int32_t lds_forcing;     // 1: forcing slice staged in LDS, 0: read through L2
     const double* params;    // [6][N]
     const double* forcing;   // [S][T]
+    const double* link;      // [T][N] linked forcing (InputLinks, one row) or nullptr
     const int32_t* scen;     // [N] or nullptr
     const int32_t* nsub;     // [T-1] RK4 sub-steps of step n = ceil((b[n+1]-b[n])/h)
     double h;                // RK4 step (reference: 0.1)
@@ -74,6 +132,7 @@ struct UdebArgs {
     const double* params;   // [37][N], ClimateUDEBParameters order (include/rscm_gpu.h)
     const double* erf;      // [S][T]
     const int32_t* scen;    // [N] or nullptr
+    const double* link;     // [T][N] linked forcing or nullptr
     const double* bounds;   // [T+1] (device)
     const int32_t* win_kfull;  // [T] first history entry that enters the cumulative-T window whole
     const double* win_partw;   // [T] weight of entry win_kfull-1 (0: not in the window)
@@ -105,6 +164,9 @@ struct GhgArgs {
     const double* params;    // [21][N]
     const double* tables;    // [S][kGhgRows][T]
     const int32_t* scen;     // [N] or null
+    const double* conc;      // [S][3][T] the concentrations themselves (linked launches)
+    InputLinks links;        // used when linked != 0: concentrations per member, no tables
+    int32_t linked;
     double* erf_co2; double* erf_ch4; double* erf_n2o;  // [T][N] each
     uint8_t* status;
 };
@@ -115,10 +177,12 @@ struct PointwiseArgs {
     int32_t n_times;
     int32_t step_begin, step_end;
     int32_t rows;            // stored rows per series (T)
-    int32_t kind;            // RSCM_KIND_OZONE_FORCING / _AEROSOL_DIRECT / _AEROSOL_INDIRECT
+    int32_t kind;            // RSCM_KIND_OZONE_FORCING / _AEROSOL_DIRECT / _AEROSOL_INDIRECT / ...
     const double* params;    // [P][N]
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
+    InputLinks links;        // used when linked != 0
+    int32_t linked;
     double* out;             // [n_outputs][rows][N]
     uint8_t* status;
 };
@@ -132,6 +196,8 @@ struct ChemArgs {
     const double* params;    // [P][N]
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
+    InputLinks links;        // used when linked != 0
+    int32_t linked;
     const double* bounds;    // [T+1]
     double* conc;            // [T][N] state, row 0 = initial value
     double* lifetime;        // [T][N]
@@ -147,7 +213,11 @@ struct CarbonArgs {
     const double* params;    // [P][N]
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
+    InputLinks links;        // used when linked != 0
+    int32_t linked;
     const double* bounds;    // [T+1]
+    const int32_t* nsub;     // CarbonCycle: [T-1] RK4 sub-steps per model step
+    double h;                // CarbonCycle: RK4 step
     double* series;          // [n_states + n_outputs][T][N], states first
     uint8_t* status;
 };
@@ -163,6 +233,8 @@ struct OceanArgs {
     const double* params;    // [24][N]
     const double* inputs;    // [S][2][T]: CO2, SST anomaly
     const int32_t* scen;     // [N] or null
+    InputLinks links;        // used when linked != 0
+    int32_t linked;
     const double* bounds;    // [T+1]
     const double* irf;       // [max(max_hist, 1)] scaled impulse response at lag k/12 yr
     double* hist;            // [(T-1)*steps][N] flux history, ppm/month

@@ -198,6 +198,12 @@ struct rscm_ens {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 
+    // linked inputs (rscm_ens_link_input)
+    struct Link { rscm_ens* src = nullptr; int32_t var = 0; int32_t off = 0; };
+    Link links[rscm::kMaxLinks];
+    int32_t n_linked = 0;
+    int32_t link_refs = 0;  // links of other ensembles into this one's series
+
     int32_t time_index = 0;
     bool params_set = false, forcing_set = false;
     std::vector<uint8_t> initial_set;  // per variable id
@@ -212,6 +218,7 @@ struct rscm_ens {
         if (kind == RSCM_KIND_TERRESTRIAL_CARBON) return var >= 1 && var <= 4;
         if (kind == RSCM_KIND_OCEAN_CARBON) return var == 1 || var == 2;
         if (kind == RSCM_KIND_HALOCARBON) return var >= 1 && var <= RSCM_HC_NSPECIES;
+        if (kind == RSCM_KIND_CARBON_CYCLE) return var >= 1 && var <= 3;
         if (kind >= RSCM_KIND_GHG_FORCING) return false;  // stateless components
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
@@ -228,19 +235,21 @@ int set_device(const rscm_ens* h)
 int refresh_schedule(rscm_ens* h)
 {
     if (!h->schedule_dirty) return RSCM_OK;
-    if (h->kind != RSCM_KIND_TWO_LAYER && h->kind != RSCM_KIND_COUPLED) {  // no RK4 component
+    if (h->kind != RSCM_KIND_TWO_LAYER && h->kind != RSCM_KIND_COUPLED && h->kind != RSCM_KIND_CARBON_CYCLE) {  // no RK4 component
         h->schedule_dirty = false;
         return RSCM_OK;
     }
     int32_t bad = -1;
-    if (!rk4_schedule(h->bounds, h->h_tl, h->nsub_tl, &bad))
+    if (h->kind == RSCM_KIND_CARBON_CYCLE) {
+        h->nsub_tl.assign(h->bounds.size() - 2, 1);
+    } else if (!rk4_schedule(h->bounds, h->h_tl, h->nsub_tl, &bad))
         return fail(RSCM_ERR_TIME_AXIS,
                     "TwoLayer RK4 step %.17g does not land on the end of model step %d "
                     "([%.17g, %.17g]) within 5e-3 (the reference panics in get_last_step)",
                     h->h_tl, bad, h->bounds[bad], h->bounds[bad + 1]);
     HIPCHK(hipMemcpyAsync(h->d_nsub_tl, h->nsub_tl.data(), h->nsub_tl.size() * sizeof(int32_t),
                           hipMemcpyHostToDevice, h->stream));
-    if (h->kind == RSCM_KIND_COUPLED) {
+    if (h->kind == RSCM_KIND_COUPLED || h->kind == RSCM_KIND_CARBON_CYCLE) {
         if (!rk4_schedule(h->bounds, h->h_cc, h->nsub_cc, &bad))
             return fail(RSCM_ERR_TIME_AXIS,
                         "CarbonCycle RK4 step %.17g does not land on the end of model step %d "
@@ -403,7 +412,7 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_OSPP)
+    if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_AGGREGATE)
         return fail(RSCM_ERR_INVALID, "unknown kind %d", kind);
     if (n_members < 1) return fail(RSCM_ERR_INVALID, "n_members must be >= 1, got %lld", (long long)n_members);
     if (n_times < 2) return fail(RSCM_ERR_INVALID, "n_times must be >= 2 (TimeAxis::from_values asserts len >= 2)");
@@ -423,11 +432,13 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
                                  RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS, RSCM_CH4_NPARAMS,
                                  RSCM_N2O_NPARAMS, RSCM_CB_NPARAMS, RSCM_TC_NPARAMS, RSCM_OC_NPARAMS,
-                                 RSCM_HC_NPARAMS, RSCM_FB_NPARAMS, RSCM_SP_NPARAMS};
-    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4, RSCM_HC_NSPECIES + 5, 5, 2};  // variable ids incl. the input block 0
+                                 RSCM_HC_NPARAMS, RSCM_FB_NPARAMS, RSCM_SP_NPARAMS, RSCM_CC_NPARAMS,
+                                 RSCM_CE_NPARAMS, RSCM_AG_NPARAMS};
+    static const int32_t kV[] = {3, 8, 8, 4, 4, 5, 2, 3, 3, 4, 6, 4, RSCM_HC_NSPECIES + 5, 5, 2, 4, 2, 2};  // variable ids incl. the input block 0
     static const int32_t kInputs[] = {1, 1, 1, 3, RSCM_OZ_NINPUTS, RSCM_AD_NINPUTS, RSCM_AI_NINPUTS,
                                       RSCM_CH4_NINPUTS, RSCM_N2O_NINPUTS, RSCM_CB_NINPUTS, RSCM_TC_NINPUTS,
-                                      RSCM_OC_NINPUTS, RSCM_HC_NINPUTS, RSCM_FB_NINPUTS, RSCM_SP_NINPUTS};
+                                      RSCM_OC_NINPUTS, RSCM_HC_NINPUTS, RSCM_FB_NINPUTS, RSCM_SP_NINPUTS,
+                                      RSCM_CC_NINPUTS, RSCM_CE_NINPUTS, RSCM_AG_NINPUTS};
     h->P = kP[kind];
     h->V = kV[kind];
     h->n_inputs = kInputs[kind];
@@ -472,6 +483,12 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
         CK(hipMalloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
         CK(hipMemcpyAsync(h->d_bounds, h->bounds.data(), (size_t)(h->T + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
+    if (kind == RSCM_KIND_AGGREGATE) {  // contributors that are neither linked nor set stay NaN = skipped
+        CK(hipMalloc(&h->d_forcing, (size_t)h->n_inputs * h->T * sizeof(double)));
+        CK(rscm::launch_fill(h->d_forcing, (int64_t)h->n_inputs * h->T, std::numeric_limits<double>::quiet_NaN(), h->stream));
+        h->n_scen = 1;
+        h->forcing_set = true;
+    }
     CK(hipMemsetAsync(h->d_status, 0, (size_t)h->N, h->stream));
     // never-written entries are NaN (builder.rs:772-780)
     CK(rscm::launch_fill(h->d_series, (int64_t)series_elems, std::numeric_limits<double>::quiet_NaN(),
@@ -486,6 +503,13 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
 int rscm_ens_destroy(rscm_ens* h)
 {
     if (!h) return RSCM_OK;
+    if (h->link_refs > 0)
+        return fail(RSCM_ERR_STATE, "%d linked input(s) of other ensembles still read this one's series: destroy or unlink them first", h->link_refs);
+    for (auto& l : h->links)
+        if (l.src) {
+            --l.src->link_refs;
+            l.src = nullptr;
+        }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_params);
@@ -538,14 +562,37 @@ int rscm_ens_set_step_size(rscm_ens* h, int32_t component, double step)
 {
     NEED(h);
     if (!(step > 0.0) || !std::isfinite(step)) return fail(RSCM_ERR_INVALID, "step must be positive and finite");
-    if (component == RSCM_COMP_TWO_LAYER)
+    if (component == RSCM_COMP_TWO_LAYER && h->kind != RSCM_KIND_CARBON_CYCLE)
         h->h_tl = step;
-    else if (component == RSCM_COMP_CARBON_CYCLE && h->kind == RSCM_KIND_COUPLED)
+    else if (component == RSCM_COMP_CARBON_CYCLE && (h->kind == RSCM_KIND_COUPLED || h->kind == RSCM_KIND_CARBON_CYCLE))
         h->h_cc = step;
     else
         return fail(RSCM_ERR_INVALID, "component %d not part of this model kind", component);
     h->schedule_dirty = true;
     return RSCM_OK;
+}
+
+int rscm_gpu_stream_create(int32_t device_id, void** out_stream)
+{
+    GUARD_BEGIN
+    if (!out_stream) return fail(RSCM_ERR_INVALID, "out_stream is NULL");
+    HIPCHK(hipSetDevice(device_id));
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = (void*)s;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_gpu_stream_destroy(int32_t device_id, void* hip_stream)
+{
+    GUARD_BEGIN
+    if (!hip_stream) return RSCM_OK;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+    HIPCHK(hipStreamDestroy((hipStream_t)hip_stream));
+    return RSCM_OK;
+    GUARD_END
 }
 
 int rscm_ens_set_stream(rscm_ens* h, void* hip_stream)
@@ -657,6 +704,48 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
     GUARD_END
 }
 
+int rscm_ens_link_input(rscm_ens* h, int32_t input_row, rscm_ens* src, int32_t src_var, int32_t source)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!src) return fail(RSCM_ERR_INVALID, "source ensemble is NULL");
+    if (src == h) return fail(RSCM_ERR_INVALID, "an ensemble cannot link to itself (its own states are read in the kernel)");
+    if (h->kind == RSCM_KIND_COUPLED || h->kind == RSCM_KIND_HALOCARBON)
+        return fail(RSCM_ERR_INVALID, "the inputs of this kind cannot be linked (they are exogenous emissions)");
+    if (input_row < 0 || input_row >= h->n_inputs || input_row >= rscm::kMaxLinks)
+        return fail(RSCM_ERR_INVALID, "input row %d out of range [0, %d)", input_row, h->n_inputs);
+    if (src_var < 1 || src_var >= src->V) return fail(RSCM_ERR_INVALID, "variable %d of the source has no stored series", src_var);
+    if (source != RSCM_SRC_EXOGENOUS && source != RSCM_SRC_UPSTREAM) return fail(RSCM_ERR_INVALID, "unknown source %d", source);
+    if (src->N != h->N || src->T != h->T || src->device != h->device)
+        return fail(RSCM_ERR_INVALID, "linked ensembles need the same members, time points and device (%lld x %d on %d vs %lld x %d on %d)",
+                    (long long)src->N, src->T, src->device, (long long)h->N, h->T, h->device);
+    if (src->rows != src->T || h->rows != h->T)
+        return fail(RSCM_ERR_INVALID, "linked ensembles must store their series (no RSCM_FLAG_NO_SERIES)");
+    auto& l = h->links[input_row];
+    if (l.src) --l.src->link_refs;
+    else ++h->n_linked;
+    l.src = src;
+    l.var = src_var;
+    l.off = source == RSCM_SRC_UPSTREAM ? 1 : 0;
+    ++src->link_refs;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_unlink_input(rscm_ens* h, int32_t input_row)
+{
+    NEED(h);
+    if (input_row < 0 || input_row >= h->n_inputs || input_row >= rscm::kMaxLinks)
+        return fail(RSCM_ERR_INVALID, "input row %d out of range [0, %d)", input_row, h->n_inputs);
+    auto& l = h->links[input_row];
+    if (l.src) {
+        --l.src->link_refs;
+        --h->n_linked;
+        l = rscm_ens::Link{};
+    }
+    return RSCM_OK;
+}
+
 int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int64_t n_values)
 {
     GUARD_BEGIN
@@ -731,10 +820,27 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
     if (h->rows != h->T && step_end > step_begin)
         return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES): use rscm_ens_run_loglik");
     if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
-    if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
+    if (!h->forcing_set && h->n_linked < h->n_inputs) return fail(RSCM_ERR_STATE, "shared input series not set");
     for (int32_t v = 1; v < h->V; ++v)
         if (h->is_state(v) && !h->initial_set[v])  // builder.rs:704-717 MissingInitialValue
             return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
+    // linked inputs: the producing ensembles' series, in launch order on one stream
+    rscm::InputLinks links{};
+    const int32_t linked = h->n_linked > 0 ? 1 : 0;
+    for (int32_t k = 0; k < rscm::kMaxLinks && k < h->n_inputs; ++k) {
+        const auto& l = h->links[k];
+        if (!l.src) continue;
+        if (l.src->stream != h->stream)
+            return fail(RSCM_ERR_STATE, "input row %d is linked to an ensemble on another stream (rscm_ens_set_stream both to the same one)", k);
+        // ClimateUDEB reads at_start / at_end, the aggregate at_end: index n+1 whatever `source` said
+        const bool reads_end = h->kind == RSCM_KIND_UDEB || h->kind == RSCM_KIND_AGGREGATE;
+        const int32_t need = step_end - 1 + (reads_end ? 1 : l.off);
+        if (step_end > step_begin && l.src->time_index < need)
+            return fail(RSCM_ERR_STATE, "input row %d reads index %d of its source, which has only been stepped to %d", k, need,
+                        l.src->time_index);
+        links.row[k] = l.src->series(l.var);
+        links.off[k] = h->kind == RSCM_KIND_AGGREGATE ? 0 : l.off;
+    }
     if (int rc = set_device(h)) return rc;
     if (int rc = refresh_schedule(h)) return rc;
 
@@ -752,7 +858,13 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
         a.params = h->d_params;
         a.forcing = h->d_forcing;
-        a.scen = h->d_scen;
+        if (linked) {
+            a.link = links.row[0];
+            a.src_off = links.off[0];
+            a.lds_forcing = 0;
+            a.n_scen = 1;
+        }
+        a.scen = linked ? nullptr : h->d_scen;
         a.nsub = h->d_nsub_tl;
         a.h = h->h_tl;
         a.ts = h->series(RSCM_TL_VAR_TS);
@@ -770,6 +882,9 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.params = h->d_params;
         a.tables = h->d_ghg_tables;
         a.scen = h->d_scen;
+        a.conc = h->d_forcing;
+        a.links = links;
+        a.linked = linked;
         a.erf_co2 = h->series(RSCM_GH_VAR_ERF_CO2);
         a.erf_ch4 = h->series(RSCM_GH_VAR_ERF_CH4);
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
@@ -802,12 +917,14 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
+        a.links = links;
+        a.linked = linked;
         a.irf = h->d_ocean_irf;
         a.hist = h->d_ocean_hist;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ocean(a, h->stream));
-    } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON) {
+    } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON || h->kind == RSCM_KIND_CARBON_CYCLE) {
         rscm::CarbonArgs a{};
         a.n_members = h->N;
         a.n_times = h->T;
@@ -817,7 +934,11 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.params = h->d_params;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
+        a.links = links;
+        a.linked = linked;
         a.bounds = h->d_bounds;
+        a.nsub = h->d_nsub_cc;
+        a.h = h->h_cc;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_carbon(a, h->stream));
@@ -832,12 +953,15 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
+        a.links = links;
+        a.linked = linked;
         a.conc = h->series(RSCM_CHEM_VAR_CONC);
         a.lifetime = h->series(RSCM_CHEM_VAR_LIFETIME);
         a.status = h->d_status;
         HIPCHK(rscm::launch_chem(a, h->stream));
     } else if ((h->kind >= RSCM_KIND_OZONE_FORCING && h->kind <= RSCM_KIND_AEROSOL_INDIRECT) ||
-               h->kind == RSCM_KIND_FOURBOX_OHU || h->kind == RSCM_KIND_OSPP) {
+               h->kind == RSCM_KIND_FOURBOX_OHU || h->kind == RSCM_KIND_OSPP || h->kind == RSCM_KIND_CO2_ERF ||
+               h->kind == RSCM_KIND_AGGREGATE) {
         rscm::PointwiseArgs a{};
         a.n_members = h->N;
         a.n_times = h->T;
@@ -848,6 +972,8 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.params = h->d_params;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
+        a.links = links;
+        a.linked = linked;
         a.out = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_pointwise(a, h->stream));
@@ -865,7 +991,8 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.efficacy_apply = h->udeb_efficacy;
         a.params = h->d_params;
         a.erf = h->d_forcing;
-        a.scen = h->d_scen;
+        a.link = linked ? links.row[0] : nullptr;
+        a.scen = linked ? nullptr : h->d_scen;
         a.bounds = h->d_bounds;
         a.win_kfull = h->d_win_kfull;
         a.win_partw = h->d_win_partw;
@@ -1122,6 +1249,7 @@ int check_loglik_ready(rscm_ens* h)
 {
     if (h->time_index != 0) return fail(RSCM_ERR_STATE, "run_loglik starts from time index 0 (call rscm_ens_rewind)");
     if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
+    if (h->n_linked) return fail(RSCM_ERR_STATE, "the fused run+likelihood launch takes no linked inputs: use rscm_ens_run and rscm_ens_loglik");
     if (!h->forcing_set) return fail(RSCM_ERR_STATE, "shared input series not set");
     for (int32_t v = 1; v < h->V; ++v)
         if (h->is_state(v) && !h->initial_set[v])

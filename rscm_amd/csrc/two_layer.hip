@@ -159,11 +159,14 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
     const double cs = a.params[4 * N + i];
     const double cd = a.params[5 * N + i];
     const int32_t scen = a.scen ? a.scen[i] : 0;
-    const double* fglob = a.forcing + (size_t)scen * a.n_times + a.src_off;
+    // a linked forcing (rscm_ens_link_input, always the non-LDS variant) is another ensemble's
+    // [T][N] series: coalesced, one stride of N per year
+    const double* fglob = a.link ? a.link + (size_t)a.src_off * N + i : a.forcing + (size_t)scen * a.n_times + a.src_off;
+    const size_t fstride = a.link ? (size_t)N : (size_t)1;
     const int32_t fl0 = scen * len - a.step_begin;  // lds_forcing[fl0 + n], n >= step_begin
     auto forcing_at = [&](int32_t n) -> double {
         if constexpr (LDS) return lds_forcing[fl0 + n];
-        else return fglob[n];
+        else return fglob[(size_t)n * fstride];
     };
 
     double ts = a.ts[(size_t)a.step_begin * N + i];

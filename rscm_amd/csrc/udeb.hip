@@ -434,7 +434,9 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         }
     }
     const int32_t scen = a.scen ? a.scen[i] : 0;
-    const double* F = a.erf + (size_t)scen * a.n_times;
+    // a linked forcing (rscm_ens_link_input) is another ensemble's [T][N] series
+    const double* F = a.link ? a.link + i : a.erf + (size_t)scen * a.n_times;
+    const size_t f_stride = a.link ? (size_t)N : (size_t)1;
     const double steps = (double)a.steps_per_year;
     const double c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
     const double c_mix = heat_capacity_per_unit_area(p.dz_mix);
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     const double* __restrict__ bounds = a.bounds;
 
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-        const double erf_start = F[n], erf_end = F[n + 1];
+        const double erf_start = F[(size_t)n * f_stride], erf_end = F[(size_t)(n + 1) * f_stride];
         const size_t r0 = (size_t)n * N + i, r1 = r0 + (size_t)N;
         // warm start (mod.rs:436-446)
         {

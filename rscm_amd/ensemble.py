@@ -50,8 +50,9 @@ class Ensemble:
     # -- lifecycle --------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.rscm_ens_destroy(self._h)
+            L.check(self._lib.rscm_ens_destroy(self._h))  # fails while other ensembles link to this one
             self._h = None
+            self._linked = {}
 
     def __del__(self):
         try:
@@ -113,9 +114,29 @@ class Ensemble:
         L.check(self._lib.rscm_ens_set_forcing(self._h, self._var(var), s.shape[0], L.dptr(s),
                                                L.iptr(sc), source))
 
+    def link_input(self, input_row, src: "Ensemble", src_var, source: int = L.SRC_EXOGENOUS) -> None:
+        """Read input row ``input_row`` (index or name) member by member from ``src``'s stored
+        series ``src_var`` instead of the scenario table: an edge of a component graph kept on the
+        device.  ``source`` is this consumer's VariableSource (``SRC_EXOGENOUS``: index n,
+        ``SRC_UPSTREAM``: n+1).  Both ensembles must share a stream; ``src`` must outlive the link."""
+        row = (self.input_rows.index(input_row) if self.input_rows else 0) if isinstance(input_row, str) else int(input_row)
+        L.check(self._lib.rscm_ens_link_input(self._h, row, src._h, src._var(src_var), source))
+        self._linked = getattr(self, "_linked", {})
+        self._linked[row] = src  # keeps the producer alive as long as this consumer
+
+    def unlink_input(self, input_row) -> None:
+        row = (self.input_rows.index(input_row) if self.input_rows else 0) if isinstance(input_row, str) else int(input_row)
+        L.check(self._lib.rscm_ens_unlink_input(self._h, row))
+        getattr(self, "_linked", {}).pop(row, None)
+
     def set_initial(self, var, values) -> None:
         v = np.atleast_1d(L.f64(values))
         L.check(self._lib.rscm_ens_set_initial(self._h, self._var(var), L.dptr(v), v.size))
+
+    def set_state(self, var, time_index: int, values) -> None:
+        """Overwrite row ``time_index`` of a stored series (1 value = broadcast, or one per member)."""
+        v = np.atleast_1d(L.f64(values))
+        L.check(self._lib.rscm_ens_set_state(self._h, self._var(var), int(time_index), L.dptr(v), v.size))
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
         L.check(self._lib.rscm_ens_set_stream(self._h, C.c_void_p(hip_stream)))
@@ -184,6 +205,8 @@ class Ensemble:
             return {k: v for k, v in self.var_ids.items() if v == 1}
         if self.kind == L.KIND_TERRESTRIAL_CARBON:
             return {k: v for k, v in self.var_ids.items() if 1 <= v <= 4}
+        if self.kind == L.KIND_CARBON_CYCLE:
+            return {k: v for k, v in self.var_ids.items() if 1 <= v <= 3}
         if self.kind >= L.KIND_GHG_FORCING:
             return {}  # stateless components
         return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}

@@ -1,0 +1,299 @@
+"""GPU tier (-m gpu): linked inputs (rscm_ens_link_input) -- component graphs assembled from
+ensembles whose inputs are other ensembles' device-resident series, stepped in graph order like
+Model::step (crates/rscm-core/src/model/runtime.rs:368-527).
+
+Parity bars:
+  * CarbonCycle -> CO2ERF -> Sum -> TwoLayer assembled from four linked ensembles and stepped in
+    lock-step: BIT-EXACT against the fused RSCM_KIND_COUPLED kernel (same arithmetic, same device
+    math library), which tests/test_gpu_parity.py holds against the CPU oracle.
+  * a linked row that carries the same numbers as a scenario-table row gives the same bits as
+    the table (two-layer, CH4 chemistry, CO2 budget, ocean carbon, ClimateUDEB), and to the last-place
+    error of sqrt / log / pow (1e-13 relative) for GhgForcing, whose table rows are built with
+    the host's libm.
+  * aggregate kind: exact against numpy restatements of compute_aggregate (schema.rs:760-802).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import assert_bit_equal, axis_values, coupled_params, emissions_syn, f_syn, two_layer_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rscm_amd
+    from rscm_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1, "no HIP device visible"
+    return rscm_amd
+
+
+class Stream:
+    def __init__(self):
+        from rscm_amd import _lib as L
+        self.L, self.h = L, C.c_void_p()
+        L.check(L.load().rscm_gpu_stream_create(0, C.byref(self.h)))
+
+    def close(self):
+        self.L.check(self.L.load().rscm_gpu_stream_destroy(0, self.h))
+
+
+def _bounds(t):
+    return np.append(t, t[-1] + (t[-1] - t[-2]))
+
+
+def _coupled_graph(ra, t, P, E, stream):
+    """The notebook's graph (registration order CarbonCycle, CO2ERF, TwoLayer + Sum aggregate)."""
+    N, b = P.shape[1], _bounds(t)
+    cc = ra.Ensemble(ra.KIND_CARBON_CYCLE, N, b)
+    ce = ra.Ensemble(ra.KIND_CO2_ERF, N, b)
+    ag = ra.Ensemble(ra.KIND_AGGREGATE, N, b)
+    tl = ra.Ensemble(ra.KIND_TWO_LAYER, N, b)
+    for e in (cc, ce, ag, tl):
+        e.set_stream(stream.h.value)
+    cc.set_params(P[[6, 7, 8]])
+    ce.set_params(P[[9, 7]])
+    ag.set_params(np.zeros((9, N)))  # Sum
+    tl.set_params(P[:6])
+    cc.set_forcing(np.stack([E, np.full(len(t), np.nan)]))
+    for var, v in (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0),
+                   ("Cumulative Emissions|CO2", 0.0)):
+        cc.set_initial(var, v)
+    tl.set_initial("Surface Temperature", 0.0)
+    tl.set_initial("Deep Ocean Temperature", 0.0)
+    # CarbonCycle is registered before TwoLayer: it sees Ts as Exogenous (index n, lagged feedback)
+    cc.link_input("Surface Temperature", tl, "Surface Temperature", ra.SRC_EXOGENOUS)
+    ce.link_input(0, cc, "Atmospheric Concentration|CO2", ra.SRC_UPSTREAM)
+    ag.link_input(0, ce, "Effective Radiative Forcing|CO2", ra.SRC_UPSTREAM)
+    tl.link_input(0, ag, "aggregate", ra.SRC_UPSTREAM)
+    return cc, ce, ag, tl
+
+
+def test_linked_graph_reproduces_fused_coupled_chain(ra):
+    t = axis_values(1750, 2100)
+    N = 3000
+    P = coupled_params(N)
+    E = emissions_syn(t)
+    with ra.Ensemble(ra.KIND_COUPLED, N, _bounds(t)) as f:
+        f.set_params(P)
+        f.set_forcing(E)
+        for var, v in (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0),
+                       ("Cumulative Emissions|CO2", 0.0), ("Surface Temperature", 0.0),
+                       ("Deep Ocean Temperature", 0.0)):
+            f.set_initial(var, v)
+        f.run()
+        want = {k: f.get_series(k) for k in f.var_ids if f.var_ids[k] > 0}
+        want_status = f.status()
+    s = Stream()
+    cc, ce, ag, tl = _coupled_graph(ra, t, P, E, s)
+    try:
+        for n in range(len(t) - 1):  # Model::step: every component once, in graph order
+            for e in (cc, ce, ag, tl):
+                e.run(n + 1, sync=False)
+        tl.sync()
+        got = {"Surface Temperature": tl.get_series("Surface Temperature"),
+               "Deep Ocean Temperature": tl.get_series("Deep Ocean Temperature"),
+               "Atmospheric Concentration|CO2": cc.get_series(1), "Cumulative Land Uptake": cc.get_series(2),
+               "Cumulative Emissions|CO2": cc.get_series(3),
+               "Effective Radiative Forcing|CO2": ce.get_series(1), "Effective Radiative Forcing": ag.get_series(1)}
+        assert set(got) == set(want)
+        for k in want:
+            assert_bit_equal(got[k], want[k], k)
+        assert np.array_equal((cc.status() | tl.status()) != 0, want_status != 0)
+        # a producer cannot go while a consumer still reads it
+        with pytest.raises(Exception, match="linked input"):
+            ag.close()
+        # stepping out of graph order is caught: the aggregate has not produced index n+1 yet
+        for e in (cc, ce, ag, tl):
+            e.rewind()
+        cc.run(1)
+        ce.run(1)
+        with pytest.raises(Exception, match="only been stepped"):
+            tl.run(1)
+    finally:
+        # consumers first; the feedback edge CarbonCycle <- TwoLayer is cut by hand
+        cc.unlink_input("Surface Temperature")
+        for e in (tl, ag, ce, cc):
+            e.close()
+        s.close()
+
+
+def test_linked_row_equals_table_row(ra):
+    """Feed-forward: a producer run over the whole axis, then the consumer.  The linked row holds
+    the numbers the table held, so the consumer's results carry the same bits."""
+    t = axis_values(1750, 2050)
+    N, b = 2000, _bounds(t)
+    s = Stream()
+    rng = np.random.default_rng(5)
+    # producer: an aggregate that just passes one exogenous series through, shifted to index n+1
+    F = f_syn(t)
+    src = ra.Ensemble(ra.KIND_AGGREGATE, N, b)
+    src.set_stream(s.h.value)
+    src.set_params(np.zeros((9, N)))
+    blk = np.full((8, len(t)), np.nan)
+    blk[0] = F
+    src.set_forcing(blk)
+    src.run()
+    out = src.get_series("aggregate")
+    assert np.isnan(out[0]).all() and np.array_equal(out[1:], np.broadcast_to(F[1:, None], (len(t) - 1, N)))
+    P = two_layer_params(N)
+    res = {}
+    for mode in ("table", "linked"):
+        for src_kind in (ra.SRC_EXOGENOUS, ra.SRC_UPSTREAM):
+            with ra.Ensemble(ra.KIND_TWO_LAYER, N, b) as e:
+                e.set_stream(s.h.value)
+                e.set_params(P)
+                e.set_initial(1, 0.0)
+                e.set_initial(2, 0.0)
+                if mode == "table":
+                    # the producer's series: NaN at index 0, F afterwards
+                    e.set_forcing(np.concatenate([[np.nan], F[1:]]), None, src_kind)
+                else:
+                    e.link_input(0, src, "aggregate", src_kind)
+                e.run()
+                res[mode, src_kind] = e.get_series(1)
+    for k in (ra.SRC_EXOGENOUS, ra.SRC_UPSTREAM):
+        assert_bit_equal(res["linked", k], res["table", k], f"two-layer source {k}")
+    assert np.isnan(res["linked", ra.SRC_EXOGENOUS][1:]).all()      # F[0] = NaN poisons the exogenous reading
+    assert np.isfinite(res["linked", ra.SRC_UPSTREAM][1:, :10]).all()
+    src.close()
+    s.close()
+    del rng
+
+
+@pytest.mark.parametrize("kind_name", ["ch4", "co2_budget", "ocean", "udeb", "ghg_olbl", "ghg_ipcctar"])
+def test_linked_inputs_of_magicc_kinds(ra, kind_name):
+    """One input row per kind is produced on the device (an aggregate passing a per-member series
+    through) and linked; the same numbers in the scenario table give the reference result."""
+    from rscm_amd import _lib as L
+    from rscm_amd import magicc
+    t = axis_values(1850, 1950)
+    T, N, b = len(t), 512, _bounds(t)
+    s = Stream()
+    yrs = t - t[0]
+    if kind_name == "ch4":
+        kind, comp = ra.KIND_CH4_CHEMISTRY, magicc.CH4ChemistryBuilder.from_parameters({}).build()
+        block = np.stack([300.0 + 2.0 * yrs, 0.01 * yrs, 40.0 + 0.1 * yrs, 500.0 + yrs, 100.0 + 0.5 * yrs])
+        row, init = 1, {"Atmospheric Concentration|CH4": 800.0}
+    elif kind_name == "co2_budget":
+        kind, comp = ra.KIND_CO2_BUDGET, magicc.CO2BudgetBuilder.from_parameters({}).build()
+        block = np.stack([0.05 * yrs, 1.0 + 0.0 * yrs, 0.01 * yrs, 0.02 * yrs])
+        row, init = 2, {"Atmospheric Concentration|CO2": 280.0}
+    elif kind_name == "ocean":
+        kind, comp = ra.KIND_OCEAN_CARBON, magicc.OceanCarbonBuilder.from_parameters({}).build()
+        block = np.stack([280.0 + 0.8 * yrs, 0.005 * yrs])
+        row, init = 0, {"Ocean Surface pCO2": 280.0, "Cumulative Ocean Uptake": 0.0}
+    elif kind_name == "udeb":
+        kind, comp = ra.KIND_UDEB, magicc.ClimateUDEBBuilder.from_parameters({}).build()
+        block = (3.0 * (1.0 - np.exp(-yrs / 40.0)))[None]
+        row, init = 0, {}
+    else:
+        method = "Olbl" if kind_name == "ghg_olbl" else "Ipcctar"
+        kind, comp = ra.KIND_GHG_FORCING, magicc.GhgForcingBuilder.from_parameters({"method": method}).build()
+        block = np.stack([278.0 + 1.5 * yrs, 722.0 + 9.0 * yrs, 270.0 + 0.5 * yrs])
+        row, init = 1, {}
+    params = np.repeat(np.asarray(comp.param_vector(), dtype=np.float64)[:, None], N, axis=1)
+    # the linked row varies per member; scenario s of the table run is member s
+    scale = 1.0 + 0.05 * np.arange(N) / N
+    per_member = block[row][None, :] * scale[:, None]            # [N][T]
+    prod = ra.Ensemble(ra.KIND_AGGREGATE, N, b)
+    prod.set_stream(s.h.value)
+    prod.set_params(np.zeros((9, N)))
+    # the pass-through writes index n+1 from index n+1 of its table: give it one scenario per member
+    blk = np.full((N, 8, T), np.nan)
+    blk[:, 0, :] = per_member
+    prod.set_forcing(blk, np.arange(N, dtype=np.int32))
+    prod.set_state("aggregate", 0, per_member[:, 0])               # index 0 is nobody's output
+    prod.run()
+    assert np.array_equal(prod.get_series("aggregate"), per_member.T)
+
+    def run(linked):
+        with ra.Ensemble(kind, N, b) as e:
+            e.set_stream(s.h.value)
+            e.set_params(params)
+            for name, v in init.items():
+                e.set_initial(name, v)
+            if kind == ra.KIND_UDEB:
+                for vname, vid in e.var_ids.items():
+                    if 1 <= vid <= 4:
+                        e.set_initial(vid, 0.0)
+            if linked:
+                if block.shape[0] > 1:
+                    e.set_forcing(block[None] if e.input_rows else block)
+                e.link_input(row, prod, "aggregate", ra.SRC_EXOGENOUS)
+            else:
+                full = np.repeat(block[None], N, axis=0)
+                full[:, row, :] = per_member
+                e.set_forcing(full if e.input_rows else full[:, 0, :], np.arange(N, dtype=np.int32))
+            e.run()
+            return {name: e.get_series(vid) for name, vid in e.var_ids.items() if vid > 0}, e.status()
+
+    want, st_w = run(False)
+    got, st_g = run(True)
+    assert np.array_equal(st_w, st_g)
+    for name in want:
+        if kind == ra.KIND_GHG_FORCING:
+            assert np.allclose(got[name], want[name], rtol=1e-13, atol=1e-15, equal_nan=True), name
+        else:
+            assert_bit_equal(got[name], want[name], f"{kind_name} {name}")
+    assert np.isfinite(got[next(iter(got))][1:]).all()
+    del L
+    prod.close()
+    s.close()
+
+
+def test_aggregate_operations(ra):
+    t = axis_values(2000, 2010)
+    T, N, b = len(t), 300, _bounds(t)
+    rng = np.random.default_rng(9)
+    rows = rng.normal(size=(8, T))
+    rows[5:] = np.nan          # three unused contributors
+    rows[2, 4] = np.nan        # a hole in a used one
+    rows[:5, 7] = np.nan       # a year where every contributor is NaN
+    w = rng.uniform(0.5, 2.0, size=(8, N))
+    for op, name in enumerate(("Sum", "Mean", "Weighted")):
+        with ra.Ensemble(ra.KIND_AGGREGATE, N, b) as e:
+            e.set_params(np.concatenate([np.full((1, N), float(op)), w]))
+            e.set_forcing(rows)
+            e.run()
+            got = e.get_series("aggregate")
+        want = np.full((T, N), np.nan)
+        for n in range(1, T):
+            acc, cnt = np.zeros(N), 0
+            for k in range(8):
+                v = rows[k, n]
+                if not np.isnan(v):
+                    acc = acc + (v * w[k] if name == "Weighted" else v)
+                    cnt += 1
+            if cnt:
+                want[n] = acc / float(cnt) if name == "Mean" else acc
+        assert_bit_equal(got, want, name)
+
+
+def test_link_argument_errors(ra):
+    t = axis_values(2000, 2010)
+    b = _bounds(t)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 8, b) as a, ra.Ensemble(ra.KIND_TWO_LAYER, 9, b) as c, \
+            ra.Ensemble(ra.KIND_TWO_LAYER, 8, b) as d, ra.Ensemble(ra.KIND_COUPLED, 8, b) as f:
+        with pytest.raises(Exception, match="same members"):
+            a.link_input(0, c, 1)
+        with pytest.raises(Exception, match="itself"):
+            a.link_input(0, a, 1)
+        with pytest.raises(Exception, match="no stored series"):
+            a.link_input(0, d, 0)
+        with pytest.raises(Exception, match="out of range"):
+            a.link_input(1, d, 1)
+        with pytest.raises(Exception, match="cannot be linked"):
+            f.link_input(0, d, 1)
+        a.link_input(0, d, 1)
+        a.set_params(two_layer_params(8))
+        a.set_initial(1, 0.0)
+        a.set_initial(2, 0.0)
+        with pytest.raises(Exception, match="another stream"):
+            a.run()
+        a.unlink_input(0)
+        with pytest.raises(Exception, match="not set"):
+            a.run()
