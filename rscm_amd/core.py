@@ -20,6 +20,7 @@ the build-time resampling of exogenous series (cold path, crates/rscm-core/src/t
 """
 from __future__ import annotations
 
+import ctypes as C
 import enum
 import math
 from bisect import bisect_left
@@ -370,7 +371,9 @@ class ComponentBuilder:
 
 
 # ------------------------------------------------------------------------------------ builder
-SUPPORTED = ("[ClimateUDEB] with exogenous 'Effective Radiative Forcing'",
+SUPPORTED = ("any graph of the built-in components with scalar links (one linked ensemble per component, "
+             "stepped in the reference's graph order); fused single-launch kernels for: "
+             "[ClimateUDEB] with exogenous 'Effective Radiative Forcing'",
              "[GhgForcing] | [OzoneForcing] | [AerosolDirect] | [AerosolIndirect] | [CH4Chemistry] | "
              "[N2OChemistry] | [CO2Budget] | [TerrestrialCarbon] | [OceanCarbon] | [HalocarbonChemistry] | "
              "[FourBoxOceanHeatUptake] | [OceanSurfacePartialPressure] with their inputs as "
@@ -483,6 +486,156 @@ class ModelBuilder:
             return self._exogenous.get_timeseries_by_name(name).interpolate_into(self._axis).values()
         return None
 
+    def _graph_order(self, aggregates) -> List[str]:
+        """Execution order of the reference: nodes in registration order (root, components,
+        aggregates), edges as ModelBuilder::build adds them, petgraph Bfs from the root (neighbours
+        come out most-recently-added edge first).  builder.rs:448-701, runtime.rs:504-527."""
+        names = ["<root>"]
+        edges: Dict[int, List[int]] = {}
+        endogenous: Dict[str, int] = {}
+        pending: List[Tuple[int, str]] = []
+
+        def add_edge(a: int, b: int) -> None:
+            edges.setdefault(a, []).append(b)
+
+        for comp in self._components:
+            node = len(names)
+            names.append(comp.type_name)
+            has_dep = False
+            for name, _, kind in comp.definitions:
+                if kind not in ("Input", "State"):
+                    continue
+                if name in endogenous:
+                    add_edge(endogenous[name], node)
+                    has_dep = True
+                elif name in aggregates:
+                    pending.append((node, name))
+                    has_dep = True
+            if not has_dep:
+                add_edge(0, node)
+            for name, _, kind in comp.definitions:
+                if kind in ("Output", "State"):
+                    if name in endogenous:
+                        add_edge(endogenous[name], node)
+                    endogenous[name] = node
+        for agg, (_, _, contributors, _) in aggregates.items():
+            node = len(names)
+            names.append(f"Aggregator:{agg}")
+            has_dep = False
+            for c in contributors:
+                if c in endogenous:
+                    add_edge(endogenous[c], node)
+                    has_dep = True
+            if not has_dep:
+                add_edge(0, node)
+            endogenous[agg] = node
+        for node, name in pending:
+            if name in endogenous:
+                add_edge(endogenous[name], node)
+        seen, order, queue = {0}, [], [0]
+        while queue:
+            n = queue.pop(0)
+            if n:
+                order.append(names[n])
+            for m in reversed(edges.get(n, [])):
+                if m not in seen:
+                    seen.add(m)
+                    queue.append(m)
+        return order
+
+    def _build_graph(self, n_members: int, endogenous, sources, exo_names, aggregates) -> "GraphModel":
+        T, bounds = len(self._axis), self._axis.bounds()
+        types = [c.type_name for c in self._components]
+        if len(set(types)) != len(types):
+            raise NotImplementedError(f"two components of the same type in one graph: {types}")
+        for c in self._components:
+            if c.type_name not in COMPONENT_KINDS:
+                raise NotImplementedError(f"component {c.type_name} has no GPU kernel; supported: " + "; ".join(SUPPORTED))
+        order = self._graph_order(aggregates)
+        missing = [n for n in types + [f"Aggregator:{a}" for a in aggregates] if n not in order]
+        if missing:
+            raise NotImplementedError(f"components not reachable from the graph root: {missing}")
+        stream = C.c_void_p()
+        L.check(L.load().rscm_gpu_stream_create(self._device, C.byref(stream)))
+        ensembles: Dict[str, Ensemble] = {}
+        var_home: Dict[str, Tuple[str, int]] = {}
+        exogenous: Dict[str, np.ndarray] = {}
+        links: List[Tuple[str, int]] = []
+        model = GraphModel(self._axis, order, ensembles, var_home, links, exogenous, sources, stream, self._device, True)
+        try:
+            def params_of(values) -> np.ndarray:
+                return np.repeat(np.array(values, dtype=np.float64)[:, None], n_members, axis=1)
+
+            for comp in self._components:
+                ens = Ensemble(COMPONENT_KINDS[comp.type_name], n_members, bounds, device=self._device)
+                ensembles[comp.type_name] = ens
+                ens.set_stream(stream.value)
+                ens.set_params(params_of(_component_params(comp)))
+                if comp.type_name == "CarbonCycle":
+                    ens.set_step_size(L.COMP_CARBON_CYCLE, comp.step_size)
+                for name, _, kind in comp.definitions:
+                    if kind in ("Output", "State"):
+                        fb = L.FOURBOX_VARS.get(ens.kind)
+                        if fb and name == fb[0]:
+                            continue  # a FourBox variable: four scalar series, not linkable to scalar inputs
+                        var_home[name] = (comp.type_name, ens.var_ids[name])
+            for agg, (_, op, contributors, weights) in aggregates.items():
+                if len(contributors) > L.AG_NINPUTS:
+                    raise NotImplementedError(f"aggregate {agg!r}: more than {L.AG_NINPUTS} contributors")
+                ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device)
+                ensembles[f"Aggregator:{agg}"] = ens
+                ens.set_stream(stream.value)
+                w = list(weights or []) + [0.0] * (L.AG_NINPUTS - len(weights or []))
+                ens.set_params(params_of([L.AG_OPERATIONS[op]] + w))
+                var_home[agg] = (f"Aggregator:{agg}", 1)
+            position = {name: k for k, name in enumerate(order)}
+
+            def wire(owner: str, rows: Sequence[str], read_end: bool) -> None:
+                ens = ensembles[owner]
+                table = np.full((len(ens.input_rows) if ens.input_rows else 1, T), NAN)
+                use_table = False
+                for k, name in enumerate(rows):
+                    if name in var_home:
+                        prod, vid = var_home[name]
+                        src = L.SRC_UPSTREAM if read_end or sources.get((name, owner)) == "UpstreamOutput" else L.SRC_EXOGENOUS
+                        ens.link_input(k, ensembles[prod], vid, src)
+                        links.append((owner, k))
+                        if position[prod] > position[owner]:
+                            model._feed_forward = False
+                            if src == L.SRC_UPSTREAM:
+                                raise NotImplementedError(
+                                    f"{owner} reads {name!r} at the end of the step but runs before its producer {prod} "
+                                    "in the reference's breadth-first order: the reference would read NaN")
+                    else:
+                        if name in endogenous:
+                            raise NotImplementedError(f"{name!r} is a FourBox variable: it cannot feed the scalar input of {owner}")
+                        vals = self._exogenous_on_axis(name, exo_names + list(rows))
+                        use_table = True
+                        if vals is not None:
+                            table[k] = vals
+                        exogenous[name] = table[k].copy()  # never supplied: a NaN series (builder.rs:772-780)
+                if use_table:
+                    ens.set_forcing(table if ens.input_rows else table[0])
+
+            for comp in self._components:
+                ens = ensembles[comp.type_name]
+                rows = ens.input_rows or [n for n, v in ens.var_ids.items() if v == 0]
+                wire(comp.type_name, list(rows), ens.kind == L.KIND_UDEB)
+            for agg, (_, _, contributors, _) in aggregates.items():
+                wire(f"Aggregator:{agg}", list(contributors), True)
+            for name, (owner, vid) in var_home.items():
+                if name in self._initial:
+                    ensembles[owner].set_initial(vid, self._initial[name])
+            for owner, ens in ensembles.items():
+                fb = L.FOURBOX_VARS.get(ens.kind)
+                if fb and fb[0] in self._initial:  # a FourBox state initialised with one scalar (builder.rs:797-804)
+                    for v in range(fb[1], fb[1] + 4):
+                        ens.set_initial(v, self._initial[fb[0]])
+        except Exception:
+            model.close()
+            raise
+        return model
+
     def build(self, n_members: int = 1, store_series: bool = True) -> "Model":
         endogenous, sources, exo_names, aggregates = self._resolve()
         types = [c.type_name for c in self._components]
@@ -529,9 +682,8 @@ class ModelBuilder:
             params = self._components[0].param_vector()
             h = {}
         else:
-            raise NotImplementedError(
-                f"component graph {types} (aggregates {list(aggregates)}) has no fused GPU kernel; "
-                "supported: " + "; ".join(SUPPORTED))
+            # any other graph of built-in components: one ensemble per component, linked on the device
+            return self._build_graph(n_members, endogenous, sources, exo_names, aggregates)
         if not store_series and kind != L.KIND_TWO_LAYER:
             store_series = True  # likelihood-only handles exist for the two-layer kind
         ens = Ensemble(kind, n_members, self._axis.bounds(), device=self._device,
@@ -556,6 +708,114 @@ class ModelBuilder:
                        L.KIND_OSPP: L.SP_PARAM_NAMES}[kind]
         return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
                      np.array(params, dtype=np.float64))
+
+
+# type name -> ensemble kind, for graphs assembled from linked ensembles
+COMPONENT_KINDS = {"TwoLayer": L.KIND_TWO_LAYER, "ClimateUDEB": L.KIND_UDEB, "CarbonCycle": L.KIND_CARBON_CYCLE,
+                   "CO2ERF": L.KIND_CO2_ERF, **STATELESS_KINDS}
+
+
+def _component_params(comp) -> List[float]:
+    if comp.type_name == "TwoLayer":
+        return [comp.parameters[k] for k in TL_PARAM_ORDER]
+    if comp.type_name == "CarbonCycle":
+        return [comp.parameters[k] for k in L.CC_PARAM_NAMES]
+    if comp.type_name == "CO2ERF":
+        return [comp.parameters[k] for k in L.CE_PARAM_NAMES]
+    return list(comp.param_vector())
+
+
+class GraphModel:
+    """A component graph the fused kernels do not cover, run as one ensemble per component (and per
+    schema aggregate) whose inputs are linked on the device (``rscm_ens_link_input``) and which are
+    stepped in the reference's order: petgraph BFS from the root over the edges
+    ``ModelBuilder::build`` adds (builder.rs:487-560, runtime.rs:368-497).  Same surface as ``Model``.
+
+    ``ensembles`` maps a component's type name (``"Aggregator:<name>"`` for aggregates) to its
+    ``Ensemble``, e.g. to give the members different parameters before ``run()``."""
+
+    def __init__(self, axis: TimeAxis, order: List[str], ensembles: Dict[str, Ensemble], var_home, links,
+                 exogenous: Dict[str, np.ndarray], sources, stream, device: int, feed_forward: bool):
+        self._axis = axis
+        self._order = order
+        self.ensembles = ensembles
+        self._var_home = var_home          # variable name -> (owner, variable id)
+        self._links = links                # (consumer, row) pairs, for teardown
+        self._exogenous = exogenous
+        self._sources = sources
+        self._stream = stream
+        self._device = device
+        self._feed_forward = feed_forward
+        self.time_index = 0
+
+    def variable_sources(self) -> Dict[Tuple[str, str], str]:
+        return dict(self._sources)
+
+    def current_time(self) -> float:
+        return self._axis.at(self.time_index)
+
+    def current_time_bounds(self) -> Tuple[float, float]:
+        return self._axis.at_bounds(self.time_index)
+
+    def step(self) -> None:
+        if not self.time_index < len(self._axis) - 1:
+            raise RuntimeError("assertion failed: self.time_index < self.time_axis.len() - 1")
+        for name in self._order:
+            self.ensembles[name].run(self.time_index + 1, sync=False)
+        self.time_index += 1
+        self.ensembles[self._order[-1]].sync()
+
+    def run(self) -> None:
+        last = len(self._axis) - 1
+        if self._feed_forward:  # no edge points backwards: every producer can finish before its consumers start
+            for name in self._order:
+                self.ensembles[name].run(last, sync=False)
+        else:
+            for n in range(self.time_index, last):
+                for name in self._order:
+                    self.ensembles[name].run(n + 1, sync=False)
+        self.time_index = last
+        self.ensembles[self._order[-1]].sync()
+
+    def finished(self) -> bool:
+        return self.time_index == len(self._axis) - 1
+
+    def timeseries(self, member: int = 0) -> TimeseriesCollection:
+        coll = TimeseriesCollection()
+        for name, vals in self._exogenous.items():
+            coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Exogenous)
+        done = set()
+        for owner in self._order:
+            ens = self.ensembles[owner]
+            fourbox = L.FOURBOX_VARS.get(ens.kind)
+            if fourbox:
+                ids = range(fourbox[1], fourbox[1] + 4)
+                boxes = np.stack([ens.get_series(v, m_begin=member, m_end=member + 1)[:, 0] for v in ids], axis=1)
+                coll.add_fourbox_timeseries(fourbox[0], FourBoxTimeseries(boxes, self._axis, "K" if ens.kind == L.KIND_UDEB else "W/m^2"))
+                done.update((owner, v) for v in ids)
+        for name, (owner, vid) in self._var_home.items():
+            if (owner, vid) in done:
+                continue
+            vals = self.ensembles[owner].get_series(vid, m_begin=member, m_end=member + 1)[:, 0]
+            coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Endogenous)
+        return coll
+
+    def close(self) -> None:
+        for consumer, row in self._links:
+            if self.ensembles[consumer]._h:
+                self.ensembles[consumer].unlink_input(row)
+        self._links = []
+        for ens in self.ensembles.values():
+            ens.close()
+        if self._stream is not None:
+            L.check(L.load().rscm_gpu_stream_destroy(self._device, self._stream))
+            self._stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Model:

@@ -133,10 +133,49 @@ def test_builder_errors():
         TwoLayerBuilder.from_parameters({k: v for k, v in P_TL.items() if k != "eta"})
     with pytest.raises(NotImplementedError):
         core.ModelBuilder().with_py_component(object())
+    class Foreign(core.Component):
+        type_name = "Foreign"
+        definitions = [("x", "", "Input"), ("y", "", "Output")]
     b = (core.ModelBuilder().with_time_axis(core.TimeAxis.from_values([0.0, 1.0, 2.0]))
-         .with_rust_component(CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build()))
-    with pytest.raises(NotImplementedError, match="no fused GPU kernel"):
+         .with_rust_component(Foreign({})))
+    with pytest.raises(NotImplementedError, match="has no GPU kernel"):
         b.build()
+
+
+def test_graph_order_is_the_reference_bfs():
+    """ModelBuilder._graph_order (the order linked ensembles are stepped in) against the oracle's
+    restatement of builder.rs:448-701 + petgraph Bfs, over every registration order of the notebook's
+    three components, with one and with two aggregates."""
+    import itertools
+    from rscm_amd.components import CarbonCycleBuilder
+    make = {"CarbonCycle": lambda: CarbonCycleBuilder.from_parameters(dict(tau=25.0, conc_pi=278.0, alpha_temperature=0.1)).build(),
+            "CO2ERF": lambda: CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build(),
+            "TwoLayer": lambda: TwoLayerBuilder.from_parameters(P_TL).build()}
+    ref = {"CarbonCycle": lambda: rm.CarbonCycle(25.0, 278.0, 0.1), "CO2ERF": lambda: rm.CO2ERF(3.7, 278.0),
+           "TwoLayer": lambda: rm.TwoLayer(*P_TL.values())}
+    init = {"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
+            "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}
+    aggs = [[("Effective Radiative Forcing", "Sum", ["Effective Radiative Forcing|CO2"])],
+            [("Effective Radiative Forcing", "Sum", ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|Other"]),
+             ("Diagnostic", "Mean", ["Surface Temperature", "Deep Ocean Temperature"])]]
+    for perm in itertools.permutations(make):
+        for agg in aggs:
+            schema = core.VariableSchema()
+            for n in list(init) + ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|Other", "Emissions|CO2|Anthropogenic"]:
+                schema.add_variable(n, "")
+            for name, op, contributors in agg:
+                schema.add_aggregate(name, "", op, contributors)
+            b = core.ModelBuilder().with_time_axis(core.TimeAxis.from_values(np.arange(1750.0, 1756.0))).with_schema(schema)
+            for k in perm:
+                b.with_rust_component(make[k]())
+            b.with_initial_values(init)
+            _, _, _, aggregates = b._resolve()
+            got = b._graph_order(aggregates)
+            m = rm.ModelBuilder(axis=rm.TimeAxis.from_values(np.arange(1750.0, 1756.0)), components=[ref[k]() for k in perm],
+                                aggregates=agg, initial_values=init,
+                                schema_variables=["Effective Radiative Forcing|Other"]).build()
+            want = [m.order_nodes[i].type_name for i in m._bfs() if m.order_nodes[i] is not None]
+            assert got == want, (perm, got, want)
 
 
 def test_priors_and_lhs():
