@@ -399,6 +399,11 @@ RSCM_API int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, c
  * rscm_ens_destroy(src) fails while links to it exist.  Not available for RSCM_KIND_COUPLED and
  * RSCM_KIND_HALOCARBON inputs, nor with RSCM_FLAG_NO_SERIES on either side. */
 RSCM_API int rscm_ens_link_input(rscm_ens* h, int32_t input_row, rscm_ens* src, int32_t src_var, int32_t source);
+/* The guard "src has been stepped far enough" can be switched off (enabled = 0) for callers that
+ * reproduce the reference's execution order as it is: its breadth-first order is not a topological
+ * one, so a component can run before the producer of a variable it reads at index n+1 and then
+ * sees what the collection holds there -- NaN in a fresh model (builder.rs:772-780).  Default on. */
+RSCM_API int rscm_ens_set_link_order_check(rscm_ens* h, int32_t enabled);
 /* Row `input_row` reads the scenario table again. */
 RSCM_API int rscm_ens_unlink_input(rscm_ens* h, int32_t input_row);
 

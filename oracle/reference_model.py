@@ -207,6 +207,10 @@ class Window:
     def previous(self) -> Optional[float]:
         return None if self.index == 0 else self.series[self.index - 1] * 1.0
 
+    def at_offset(self, k: int) -> Optional[float]:
+        j = self.index + k
+        return self.series[j] * 1.0 if 0 <= j < len(self.series) else None
+
 
 @dataclass
 class Req:
@@ -304,6 +308,85 @@ class CO2ERF(Component):
     def solve(self, t0, t1, w):
         return {"Effective Radiative Forcing|CO2":
                 self.calculate_erf(w["Atmospheric Concentration|CO2"].get())}
+
+
+# --------------------------------------------------------------------------- rscm-magicc adapters
+class _StepOracle(Component):
+    """A rscm-magicc component inside the generic stepper: the window reads are restated here
+    (file:line per class), the arithmetic of one step is the C oracle's single-step function
+    (``oracle/cbind.py``), so a graph of these exercises exactly the index conventions."""
+
+    def __init__(self, params):
+        self.params = list(params)
+
+
+class CH4Chemistry(_StepOracle):
+    """crates/rscm-magicc/src/chemistry/ch4.rs solve(): emissions / temperature / precursors through
+    get(), own concentration at_start() and previous().unwrap_or(current)."""
+    type_name = "CH4Chemistry"
+    defs = [Req("Emissions|CH4", INPUT), Req("Surface Temperature", INPUT), Req("Emissions|NOx", INPUT),
+            Req("Emissions|CO", INPUT), Req("Emissions|NMVOC", INPUT),
+            Req("Lifetime|CH4", OUTPUT), Req("Atmospheric Concentration|CH4", STATE)]
+
+    def solve(self, t0, t1, w):
+        from oracle import cbind
+        c = w["Atmospheric Concentration|CH4"]
+        cur = c.at_start()
+        prev = c.previous()
+        conc, life = cbind.ch4_solve_concentration(
+            self.params, cur if prev is None else prev, cur, w["Emissions|CH4"].get(), w["Surface Temperature"].get(),
+            w["Emissions|NOx"].get(), w["Emissions|CO"].get(), w["Emissions|NMVOC"].get())
+        return {"Atmospheric Concentration|CH4": conc, "Lifetime|CH4": life}
+
+
+class N2OChemistry(_StepOracle):
+    """crates/rscm-magicc/src/chemistry/n2o.rs:203-218: the stratospheric delay reads
+    at_offset(-delay) (else previous) and at_offset(-(delay+1)) (else the former)."""
+    type_name = "N2OChemistry"
+    defs = [Req("Emissions|N2O", INPUT), Req("Lifetime|N2O", OUTPUT), Req("Atmospheric Concentration|N2O", STATE)]
+
+    def solve(self, t0, t1, w):
+        from oracle import cbind
+        c = w["Atmospheric Concentration|N2O"]
+        cur = c.at_start()
+        prev = c.previous()
+        prev = cur if prev is None else prev
+        delay = max(int(self.params[4]), 1)
+        t_delay = c.at_offset(-delay)
+        t_delay = prev if t_delay is None else t_delay
+        t_delay_m1 = c.at_offset(-(delay + 1))
+        t_delay_m1 = t_delay if t_delay_m1 is None else t_delay_m1
+        conc, life = cbind.n2o_solve_concentration(self.params, prev, cur, (t_delay + t_delay_m1) / 2.0,
+                                                   w["Emissions|N2O"].get(), t1 - t0)
+        return {"Atmospheric Concentration|N2O": conc, "Lifetime|N2O": life}
+
+
+class GhgForcing(_StepOracle):
+    """crates/rscm-magicc/src/forcing/ghg.rs:272-345: three concentrations through get()."""
+    type_name = "GhgForcing"
+    defs = [Req("Atmospheric Concentration|CO2", INPUT), Req("Atmospheric Concentration|CH4", INPUT),
+            Req("Atmospheric Concentration|N2O", INPUT), Req("Effective Radiative Forcing|CO2", OUTPUT),
+            Req("Effective Radiative Forcing|CH4", OUTPUT), Req("Effective Radiative Forcing|N2O", OUTPUT)]
+
+    def solve(self, t0, t1, w):
+        from oracle import cbind
+        f = cbind.ghg_forcings(self.params, w["Atmospheric Concentration|CO2"].get(),
+                               w["Atmospheric Concentration|CH4"].get(), w["Atmospheric Concentration|N2O"].get())
+        return {"Effective Radiative Forcing|CO2": f["co2_erf"], "Effective Radiative Forcing|CH4": f["ch4_erf"],
+                "Effective Radiative Forcing|N2O": f["n2o_erf"]}
+
+
+class AerosolIndirect(_StepOracle):
+    """crates/rscm-magicc/src/forcing/aerosol_indirect.rs:75-170: SOx and OC emissions through get()."""
+    type_name = "AerosolIndirect"
+    defs = [Req("Emissions|SOx", INPUT), Req("Emissions|OC", INPUT),
+            Req("Effective Radiative Forcing|Aerosol|Indirect", OUTPUT)]
+
+    def solve(self, t0, t1, w):
+        from oracle import cbind
+        out = cbind.pointwise_eval(cbind.PW_AEROSOL_INDIRECT, self.params,
+                                   [w["Emissions|SOx"].get(), w["Emissions|OC"].get()])
+        return {"Effective Radiative Forcing|Aerosol|Indirect": float(out[0])}
 
 
 # --------------------------------------------------------------------------- aggregates

@@ -246,6 +246,7 @@ SIGNATURES = {
     "rscm_ens_set_params_aos": (C.c_int, [_h, _dp]),
     "rscm_ens_set_forcing": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, _ip, C.c_int32]),
     "rscm_ens_link_input": (C.c_int, [_h, C.c_int32, _h, C.c_int32, C.c_int32]),
+    "rscm_ens_set_link_order_check": (C.c_int, [_h, C.c_int32]),
     "rscm_ens_unlink_input": (C.c_int, [_h, C.c_int32]),
     "rscm_ens_set_initial": (C.c_int, [_h, C.c_int32, _dp, C.c_int64]),
     "rscm_ens_set_state": (C.c_int, [_h, C.c_int32, C.c_int32, _dp, C.c_int64]),

@@ -601,11 +601,11 @@ class ModelBuilder:
                         ens.link_input(k, ensembles[prod], vid, src)
                         links.append((owner, k))
                         if position[prod] > position[owner]:
+                            # lagged feedback, or -- the breadth-first order is not a topological one -- a
+                            # component that runs before the producer of what it reads at n+1 and, like
+                            # in the reference, finds NaN there
                             model._feed_forward = False
-                            if src == L.SRC_UPSTREAM:
-                                raise NotImplementedError(
-                                    f"{owner} reads {name!r} at the end of the step but runs before its producer {prod} "
-                                    "in the reference's breadth-first order: the reference would read NaN")
+                            L.check(L.load().rscm_ens_set_link_order_check(ens._h, 0))
                     else:
                         if name in endogenous:
                             raise NotImplementedError(f"{name!r} is a FourBox variable: it cannot feed the scalar input of {owner}")

@@ -202,6 +202,7 @@ struct rscm_ens {
     struct Link { rscm_ens* src = nullptr; int32_t var = 0; int32_t off = 0; };
     Link links[rscm::kMaxLinks];
     int32_t n_linked = 0;
+    bool link_order_check = true;
     int32_t link_refs = 0;  // links of other ensembles into this one's series
 
     int32_t time_index = 0;
@@ -732,6 +733,13 @@ int rscm_ens_link_input(rscm_ens* h, int32_t input_row, rscm_ens* src, int32_t s
     GUARD_END
 }
 
+int rscm_ens_set_link_order_check(rscm_ens* h, int32_t enabled)
+{
+    NEED(h);
+    h->link_order_check = enabled != 0;
+    return RSCM_OK;
+}
+
 int rscm_ens_unlink_input(rscm_ens* h, int32_t input_row)
 {
     NEED(h);
@@ -835,7 +843,7 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         // ClimateUDEB reads at_start / at_end, the aggregate at_end: index n+1 whatever `source` said
         const bool reads_end = h->kind == RSCM_KIND_UDEB || h->kind == RSCM_KIND_AGGREGATE;
         const int32_t need = step_end - 1 + (reads_end ? 1 : l.off);
-        if (step_end > step_begin && l.src->time_index < need)
+        if (h->link_order_check && step_end > step_begin && l.src->time_index < need)
             return fail(RSCM_ERR_STATE, "input row %d reads index %d of its source, which has only been stepped to %d", k, need,
                         l.src->time_index);
         links.row[k] = l.src->series(l.var);
