@@ -434,6 +434,12 @@ RSCM_API int rscm_gpu_stream_destroy(int32_t device_id, void* hip_stream);
  * rscm_ens_run returns after the work has completed; rscm_ens_run_async only enqueues. */
 RSCM_API int rscm_ens_run(rscm_ens* h, int32_t step_begin, int32_t step_end);
 RSCM_API int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end);
+/* Model::run over a graph of linked ensembles (runtime.rs:504-527): for every step n in
+ * [step_begin, step_end) each handle, in the order given (the graph order), advances by that one
+ * step -- n_handles asynchronous launches per step on the handles' common stream, without
+ * returning to the caller in between.  Every handle must stand at step_begin; follow with
+ * rscm_ens_sync on any of them. */
+RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end);
 RSCM_API int rscm_ens_sync(rscm_ens* h);
 RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
 /* Rewind to time index 0 keeping parameters, forcing and initial values (outputs are

@@ -255,6 +255,7 @@ SIGNATURES = {
     "rscm_gpu_stream_destroy": (C.c_int, [C.c_int32, C.c_void_p]),
     "rscm_ens_set_stream": (C.c_int, [_h, C.c_void_p]),
     "rscm_ens_run": (C.c_int, [_h, C.c_int32, C.c_int32]),
+    "rscm_ens_run_lockstep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
     "rscm_ens_run_async": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "rscm_ens_sync": (C.c_int, [_h]),
     "rscm_ens_time_index": (C.c_int, [_h, _ip]),

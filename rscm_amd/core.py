@@ -29,7 +29,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib as L
-from .ensemble import Ensemble
+from .ensemble import Ensemble, run_lockstep
 
 NAN = float("nan")
 
@@ -771,9 +771,7 @@ class GraphModel:
             for name in self._order:
                 self.ensembles[name].run(last, sync=False)
         else:
-            for n in range(self.time_index, last):
-                for name in self._order:
-                    self.ensembles[name].run(n + 1, sync=False)
+            run_lockstep([self.ensembles[name] for name in self._order], last, sync=False)
         self.time_index = last
         self.ensembles[self._order[-1]].sync()
 

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(kBlock) void pointwise_kernel(PointwiseArgs a)
     const int32_t T = a.n_times;
     double p[S::P];
 #pragma unroll
-    for (int j = 0; j < S::P; ++j) p[j] = a.params[(size_t)j * N + i];
+    for (int j = 0; j < S::P; ++j) {
+        // the aggregate's eight weight rows matter to the Weighted operation only
+        if (KIND == 17 && j > 0 && p[0] != 2.0) p[j] = 0.0;
+        else p[j] = a.params[(size_t)j * N + i];
+    }
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
     a.status[i] = 0;

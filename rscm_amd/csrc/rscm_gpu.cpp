@@ -816,9 +816,10 @@ int rscm_ens_rewind(rscm_ens* h)
     return RSCM_OK;
 }
 
-int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
+// One launch of the kind's kernel over [step_begin, step_end).  `timed` brackets it with the events
+// rscm_ens_last_run_ms reads; the lock-step loop of rscm_ens_run_lockstep leaves them out.
+static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
 {
-    GUARD_BEGIN
     NEED(h);
     if (step_begin < 0 || step_end > h->T - 1 || step_begin > step_end)
         return fail(RSCM_ERR_STATE, "steps [%d, %d) outside [0, %d] (Model::step asserts time_index < len-1)",
@@ -854,7 +855,7 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
 
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (h->kind == RSCM_KIND_TWO_LAYER) {
         rscm::TwoLayerArgs a{};
         a.n_members = h->N;
@@ -1043,9 +1044,35 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
         a.status = h->d_status;
         HIPCHK(rscm::launch_coupled(a, h->mode, h->stream));
     }
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    h->timed = true;
+    if (timed) {
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        h->timed = true;
+    }
     h->time_index = step_end;
+    return RSCM_OK;
+}
+
+int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
+{
+    GUARD_BEGIN
+    return run_range(h, step_begin, step_end, true);
+    GUARD_END
+}
+
+int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end)
+{
+    GUARD_BEGIN
+    if (!handles || n_handles < 1) return fail(RSCM_ERR_INVALID, "need at least one handle");
+    for (int32_t k = 0; k < n_handles; ++k) {
+        if (!handles[k]) return fail(RSCM_ERR_INVALID, "handle %d is NULL", k);
+        if (handles[k]->stream != handles[0]->stream)
+            return fail(RSCM_ERR_STATE, "handle %d runs on another stream than handle 0", k);
+        if (handles[k]->time_index != step_begin)
+            return fail(RSCM_ERR_STATE, "handle %d is at time index %d, not at step_begin %d", k, handles[k]->time_index, step_begin);
+    }
+    for (int32_t n = step_begin; n < step_end; ++n)
+        for (int32_t k = 0; k < n_handles; ++k)
+            if (int rc = run_range(handles[k], n, n + 1, false)) return rc;
     return RSCM_OK;
     GUARD_END
 }

@@ -311,6 +311,17 @@ class _PinnedOwner:
             pass
 
 
+def run_lockstep(ensembles: Sequence["Ensemble"], step_end: Optional[int] = None, *, sync: bool = True) -> None:
+    """``Model::run`` over linked ensembles: every step, each ensemble in the order given advances by
+    one step (``rscm_ens_run_lockstep``); all must stand at the same time index and share a stream."""
+    first = ensembles[0]
+    end = first.n_times - 1 if step_end is None else step_end
+    arr = (C.c_void_p * len(ensembles))(*[e._h.value for e in ensembles])
+    L.check(first._lib.rscm_ens_run_lockstep(arr, len(ensembles), first.time_index, end))
+    if sync:
+        first.sync()
+
+
 def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     """numpy array over page-locked host memory (hipHostMalloc); freed with the array."""
     lib = L.load()
