@@ -213,6 +213,48 @@ def cpu_baseline(threads, target_seconds=12.0):
                       f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads"}
 
 
+def linked_graph_extra(members, device, stream, years):
+    import time
+    import rscm_amd
+    from rscm_amd.ensemble import run_lockstep
+    t = np.arange(T0, T1 + 1, dtype=np.float64)
+    bounds = np.append(t, t[-1] + 1.0)
+    fused = make_ensemble(members, device, 0, 1, 0, stream, coupled=True)
+    P = fused.get_params()
+    fused.close()
+    kinds = (rscm_amd.KIND_CARBON_CYCLE, rscm_amd.KIND_CO2_ERF, rscm_amd.KIND_AGGREGATE, rscm_amd.KIND_TWO_LAYER)
+    cc, ce, ag, tl = (rscm_amd.Ensemble(k, members, bounds, device=device) for k in kinds)
+    for e in (cc, ce, ag, tl):
+        e.set_stream(stream)
+    cc.set_params(P[[6, 7, 8]])
+    ce.set_params(P[[9, 7]])
+    ag.set_params(np.zeros((9, members)))
+    tl.set_params(P[:6])
+    yrs = np.array([1750.0, 1850.0, 1950.0, 2000.0, 2020.0, 2050.0, 2100.0])
+    cc.set_forcing(np.stack([np.interp(t, yrs, [0.0, 0.5, 3.0, 7.0, 10.0, 5.0, 1.0]), np.full(len(t), np.nan)]))
+    for var, v in (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0), ("Cumulative Emissions|CO2", 0.0)):
+        cc.set_initial(var, v)
+    tl.set_initial(1, 0.0)
+    tl.set_initial(2, 0.0)
+    cc.link_input(1, tl, 1, rscm_amd.SRC_EXOGENOUS)   # lagged temperature feedback
+    ce.link_input(0, cc, 1, rscm_amd.SRC_UPSTREAM)
+    ag.link_input(0, ce, 1, rscm_amd.SRC_UPSTREAM)
+    tl.link_input(0, ag, 1, rscm_amd.SRC_UPSTREAM)
+    best = float("inf")
+    for _ in range(3):
+        for e in (cc, ce, ag, tl):
+            e.rewind()
+        tl.sync()
+        t0 = time.perf_counter()
+        run_lockstep((cc, ce, ag, tl))
+        best = min(best, time.perf_counter() - t0)
+    cc.unlink_input(1)
+    for e in (tl, ag, ce, cc):
+        e.close()
+    return {"member_years_per_s": members * years / best, "ms": best * 1e3, "launches": 4 * years,
+            "note": "CarbonCycle, CO2ERF, Sum, TwoLayer as four linked ensembles, 4 launches per model step"}
+
+
 def end_to_end_extra(members, device, mode, stream, years):
     import time
     from rscm_amd.ensemble import pinned_empty
@@ -321,6 +363,10 @@ def main():
             e4.close()
             extra[label] = {"member_years_per_s": 1_000_000 * years * 5 / w4, "kernel_ms": k4,
                             "hbm_frac": 24.0 * 1_000_000 * years / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        # the same coupled chain assembled from four linked ensembles and stepped in graph order
+        # (rscm_ens_link_input / rscm_ens_run_lockstep): what an arbitrary component graph costs
+        extra["coupled_linked_1e6"] = linked_graph_extra(1_000_000, local_rank, stream, years)
 
         # SURVEY 8d asks for the end-to-end figure beside the resident one: host parameters in,
         # run, full Ts and Td series out into page-locked buffers (never reported as `value`)
