@@ -309,10 +309,12 @@ class VariableSchema:
 
     def __init__(self) -> None:
         self.variables: Dict[str, str] = {}
+        self.grid_types: Dict[str, "GridType"] = {}
         self.aggregates: Dict[str, Tuple[str, str, List[str], Optional[List[float]]]] = {}
 
     def add_variable(self, name: str, unit: str, grid_type=None) -> "VariableSchema":
         self.variables[name] = unit
+        self.grid_types[name] = grid_type or GridType.Scalar
         return self
 
     def add_aggregate(self, name: str, unit: str, operation: str, contributors: Sequence[str],
@@ -404,6 +406,7 @@ class ModelBuilder:
         self._exogenous = TimeseriesCollection()
         self._schema: Optional[VariableSchema] = None
         self._device = 0
+        self._grid_weights: Dict["GridType", List[float]] = {}
 
     def with_time_axis(self, time_axis: TimeAxis) -> "ModelBuilder":
         self._axis = time_axis
@@ -435,6 +438,19 @@ class ModelBuilder:
 
     def with_schema(self, schema: VariableSchema) -> "ModelBuilder":
         self._schema = schema
+        return self
+
+    def with_grid_weights(self, grid_type: "GridType", weights: Sequence[float]) -> "ModelBuilder":
+        """builder.rs:56-103: area weights used wherever a FourBox variable is aggregated to a scalar
+        (default 0.25 each, FourBoxGrid::magicc_standard)."""
+        w = [float(x) for x in weights]
+        if grid_type != GridType.FourBox:
+            raise NotImplementedError("only FourBox weights are used on the device path")
+        if len(w) != 4:
+            raise ValueError(f"Weights length {len(w)} does not match FourBox grid size 4")
+        if abs(sum(w) - 1.0) >= 1e-6:
+            raise ValueError(f"Weights must sum to 1.0, got {sum(w)}")
+        self._grid_weights[grid_type] = w
         return self
 
     def with_device(self, device: int) -> "ModelBuilder":
@@ -486,10 +502,14 @@ class ModelBuilder:
             return self._exogenous.get_timeseries_by_name(name).interpolate_into(self._axis).values()
         return None
 
-    def _graph_order(self, aggregates) -> List[str]:
+    def _graph_order(self, aggregates, topological: bool = False) -> List[str]:
         """Execution order of the reference: nodes in registration order (root, components,
         aggregates), edges as ModelBuilder::build adds them, petgraph Bfs from the root (neighbours
-        come out most-recently-added edge first).  builder.rs:448-701, runtime.rs:504-527."""
+        come out most-recently-added edge first).  builder.rs:448-701, runtime.rs:504-527.
+
+        ``topological`` (an extension) orders the same nodes so that every edge points forwards,
+        ties broken by the breadth-first position: the order in which no component reads a
+        value of the current step before it has been produced."""
         names = ["<root>"]
         edges: Dict[int, List[int]] = {}
         endogenous: Dict[str, int] = {}
@@ -541,9 +561,32 @@ class ModelBuilder:
                 if m not in seen:
                     seen.add(m)
                     queue.append(m)
-        return order
+        if not topological:
+            return order
+        rank = {name: k for k, name in enumerate(order)}
+        for name in names[1:]:
+            rank.setdefault(name, len(rank))
+        indeg = {n: 0 for n in range(1, len(names))}
+        for a, targets in edges.items():
+            for b in set(targets):
+                if a:
+                    indeg[b] += 1
+        ready = sorted((n for n, d in indeg.items() if d == 0), key=lambda n: rank[names[n]])
+        topo: List[str] = []
+        while ready:
+            n = ready.pop(0)
+            topo.append(names[n])
+            for m in set(edges.get(n, [])):
+                indeg[m] -= 1
+                if indeg[m] == 0:
+                    ready.append(m)
+            ready.sort(key=lambda k: rank[names[k]])
+        if len(topo) != len(names) - 1:
+            raise ValueError("the component graph has a cycle")
+        return topo
 
-    def _build_graph(self, n_members: int, endogenous, sources, exo_names, aggregates) -> "GraphModel":
+    def _build_graph(self, n_members: int, endogenous, sources, exo_names, aggregates,
+                     execution_order: str = "reference") -> "GraphModel":
         T, bounds = len(self._axis), self._axis.bounds()
         types = [c.type_name for c in self._components]
         if len(set(types)) != len(types):
@@ -551,7 +594,9 @@ class ModelBuilder:
         for c in self._components:
             if c.type_name not in COMPONENT_KINDS:
                 raise NotImplementedError(f"component {c.type_name} has no GPU kernel; supported: " + "; ".join(SUPPORTED))
-        order = self._graph_order(aggregates)
+        if execution_order not in ("reference", "topological"):
+            raise ValueError("execution_order must be 'reference' or 'topological'")
+        order = self._graph_order(aggregates, topological=execution_order == "topological")
         missing = [n for n in types + [f"Aggregator:{a}" for a in aggregates] if n not in order]
         if missing:
             raise NotImplementedError(f"components not reachable from the graph root: {missing}")
@@ -577,7 +622,25 @@ class ModelBuilder:
                     if kind in ("Output", "State"):
                         fb = L.FOURBOX_VARS.get(ens.kind)
                         if fb and name == fb[0]:
-                            continue  # a FourBox variable: four scalar series, not linkable to scalar inputs
+                            # A FourBox variable is four scalar series.  Whoever wants it as a scalar
+                            # -- the schema (write transform: the scalar is what the collection stores,
+                            # runtime.rs:452-470) or a reader (read transform, state/aggregating.rs:
+                            # 162-176) -- gets sum(value * weight) over the boxes, formed by a Weighted
+                            # aggregate ensemble that runs right after the producer, index by index.
+                            tname = f"Transform:{name}"
+                            tr = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device)
+                            ensembles[tname] = tr
+                            tr.set_stream(stream.value)
+                            w = self._grid_weights.get(GridType.FourBox, [0.25, 0.25, 0.25, 0.25])
+                            tr.set_params(params_of([L.AG_OPERATIONS["Weighted"]] + list(w) + [0.0] * 4))
+                            for k in range(4):
+                                tr.link_input(k, ens, fb[1] + k, L.SRC_UPSTREAM)
+                                links.append((tname, k))
+                            order.insert(order.index(comp.type_name) + 1, tname)
+                            var_home[name] = (tname, 1)
+                            stored_scalar = self._schema is not None and self._schema.grid_types.get(name) == GridType.Scalar
+                            model._fourbox[name] = (comp.type_name, fb[1], stored_scalar)
+                            continue
                         var_home[name] = (comp.type_name, ens.var_ids[name])
             for agg, (_, op, contributors, weights) in aggregates.items():
                 if len(contributors) > L.AG_NINPUTS:
@@ -626,17 +689,27 @@ class ModelBuilder:
             for name, (owner, vid) in var_home.items():
                 if name in self._initial:
                     ensembles[owner].set_initial(vid, self._initial[name])
-            for owner, ens in ensembles.items():
+            for owner, ens in list(ensembles.items()):
                 fb = L.FOURBOX_VARS.get(ens.kind)
                 if fb and fb[0] in self._initial:  # a FourBox state initialised with one scalar (builder.rs:797-804)
+                    w = self._grid_weights.get(GridType.FourBox, [0.25, 0.25, 0.25, 0.25])
+                    x0 = self._initial[fb[0]]
                     for v in range(fb[1], fb[1] + 4):
-                        ens.set_initial(v, self._initial[fb[0]])
+                        ens.set_initial(v, x0)
+                    s0 = 0.0
+                    for wk in w:  # the scalar view of index 0, summed like aggregate_global
+                        s0 = s0 + x0 * wk
+                    ensembles[f"Transform:{fb[0]}"].set_initial(1, s0)
         except Exception:
             model.close()
             raise
         return model
 
-    def build(self, n_members: int = 1, store_series: bool = True) -> "Model":
+    def build(self, n_members: int = 1, store_series: bool = True, execution_order: str = "reference") -> "Model":
+        """``execution_order`` (graphs without a fused kernel only): "reference" steps the components
+        in the reference's breadth-first order, which can run a component before the producer of a
+        value it reads at the end of the step (it then reads NaN, which an aggregate skips);
+        "topological" is the order in which that cannot happen."""
         endogenous, sources, exo_names, aggregates = self._resolve()
         types = [c.type_name for c in self._components]
         erf = "Effective Radiative Forcing"
@@ -683,7 +756,7 @@ class ModelBuilder:
             h = {}
         else:
             # any other graph of built-in components: one ensemble per component, linked on the device
-            return self._build_graph(n_members, endogenous, sources, exo_names, aggregates)
+            return self._build_graph(n_members, endogenous, sources, exo_names, aggregates, execution_order)
         if not store_series and kind != L.KIND_TWO_LAYER:
             store_series = True  # likelihood-only handles exist for the two-layer kind
         ens = Ensemble(kind, n_members, self._axis.bounds(), device=self._device,
@@ -746,6 +819,7 @@ class GraphModel:
         self._stream = stream
         self._device = device
         self._feed_forward = feed_forward
+        self._fourbox: Dict[str, Tuple[str, int, bool]] = {}  # FourBox variable -> (producer, first id, stored as scalar)
         self.time_index = 0
 
     def variable_sources(self) -> Dict[Tuple[str, str], str]:
@@ -782,17 +856,16 @@ class GraphModel:
         coll = TimeseriesCollection()
         for name, vals in self._exogenous.items():
             coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Exogenous)
-        done = set()
-        for owner in self._order:
+        skip = set()
+        for name, (owner, first, stored_scalar) in self._fourbox.items():
+            if stored_scalar:
+                continue  # the collection holds the aggregated scalar (write transform)
             ens = self.ensembles[owner]
-            fourbox = L.FOURBOX_VARS.get(ens.kind)
-            if fourbox:
-                ids = range(fourbox[1], fourbox[1] + 4)
-                boxes = np.stack([ens.get_series(v, m_begin=member, m_end=member + 1)[:, 0] for v in ids], axis=1)
-                coll.add_fourbox_timeseries(fourbox[0], FourBoxTimeseries(boxes, self._axis, "K" if ens.kind == L.KIND_UDEB else "W/m^2"))
-                done.update((owner, v) for v in ids)
+            boxes = np.stack([ens.get_series(v, m_begin=member, m_end=member + 1)[:, 0] for v in range(first, first + 4)], axis=1)
+            coll.add_fourbox_timeseries(name, FourBoxTimeseries(boxes, self._axis, "K" if ens.kind == L.KIND_UDEB else "W/m^2"))
+            skip.add(name)
         for name, (owner, vid) in self._var_home.items():
-            if (owner, vid) in done:
+            if name in skip:
                 continue
             vals = self.ensembles[owner].get_series(vid, m_begin=member, m_end=member + 1)[:, 0]
             coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Endogenous)

@@ -458,3 +458,172 @@ def test_graph_model_magicc_lite_chain_with_feedback(ra, aerosol_first):
     m2.close()
     model.close()
     del cbind
+
+
+@pytest.mark.parametrize("execution_order", ["reference", "topological"])
+def test_full_emissions_driven_magicc_graph_closed_loop(ra, execution_order):
+    """The reference's emissions-driven MAGICC model (tests/regression/test_ghg_forcing.py:399-563:
+    the ten rscm-magicc components in its registration order, FourBox surface temperature read as a
+    scalar, FourBox aerosol forcing stored as a scalar, Sum of eight forcings) on synthetic
+    emissions, as ten linked ensembles plus two grid transforms and the aggregate.
+
+    Closed-loop check: every component's outputs are recomputed by its CPU oracle from the inputs
+    that component saw -- the device's own series, picked by the reference's rules restated here
+    (exogenous and lagged reads at index n, upstream reads at n+1 -- NaN if the producer runs later
+    in the execution order; ClimateUDEB at n and n+1; aggregates at n+1 with NaN skipped; FourBox
+    -> scalar = sum of value * 0.25) -- and must agree with what the device stored.  Tolerances are
+    those of the single-component GPU tests."""
+    import rscm_amd.core as core
+    from oracle import cbind as orc
+    from rscm_amd import _lib as L
+    from rscm_amd import magicc as B
+    t = np.arange(1750.0, 1831.0)
+    T, yrs, b = len(t), t - 1750.0, _bounds(t)
+    exo = {"Emissions|CO2|Fossil": 0.08 * yrs, "Emissions|CO2|Land Use": 0.5 + 0.0 * yrs, "Emissions|CH4": 200.0 + 2.0 * yrs,
+           "Emissions|N2O": 7.0 + 0.05 * yrs, "Emissions|NOx": 10.0 + 0.2 * yrs, "Emissions|CO": 300.0 + 2.0 * yrs,
+           "Emissions|NMVOC": 60.0 + 0.5 * yrs, "Emissions|SOx": 2.0 + 0.1 * yrs, "Emissions|BC": 2.5 + 0.02 * yrs,
+           "Emissions|OC": 10.0 + 0.1 * yrs, "EESC": 1400.0 + 3.0 * yrs}
+    init = {"Atmospheric Concentration|CO2": 278.0, "Atmospheric Concentration|CH4": 722.0, "Atmospheric Concentration|N2O": 270.0,
+            "Surface Temperature": 0.0, "Ocean Surface pCO2": 278.0, "Cumulative Ocean Uptake": 0.0,
+            "Carbon Pool|Plant": 884.86, "Carbon Pool|Detritus": 92.77, "Carbon Pool|Soil": 1681.53, "Carbon Pool|Humus": 836.0,
+            "Effective Radiative Forcing": 0.0}  # ClimateUDEB reads the aggregate at_start of step 0
+    contributors = ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|CH4", "Effective Radiative Forcing|N2O",
+                    "Effective Radiative Forcing|O3|Stratospheric", "Effective Radiative Forcing|O3|Tropospheric",
+                    "Effective Radiative Forcing|O3|Temperature Feedback", "Effective Radiative Forcing|Aerosol|Direct",
+                    "Effective Radiative Forcing|Aerosol|Indirect"]
+    schema = core.VariableSchema()
+    scalars = list(exo) + [k for k in init if k not in ("Surface Temperature", "Effective Radiative Forcing")] + contributors + [
+        "Heat Uptake", "Ocean Heat Content", "Sea Surface Temperature", "Carbon Flux|Terrestrial", "Carbon Flux|Ocean",
+        "Emissions|CO2|Net", "Airborne Fraction|CO2", "Lifetime|CH4", "Lifetime|N2O"]
+    for n in scalars:
+        schema.add_variable(n, "")
+    schema.add_variable("Surface Temperature", "K", core.GridType.FourBox)
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum", contributors)
+    comps = [B.CH4ChemistryBuilder.from_parameters({}).build(), B.N2OChemistryBuilder.from_parameters({}).build(),
+             B.GhgForcingBuilder.from_parameters({"method": "Ipcctar"}).build(), B.OzoneForcingBuilder.from_parameters({}).build(),
+             B.AerosolDirectBuilder.from_parameters({}).build(), B.AerosolIndirectBuilder.from_parameters({}).build(),
+             B.ClimateUDEBBuilder.from_parameters({}).build(), B.TerrestrialCarbonBuilder.from_parameters({}).build(),
+             B.OceanCarbonBuilder.from_parameters({}).build(), B.CO2BudgetBuilder.from_parameters({}).build()]
+    by_name = {c.type_name: c for c in comps}
+    axis = core.TimeAxis.from_values(t)
+    bld = core.ModelBuilder().with_time_axis(axis).with_schema(schema).with_initial_values(init)
+    for c in comps:
+        bld.with_rust_component(c)
+    for name, vals in exo.items():
+        bld.with_exogenous_variable(name, core.Timeseries(vals, axis, "", core.InterpolationStrategy.Linear))
+    model = bld.build(execution_order=execution_order)
+    order = list(model._order)
+    pos = {n: k for k, n in enumerate(order)}
+    if execution_order == "reference":  # hand-derived from the edges of builder.rs and petgraph's Bfs
+        assert [n for n in order if not n.startswith("Transform:")] == [
+            "AerosolIndirect", "AerosolDirect", "N2OChemistry", "CH4Chemistry", "Aggregator:Effective Radiative Forcing",
+            "GhgForcing", "OzoneForcing", "ClimateUDEB", "OceanCarbon", "TerrestrialCarbon", "CO2Budget"]
+    else:
+        assert pos["GhgForcing"] < pos["Aggregator:Effective Radiative Forcing"] > pos["OzoneForcing"]
+    model.run()
+    coll = model.timeseries()
+    S = {n: coll.get_timeseries_by_name(n).values() for n in coll.names() if coll.get_timeseries_by_name(n) is not None}
+    boxes = coll.get_fourbox_timeseries_by_name("Surface Temperature").values()  # [T][4]
+    ad = model.ensembles["AerosolDirect"]
+    ad_boxes = np.stack([ad.get_series(v)[:, 0] for v in range(1, 5)], axis=1)
+    assert "Effective Radiative Forcing|Aerosol|Direct" in S and S["Effective Radiative Forcing|Aerosol|Direct"].shape == (T,)
+
+    def scalar_of(bx):
+        s = np.zeros(len(bx))
+        for k in range(4):
+            s = s + bx[:, k] * 0.25
+        return s
+
+    S["Surface Temperature"] = scalar_of(boxes)
+    assert_bit_equal(S["Effective Radiative Forcing|Aerosol|Direct"][1:], scalar_of(ad_boxes)[1:], "write transform of the aerosol forcing")
+    producer = {}
+    for c in comps:
+        for name, _, kind in c.definitions:
+            if kind in ("Output", "State"):
+                producer[name] = c.type_name
+    producer["Effective Radiative Forcing"] = "Aggregator:Effective Radiative Forcing"
+    sources = model.variable_sources()
+
+    def seen(name, consumer, force_end=False):
+        """What `consumer` read of `name` at every step n (length T, last entry unused)."""
+        out = np.full(T, np.nan)
+        if name not in producer:
+            return np.asarray(exo[name], dtype=np.float64).copy()
+        if force_end or sources.get((name, consumer)) == "UpstreamOutput":
+            if pos[producer[name]] < pos[consumer]:
+                out[:-1] = S[name][1:]
+            return out       # a producer that runs later has not written index n+1 yet: NaN
+        out[:-1] = S[name][:-1]
+        return out
+
+    def check(name, got, want, tol):
+        assert (np.isnan(got) == np.isnan(want)).all(), (name, np.isnan(got).sum(), np.isnan(want).sum())
+        ok = ~np.isnan(want)
+        err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+        assert err.size == 0 or err.max() <= tol, (name, err.max())
+
+    def P(c):
+        return np.asarray(by_name[c].param_vector(), dtype=np.float64)
+
+    def block(c, rows):
+        return np.stack([seen(r, c) for r in rows])
+
+    # chemistry
+    conc, life = orc.chem_run(orc.CHEM_CH4, b, P("CH4Chemistry"), block("CH4Chemistry", L.CH4_INPUTS), 722.0)
+    check("CH4", S["Atmospheric Concentration|CH4"], conc[:, 0], 1e-12)
+    check("Lifetime|CH4", S["Lifetime|CH4"], life[:, 0], 1e-12)
+    conc, life = orc.chem_run(orc.CHEM_N2O, b, P("N2OChemistry"), block("N2OChemistry", L.N2O_INPUTS), 270.0)
+    check("N2O", S["Atmospheric Concentration|N2O"], conc[:, 0], 1e-12)
+    # forcings
+    g = orc.ghg_run(T, P("GhgForcing"), block("GhgForcing", L.GH_INPUTS))
+    for key, name in zip(orc.GHG_VARS, ("Effective Radiative Forcing|CO2", "Effective Radiative Forcing|CH4", "Effective Radiative Forcing|N2O")):
+        check(name, S[name], g[key][:, 0], 1e-12)
+    o = orc.pointwise_run(orc.PW_OZONE, T, P("OzoneForcing"), block("OzoneForcing", L.OZ_INPUTS))
+    for k, name in enumerate(contributors[3:6]):
+        check(name, S[name], o[k, :, 0], 1e-12)
+    o = orc.pointwise_run(orc.PW_AEROSOL_DIRECT, T, P("AerosolDirect"), block("AerosolDirect", L.AD_INPUTS))
+    check("aerosol direct boxes", ad_boxes, o[:, :, 0].T, 1e-12)
+    o = orc.pointwise_run(orc.PW_AEROSOL_INDIRECT, T, P("AerosolIndirect"), block("AerosolIndirect", L.AI_INPUTS))
+    check(contributors[7], S[contributors[7]], o[0, :, 0], 1e-12)
+    # the aggregate: contributors at n+1, NaN skipped, all-NaN -> NaN; index 0 is the initial value
+    agg = np.full(T, np.nan)
+    agg[0] = 0.0
+    rows = [seen(c, "Aggregator:Effective Radiative Forcing", force_end=True) for c in contributors]
+    for n in range(T - 1):
+        acc, cnt = 0.0, 0
+        for r in rows:
+            if not np.isnan(r[n]):
+                acc, cnt = acc + r[n], cnt + 1
+        agg[n + 1] = acc if cnt else np.nan
+    assert_bit_equal(S["Effective Radiative Forcing"], agg, "Sum of eight forcings")
+    seen_by_agg = [c for c, r in zip(contributors, rows) if not np.isnan(r[:-1]).all()]
+    if execution_order == "reference":
+        # petgraph's order runs the aggregate before GhgForcing and OzoneForcing: it holds the aerosol terms only
+        assert seen_by_agg == contributors[6:]
+    else:
+        assert seen_by_agg == contributors
+    # climate: at_start / at_end of the aggregate
+    u, st = orc.udeb_run(b, P("ClimateUDEB"), S["Effective Radiative Forcing"])
+    assert st[0] == 0
+    for k, key in enumerate(("st0", "st1", "st2", "st3")):
+        check(f"Surface Temperature box {k}", boxes[:, k], u[key][:, 0], 1e-9)
+    check("Sea Surface Temperature", S["Sea Surface Temperature"], u["sst"][:, 0], 1e-9)
+    check("Heat Uptake", S["Heat Uptake"], u["heat_uptake"][:, 0], 1e-9)
+    # carbon cycle
+    tc = orc.carbon_run(orc.CARBON_TERRESTRIAL, b, P("TerrestrialCarbon"), block("TerrestrialCarbon", L.TC_INPUTS),
+                        [884.86, 92.77, 1681.53, 836.0])
+    for k, name in enumerate(("Carbon Pool|Plant", "Carbon Pool|Detritus", "Carbon Pool|Soil", "Carbon Pool|Humus", "Carbon Flux|Terrestrial")):
+        check(name, S[name], tc[k, :, 0], 1e-12)
+    oc = orc.ocean_run(b, P("OceanCarbon"), block("OceanCarbon", L.OC_INPUTS), 278.0, 0.0)
+    for k, name in enumerate(("Ocean Surface pCO2", "Cumulative Ocean Uptake", "Carbon Flux|Ocean")):
+        check(name, S[name], oc[k, :, 0], 1e-9)
+    cb = orc.carbon_run(orc.CARBON_BUDGET, b, P("CO2Budget"), block("CO2Budget", L.CB_INPUTS), [278.0])
+    for k, name in enumerate(("Atmospheric Concentration|CO2", "Emissions|CO2|Net", "Airborne Fraction|CO2")):
+        check(name, S[name], cb[k, :, 0], 1e-12)
+    # the chain is alive: concentrations respond to emissions, the ocean takes carbon up
+    assert S["Atmospheric Concentration|CO2"][-1] > 285.0 and S["Atmospheric Concentration|CH4"][-1] > 900.0
+    assert S["Cumulative Ocean Uptake"][-1] > 0.0
+    if execution_order == "topological":
+        assert S["Effective Radiative Forcing"][-1] > S["Effective Radiative Forcing|Aerosol|Indirect"][-1] + 0.3
+        assert boxes[-1].mean() > 0.05
+    model.close()
