@@ -255,6 +255,25 @@ def linked_graph_extra(members, device, stream, years):
             "note": "CarbonCycle, CO2ERF, Sum, TwoLayer as four linked ensembles, 4 launches per model step"}
 
 
+def magicc_chain_extra(members, years):
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    model = mod.build_chain(members, years, "topological")
+    t0 = time.perf_counter()
+    model.run()
+    dt = time.perf_counter() - t0
+    warm = model.ensembles["Transform:Surface Temperature"].summary(1, years)
+    n = len(model._order)
+    model.close()
+    return {"member_years_per_s": members * years / dt, "ms": dt * 1e3, "launches": n * years, "ensembles": n,
+            "finite_members": warm["count"], "mean_warming_K": warm["mean"],
+            "note": "10 components + aggregate + 2 grid transforms, lock-step in topological order"}
+
+
 def end_to_end_extra(members, device, mode, stream, years):
     import time
     from rscm_amd.ensemble import pinned_empty
@@ -367,6 +386,10 @@ def main():
         # the same coupled chain assembled from four linked ensembles and stepped in graph order
         # (rscm_ens_link_input / rscm_ens_run_lockstep): what an arbitrary component graph costs
         extra["coupled_linked_1e6"] = linked_graph_extra(1_000_000, local_rank, stream, years)
+
+        # BASELINE.json configs[3]: the emissions-driven MAGICC graph (ten rscm-magicc components, Sum of
+        # eight forcings, FourBox transforms) as linked ensembles, ClimateUDEB / OceanCarbon at 12 sub-steps
+        extra["magicc_chain_1e5"] = magicc_chain_extra(100_000, years)
 
         # SURVEY 8d asks for the end-to-end figure beside the resident one: host parameters in,
         # run, full Ts and Td series out into page-locked buffers (never reported as `value`)
