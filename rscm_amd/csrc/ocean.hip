@@ -62,7 +62,12 @@ __device__ __forceinline__ double mac(double acc, double f, double r)
 
 // YEARS consecutive model steps starting at n: one pass over the old pulses feeds the
 // STEPS*YEARS running sums of all their sub-steps.
-template <int STEPS, int YEARS, bool FUSED, class Inputs>
+// PHASE splits a two-year tile over two launches, for callers that advance one step at a time
+// (linked graphs: next year's CO2 depends on this year's flux): 1 = the pass over the old pulses
+// and the first year, the second year's running sums parked in a.partial; 2 = the second year,
+// resumed from them.  The same sums in the same order as PHASE 0, half the history traffic of two
+// one-year tiles.
+template <int STEPS, int YEARS, bool FUSED, int PHASE, class Inputs>
 __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember& m, const Inputs& in,
                                            const double* __restrict__ irf, double* __restrict__ hist, int64_t i, int32_t n)
 {
@@ -80,6 +85,11 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     // ---- the old pulses, oldest first.  Head: the first K-1 of them are still outside the
     // window of the later sub-steps (bounded history), so each term is predicated.
     int64_t j = lo(0);
+    if constexpr (PHASE == 2) {
+        j = m0;  // the old pulses were summed by the PHASE 1 launch
+#pragma unroll
+        for (int k = STEPS; k < K; ++k) A[k] = a.partial[(size_t)(k - STEPS) * N + i];
+    }
     const int64_t head_end = (j + K - 1 < m0) ? j + K - 1 : m0;
     for (; j < head_end; ++j) {
         const double f = hist[(size_t)j * N];
@@ -112,9 +122,14 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     // ---- the tile's own sub-steps (solve_ocean, carbon/ocean.rs:116-160), its pulses in registers
     double fy[K];
     const size_t r0 = (size_t)n * N + i;
-    double pco2 = a.series[r0], cumulative = a.series[vs + r0];
+    constexpr int Y0 = PHASE == 2 ? 1 : 0, Y1 = PHASE == 1 ? 1 : YEARS;
+    double pco2 = a.series[r0 + (size_t)Y0 * N], cumulative = a.series[vs + r0 + (size_t)Y0 * N];
+    if constexpr (PHASE == 2) {
 #pragma unroll
-    for (int y = 0; y < YEARS; ++y) {
+        for (int q = 0; q < STEPS; ++q) fy[q] = hist[(size_t)(m0 + q) * N];  // the first year's pulses
+    }
+#pragma unroll
+    for (int y = Y0; y < Y1; ++y) {
         const double co2 = in.at(0, n + y), delta_sst = in.at(1, n + y);
         const double dt = a.bounds[n + y + 1] - a.bounds[n + y];
         const double dt_month = dt / (double)STEPS;
@@ -140,6 +155,10 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
         a.series[r1] = pco2;
         a.series[vs + r1] = cumulative;
         a.series[2 * vs + r1] = total;
+    }
+    if constexpr (PHASE == 1) {
+#pragma unroll
+        for (int k = STEPS; k < K; ++k) a.partial[(size_t)(k - STEPS) * N + i] = A[k];
     }
 }
 
@@ -167,8 +186,16 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
     int32_t n = a.step_begin;
     // two model steps per pass over the history while two remain: half the HBM traffic, the same
     // sums in the same order
-    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2, FUSED>(a, m, in, irf, hist, i, n);
-    if (n < a.step_end) ocean_tile<STEPS, 1, FUSED>(a, m, in, irf, hist, i, n);
+    if (a.phase == 1) {
+        ocean_tile<STEPS, 2, FUSED, 1>(a, m, in, irf, hist, i, n);
+        return;
+    }
+    if (a.phase == 2) {
+        ocean_tile<STEPS, 2, FUSED, 2>(a, m, in, irf, hist, i, n - 1);
+        return;
+    }
+    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2, FUSED, 0>(a, m, in, irf, hist, i, n);
+    if (n < a.step_end) ocean_tile<STEPS, 1, FUSED, 0>(a, m, in, irf, hist, i, n);
 }
 
 }  // namespace

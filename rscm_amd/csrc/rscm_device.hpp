@@ -238,6 +238,8 @@ struct OceanArgs {
     const double* bounds;    // [T+1]
     const double* irf;       // [max(max_hist, 1)] scaled impulse response at lag k/12 yr
     double* hist;            // [(T-1)*steps][N] flux history, ppm/month
+    double* partial;         // [steps][N] running sums parked between the two launches of a split tile
+    int32_t phase;           // 0: whole tiles; 1 / 2: first / second year of a two-year tile (one-step launches)
     double* series;          // [3][T][N]: pCO2, cumulative uptake, flux
     uint8_t* status;
 };

@@ -165,6 +165,8 @@ struct rscm_ens {
     // OceanCarbon: flux history (internal state) and the tabulated impulse response
     double* d_ocean_hist = nullptr;  // [(T-1)*steps][N]
     double* d_ocean_irf = nullptr;   // [max(max_hist, 1)]
+    double* d_ocean_partial = nullptr;  // [steps][N] split-tile running sums (one-step launches)
+    int32_t ocean_partial_step = -1;    // the step whose sums d_ocean_partial holds, -1: none
     int32_t ocean_steps = 0;
     int64_t ocean_max_hist = 0;
     bool ocean_ready = false;
@@ -293,6 +295,13 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,
                         "flux history of %lld members x %d months: %s", (long long)h->N, (h->T - 1) * 12, hipGetErrorString(e));
     }
+    if (!h->d_ocean_partial) {
+        const hipError_t e = hipMalloc(&h->d_ocean_partial, (size_t)12 * h->N * sizeof(double));
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "split-tile sums of %lld members: %s",
+                        (long long)h->N, hipGetErrorString(e));
+    }
+    h->ocean_partial_step = -1;  // sums parked under another response table are void
     h->ocean_steps = 12;
     h->ocean_max_hist = (int64_t)max_hist;
     h->ocean_ready = true;
@@ -523,6 +532,7 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_ghg_tables);
     (void)hipFree(h->d_ocean_hist);
     (void)hipFree(h->d_ocean_irf);
+    (void)hipFree(h->d_ocean_partial);
     (void)hipFree(h->d_ocean);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
@@ -806,6 +816,7 @@ int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;  // a restored checkpoint carries its own state rows
     h->time_index = tidx;
+    h->ocean_partial_step = -1;
     return RSCM_OK;
 }
 
@@ -813,6 +824,7 @@ int rscm_ens_rewind(rscm_ens* h)
 {
     NEED(h);
     h->time_index = 0;
+    h->ocean_partial_step = -1;
     return RSCM_OK;
 }
 
@@ -930,6 +942,18 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.linked = linked;
         a.irf = h->d_ocean_irf;
         a.hist = h->d_ocean_hist;
+        // one step at a time (linked graphs, Model::step): pair the steps up so that the history is
+        // read once per two steps, as the two-year tiles of a whole run do
+        a.partial = h->d_ocean_partial;
+        a.phase = 0;
+        if (step_end - step_begin == 1 && h->d_ocean_partial) {
+            if (h->ocean_partial_step == step_begin) {
+                a.phase = 2;
+            } else if (step_begin + 1 < h->T - 1) {
+                a.phase = 1;
+            }
+        }
+        h->ocean_partial_step = a.phase == 1 ? step_begin + 1 : -1;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ocean(a, h->stream));

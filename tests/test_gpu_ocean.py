@@ -64,6 +64,11 @@ def test_ocean_gpu_bit_exact_without_temperature_feedback(ra, orc, model):
     assert np.array_equal(got, want, equal_nan=True)
     # three launches, boundaries inside a year group of the convolution: the same bits
     assert np.array_equal(_gpu(ra, b, P, inputs, 278.0, 0.0, scen=scen, chunks=(1, 17)), got, equal_nan=True)
+    # one step per launch (Model::step, linked graphs): the steps are paired up into split two-year
+    # tiles -- the same bits again, also when single steps and longer launches alternate
+    assert np.array_equal(_gpu(ra, b, P, inputs, 278.0, 0.0, scen=scen, chunks=range(1, T)), got, equal_nan=True)
+    mixed = (1, 2, 3, 10, 11, 12, 13, 30, 31, 58, 59)
+    assert np.array_equal(_gpu(ra, b, P, inputs, 278.0, 0.0, scen=scen, chunks=mixed), got, equal_nan=True)
 
 
 @pytest.mark.parametrize("n", [1, 63, 257])
@@ -97,6 +102,7 @@ def test_ocean_gpu_bounded_history(ra, orc, max_hist):
     got = _gpu(ra, b, P, inputs[:1], 280.0, 0.0)
     assert np.array_equal(got, want, equal_nan=True)
     assert np.array_equal(_gpu(ra, b, P, inputs[:1], 280.0, 0.0, chunks=(3, 20)), got, equal_nan=True)
+    assert np.array_equal(_gpu(ra, b, P, inputs[:1], 280.0, 0.0, chunks=range(1, T)), got, equal_nan=True)  # split tiles
 
 
 def test_ocean_through_the_reference_shaped_front(ra, orc):
