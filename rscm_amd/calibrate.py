@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib as L
-from .core import Model, ModelBuilder
+from .core import GraphModel, Model, ModelBuilder
 
 
 # ------------------------------------------------------------------------------------ priors
@@ -324,14 +324,26 @@ class ModelRunner:
     """
 
     def __init__(self, model: ModelBuilder, param_names: Sequence[str],
-                 output_variables: Sequence[str], mode: int = L.MODE_EXACT):
+                 output_variables: Sequence[str], mode: int = L.MODE_EXACT, execution_order: str = "reference"):
         self._builder = model
         self._param_names = list(param_names)
         self._outputs = list(output_variables)
         self._mode = mode
         self._models: Dict[int, Model] = {}
         self._lik_models: Dict[int, Model] = {}
+        self._execution_order = execution_order
         probe = self._model(1)
+        # a graph without a fused kernel: one linked ensemble per component (core.GraphModel); parameters
+        # are addressed as "Component.name", or by the bare name where only one component has it
+        self._graph = isinstance(probe, GraphModel)
+        if self._graph:
+            unknown = [p for p in self._param_names if p not in probe.param_home]
+            if unknown:
+                raise ValueError(f"unknown (or ambiguous) model parameter(s) {unknown}; known: {sorted(probe.param_home)}")
+            for v in self._outputs:
+                probe.variable_home(v)
+            self._rows = []
+            return
         unknown = [p for p in self._param_names if p not in probe.param_order]
         if unknown:
             raise ValueError(f"unknown model parameter(s) {unknown}; known: {list(probe.param_order)}")
@@ -352,8 +364,9 @@ class ModelRunner:
         if n not in self._models:
             if len(self._models) >= 4:  # bounded cache of device ensembles
                 self._models.pop(next(iter(self._models))).close()
-            m = self._builder.build(n_members=n)
-            m.ensemble.set_mode(self._mode)
+            m = self._builder.build(n_members=n, execution_order=self._execution_order)
+            if not isinstance(m, GraphModel):
+                m.ensemble.set_mode(self._mode)
             self._models[n] = m
         return self._models[n]
 
@@ -372,6 +385,10 @@ class ModelRunner:
         if p.ndim != 2 or p.shape[1] != len(self._param_names):
             got = p.shape[1] if p.ndim == 2 else len(p)
             raise ValueError(f"Expected {len(self._param_names)} parameters, got {got}")  # :225-231
+        if self._graph:
+            m.set_member_params(self._param_names, p)
+            m.rewind()
+            return
         full = np.repeat(m.base_params[:, None], p.shape[0], axis=1)
         full[self._rows, :] = p.T
         m.ensemble.set_params(full)
@@ -383,7 +400,10 @@ class ModelRunner:
             raise ValueError(f"Expected {len(self._param_names)} parameters, got {len(p)}")
         m = self._model(p.shape[0])
         self._load(m, p)
-        m.ensemble.run()
+        if self._graph:
+            m.run()
+        else:
+            m.ensemble.run()
         return m
 
     def run(self, params: Sequence[float]) -> Dict[str, Dict[float, float]]:
@@ -396,9 +416,9 @@ class ModelRunner:
             return []
         m = self._run(np.asarray(param_sets, dtype=np.float64))
         times = m._axis.values()
-        series = {v: m.ensemble.get_series(v) for v in self._outputs}
+        series = {v: (m.get_series(v) if self._graph else m.ensemble.get_series(v)) for v in self._outputs}
         out = []
-        for i in range(m.ensemble.n_members):
+        for i in range(len(param_sets)):
             member = {}
             for v, s in series.items():
                 col = s[:, i]
@@ -419,9 +439,11 @@ class ModelRunner:
             raise ValueError(f"Expected {len(self._param_names)} parameters, got {len(p)}")
         probe = self._model(1)
         ov, ot, val, sig = [], [], [], []
-        fused = probe.ensemble.kind == L.KIND_TWO_LAYER
+        fused = not self._graph and probe.ensemble.kind == L.KIND_TWO_LAYER
         for name, vt in target.variables():
-            if name not in probe.ensemble.var_ids or probe.ensemble.var_ids[name] == 0:
+            if self._graph:
+                probe.variable_home(name)
+            elif name not in probe.ensemble.var_ids or probe.ensemble.var_ids[name] == 0:
                 raise KeyError(f"Model output missing variable: {name}")
             prev = -1
             for obs in vt.observations:
@@ -448,6 +470,18 @@ class ModelRunner:
             m = self._lik_model(p.shape[0])
             self._load(m, p)
             local = m.ensemble.run_loglik(ov, ot, val, sig, likelihood.normalize)
+        elif self._graph:
+            # observations grouped by the ensemble that holds their variable, in the target's order;
+            # a member that fails anywhere is -inf (-inf + finite)
+            m = self._run(p)
+            local = np.zeros(p.shape[0])
+            groups: Dict[int, Tuple[object, list]] = {}
+            for k, name in enumerate(ov):
+                ens, vid = m.variable_home(name)
+                groups.setdefault(id(ens), (ens, []))[1].append((vid, ot[k], val[k], sig[k]))
+            for ens, obs in groups.values():
+                v, t_, x, s = zip(*obs)
+                local = local + ens.loglik(list(v), list(t_), list(x), list(s), likelihood.normalize)
         else:
             m = self._run(p)
             local = m.ensemble.loglik(ov, ot, val, sig, likelihood.normalize)
@@ -792,6 +826,9 @@ class DeviceEnsembleSampler:
             raise ValueError(f"Stretch move scale parameter must be > 1.0, got {stretch_a}")
         if list(params.param_names) != runner.param_names:
             raise ValueError("the parameter set must name the runner's parameters, in its order")
+        if getattr(runner, "_graph", False):
+            raise NotImplementedError("the device sampler drives one evaluating ensemble; a graph of linked "
+                                      "ensembles is calibrated with EnsembleSampler (batched evaluations on the GPU)")
         self.params, self.runner, self.likelihood, self.target = params, runner, likelihood, target
         self.a = float(stretch_a)
         self.default_n_walkers = max(2 * len(params), 32)

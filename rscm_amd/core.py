@@ -615,7 +615,13 @@ class ModelBuilder:
                 ens = Ensemble(COMPONENT_KINDS[comp.type_name], n_members, bounds, device=self._device)
                 ensembles[comp.type_name] = ens
                 ens.set_stream(stream.value)
-                ens.set_params(params_of(_component_params(comp)))
+                base = _component_params(comp)
+                ens.set_params(params_of(base))
+                model.base_params[comp.type_name] = np.array(base, dtype=np.float64)
+                for row, pname in enumerate(_component_param_names(comp)):
+                    model.param_home[f"{comp.type_name}.{pname}"] = (comp.type_name, row)
+                    # a bare name addresses the parameter only if no other component has one of that name
+                    model.param_home[pname] = (comp.type_name, row) if pname not in model.param_home else ("", -1)
                 if comp.type_name == "CarbonCycle":
                     ens.set_step_size(L.COMP_CARBON_CYCLE, comp.step_size)
                 for name, _, kind in comp.definitions:
@@ -680,6 +686,7 @@ class ModelBuilder:
                 if use_table:
                     ens.set_forcing(table if ens.input_rows else table[0])
 
+            model.param_home = {k: v for k, v in model.param_home.items() if v[1] >= 0}
             for comp in self._components:
                 ens = ensembles[comp.type_name]
                 rows = ens.input_rows or [n for n, v in ens.var_ids.items() if v == 0]
@@ -788,6 +795,23 @@ COMPONENT_KINDS = {"TwoLayer": L.KIND_TWO_LAYER, "ClimateUDEB": L.KIND_UDEB, "Ca
                    "CO2ERF": L.KIND_CO2_ERF, **STATELESS_KINDS}
 
 
+def _component_param_names(comp) -> Tuple[str, ...]:
+    if comp.type_name == "TwoLayer":
+        return tuple(TL_PARAM_ORDER)
+    if comp.type_name == "CarbonCycle":
+        return tuple(L.CC_PARAM_NAMES)
+    if comp.type_name == "CO2ERF":
+        return tuple(L.CE_PARAM_NAMES)
+    kind = COMPONENT_KINDS[comp.type_name]
+    table = {L.KIND_UDEB: L.UD_PARAM_NAMES, L.KIND_GHG_FORCING: L.GH_PARAM_NAMES, L.KIND_OZONE_FORCING: L.OZ_PARAM_NAMES,
+             L.KIND_AEROSOL_DIRECT: L.AD_PARAM_NAMES, L.KIND_AEROSOL_INDIRECT: L.AI_PARAM_NAMES,
+             L.KIND_CH4_CHEMISTRY: L.CH4_PARAM_NAMES, L.KIND_N2O_CHEMISTRY: L.N2O_PARAM_NAMES,
+             L.KIND_CO2_BUDGET: L.CB_PARAM_NAMES, L.KIND_TERRESTRIAL_CARBON: L.TC_PARAM_NAMES,
+             L.KIND_OCEAN_CARBON: L.OC_PARAM_NAMES, L.KIND_HALOCARBON: L.HC_PARAM_NAMES,
+             L.KIND_FOURBOX_OHU: L.FB_PARAM_NAMES, L.KIND_OSPP: L.SP_PARAM_NAMES}
+    return tuple(table[kind])
+
+
 def _component_params(comp) -> List[float]:
     if comp.type_name == "TwoLayer":
         return [comp.parameters[k] for k in TL_PARAM_ORDER]
@@ -821,6 +845,44 @@ class GraphModel:
         self._feed_forward = feed_forward
         self._fourbox: Dict[str, Tuple[str, int, bool]] = {}  # FourBox variable -> (producer, first id, stored as scalar)
         self.time_index = 0
+        # component parameters: "Type.name" -> (owner, row); bare names too where they are unique
+        self.param_home: Dict[str, Tuple[str, int]] = {}
+        self.base_params: Dict[str, np.ndarray] = {}
+
+    @property
+    def n_members(self) -> int:
+        return next(iter(self.ensembles.values())).n_members
+
+    def rewind(self) -> None:
+        for ens in self.ensembles.values():
+            ens.rewind()
+        self.time_index = 0
+
+    def variable_home(self, name: str) -> Tuple[Ensemble, int]:
+        """The ensemble and variable id that hold the scalar series of ``name``."""
+        if name not in self._var_home:
+            raise KeyError(f"Model output missing variable: {name}")
+        owner, vid = self._var_home[name]
+        return self.ensembles[owner], vid
+
+    def get_series(self, name: str, **kw) -> np.ndarray:
+        ens, vid = self.variable_home(name)
+        return ens.get_series(vid, **kw)
+
+    def set_member_params(self, names: Sequence[str], values) -> None:
+        """``values[N][len(names)]``: per-member values of the named component parameters; every
+        other parameter keeps the value its component was built with."""
+        v = np.asarray(values, dtype=np.float64)
+        if v.ndim != 2 or v.shape != (self.n_members, len(names)):
+            raise ValueError(f"Expected {len(names)} parameters for {self.n_members} members, got {v.shape}")
+        per_owner: Dict[str, np.ndarray] = {}
+        for k, name in enumerate(names):
+            owner, row = self.param_home[name]
+            if owner not in per_owner:
+                per_owner[owner] = np.repeat(self.base_params[owner][:, None], self.n_members, axis=1)
+            per_owner[owner][row] = v[:, k]
+        for owner, full in per_owner.items():
+            self.ensembles[owner].set_params(full)
 
     def variable_sources(self) -> Dict[Tuple[str, str], str]:
         return dict(self._sources)

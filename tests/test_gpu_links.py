@@ -627,3 +627,69 @@ def test_full_emissions_driven_magicc_graph_closed_loop(ra, execution_order):
         assert S["Effective Radiative Forcing"][-1] > S["Effective Radiative Forcing|Aerosol|Indirect"][-1] + 0.3
         assert boxes[-1].mean() > 0.05
     model.close()
+
+
+def test_calibrating_a_linked_graph(ra):
+    """rscm-calibrate over a graph without a fused kernel: ModelRunner batches the members through
+    the linked ensembles, the Gaussian log-likelihood is reduced on the device per owning ensemble.
+    Checks: run_batch of a graph == the same members run one by one; log-likelihoods == the host
+    formula on the extracted series (likelihood.rs:167-250); the stretch-move sampler recovers the
+    parameters that generated the pseudo-observations (ECS-like lambda0 of TwoLayer and the CO2
+    fertilisation-like conc_pi-free tau of CarbonCycle, two different components)."""
+    import rscm_amd.calibrate as cal
+    import rscm_amd.core as core
+    from rscm_amd.components import CarbonCycleBuilder, CO2ERFBuilder
+    from rscm_amd.two_layer import TwoLayerBuilder
+    t = np.arange(1750.0, 1901.0)
+    axis = core.TimeAxis.from_values(t)
+    tl = dict(lambda0=1.1, a=0.0, efficacy=1.2, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    schema = core.VariableSchema()
+    names = ["Emissions|CO2|Anthropogenic", "Surface Temperature", "Deep Ocean Temperature", "Atmospheric Concentration|CO2",
+             "Cumulative Land Uptake", "Cumulative Emissions|CO2", "Effective Radiative Forcing|CO2", "Effective Radiative Forcing|Other"]
+    for n in names:
+        schema.add_variable(n, "")
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum", ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|Other"])
+
+    def builder():
+        return (core.ModelBuilder().with_time_axis(axis).with_schema(schema)
+                .with_rust_component(CarbonCycleBuilder.from_parameters(dict(tau=25.0, conc_pi=278.0, alpha_temperature=0.05)).build())
+                .with_rust_component(CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build())
+                .with_rust_component(TwoLayerBuilder.from_parameters(tl).build())
+                .with_exogenous_variable("Emissions|CO2|Anthropogenic", core.Timeseries(emissions_syn(t) + 1.0, axis, "", core.InterpolationStrategy.Linear))
+                .with_exogenous_variable("Effective Radiative Forcing|Other", core.Timeseries(0.2 * np.sin(t / 9.0), axis, "", core.InterpolationStrategy.Linear))
+                .with_initial_values({"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
+                                      "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+
+    pnames = ["TwoLayer.lambda0", "tau"]   # qualified, and bare where unique
+    outputs = ["Surface Temperature", "Atmospheric Concentration|CO2"]
+    runner = cal.ModelRunner(builder(), pnames, outputs)
+    assert runner._graph
+    with pytest.raises(ValueError, match="ambiguous"):
+        cal.ModelRunner(builder(), ["conc_pi"], outputs)   # CarbonCycle and CO2ERF both have one
+    truth = [1.25, 30.0]
+    sets = np.array([truth, [0.9, 20.0], [1.4, 38.0]])
+    batch = runner.run_batch(sets)
+    for k, ps in enumerate(sets):
+        one = runner.run(list(ps))
+        for v in outputs:
+            assert one[v] == batch[k][v]
+    assert len(batch[0]["Surface Temperature"]) == len(t) and batch[0]["Atmospheric Concentration|CO2"][1900.0] > 300.0
+    target = cal.Target()
+    obs_years = np.arange(1800.0, 1901.0, 10.0)
+    for v, sigma in (("Surface Temperature", 0.005), ("Atmospheric Concentration|CO2", 0.1)):
+        for y in obs_years:
+            target.add_observation(v, float(y), batch[0][v][float(y)], sigma)
+    lik = cal.GaussianLikelihood()
+    ll = runner.log_likelihood_batch(sets, target, lik)
+    want = [sum(-0.5 * ((batch[0][v][float(y)] - batch[k][v][float(y)]) / s) ** 2
+                for v, s in (("Surface Temperature", 0.005), ("Atmospheric Concentration|CO2", 0.1)) for y in obs_years) for k in range(3)]
+    assert ll[0] == 0.0 and np.allclose(ll, want, rtol=1e-10, atol=1e-12)
+    params = cal.ParameterSet().add("TwoLayer.lambda0", cal.Uniform(0.8, 1.6)).add("tau", cal.Uniform(15.0, 45.0))
+    sampler = cal.EnsembleSampler(params, runner, lik, target)
+    chain = sampler.run(400, cal.WalkerInit.from_prior(), n_walkers=64, rng=np.random.default_rng(3))
+    flat = chain.flat_samples(discard=300)
+    med = np.median(flat, axis=0)
+    assert abs(med[0] - truth[0]) < 0.02 and abs(med[1] - truth[1]) < 1.0, med
+    with pytest.raises(NotImplementedError, match="EnsembleSampler"):
+        cal.DeviceEnsembleSampler(params, runner, lik, target)
+    runner.close()
