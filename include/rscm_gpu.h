@@ -445,6 +445,11 @@ RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
 /* Rewind to time index 0 keeping parameters, forcing and initial values (outputs are
  * overwritten by the next run). */
 RSCM_API int rscm_ens_rewind(rscm_ens* h);
+/* Back to a fresh collection: time index 0 and every stored row after index 0 NaN again
+ * (builder.rs:772-780), index 0 (initial values) kept.  rscm_ens_rewind alone leaves the rows of the
+ * previous run in place, which nothing reads before rewriting them -- except a linked consumer that
+ * runs ahead of its producer (rscm_ens_set_link_order_check). */
+RSCM_API int rscm_ens_clear_series(rscm_ens* h);
 /* Device time of the most recent rscm_ens_run* launch sequence, from HIP events recorded on
  * the launch stream (valid after a sync). */
 RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);

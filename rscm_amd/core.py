@@ -674,6 +674,7 @@ class ModelBuilder:
                             # component that runs before the producer of what it reads at n+1 and, like
                             # in the reference, finds NaN there
                             model._feed_forward = False
+                            model._reads_unwritten = model._reads_unwritten or src == L.SRC_UPSTREAM
                             L.check(L.load().rscm_ens_set_link_order_check(ens._h, 0))
                     else:
                         if name in endogenous:
@@ -843,6 +844,7 @@ class GraphModel:
         self._stream = stream
         self._device = device
         self._feed_forward = feed_forward
+        self._reads_unwritten = False  # some component reads index n+1 of a producer that runs after it
         self._fourbox: Dict[str, Tuple[str, int, bool]] = {}  # FourBox variable -> (producer, first id, stored as scalar)
         self.time_index = 0
         # component parameters: "Type.name" -> (owner, row); bare names too where they are unique
@@ -854,8 +856,13 @@ class GraphModel:
         return next(iter(self.ensembles.values())).n_members
 
     def rewind(self) -> None:
+        """Back to a fresh model.  Where a component runs ahead of a producer it reads at n+1, the
+        rows of the previous run must not be found there: they are cleared to NaN."""
         for ens in self.ensembles.values():
-            ens.rewind()
+            if self._reads_unwritten:
+                ens.clear_series()
+            else:
+                ens.rewind()
         self.time_index = 0
 
     def variable_home(self, name: str) -> Tuple[Ensemble, int]:

@@ -1076,6 +1076,21 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
     return RSCM_OK;
 }
 
+int rscm_ens_clear_series(rscm_ens* h)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (int rc = set_device(h)) return rc;
+    if (h->rows > 1)
+        for (int32_t v = 1; v < h->V; ++v)
+            HIPCHK(rscm::launch_fill(h->series(v) + h->N, (int64_t)(h->rows - 1) * h->N,
+                                     std::numeric_limits<double>::quiet_NaN(), h->stream));
+    h->time_index = 0;
+    h->ocean_partial_step = -1;
+    return RSCM_OK;
+    GUARD_END
+}
+
 int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     GUARD_BEGIN

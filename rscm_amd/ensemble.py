@@ -177,6 +177,10 @@ class Ensemble:
     def rewind(self) -> None:
         L.check(self._lib.rscm_ens_rewind(self._h))
 
+    def clear_series(self) -> None:
+        """Rewind and make every stored row after index 0 NaN again (a fresh collection)."""
+        L.check(self._lib.rscm_ens_clear_series(self._h))
+
     def finished(self) -> bool:
         return self.time_index == self.n_times - 1
 

@@ -626,6 +626,13 @@ def test_full_emissions_driven_magicc_graph_closed_loop(ra, execution_order):
     if execution_order == "topological":
         assert S["Effective Radiative Forcing"][-1] > S["Effective Radiative Forcing|Aerosol|Indirect"][-1] + 0.3
         assert boxes[-1].mean() > 0.05
+    # a second run of the same model object is a fresh run: what the aggregate read as NaN the first
+    # time (rows its producers had not written yet) must not be found filled in by the first run
+    model.rewind()
+    model.run()
+    again = model.timeseries()
+    for name in ("Effective Radiative Forcing", "Atmospheric Concentration|CO2", "Sea Surface Temperature"):
+        assert_bit_equal(again.get_timeseries_by_name(name).values(), coll.get_timeseries_by_name(name).values(), f"rerun {name}")
     model.close()
 
 
