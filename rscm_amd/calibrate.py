@@ -365,7 +365,9 @@ class ModelRunner:
             if len(self._models) >= 4:  # bounded cache of device ensembles
                 self._models.pop(next(iter(self._models))).close()
             m = self._builder.build(n_members=n, execution_order=self._execution_order)
-            if not isinstance(m, GraphModel):
+            if isinstance(m, GraphModel):
+                m.set_mode(self._mode)
+            else:
                 m.ensemble.set_mode(self._mode)
             self._models[n] = m
         return self._models[n]

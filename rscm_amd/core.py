@@ -855,6 +855,12 @@ class GraphModel:
     def n_members(self) -> int:
         return next(iter(self.ensembles.values())).n_members
 
+    def set_mode(self, mode: int) -> None:
+        """Arithmetic mode of every ensemble of the graph (``MODE_FAST``: fused multiply-adds in
+        the two-layer RK4 and the OceanCarbon convolution; the other kinds compute the same either way)."""
+        for ens in self.ensembles.values():
+            ens.set_mode(mode)
+
     def rewind(self) -> None:
         """Back to a fresh model.  Where a component runs ahead of a producer it reads at n+1, the
         rows of the previous run must not be found there: they are cleared to NaN."""

@@ -71,9 +71,12 @@ if __name__ == "__main__":
     ap.add_argument("--members", type=int, default=100_000)
     ap.add_argument("--years", type=int, default=750)
     ap.add_argument("--order", default="topological")
+    ap.add_argument("--fast", action="store_true", help="RSCM_MODE_FAST: fused multiply-adds in the ocean convolution")
     args = ap.parse_args()
     t0 = time.perf_counter()
     model = build_chain(args.members, args.years, args.order)
+    if args.fast:
+        model.set_mode(L.MODE_FAST)
     free, total = L.mem_info(0)
     print(f"built {len(model._order)} linked ensembles for {args.members} members in {time.perf_counter()-t0:.1f} s; "
           f"HBM in use {(total-free)/2**30:.1f} GiB; order: {model._order}", flush=True)

@@ -754,3 +754,61 @@ def test_halocarbon_eesc_feeds_ozone(ra):
         assert (np.isnan(g) == np.isnan(w)).all() and np.allclose(g[1:], w[1:], rtol=1e-12, atol=1e-15), name
     assert got.get_timeseries_by_name("Effective Radiative Forcing|O3|Stratospheric").values()[-1] < -0.01
     model.close()
+
+
+def test_link_bookkeeping_and_lockstep_errors(ra):
+    """Relinking a row moves the reference from the old producer to the new one; destroying a
+    consumer releases its producers; rscm_ens_run_lockstep refuses handles that stand at different
+    time indices or run on different streams; clear_series makes rows after index 0 NaN again."""
+    from rscm_amd.ensemble import run_lockstep
+    t = axis_values(2000, 2010)
+    b = _bounds(t)
+    s = Stream()
+    P = two_layer_params(8)
+
+    def two_layer():
+        e = ra.Ensemble(ra.KIND_TWO_LAYER, 8, b)
+        e.set_stream(s.h.value)
+        e.set_params(P)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        return e
+
+    p1, p2, c = two_layer(), two_layer(), two_layer()
+    p1.set_forcing(f_syn(t))
+    p2.set_forcing(2.0 * f_syn(t))
+    c.link_input(0, p1, 1)
+    c.link_input(0, p2, 1)          # relink: p1 is free again
+    p1.close()
+    with pytest.raises(Exception, match="linked input"):
+        p2.close()
+    p2.run()
+    c.run()
+    want = c.get_series(1)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 8, b) as ref:   # the same numbers through the table: Ts of p2, member 0 .. 7 as scenarios
+        ref.set_params(P)
+        ref.set_initial(1, 0.0)
+        ref.set_initial(2, 0.0)
+        ref.set_forcing(p2.get_series(1).T.copy(), np.arange(8, dtype=np.int32))
+        ref.run()
+        assert_bit_equal(want, ref.get_series(1), "linked to the second producer")
+    # lock-step preconditions
+    p2.rewind()
+    with pytest.raises(Exception, match="time index"):
+        run_lockstep((p2, c))
+    c.rewind()
+    other = ra.Ensemble(ra.KIND_TWO_LAYER, 8, b)     # keeps its own stream
+    other.set_params(P)
+    with pytest.raises(Exception, match="another stream"):
+        run_lockstep((p2, other))
+    other.close()
+    run_lockstep((p2, c), 4)
+    assert p2.time_index == 4 and c.time_index == 4
+    run_lockstep((p2, c))
+    assert_bit_equal(c.get_series(1), want, "lock-step in two legs")
+    c.clear_series()
+    cleared = c.get_series(1, 0, len(t))
+    assert c.time_index == 0 and (cleared[0] == 0.0).all()
+    c.close()                        # releases p2
+    p2.close()
+    s.close()
