@@ -438,7 +438,8 @@ RSCM_API int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_en
  * [step_begin, step_end) each handle, in the order given (the graph order), advances by that one
  * step -- n_handles asynchronous launches per step on the handles' common stream, without
  * returning to the caller in between.  Every handle must stand at step_begin; follow with
- * rscm_ens_sync on any of them. */
+ * rscm_ens_sync on any of them.  If a launch is refused part-way (a state error of one handle), the
+ * handles before it in the order have advanced one step further than those after it. */
 RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end);
 RSCM_API int rscm_ens_sync(rscm_ens* h);
 RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
