@@ -812,3 +812,59 @@ def test_link_bookkeeping_and_lockstep_errors(ra):
     c.close()                        # releases p2
     p2.close()
     s.close()
+
+
+def test_carbon_cycle_and_co2_erf_kinds_on_their_own(ra):
+    """RSCM_KIND_CARBON_CYCLE / RSCM_KIND_CO2_ERF with table inputs (no links) against the generic
+    stepper: CarbonCycle with exogenous emissions and temperature, two RK4 step sizes, scenario map;
+    CO2ERF at the reference's known-answer points (co2_erf.rs:94-114: 0 at C0, erf_2xco2 at 2 C0)."""
+    from oracle import reference_model as rm
+    t = np.arange(1750.0, 1851.0)
+    T, b = len(t), _bounds(t)
+    E = np.stack([emissions_syn(t) + 0.5, 3.0 + 0.0 * t])
+    Temp = np.stack([0.01 * (t - 1750.0), 1.0 + 0.0 * t])
+    N = 6
+    rng = np.random.default_rng(4)
+    P = np.stack([rng.uniform(15.0, 40.0, N), np.full(N, 278.0), rng.uniform(0.0, 0.1, N)])
+    scen = (np.arange(N) % 2).astype(np.int32)
+    for h in (0.1, 0.25):
+        with ra.Ensemble(ra.KIND_CARBON_CYCLE, N, b) as e:
+            e.set_params(P)
+            e.set_step_size(1, h)
+            e.set_forcing(np.stack([np.stack([E[s], Temp[s]]) for s in range(2)]), scen)
+            for var, v in ((1, 280.0), (2, 0.0), (3, 0.0)):
+                e.set_initial(var, v)
+            e.run(40)
+            e.run()
+            got = [e.get_series(v) for v in (1, 2, 3)]
+            assert not e.status().any()
+        for i in range(N):
+            s = int(scen[i])
+            m = rm.ModelBuilder(axis=rm.TimeAxis.from_values(t), components=[rm.CarbonCycle(P[0, i], P[1, i], P[2, i], step=h)],
+                                initial_values={"Atmospheric Concentration|CO2": 280.0, "Cumulative Land Uptake": 0.0,
+                                                "Cumulative Emissions|CO2": 0.0},
+                                exogenous={"Emissions|CO2|Anthropogenic": rm.ExoSeries(list(E[s]), rm.TimeAxis.from_values(t)),
+                                           "Surface Temperature": rm.ExoSeries(list(Temp[s]), rm.TimeAxis.from_values(t))}).build()
+            m.run()
+            for k, name in enumerate(("Atmospheric Concentration|CO2", "Cumulative Land Uptake", "Cumulative Emissions|CO2")):
+                w = np.array(m.data[name])
+                assert np.allclose(got[k][:, i], w, rtol=1e-12, atol=0.0), (h, i, name)
+            assert_bit_equal(got[2][:, i], np.array(m.data["Cumulative Emissions|CO2"]), "cumulative emissions involve no exp")
+    with pytest.raises(Exception, match="does not land"):
+        with ra.Ensemble(ra.KIND_CARBON_CYCLE, N, b) as e:
+            e.set_params(P)
+            e.set_step_size(1, 0.3)   # ceil(1/0.3) = 4 steps of 0.3 overshoot the year by 0.2
+            e.set_forcing(np.stack([E[0], Temp[0]]))
+            for var in (1, 2, 3):
+                e.set_initial(var, 0.0)
+            e.run()
+    conc = np.array([278.0, 556.0, 417.0, 0.0])
+    with ra.Ensemble(ra.KIND_CO2_ERF, 3, _bounds(np.array([0.0, 1.0, 2.0, 3.0]))) as e:
+        e.set_params(np.array([[3.7, 4.0, 3.7], [278.0, 278.0, 300.0]]))
+        e.set_forcing(conc)  # C at indices 0, 1, 2 is read by steps 0, 1, 2 (exogenous: index n)
+        e.run()
+        got = e.get_series(1)
+    assert np.isnan(got[0]).all()
+    assert got[1, 0] == 0.0 and abs(got[2, 0] - 3.7) < 1e-15 and abs(got[2, 1] - 4.0) < 1e-15
+    want = rm.CO2ERF(3.7, 300.0).calculate_erf(417.0)
+    assert abs(got[3, 2] - want) < 1e-15
