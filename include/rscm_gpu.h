@@ -417,6 +417,16 @@ RSCM_API int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const
 /* RSCM_KIND_UDEB and RSCM_KIND_OCEAN_CARBON keep the reference's internal ComponentState (ocean
  * columns, flux history) on the device: for them tidx must be 0 or the current index. */
 RSCM_API int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx);
+/* The internal ComponentState of the kinds that have one -- what the reference serialises next to the
+ * collection in a checkpoint (runtime.rs:270-282): RSCM_KIND_UDEB: ocean layer temperatures
+ * [2][n_layers][N], the per-member scalars [11][N] and the temperature history rows 0..time_index;
+ * RSCM_KIND_OCEAN_CARBON: the flux history of the time_index * 12 months so far.  One flat block of
+ * doubles whose length depends on the current time index (0 for every other kind).
+ * rscm_ens_set_internal_state puts such a block back and moves the stepper to `time_index` (the
+ * one it was taken at); the stored series rows are restored with rscm_ens_set_state. */
+RSCM_API int rscm_ens_internal_state_size(rscm_ens* h, int64_t* n_doubles);
+RSCM_API int rscm_ens_get_internal_state(rscm_ens* h, double* out);
+RSCM_API int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles, int32_t time_index);
 /* Use an existing hipStream_t (as void*) for all launches and copies; NULL = own stream. */
 RSCM_API int rscm_ens_set_stream(rscm_ens* h, void* hip_stream);
 /* A non-blocking hipStream_t on `device_id` for callers without a HIP runtime of their own (linked

@@ -871,6 +871,23 @@ class GraphModel:
                 ens.rewind()
         self.time_index = 0
 
+    def checkpoint(self) -> Dict[str, object]:
+        """Everything needed to continue from the current step in another model object built from
+        the same builder: per ensemble the current row of every stored variable (linked consumers
+        read outputs as well as states), the rows the chemistry looks back at, the internal
+        component states (runtime.rs:270-282)."""
+        for ens in self.ensembles.values():
+            ens.sync()
+        return {"time_index": self.time_index, "order": list(self._order),
+                "ensembles": {name: ens.checkpoint(all_variables=True) for name, ens in self.ensembles.items()}}
+
+    def restore(self, ck: Dict[str, object]) -> None:
+        if ck["order"] != list(self._order) or set(ck["ensembles"]) != set(self.ensembles):
+            raise ValueError("checkpoint does not match this graph")
+        for name, ens in self.ensembles.items():
+            ens.restore(ck["ensembles"][name])
+        self.time_index = int(ck["time_index"])
+
     def variable_home(self, name: str) -> Tuple[Ensemble, int]:
         """The ensemble and variable id that hold the scalar series of ``name``."""
         if name not in self._var_home:

@@ -820,6 +820,79 @@ int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
     return RSCM_OK;
 }
 
+typedef std::vector<std::pair<double*, int64_t>> StatePieces;
+
+// the pieces of a handle's internal component state at time index k: (device pointer, doubles)
+static void internal_pieces(const rscm_ens* h, int32_t k, StatePieces& p)
+{
+    if (h->kind == RSCM_KIND_UDEB && h->d_ocean && h->d_scal && h->d_hist) {
+        p.emplace_back(h->d_ocean, (int64_t)2 * h->udeb_n_layers * h->N);
+        p.emplace_back(h->d_scal, (int64_t)rscm::kUdebScalars * h->N);
+        p.emplace_back(h->d_hist, (int64_t)(k + 1) * h->N);
+    } else if (h->kind == RSCM_KIND_OCEAN_CARBON && h->d_ocean_hist) {
+        p.emplace_back(h->d_ocean_hist, (int64_t)k * h->ocean_steps * h->N);
+    }
+}
+
+int rscm_ens_internal_state_size(rscm_ens* h, int64_t* n_doubles)
+{
+    NEED(h);
+    if (!n_doubles) return fail(RSCM_ERR_INVALID, "n_doubles is NULL");
+    int64_t n = 0;
+    StatePieces pieces;
+    internal_pieces(h, h->time_index, pieces);
+    for (const auto& piece : pieces) n += piece.second;
+    *n_doubles = n;
+    return RSCM_OK;
+}
+
+int rscm_ens_get_internal_state(rscm_ens* h, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    if (int rc = set_device(h)) return rc;
+    StatePieces pieces;
+    internal_pieces(h, h->time_index, pieces);
+    for (const auto& piece : pieces) {
+        if (piece.second > 0)
+            HIPCHK(hipMemcpyAsync(out, piece.first, (size_t)piece.second * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        out += piece.second;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles, int32_t time_index)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (time_index < 0 || time_index > h->rows - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", time_index);
+    if ((h->kind == RSCM_KIND_UDEB && !h->udeb_ready) || (h->kind == RSCM_KIND_OCEAN_CARBON && !h->ocean_ready))
+        return fail(RSCM_ERR_STATE, "set the parameters first: they size the internal state");
+    StatePieces pieces;
+    internal_pieces(h, time_index, pieces);
+    int64_t n = 0;
+    for (const auto& piece : pieces) n += piece.second;
+    if (n != n_doubles) return fail(RSCM_ERR_INVALID, "internal state at time index %d is %lld doubles, got %lld", time_index, (long long)n, (long long)n_doubles);
+    if (n > 0 && !in) return fail(RSCM_ERR_INVALID, "in is NULL");
+    if (int rc = set_device(h)) return rc;
+    for (const auto& piece : pieces) {
+        if (piece.second > 0)
+            HIPCHK(hipMemcpyAsync(piece.first, in, (size_t)piece.second * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        in += piece.second;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (time_index > 0)
+        for (int32_t v = 1; v < h->V; ++v)
+            if (h->is_state(v)) h->initial_set[v] = 1;
+    h->time_index = time_index;
+    h->ocean_partial_step = -1;
+    return RSCM_OK;
+    GUARD_END
+}
+
 int rscm_ens_rewind(rscm_ens* h)
 {
     NEED(h);

@@ -191,38 +191,41 @@ class Ensemble:
 
     # -- checkpoint / resume ------------------------------------------------------------------
     def state_vars(self) -> Dict[str, int]:
-        if self.kind == L.KIND_TWO_LAYER:
-            return {k: v for k, v in self.var_ids.items() if v in (1, 2)}
-        if self.kind == L.KIND_UDEB:
-            raise NotImplementedError("ClimateUDEB keeps internal ocean state on the device; "
-                                      "host checkpoints are not available for this kind yet")
-        if self.kind in (L.KIND_CH4_CHEMISTRY, L.KIND_N2O_CHEMISTRY):
-            # the update reads the two latest concentrations (previous() / at_start()) and, for
-            # N2O, rows further back: one row is not enough to resume from
-            raise NotImplementedError("host checkpoints of the chemistry kinds need the concentration history")
-        if self.kind == L.KIND_OCEAN_CARBON:
-            raise NotImplementedError("OceanCarbon keeps its flux history on the device; "
-                                      "host checkpoints are not available for this kind yet")
-        if self.kind == L.KIND_HALOCARBON:
-            return {k: v for k, v in self.var_ids.items() if 1 <= v <= len(L.HC_SPECIES)}
-        if self.kind == L.KIND_CO2_BUDGET:
-            return {k: v for k, v in self.var_ids.items() if v == 1}
-        if self.kind == L.KIND_TERRESTRIAL_CARBON:
-            return {k: v for k, v in self.var_ids.items() if 1 <= v <= 4}
-        if self.kind == L.KIND_CARBON_CYCLE:
-            return {k: v for k, v in self.var_ids.items() if 1 <= v <= 3}
-        if self.kind >= L.KIND_GHG_FORCING:
-            return {}  # stateless components
-        return {k: v for k, v in self.var_ids.items() if 1 <= v <= 5}
+        """The State variables of the kind (what the stepper reads back at the next step)."""
+        ids = {L.KIND_TWO_LAYER: (1, 2), L.KIND_COUPLED: (1, 5), L.KIND_UDEB: (1, 4), L.KIND_CH4_CHEMISTRY: (1, 1),
+               L.KIND_N2O_CHEMISTRY: (1, 1), L.KIND_CO2_BUDGET: (1, 1), L.KIND_TERRESTRIAL_CARBON: (1, 4),
+               L.KIND_OCEAN_CARBON: (1, 2), L.KIND_HALOCARBON: (1, len(L.HC_SPECIES)), L.KIND_CARBON_CYCLE: (1, 3)}
+        lo, hi = ids.get(self.kind, (1, 0))  # the other kinds are stateless
+        return {k: v for k, v in self.var_ids.items() if lo <= v <= hi}
 
-    def checkpoint(self) -> Dict[str, object]:
-        """What is needed to resume: time index, parameters, and row ``time_index`` of every state
-        variable (the reference's JSON checkpoint holds time_index + the whole collection,
-        crates/rscm-core/src/model/runtime.rs:270-282; rows before the index are history)."""
+    def _history_depth(self) -> int:
+        """Rows before the current one that the next step reads (previous() / at_offset(-k))."""
+        if self.kind == L.KIND_CH4_CHEMISTRY:
+            return 1
+        if self.kind == L.KIND_N2O_CHEMISTRY:  # at_offset(-(strat_delay + 1)), n2o.rs:203-218
+            return int(max(1.0, np.nanmax(self.get_params()[L.N2O_PARAM_NAMES.index("strat_delay")]))) + 1
+        return 0
+
+    def checkpoint(self, all_variables: bool = False) -> Dict[str, object]:
+        """What is needed to resume: time index, parameters, row ``time_index`` of every state
+        variable (``all_variables``: of every stored variable -- what linked consumers read), the
+        earlier rows the chemistry kinds look back at, and the internal component state of
+        ClimateUDEB / OceanCarbon.  The reference's checkpoint holds time_index, the whole collection
+        and the component states (crates/rscm-core/src/model/runtime.rs:270-282)."""
         k = self.time_index
+        names = {n: v for n, v in self.var_ids.items() if v > 0} if all_variables else self.state_vars()
+        depth = min(self._history_depth(), k)
+        history = {name: self.get_series(v, k - depth, k) for name, v in self.state_vars().items()} if depth else {}
+        n = C.c_int64()
+        L.check(self._lib.rscm_ens_internal_state_size(self._h, C.byref(n)))
+        internal = None
+        if n.value:
+            internal = np.empty(n.value)
+            L.check(self._lib.rscm_ens_get_internal_state(self._h, L.dptr(internal)))
         return {"kind": self.kind, "n_members": self.n_members, "bounds": self.bounds.copy(),
                 "time_index": k, "params": self.get_params(),
-                "state": {name: self.get_series(v, k, k + 1)[0] for name, v in self.state_vars().items()}}
+                "state": {name: self.get_series(v, k, k + 1)[0] for name, v in names.items()},
+                "history": history, "internal": internal}
 
     def restore(self, ck: Dict[str, object]) -> None:
         if (ck["kind"] != self.kind or ck["n_members"] != self.n_members
@@ -231,9 +234,16 @@ class Ensemble:
         self.set_params(ck["params"])
         k = int(ck["time_index"])
         for name, row in ck["state"].items():
-            v = L.f64(row)
-            L.check(self._lib.rscm_ens_set_state(self._h, self._var(name), k, L.dptr(v), v.size))
-        L.check(self._lib.rscm_ens_set_time_index(self._h, k))
+            self.set_state(name, k, row)
+        for name, rows in ck.get("history", {}).items():
+            for d, row in enumerate(rows):
+                self.set_state(name, k - len(rows) + d, row)
+        internal = ck.get("internal")
+        if internal is not None:
+            blob = L.f64(internal)
+            L.check(self._lib.rscm_ens_set_internal_state(self._h, L.dptr(blob), blob.size, k))
+        else:
+            L.check(self._lib.rscm_ens_set_time_index(self._h, k))
 
     # -- outputs ----------------------------------------------------------------------------
     def get_series(self, var, t_begin: int = 0, t_end: Optional[int] = None, t_stride: int = 1,

@@ -868,3 +868,46 @@ def test_carbon_cycle_and_co2_erf_kinds_on_their_own(ra):
     assert got[1, 0] == 0.0 and abs(got[2, 0] - 3.7) < 1e-15 and abs(got[2, 1] - 4.0) < 1e-15
     want = rm.CO2ERF(3.7, 300.0).calculate_erf(417.0)
     assert abs(got[3, 2] - want) < 1e-15
+
+
+def test_graph_checkpoint_resumes_the_full_chain_bit_identically(ra):
+    """Checkpoint / resume (Model::checkpoint / from_checkpoint, runtime.rs:270-282) of the
+    emissions-driven MAGICC graph: time index, the current row of every stored variable, the rows the
+    chemistry looks back at (N2O: strat_delay + 1), and the internal component states -- ClimateUDEB's
+    ocean columns and temperature history, OceanCarbon's flux history.  A fresh model object restored
+    at step 33 (odd: inside a split ocean tile) continues to the same bits."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    years, N = 70, 96
+    a = mod.build_chain(N, years, "topological")
+    a.run()
+    names = ["Atmospheric Concentration|CO2", "Atmospheric Concentration|CH4", "Atmospheric Concentration|N2O", "Sea Surface Temperature",
+             "Cumulative Ocean Uptake", "Carbon Pool|Soil", "Effective Radiative Forcing", "Effective Radiative Forcing|O3|Tropospheric"]
+    want = {n: a.get_series(n) for n in names}
+    a.close()
+    b1 = mod.build_chain(N, years, "topological")
+    for _ in range(33):
+        b1.step()
+    ck = b1.checkpoint()
+    b1.close()
+    assert ck["time_index"] == 33 and ck["ensembles"]["OceanCarbon"]["internal"].size == 33 * 12 * N
+    assert ck["ensembles"]["N2OChemistry"]["history"]["Atmospheric Concentration|N2O"].shape[0] >= 2
+    b2 = mod.build_chain(N, years, "topological")
+    b2.restore(ck)
+    assert b2.time_index == 33
+    b2.step()
+    b2.run()
+    for n in names:
+        assert_bit_equal(b2.get_series(n)[33:], want[n][33:], f"resumed {n}")
+    assert np.isfinite(want["Sea Surface Temperature"][1:]).all()
+    with pytest.raises(ValueError, match="does not match"):
+        other = mod.build_chain(N, years, "reference")
+        try:
+            other.restore(ck)
+        finally:
+            other.close()
+    b2.close()
