@@ -791,6 +791,56 @@ class ModelBuilder:
                      np.array(params, dtype=np.float64))
 
 
+def save_checkpoint(path, ck: Dict[str, object]) -> None:
+    """A checkpoint (of an ``Ensemble`` or a ``GraphModel``) as one ``.npz`` of plain arrays: nested
+    keys joined with ``/``; nothing is pickled, so loading executes nothing from the file."""
+    flat: Dict[str, np.ndarray] = {}
+
+    def walk(prefix: str, value) -> None:
+        if isinstance(value, dict):
+            flat[prefix + "/__dict__"] = np.array(len(value))
+            for k, v in value.items():
+                if "/" in str(k):
+                    raise ValueError(f"key {k!r} contains '/'")
+                walk(f"{prefix}/{k}", v)
+        elif value is None:
+            flat[prefix + "/__none__"] = np.array(0)
+        elif isinstance(value, (list, tuple)) and all(isinstance(x, str) for x in value):
+            flat[prefix + "/__strings__"] = np.array(list(value), dtype=np.str_)
+        else:
+            flat[prefix] = np.asarray(value)
+
+    walk("", ck)
+    np.savez(path, **{k.lstrip("/").replace("|", "__BAR__"): v for k, v in flat.items()})
+
+
+def load_checkpoint(path) -> Dict[str, object]:
+    out: Dict[str, object] = {}
+    with np.load(path, allow_pickle=False) as z:
+        for raw in z.files:
+            parts = raw.replace("__BAR__", "|").split("/")
+            node = out
+            leaf = parts[-1]
+            if leaf in ("__dict__", "__none__", "__strings__"):
+                parts, marker = parts[:-1], leaf
+            else:
+                marker = None
+            for p_ in parts[:-1]:
+                node = node.setdefault(p_, {})
+            if not parts:
+                continue
+            if marker == "__dict__":
+                node.setdefault(parts[-1], {})
+            elif marker == "__none__":
+                node[parts[-1]] = None
+            elif marker == "__strings__":
+                node[parts[-1]] = [str(x) for x in z[raw]]
+            else:
+                v = z[raw]
+                node[parts[-1]] = v.item() if v.ndim == 0 else v
+    return out
+
+
 # type name -> ensemble kind, for graphs assembled from linked ensembles
 COMPONENT_KINDS = {"TwoLayer": L.KIND_TWO_LAYER, "ClimateUDEB": L.KIND_UDEB, "CarbonCycle": L.KIND_CARBON_CYCLE,
                    "CO2ERF": L.KIND_CO2_ERF, **STATELESS_KINDS}

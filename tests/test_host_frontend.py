@@ -273,3 +273,27 @@ def test_config_loader_layers():
     assert len(b._axis) == 351 and b._axis.at(0) == 1750.0 and b._axis.at(350) == 2100.0
     with pytest.raises(ValueError, match="Unknown model type"):
         cfg.build_model({"model": {"type": "nope"}})
+
+
+def test_checkpoint_files_round_trip(tmp_path):
+    """save_checkpoint / load_checkpoint: a nested checkpoint as plain arrays in one .npz (nothing
+    pickled), variable names with '|' and ':' intact, None and NaN preserved."""
+    ck = {"time_index": 33, "order": ["A", "Transform:Surface Temperature"],
+          "ensembles": {"A": {"kind": 2, "n_members": 4, "bounds": np.arange(5.0), "time_index": 33, "params": np.ones((3, 4)),
+                              "state": {"Surface Temperature|NorthernOcean": np.arange(4.0)}, "history": {}, "internal": None},
+                        "Transform:Surface Temperature": {"kind": 17, "n_members": 4, "bounds": np.arange(5.0), "time_index": 33,
+                                                          "params": np.ones((9, 4)), "state": {"aggregate": np.array([1.0, np.nan, 2.0, 3.0])},
+                                                          "history": {"x": np.ones((2, 4))}, "internal": np.arange(7.0)}}}
+    core.save_checkpoint(tmp_path / "c.npz", ck)
+    back = core.load_checkpoint(tmp_path / "c.npz")
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return isinstance(b, dict) and set(a) == set(b) and all(same(a[k], b[k]) for k in a)
+        if a is None or isinstance(a, list):
+            return a == b
+        return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+    assert same(ck, back) and isinstance(back["time_index"], int)
+    with pytest.raises(ValueError, match="contains '/'"):
+        core.save_checkpoint(tmp_path / "d.npz", {"a/b": 1})
