@@ -870,7 +870,7 @@ def test_carbon_cycle_and_co2_erf_kinds_on_their_own(ra):
     assert abs(got[3, 2] - want) < 1e-15
 
 
-def test_graph_checkpoint_resumes_the_full_chain_bit_identically(ra):
+def test_graph_checkpoint_resumes_the_full_chain_bit_identically(ra, tmp_path):
     """Checkpoint / resume (Model::checkpoint / from_checkpoint, runtime.rs:270-282) of the
     emissions-driven MAGICC graph: time index, the current row of every stored variable, the rows the
     chemistry looks back at (N2O: strat_delay + 1), and the internal component states -- ClimateUDEB's
@@ -896,6 +896,9 @@ def test_graph_checkpoint_resumes_the_full_chain_bit_identically(ra):
     b1.close()
     assert ck["time_index"] == 33 and ck["ensembles"]["OceanCarbon"]["internal"].size == 33 * 12 * N
     assert ck["ensembles"]["N2OChemistry"]["history"]["Atmospheric Concentration|N2O"].shape[0] >= 2
+    import rscm_amd.core as core
+    core.save_checkpoint(tmp_path / "chain.npz", ck)   # through a file: plain arrays, nothing pickled
+    ck = core.load_checkpoint(tmp_path / "chain.npz")
     b2 = mod.build_chain(N, years, "topological")
     b2.restore(ck)
     assert b2.time_index == 33
