@@ -812,3 +812,49 @@ def test_summary_series_equals_row_summaries(ra, orc):
         part = e.summary_series("Deep Ocean Temperature", 10, 20)
         row = e.get_series(2, 10, 20)
         assert np.allclose(part["mean"], np.nanmean(row, axis=1), rtol=1e-12) and np.array_equal(part["max"], np.nanmax(row, axis=1))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_coupled_chain_fuzz(ra, orc, seed):
+    """Seeded random configurations of the fused coupled chain -- axis length, irregular step
+    lengths, the two RK4 step sizes, scenarios (LDS and L2 paths) with or without a map, member-wise
+    initial values, launch chunking -- against the oracle: 1e-11 on bounded members (device exp /
+    log), cumulative emissions (no transcendental) bit for bit, status flags exact."""
+    rng = np.random.default_rng(5000 + seed)
+    T = int(rng.integers(3, 200))
+    n = int(rng.choice([1, 63, 64, 65, 300, 1025]))
+    h_tl = float(rng.choice([0.0625, 0.125, 0.25]))
+    h_cc = float(rng.choice([0.0625, 0.125, 0.25, 0.5]))
+    lengths = rng.integers(1, 5, T) * 0.5
+    b = np.concatenate([[1750.0], 1750.0 + np.cumsum(lengths)])
+    S = int(rng.choice([1, 1, 3, 30]))
+    E = np.abs(rng.normal(3.0, 3.0, (S, T)))
+    scen = rng.integers(0, S, n).astype(np.int32) if (S > 1 or rng.random() < 0.3) else None
+    P = coupled_params(n, seed=seed)
+    init = dict(ts=rng.normal(0.0, 0.2, n) if rng.random() < 0.5 else 0.0, td=0.0,
+                conc=rng.uniform(270.0, 300.0, n) if rng.random() < 0.5 else 278.0, cum_uptake=0.0, cum_emis=1.5)
+    want = orc.coupled_run(b, P, E, init, scen=scen, h_tl=h_tl, h_cc=h_cc, threads=8)
+    cuts = sorted(set(int(x) for x in rng.integers(0, T, int(rng.integers(0, 3)))))
+    with ra.Ensemble(ra.KIND_COUPLED, n, b) as e:
+        e.set_step_size(0, h_tl)
+        e.set_step_size(1, h_cc)
+        e.set_params(P)
+        e.set_forcing(E, scen)
+        for key, name in CP_NAMES.items():
+            if key in init:
+                e.set_initial(name, init[key])
+        for c in cuts:
+            if c > e.time_index:
+                e.run(c)
+        e.run()
+        got = {key: e.get_series(name) for key, name in CP_NAMES.items()}
+        st = e.status()
+    what = f"seed {seed} (T={T}, n={n}, S={S}, h_tl={h_tl}, h_cc={h_cc}, cuts={cuts})"
+    bounded = _bounded(want["ts"])
+    for key in CP_NAMES:
+        g, w = got[key], want[key]
+        assert (np.isnan(g[:, bounded]) == np.isnan(w[:, bounded])).all(), f"{what} {key}"
+        assert _close(g[1:, bounded], w[1:, bounded], FAST_RTOL).all(), f"{what} {key}"
+    assert_bit_equal(got["cum_emis"], want["cum_emis"], f"{what} cumulative emissions")
+    finite = np.isfinite(want["ts"][-1]) & np.isfinite(want["td"][-1]) & np.isfinite(want["conc"][-1]) & np.isfinite(want["cum_uptake"][-1])
+    assert np.array_equal(st[bounded] == 0, finite[bounded]), what
