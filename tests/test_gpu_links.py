@@ -914,3 +914,72 @@ def test_graph_checkpoint_resumes_the_full_chain_bit_identically(ra, tmp_path):
         finally:
             other.close()
     b2.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_graph_model_random_registration_orders(ra, seed):
+    """The five-component chain of test_graph_model_magicc_lite_chain_with_feedback registered in a
+    random order, with a random aggregate operation and N2O delay: whatever petgraph's breadth-first
+    order and the registration-order classification make of it (lagged reads, reads of rows not
+    written yet), the linked ensembles must reproduce the generic stepper variable by variable.
+    Orders that leave components unreachable from the root are refused."""
+    import rscm_amd.core as core
+    from oracle import reference_model as rm
+    from rscm_amd import magicc
+    from rscm_amd.two_layer import TwoLayerBuilder
+    rng = np.random.default_rng(700 + seed)
+    t = np.arange(1850.0, 1911.0)
+    yrs = t - t[0]
+    tl = dict(lambda0=1.2, a=0.0, efficacy=1.1, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    exo = {"Emissions|CH4": 250.0 + 3.0 * yrs, "Emissions|NOx": 30.0 + 0.2 * yrs, "Emissions|CO": 400.0 + 2.0 * yrs,
+           "Emissions|NMVOC": 80.0 + 0.5 * yrs, "Emissions|N2O": 8.0 + 0.05 * yrs,
+           "Atmospheric Concentration|CO2": 285.0 + 0.3 * yrs + 0.004 * yrs ** 2,
+           "Emissions|SOx": 5.0 + 0.6 * yrs, "Emissions|OC": 12.0 + 0.1 * yrs}
+    init = {"Atmospheric Concentration|CH4": 800.0, "Atmospheric Concentration|N2O": 273.0,
+            "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}
+    contributors = ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|CH4", "Effective Radiative Forcing|N2O",
+                    "Effective Radiative Forcing|Aerosol|Indirect"]
+    op = str(rng.choice(["Sum", "Mean"]))
+    delay = int(rng.integers(1, 5))
+    comps = [magicc.CH4ChemistryBuilder.from_parameters({"include_temp_feedback": True}).build(),
+             magicc.N2OChemistryBuilder.from_parameters({"strat_delay": delay}).build(),
+             magicc.GhgForcingBuilder.from_parameters({"method": str(rng.choice(["Olbl", "Ipcctar"]))}).build(),
+             magicc.AerosolIndirectBuilder.from_parameters({}).build(),
+             TwoLayerBuilder.from_parameters(tl).build()]
+    perm = rng.permutation(5)
+    comps = [comps[k] for k in perm]
+    ref_of = {"CH4Chemistry": rm.CH4Chemistry, "N2OChemistry": rm.N2OChemistry, "GhgForcing": rm.GhgForcing,
+              "AerosolIndirect": rm.AerosolIndirect}
+    schema = core.VariableSchema()
+    for n in list(exo) + list(init) + contributors + ["Lifetime|CH4", "Lifetime|N2O"]:
+        schema.add_variable(n, "")
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", op, contributors)
+    axis = core.TimeAxis.from_values(t)
+    b = core.ModelBuilder().with_time_axis(axis).with_schema(schema).with_initial_values(init)
+    for c in comps:
+        b.with_rust_component(c)
+    for name, vals in exo.items():
+        b.with_exogenous_variable(name, core.Timeseries(vals, axis, "", core.InterpolationStrategy.Linear))
+    ref = rm.ModelBuilder(
+        axis=rm.TimeAxis.from_values(t),
+        components=[rm.TwoLayer(*[tl[k] for k in core.TL_PARAM_ORDER]) if c.type_name == "TwoLayer" else ref_of[c.type_name](c.param_vector())
+                    for c in comps],
+        aggregates=[("Effective Radiative Forcing", op, contributors)], initial_values=init,
+        exogenous={k: rm.ExoSeries(list(v), rm.TimeAxis.from_values(t)) for k, v in exo.items()}).build()
+    ref_order = [ref.order_nodes[i].type_name for i in ref._bfs() if ref.order_nodes[i] is not None]
+    names = [c.type_name for c in comps]
+    if len(ref_order) < 6:
+        with pytest.raises(NotImplementedError, match="not reachable"):
+            b.build()
+        return
+    model = b.build()
+    assert list(model._order) == ref_order, (names, model._order, ref_order)
+    model.run()
+    ref.run()
+    got = model.timeseries()
+    for name, want in ref.data.items():
+        g, w = got.get_timeseries_by_name(name).values(), np.array(want)
+        assert (np.isnan(g) == np.isnan(w)).all(), (names, op, name)
+        ok = ~np.isnan(w)
+        assert (np.abs(g[ok] - w[ok]) <= 1e-11 * np.maximum(1.0, np.abs(w[ok]))).all(), (names, op, name)
+    model.close()
