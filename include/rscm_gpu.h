@@ -542,6 +542,14 @@ RSCM_API int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double 
 /* The same four numbers for every time index in [t_begin, t_end) in two launches:
  * out[(t_end - t_begin)][4].  Each row carries the bits rscm_ens_summary returns for it. */
 RSCM_API int rscm_ens_summary_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end, double* out);
+/* Ensemble quantiles of a stored variable at every time index of [t_begin, t_end): the plume (median,
+ * 5-95 % band ...) reduced on the device.  Definition: numpy.nanquantile(row, q, method="linear") --
+ * NaN members left out, virtual index (n - 1) q, numpy's interpolation -- so the results carry numpy's
+ * bits.  out[(t - t_begin)][n_q]; count[(t - t_begin)] (or NULL) = members that are not NaN.  Rows beyond
+ * the current time index: count 0, quantiles NaN.  An extension: the reference has no ensemble
+ * statistics; q in [0, 1]. */
+RSCM_API int rscm_ens_quantile_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end, int32_t n_q,
+                                      const double* q, double* out, double* count);
 
 /* Copy the parameter matrix back to the host as [P][N] (e.g. after rscm_ens_sample_lhs). */
 RSCM_API int rscm_ens_get_params(rscm_ens* h, double* out_soa);

@@ -272,6 +272,7 @@ SIGNATURES = {
     "rscm_ens_status": (C.c_int, [_h, _bp]),
     "rscm_ens_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
     "rscm_ens_run_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
+    "rscm_ens_quantile_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "rscm_ens_summary_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rscm_sampler_create": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp, _dp, C.c_int32, _ip, _ip,
                                       _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.POINTER(_h)]),

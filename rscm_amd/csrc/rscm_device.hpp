@@ -317,6 +317,9 @@ hipError_t launch_summary(const double* row, int64_t n, double* partial, int32_t
 int32_t summary_blocks(int64_t n);
 hipError_t launch_summary_rows(const double* rows, int64_t n, int32_t n_rows, double* partial, int32_t n_blocks,
                                double* out, hipStream_t s);
+// per row of rows[n_rows][N]: out[r] = {count of non-NaN, quantile q[0], ..., q[n_q-1]} (numpy nanquantile, linear)
+hipError_t launch_quantile_rows(const double* rows, int64_t N, int32_t n_rows, const double* d_q, int32_t n_q, double* d_out,
+                                hipStream_t s);
 hipError_t launch_lhs(double* params, int32_t n_params, int64_t n_local, uint64_t seed,
                       const double* low, const double* high, int64_t member_offset,
                       int64_t n_total, hipStream_t s);

@@ -1810,6 +1810,45 @@ int rscm_ens_summary_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_
     GUARD_END
 }
 
+int rscm_ens_quantile_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_end, int32_t n_q, const double* q, double* out,
+                             double* count)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (var_id < 1 || var_id >= h->V || t_begin < 0 || t_end > h->T || t_begin > t_end || !out || n_q < 1 || !q)
+        return fail(RSCM_ERR_INVALID, "bad variable / time range / quantile list");
+    for (int32_t k = 0; k < n_q; ++k)
+        if (!(q[k] >= 0.0 && q[k] <= 1.0)) return fail(RSCM_ERR_INVALID, "Quantiles must be in the range [0, 1], got %g", q[k]);
+    if (h->rows != h->T) return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES)");
+    const int32_t n_rows = t_end - t_begin;
+    const int32_t computed = std::max(0, std::min(t_end, h->time_index + 1) - t_begin);
+    for (int32_t r = computed; r < n_rows; ++r) {
+        for (int32_t k = 0; k < n_q; ++k) out[(size_t)r * n_q + k] = std::numeric_limits<double>::quiet_NaN();
+        if (count) count[r] = 0.0;
+    }
+    if (computed == 0) return RSCM_OK;
+    if (int rc = set_device(h)) return rc;
+    double* d_q = nullptr;
+    double* d_out = nullptr;
+    std::vector<double> host((size_t)computed * (n_q + 1));
+    HIPCHK(hipMalloc(&d_q, (size_t)n_q * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, host.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, q, (size_t)n_q * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = rscm::launch_quantile_rows(h->series(var_id) + (size_t)t_begin * h->N, h->N, computed, d_q, n_q, d_out, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_q);
+    (void)hipFree(d_out);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "quantile_series: %s", hipGetErrorString(e));
+    for (int32_t r = 0; r < computed; ++r) {
+        if (count) count[r] = host[(size_t)r * (n_q + 1)];
+        for (int32_t k = 0; k < n_q; ++k) out[(size_t)r * n_q + k] = host[(size_t)r * (n_q + 1) + 1 + k];
+    }
+    return RSCM_OK;
+    GUARD_END
+}
+
 int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4])
 {
     GUARD_BEGIN

@@ -313,6 +313,17 @@ class Ensemble:
             mean = np.where(cnt > 0, out[:, 1] / np.where(cnt > 0, cnt, 1.0), np.nan)
         return {"count": cnt.astype(np.int64), "mean": mean, "min": out[:, 2].copy(), "max": out[:, 3].copy()}
 
+    def quantile_series(self, var, q, t_begin: int = 0, t_end: Optional[int] = None) -> Dict[str, np.ndarray]:
+        """Ensemble quantiles at every time index of ``[t_begin, t_end)``, reduced on the device:
+        ``numpy.nanquantile(series[t], q)`` (linear method) per row.  Returns ``{"count": [rows],
+        "quantiles": [rows][len(q)]}``."""
+        qq = np.atleast_1d(L.f64(q))
+        t_end = self.n_times if t_end is None else t_end
+        rows = max(0, t_end - t_begin)
+        out, cnt = np.empty((rows, qq.size)), np.empty(rows)
+        L.check(self._lib.rscm_ens_quantile_series(self._h, self._var(var), t_begin, t_end, qq.size, L.dptr(qq), L.dptr(out), L.dptr(cnt)))
+        return {"count": cnt.astype(np.int64), "quantiles": out}
+
 
 class _PinnedOwner:
     def __init__(self, ptr):

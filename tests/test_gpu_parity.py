@@ -858,3 +858,45 @@ def test_coupled_chain_fuzz(ra, orc, seed):
     assert_bit_equal(got["cum_emis"], want["cum_emis"], f"{what} cumulative emissions")
     finite = np.isfinite(want["ts"][-1]) & np.isfinite(want["td"][-1]) & np.isfinite(want["conc"][-1]) & np.isfinite(want["cum_uptake"][-1])
     assert np.array_equal(st[bounded] == 0, finite[bounded]), what
+
+
+def test_quantile_series_is_numpy_nanquantile(ra, orc):
+    """rscm_ens_quantile_series: per time index numpy.nanquantile(row, q, method='linear') over the
+    members -- the same order statistics and numpy's interpolation, so the same bits; NaN members left
+    out, all-NaN rows NaN with count 0, rows not computed yet empty; +-inf members are ordinary
+    order statistics (interpolating next to one gives what numpy's arithmetic gives)."""
+    t = axis_values(1750, 1830)
+    b = np.append(t, t[-1] + 1.0)
+    n = 70_001
+    P = two_layer_params(n)
+    P[4, ::1000] = np.nan          # members whose series is NaN from the first step on
+    q = [0.0, 0.05, 0.17, 0.5, 0.83, 0.95, 1.0]
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(f_syn(t))
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run(60)
+        ts = e.get_series(1)
+        got = e.quantile_series(1, q)
+        with np.errstate(all="ignore"):
+            want = np.nanquantile(ts[:61], q, axis=1).T
+        assert_bit_equal(got["quantiles"][:61], want, "quantiles of the computed rows")
+        assert np.array_equal(got["count"][:61], (~np.isnan(ts[:61])).sum(axis=1))
+        assert (got["count"][61:] == 0).all() and np.isnan(got["quantiles"][61:]).all()
+        sub = e.quantile_series("Deep Ocean Temperature", 0.5, 10, 12)
+        assert sub["quantiles"].shape == (2, 1)
+        assert_bit_equal(sub["quantiles"][:, 0], np.nanmedian(e.get_series(2)[10:12], axis=1), "median")
+        # an all-NaN row, and infinities among the members
+        e.set_state(1, 5, np.nan)
+        row = ts[6].copy()
+        row[3], row[7] = np.inf, -np.inf
+        e.set_state(1, 6, row)
+        g = e.quantile_series(1, q, 5, 7)
+        assert g["count"][0] == 0 and np.isnan(g["quantiles"][0]).all()
+        with np.errstate(all="ignore"):
+            w = np.nanquantile(row, q)
+        assert np.array_equal(g["quantiles"][1], w, equal_nan=True)   # numpy's own inf arithmetic at q = 0 and 1 included
+        assert np.isfinite(g["quantiles"][1][1:-1]).all()
+        with pytest.raises(Exception, match="Quantiles must be in the range"):
+            e.quantile_series(1, [1.5])
