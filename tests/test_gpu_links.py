@@ -983,3 +983,90 @@ def test_graph_model_random_registration_orders(ra, seed):
         ok = ~np.isnan(w)
         assert (np.abs(g[ok] - w[ok]) <= 1e-11 * np.maximum(1.0, np.abs(w[ok]))).all(), (names, op, name)
     model.close()
+
+
+def test_ssp245_emissions_driven_against_magicc7(ra):
+    """The reference's own emissions-driven regression scenario (tests/regression/test_ghg_forcing.py::
+    test_03_emissions_driven: SSP245 emissions 1750-2100 from MAGICC7's output file, committed as
+    tests/golden/magicc7_emissions_driven.json by make_emissions_goldens.py; xfail upstream) through
+    the ten-component graph on the GPU, wired and initialised as that test does.
+
+    Upstream compares concentrations at rtol 5e-2 and expects to fail.  Stepped in the reference's
+    breadth-first order the total forcing holds the aerosol terms only (the aggregate runs before
+    GhgForcing and OzoneForcing) and the model cools; stepped in topological order, with the initial
+    value of the aggregate that ClimateUDEB's at_start() needs, the chain lands on MAGICC7: CO2 within
+    the upstream tolerance over the whole run, forcing and warming in 2100 within 2 % and 0.2 K.  CH4
+    and N2O keep the deviations the upstream issues (#108-#110: simplified chemistry) describe."""
+    import json
+    import os
+    import rscm_amd.core as core
+    from rscm_amd import magicc as B
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "magicc7_emissions_driven.json")))
+    V = {k: np.array(v) for k, v in g["variables"].items()}
+    t = np.array(g["years"], dtype=float)
+    assert t[0] == 1750.0 and t[-1] == 2100.0 and g["config"]["core_climatesensitivity"] == 3.0
+
+    def sectors(base):  # _extract_emissions of the upstream test: MAGICC's two sectors summed
+        return V[f"{base}|MAGICC Fossil and Industrial"] + V[f"{base}|MAGICC AFOLU"]
+
+    exo = {"Emissions|CO2|Fossil": V["Emissions|CO2"], "Emissions|CO2|Land Use": 0.0 * t, "Emissions|CH4": V["Emissions|CH4"],
+           "Emissions|N2O": V["Emissions|N2O"], "Emissions|NOx": sectors("Emissions|NOx"), "Emissions|CO": sectors("Emissions|CO"),
+           "Emissions|NMVOC": sectors("Emissions|NMVOC"), "Emissions|SOx": sectors("Emissions|SOx"),
+           "Emissions|BC": sectors("Emissions|BC"), "Emissions|OC": sectors("Emissions|OC"), "EESC": 0.0 * t}
+    co2_0, ch4_0, n2o_0 = (float(V[f"Atmospheric Concentrations|{s}"][0]) for s in ("CO2", "CH4", "N2O"))
+    init = {"Atmospheric Concentration|CO2": co2_0, "Atmospheric Concentration|CH4": ch4_0, "Atmospheric Concentration|N2O": n2o_0,
+            "Surface Temperature": 0.0, "Ocean Surface pCO2": co2_0, "Cumulative Ocean Uptake": 0.0,
+            "Carbon Pool|Plant": 884.86, "Carbon Pool|Detritus": 92.77, "Carbon Pool|Soil": 1681.53, "Carbon Pool|Humus": 836.0}
+    contributors = ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|CH4", "Effective Radiative Forcing|N2O",
+                    "Effective Radiative Forcing|O3|Stratospheric", "Effective Radiative Forcing|O3|Tropospheric",
+                    "Effective Radiative Forcing|O3|Temperature Feedback", "Effective Radiative Forcing|Aerosol|Direct",
+                    "Effective Radiative Forcing|Aerosol|Indirect"]
+
+    def run(order, erf0):
+        schema = core.VariableSchema()
+        for n in list(exo) + [k for k in init if k != "Surface Temperature"] + contributors + [
+                "Heat Uptake", "Ocean Heat Content", "Sea Surface Temperature", "Carbon Flux|Terrestrial", "Carbon Flux|Ocean",
+                "Emissions|CO2|Net", "Airborne Fraction|CO2", "Lifetime|CH4", "Lifetime|N2O"]:
+            schema.add_variable(n, "")
+        schema.add_variable("Surface Temperature", "K", core.GridType.FourBox)
+        schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum", contributors)
+        comps = [B.CH4ChemistryBuilder.from_parameters({"ch4_pi": ch4_0}).build(), B.N2OChemistryBuilder.from_parameters({"n2o_pi": n2o_0}).build(),
+                 B.GhgForcingBuilder.from_parameters({"method": "Ipcctar", "delq2xco2": 3.71, "co2_pi": co2_0, "ch4_pi": ch4_0,
+                                                      "n2o_pi": n2o_0}).build(),
+                 B.OzoneForcingBuilder.from_parameters({}).build(), B.AerosolDirectBuilder.from_parameters({}).build(),
+                 B.AerosolIndirectBuilder.from_parameters({}).build(),
+                 B.ClimateUDEBBuilder.from_parameters({"ecs": 3.0, "rf_2xco2": 3.71}).build(),
+                 B.TerrestrialCarbonBuilder.from_parameters({}).build(), B.OceanCarbonBuilder.from_parameters({}).build(),
+                 B.CO2BudgetBuilder.from_parameters({}).build()]
+        axis = core.TimeAxis.from_values(t)
+        iv = dict(init)
+        if erf0:
+            iv["Effective Radiative Forcing"] = 0.0
+        b = core.ModelBuilder().with_time_axis(axis).with_schema(schema).with_initial_values(iv)
+        for c in comps:
+            b.with_rust_component(c)
+        for name, vals in exo.items():
+            b.with_exogenous_variable(name, core.Timeseries(vals, axis, "", core.InterpolationStrategy.Linear))
+        m = b.build(execution_order=order)
+        m.run()
+        ts = m.timeseries()
+        out = {n: ts.get_timeseries_by_name(n).values() for n in ("Atmospheric Concentration|CO2", "Atmospheric Concentration|CH4",
+                                                                "Atmospheric Concentration|N2O", "Effective Radiative Forcing")}
+        out["T"] = ts.get_fourbox_timeseries_by_name("Surface Temperature").values().mean(axis=1)
+        m.close()
+        return out
+
+    def max_rel(ours, magicc):  # the upstream comparison: our index n+1 against MAGICC7's year n
+        a, e = ours[1:], magicc[:-1]
+        return float(np.max(np.abs(a - e) / np.abs(e)))
+
+    as_upstream = run("reference", False)
+    assert as_upstream["Effective Radiative Forcing"][-1] < 0.0          # aerosols only: negative total forcing in 2100
+    assert max_rel(as_upstream["Atmospheric Concentration|CO2"], V["Atmospheric Concentrations|CO2"]) > 0.05   # upstream's xfail
+    fixed = run("topological", True)
+    assert max_rel(fixed["Atmospheric Concentration|CO2"], V["Atmospheric Concentrations|CO2"]) < 0.05          # upstream's tolerance
+    assert max_rel(fixed["Atmospheric Concentration|N2O"], V["Atmospheric Concentrations|N2O"]) < 0.08
+    assert max_rel(fixed["Atmospheric Concentration|CH4"], V["Atmospheric Concentrations|CH4"]) < 0.20
+    assert abs(fixed["Effective Radiative Forcing"][-1] / V["Effective Radiative Forcing"][-2] - 1.0) < 0.03
+    assert abs(fixed["T"][-1] - V["Surface Temperature"][-2]) < 0.25
+    assert np.isfinite(fixed["T"]).all()
