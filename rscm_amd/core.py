@@ -499,8 +499,23 @@ class ModelBuilder:
 
     def _exogenous_on_axis(self, name: str, exo_names: List[str]) -> Optional[np.ndarray]:
         if name in exo_names and name in self._exogenous:
-            return self._exogenous.get_timeseries_by_name(name).interpolate_into(self._axis).values()
+            ts = self._exogenous.get_timeseries_by_name(name)
+            self._check_units(name, ts.units)
+            return ts.interpolate_into(self._axis).values()
         return None
+
+    def _check_units(self, name: str, supplied: str) -> None:
+        """The reference converts between compatible units when a series, the schema and a component
+        disagree (builder.rs:141-338).  There is no units registry on this path -- every factor is
+        1.0 -- so a disagreement that is more than spelling is refused instead of computed wrongly."""
+        def norm(u: str) -> str:
+            return "".join(str(u).split()).replace("**", "^")
+        wanted = {norm(u) for c in self._components for n, u, k in c.definitions if n == name and k in ("Input", "State") and u}
+        if self._schema and self._schema.variables.get(name):
+            wanted.add(norm(self._schema.variables[name]))
+        if supplied and wanted and norm(supplied) not in wanted:
+            raise NotImplementedError(f"unit conversion is not available on the GPU path: {name!r} is supplied in "
+                                      f"{supplied!r}, expected {sorted(wanted)}")
 
     def _graph_order(self, aggregates, topological: bool = False) -> List[str]:
         """Execution order of the reference: nodes in registration order (root, components,

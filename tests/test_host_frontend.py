@@ -297,3 +297,19 @@ def test_checkpoint_files_round_trip(tmp_path):
     assert same(ck, back) and isinstance(back["time_index"], int)
     with pytest.raises(ValueError, match="contains '/'"):
         core.save_checkpoint(tmp_path / "d.npz", {"a/b": 1})
+
+
+def test_units_that_differ_by_more_than_spelling_are_refused():
+    """The reference converts compatible units (builder.rs:141-338); this path has no units registry
+    (every factor is 1.0), so a series supplied in another unit is refused, not silently mis-scaled.
+    Spelling differences (blanks) are not a mismatch."""
+    axis = core.TimeAxis.from_values(np.arange(1750.0, 1756.0))
+    def builder(unit):
+        return (core.ModelBuilder().with_time_axis(axis)
+                .with_rust_component(TwoLayerBuilder.from_parameters(P_TL).build())
+                .with_exogenous_variable("Effective Radiative Forcing", core.Timeseries(np.ones(6), axis, unit, core.InterpolationStrategy.Linear))
+                .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    with pytest.raises(NotImplementedError, match="unit conversion is not available"):
+        builder("mW/m^2").build()
+    b = builder("W / m^2")
+    assert b._exogenous_on_axis("Effective Radiative Forcing", ["Effective Radiative Forcing"]) is not None
