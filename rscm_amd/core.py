@@ -622,6 +622,8 @@ class ModelBuilder:
         exogenous: Dict[str, np.ndarray] = {}
         links: List[Tuple[str, int]] = []
         model = GraphModel(self._axis, order, ensembles, var_home, links, exogenous, sources, stream, self._device, True)
+        model._builder = self
+        model._execution_order = execution_order
         try:
             def params_of(values) -> np.ndarray:
                 return np.repeat(np.array(values, dtype=np.float64)[:, None], n_members, axis=1)
@@ -802,8 +804,10 @@ class ModelBuilder:
                        L.KIND_TERRESTRIAL_CARBON: L.TC_PARAM_NAMES, L.KIND_OCEAN_CARBON: L.OC_PARAM_NAMES,
                        L.KIND_HALOCARBON: L.HC_PARAM_NAMES, L.KIND_FOURBOX_OHU: L.FB_PARAM_NAMES,
                        L.KIND_OSPP: L.SP_PARAM_NAMES}[kind]
-        return Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
-                     np.array(params, dtype=np.float64))
+        model = Model(ens, self._axis, sources, endogenous, forcing, dict(self._initial), param_order,
+                      np.array(params, dtype=np.float64))
+        model._builder = self
+        return model
 
 
 def save_checkpoint(path, ck: Dict[str, object]) -> None:
@@ -936,6 +940,19 @@ class GraphModel:
                 ens.rewind()
         self.time_index = 0
 
+    _builder: Optional["ModelBuilder"] = None
+    _execution_order = "reference"
+
+    def to_toml(self) -> str:
+        from . import serialise
+        return serialise.dumps(serialise.describe(self._builder, self))
+
+    from_toml = staticmethod(lambda text: Model.from_toml(text))
+
+    def as_dot(self) -> str:
+        from . import serialise
+        return serialise.as_dot(self._builder)
+
     def checkpoint(self) -> Dict[str, object]:
         """Everything needed to continue from the current step in another model object built from
         the same builder: per ensemble the current row of every stored variable (linked consumers
@@ -1062,6 +1079,37 @@ class Model:
         self._initial = initial
         self.param_order = tuple(param_order)
         self.base_params = base_params
+
+    _builder: Optional["ModelBuilder"] = None
+
+    @property
+    def n_members(self) -> int:
+        return self.ensemble.n_members
+
+    @property
+    def time_index(self) -> int:
+        return self.ensemble.time_index
+
+    def checkpoint(self) -> Dict[str, object]:
+        return self.ensemble.checkpoint()
+
+    def restore(self, ck: Dict[str, object]) -> None:
+        self.ensemble.restore(ck)
+
+    def to_toml(self) -> str:
+        """Model::to_toml (runtime.rs:270-300): description + state as TOML text (rscm_amd/serialise.py)."""
+        from . import serialise
+        return serialise.dumps(serialise.describe(self._builder, self))
+
+    @staticmethod
+    def from_toml(text: str):
+        """Model::from_toml: the model a ``to_toml`` text describes, at the step it was taken at."""
+        from . import serialise
+        return serialise.rebuild(serialise.loads(text))
+
+    def as_dot(self) -> str:
+        from . import serialise
+        return serialise.as_dot(self._builder)
 
     def variable_sources(self) -> Dict[Tuple[str, str], str]:
         return dict(self._sources)

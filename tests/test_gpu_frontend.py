@@ -268,3 +268,46 @@ def test_calibration_recovers_parameters(api):
     with pytest.raises(ValueError, match="even"):
         sampler.run(1, cal.WalkerInit.from_prior(), n_walkers=5)
     runner.close()
+
+
+def test_model_toml_round_trip_like_the_reference(api):
+    """tests/test_model.py::test_model_serialisation of the reference, on the GPU front: step once,
+    to_toml, Model.from_toml, same graph and current time, and the rest of the run gives the same
+    series -- here bit for bit -- for a fused model and for a graph of linked ensembles."""
+    c = api.core
+    t = np.arange(1750.0, 1781.0)
+    axis = c.TimeAxis.from_values(t)
+    erf = c.Timeseries(np.asarray([1.0] * len(t)), axis, "W / m^2", c.InterpolationStrategy.Next)
+    tl = dict(lambda0=1.1, a=0.02, efficacy=1.2, eta=0.7, heat_capacity_deep=100.0, heat_capacity_surface=8.0)
+    model = (c.ModelBuilder().with_time_axis(axis).with_rust_component(api.TwoLayerBuilder.from_parameters(tl).build())
+             .with_exogenous_variable("Effective Radiative Forcing", erf)
+             .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}).build())
+    assert "TwoLayer" in model.as_dot()
+    model.step()
+    text = model.to_toml()
+    assert "[[components]]" in text and 'type = "TwoLayer"' in text
+    new_model = c.Model.from_toml(text)
+    assert new_model.as_dot() == model.as_dot() and new_model.current_time() == model.current_time() == 1751.0
+    model.run()
+    new_model.run()
+    assert_bit_equal(new_model.timeseries().get_timeseries_by_name("Surface Temperature").values(),
+                     model.timeseries().get_timeseries_by_name("Surface Temperature").values(), "fused model")
+    model.close()
+    new_model.close()
+    # a graph model: the notebook's chain with a second aggregate, checkpointed mid-run
+    b, _, _, _ = _coupled_builder(api, t)
+    b._schema.add_aggregate("Diagnostic", "K", "Mean", ["Surface Temperature", "Deep Ocean Temperature"])
+    g = b.build(n_members=2)
+    assert isinstance(g, c.GraphModel)
+    for _ in range(7):
+        g.step()
+    h = c.Model.from_toml(g.to_toml())
+    assert isinstance(h, c.GraphModel) and h.time_index == 7 and h.as_dot() == g.as_dot() and h.n_members == 2
+    g.run()
+    h.run()
+    for name in ("Surface Temperature", "Atmospheric Concentration|CO2", "Effective Radiative Forcing", "Diagnostic"):
+        assert_bit_equal(h.get_series(name)[7:], g.get_series(name)[7:], name)
+    with pytest.raises(ValueError, match="not a model written by rscm_amd"):
+        c.Model.from_toml("[model]\nformat = \"something else\"\n")
+    g.close()
+    h.close()

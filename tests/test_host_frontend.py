@@ -313,3 +313,36 @@ def test_units_that_differ_by_more_than_spelling_are_refused():
         builder("mW/m^2").build()
     b = builder("W / m^2")
     assert b._exogenous_on_axis("Effective Radiative Forcing", ["Effective Radiative Forcing"]) is not None
+
+
+def test_toml_writer_round_trips_through_tomli():
+    """serialise.dumps / loads: nested tables, arrays of tables, NaN / inf, names with '|' and ':',
+    nested number arrays -- what Model.to_toml writes."""
+    from rscm_amd import serialise
+    doc = {"model": {"format": "rscm_amd-model-1", "graph": True, "n_members": 2, "time_index": 3},
+           "time_axis": {"bounds": np.array([1750.0, 1751.0, 1752.5])},
+           "components": [{"type": "TwoLayer", "parameters": {"lambda0": 1.0, "a": 0.0}},
+                          {"type": "CarbonCycle", "step_size": 0.1, "parameters": {"tau": 25.0}}],
+           "initial_values": {"Surface Temperature": 0.0, "Atmospheric Concentration|CO2": 278.0},
+           "state": {"ensembles": {"Aggregator:Effective Radiative Forcing": {"kind": 17, "params": [[0.0, 0.0], [1.0, 1.0]],
+                                                                               "state": {"aggregate": [float("nan"), float("inf")]}, "history": {}}}}}
+    back = serialise.loads(serialise.dumps(doc))
+    assert back["model"] == doc["model"] and back["time_axis"]["bounds"] == [1750.0, 1751.0, 1752.5]
+    assert back["components"][1] == {"type": "CarbonCycle", "step_size": 0.1, "parameters": {"tau": 25.0}}
+    assert back["initial_values"]["Atmospheric Concentration|CO2"] == 278.0
+    agg = back["state"]["ensembles"]["Aggregator:Effective Radiative Forcing"]
+    assert agg["params"] == [[0.0, 0.0], [1.0, 1.0]] and np.isnan(agg["state"]["aggregate"][0]) and agg["state"]["aggregate"][1] == float("inf")
+    assert agg["history"] == {}
+    assert set(serialise.component_registry()) >= {"TwoLayer", "CarbonCycle", "CO2ERF", "ClimateUDEB", "GhgForcing", "OceanCarbon"}
+
+
+def test_as_dot_lists_nodes_and_labelled_edges():
+    from rscm_amd import serialise
+    dot = serialise.as_dot(_coupled_builder().with_initial_values(
+        {"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
+         "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    assert dot.startswith("digraph {") and '1 [ label = "CarbonCycle" ]' in dot and '4 [ label = "Aggregator:Effective Radiative Forcing" ]' in dot
+    assert '1 -> 2 [ label = "Atmospheric Concentration|CO2" ]' in dot      # CarbonCycle -> CO2ERF
+    assert '2 -> 4 [ label = "Effective Radiative Forcing|CO2" ]' in dot    # CO2ERF -> aggregate
+    assert '4 -> 3 [ label = "Effective Radiative Forcing" ]' in dot        # aggregate -> TwoLayer
+    assert '0 -> 1 [ label = "" ]' in dot                                   # CarbonCycle hangs off the root
