@@ -304,35 +304,95 @@ class TimeseriesCollection:
 
 
 # ------------------------------------------------------------------------------------ schema
+class SchemaVariableDefinition:
+    """python/rscm/_lib/core/__init__.pyi: one declared variable (name, unit, grid type)."""
+
+    def __init__(self, name: str, unit: str, grid_type: "GridType"):
+        self.name, self.unit, self.grid_type = name, unit, grid_type
+
+    def __repr__(self) -> str:
+        return f"SchemaVariableDefinition({self.name!r}, {self.unit!r}, {self.grid_type.name})"
+
+
+class AggregateDefinition:
+    """One aggregate of the schema.  Unpacks as ``(unit, operation_type, contributors, weights)``."""
+
+    def __init__(self, name: str, unit: str, operation_type: str, contributors: List[str], weights: Optional[List[float]],
+                 grid_type: "GridType"):
+        self.name, self.unit, self.operation_type = name, unit, operation_type
+        self.contributors, self.weights, self.grid_type = contributors, weights, grid_type
+
+    def __iter__(self):
+        return iter((self.unit, self.operation_type, self.contributors, self.weights))
+
+    def __getitem__(self, k):
+        return (self.unit, self.operation_type, self.contributors, self.weights)[k]
+
+
 class VariableSchema:
-    """python/rscm/_lib/core/__init__.pyi:322-404 (scalar variables and aggregates)."""
+    """python/rscm/_lib/core/__init__.pyi:322-404; validation as crates/rscm-core/src/schema.rs
+    (undefined contributors, unit / grid type / weight-count mismatches, circular aggregates)."""
 
     def __init__(self) -> None:
-        self.variables: Dict[str, str] = {}
-        self.grid_types: Dict[str, "GridType"] = {}
-        self.aggregates: Dict[str, Tuple[str, str, List[str], Optional[List[float]]]] = {}
+        self.variables: Dict[str, SchemaVariableDefinition] = {}
+        self.aggregates: Dict[str, AggregateDefinition] = {}
+
+    @property
+    def grid_types(self) -> Dict[str, "GridType"]:
+        return {n: v.grid_type for n, v in self.variables.items()}
 
     def add_variable(self, name: str, unit: str, grid_type=None) -> "VariableSchema":
-        self.variables[name] = unit
-        self.grid_types[name] = grid_type or GridType.Scalar
+        self.variables[name] = SchemaVariableDefinition(name, unit, grid_type or GridType.Scalar)
         return self
 
     def add_aggregate(self, name: str, unit: str, operation: str, contributors: Sequence[str],
                       weights: Optional[Sequence[float]] = None, grid_type=None) -> "VariableSchema":
         if operation not in ("Sum", "Mean", "Weighted"):
-            raise ValueError(f"unknown aggregate operation {operation!r}")
-        self.aggregates[name] = (unit, operation, list(contributors),
-                                 list(weights) if weights is not None else None)
+            raise ValueError(f"Unknown operation {operation!r}: expected 'Sum', 'Mean' or 'Weighted'")
+        if operation == "Weighted" and weights is None:
+            raise ValueError("weights must be provided for the 'Weighted' operation")
+        self.aggregates[name] = AggregateDefinition(name, unit, operation, list(contributors),
+                                                    list(weights) if weights is not None else None, grid_type or GridType.Scalar)
         return self
 
     def contains(self, name: str) -> bool:
         return name in self.variables or name in self.aggregates
 
+    def get_grid_type(self, name: str) -> Optional["GridType"]:
+        if name in self.variables:
+            return self.variables[name].grid_type
+        return self.aggregates[name].grid_type if name in self.aggregates else None
+
     def validate(self) -> None:
-        for name, (_, _, contributors, _) in self.aggregates.items():
-            for c in contributors:
+        def norm(u: str) -> str:
+            return "".join(str(u).split())
+        for name, agg in self.aggregates.items():
+            for c in agg.contributors:
                 if not self.contains(c):
-                    raise ValueError(f"aggregate {name!r}: contributor {c!r} is not in the schema")
+                    raise ValueError(f"Undefined contributor: aggregate {name!r}: contributor {c!r} is not in the schema")
+                unit = self.variables[c].unit if c in self.variables else self.aggregates[c].unit
+                if unit and agg.unit and norm(unit) != norm(agg.unit):
+                    raise ValueError(f"Unit mismatch: contributor {c!r} has unit {unit!r}, aggregate {name!r} has {agg.unit!r}")
+                if self.get_grid_type(c) != agg.grid_type:
+                    raise ValueError(f"Grid type mismatch: contributor {c!r} is {self.get_grid_type(c).name}, "
+                                     f"aggregate {name!r} is {agg.grid_type.name}")
+            if agg.operation_type == "Weighted" and len(agg.weights or []) != len(agg.contributors):
+                raise ValueError(f"Weight count mismatch: aggregate {name!r} has {len(agg.contributors)} contributors "
+                                 f"and {len(agg.weights or [])} weights")
+        state: Dict[str, int] = {}
+
+        def visit(n: str) -> None:
+            if state.get(n) == 1:
+                raise ValueError(f"Circular dependency among the aggregates at {n!r}")
+            if state.get(n) == 2 or n not in self.aggregates:
+                return
+            state[n] = 1
+            for c in self.aggregates[n].contributors:
+                visit(c)
+            state[n] = 2
+
+        for n in self.aggregates:
+            visit(n)
 
 
 # ------------------------------------------------------------------------------------ components
@@ -511,8 +571,8 @@ class ModelBuilder:
         def norm(u: str) -> str:
             return "".join(str(u).split()).replace("**", "^")
         wanted = {norm(u) for c in self._components for n, u, k in c.definitions if n == name and k in ("Input", "State") and u}
-        if self._schema and self._schema.variables.get(name):
-            wanted.add(norm(self._schema.variables[name]))
+        if self._schema and name in self._schema.variables and self._schema.variables[name].unit:
+            wanted.add(norm(self._schema.variables[name].unit))
         if supplied and wanted and norm(supplied) not in wanted:
             raise NotImplementedError(f"unit conversion is not available on the GPU path: {name!r} is supplied in "
                                       f"{supplied!r}, expected {sorted(wanted)}")

@@ -115,7 +115,7 @@ def describe(builder, model) -> Dict[str, object]:
                                  "bounds": ts.time_axis.bounds(), "values": ts.values()})
     if builder._schema is not None:
         s = builder._schema
-        doc["schema"] = {"variables": [{"name": n, "unit": u, "grid": s.grid_types[n].name} for n, u in s.variables.items()],
+        doc["schema"] = {"variables": [{"name": n, "unit": v.unit, "grid": v.grid_type.name} for n, v in s.variables.items()],
                          "aggregates": [{"name": n, "unit": u, "operation": op, "contributors": list(c),
                                          **({"weights": list(w)} if w is not None else {})}
                                         for n, (u, op, c, w) in s.aggregates.items()]}

@@ -346,3 +346,48 @@ def test_as_dot_lists_nodes_and_labelled_edges():
     assert '2 -> 4 [ label = "Effective Radiative Forcing|CO2" ]' in dot    # CO2ERF -> aggregate
     assert '4 -> 3 [ label = "Effective Radiative Forcing" ]' in dot        # aggregate -> TwoLayer
     assert '0 -> 1 [ label = "" ]' in dot                                   # CarbonCycle hangs off the root
+
+
+def test_variable_schema_api_and_validation():
+    """VariableSchema as the reference's Python API exposes it (python/rscm/_lib/core/__init__.pyi:
+    322-404): definition objects with name / unit / grid_type / operation_type / contributors /
+    weights, and validate() refusing what crates/rscm-core/src/schema.rs refuses."""
+    s = core.VariableSchema()
+    assert s.variables == {} and s.aggregates == {}
+    s.add_variable("Emissions|CO2", "GtCO2/yr").add_variable("Regional Temperature", "K", core.GridType.FourBox)
+    v = s.variables["Emissions|CO2"]
+    assert (v.name, v.unit, v.grid_type) == ("Emissions|CO2", "GtCO2/yr", core.GridType.Scalar)
+    assert s.variables["Regional Temperature"].grid_type == core.GridType.FourBox
+    s.add_variable("ERF|CO2", "W/m^2").add_variable("ERF|CH4", "W / m^2")
+    s.add_aggregate("Total ERF", "W/m^2", "Sum", ["ERF|CO2", "ERF|CH4"])
+    a = s.aggregates["Total ERF"]
+    assert (a.name, a.unit, a.operation_type, a.contributors, a.weights) == ("Total ERF", "W/m^2", "Sum", ["ERF|CO2", "ERF|CH4"], None)
+    unit, op, contributors, weights = a            # the tuple view the builder uses
+    assert (unit, op, contributors, weights) == ("W/m^2", "Sum", ["ERF|CO2", "ERF|CH4"], None)
+    s.add_aggregate("Weighted Total", "W/m^2", "Weighted", ["ERF|CO2", "ERF|CH4"], weights=[0.6, 0.4])
+    assert s.aggregates["Weighted Total"].weights == [0.6, 0.4]
+    assert s.contains("ERF|CO2") and s.contains("Total ERF") and not s.contains("Nonexistent")
+    s.validate()
+    core.VariableSchema().validate()
+    with pytest.raises(ValueError, match="weights must be provided"):
+        s.add_aggregate("W", "units", "Weighted", ["ERF|CO2"])
+    with pytest.raises(ValueError, match="Unknown operation"):
+        s.add_aggregate("Bad", "units", "Invalid", ["ERF|CO2"])
+
+    def failing(build, match):
+        sch = core.VariableSchema()
+        build(sch)
+        with pytest.raises(ValueError, match=match):
+            sch.validate()
+
+    failing(lambda x: x.add_variable("A", "u").add_aggregate("T", "u", "Sum", ["A", "B"]), "Undefined contributor")
+    failing(lambda x: x.add_variable("A", "W/m^2").add_variable("B", "GtCO2/yr").add_aggregate("T", "W/m^2", "Sum", ["A", "B"]), "Unit mismatch")
+    failing(lambda x: x.add_variable("G", "K").add_variable("R", "K", core.GridType.FourBox).add_aggregate("T", "K", "Sum", ["G", "R"]),
+            "Grid type mismatch")
+    failing(lambda x: x.add_variable("A", "u").add_variable("B", "u").add_variable("C", "u")
+            .add_aggregate("T", "u", "Weighted", ["A", "B", "C"], weights=[0.5, 0.5]), "Weight count mismatch")
+    failing(lambda x: x.add_aggregate("A", "u", "Sum", ["B"]).add_aggregate("B", "u", "Sum", ["A"]), "Circular dependency")
+    with pytest.raises(ValueError, match="sum to 1.0"):
+        core.ModelBuilder().with_grid_weights(core.GridType.FourBox, [0.5, 0.5, 0.5, 0.5])
+    with pytest.raises(ValueError, match="does not match FourBox grid size"):
+        core.ModelBuilder().with_grid_weights(core.GridType.FourBox, [0.5, 0.5])
