@@ -479,8 +479,14 @@ class ModelBuilder:
     with_component = with_rust_component
 
     def with_py_component(self, component) -> "ModelBuilder":
-        raise NotImplementedError("Python-defined components cannot be fused into a GPU kernel; "
-                                  "supported graphs: " + "; ".join(SUPPORTED))
+        """A component written in Python (``rscm_amd.component.PythonComponent.build(obj)``).  It cannot
+        be part of a kernel: its ``solve`` runs on the host between the launches of the graph's linked
+        ensembles, once per member and step (``GraphModel``)."""
+        from .component import PythonComponent
+        if not isinstance(component, PythonComponent):
+            raise NotImplementedError("with_py_component takes PythonComponent.build(<rscm_amd.component.Component instance>)")
+        self._components.append(component)
+        return self
 
     def with_initial_values(self, initial_values: Dict[str, float]) -> "ModelBuilder":
         self._initial.update({k: float(v) for k, v in initial_values.items()})
@@ -667,7 +673,7 @@ class ModelBuilder:
         if len(set(types)) != len(types):
             raise NotImplementedError(f"two components of the same type in one graph: {types}")
         for c in self._components:
-            if c.type_name not in COMPONENT_KINDS:
+            if c.type_name not in COMPONENT_KINDS and not getattr(c, "is_python", False):
                 raise NotImplementedError(f"component {c.type_name} has no GPU kernel; supported: " + "; ".join(SUPPORTED))
         if execution_order not in ("reference", "topological"):
             raise ValueError("execution_order must be 'reference' or 'topological'")
@@ -688,7 +694,22 @@ class ModelBuilder:
             def params_of(values) -> np.ndarray:
                 return np.repeat(np.array(values, dtype=np.float64)[:, None], n_members, axis=1)
 
+            owner_of: Dict[str, str] = {}  # storage ensemble of a Python component's variable -> the component
             for comp in self._components:
+                if getattr(comp, "is_python", False):
+                    # a host component: its outputs live in one device series each (an aggregate-kind
+                    # ensemble used as storage, never launched), so that GPU components can link to them
+                    for name in comp.output_names():
+                        sname = f"{comp.type_name}:{name}"
+                        store = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device)
+                        ensembles[sname] = store
+                        store.set_stream(stream.value)
+                        store.set_params(params_of([0.0] * (1 + L.AG_NINPUTS)))
+                        var_home[name] = (sname, 1)
+                        owner_of[sname] = comp.type_name
+                    model._host_nodes[comp.type_name] = _HostNode(comp)
+                    model._feed_forward = False
+                    continue
                 ens = Ensemble(COMPONENT_KINDS[comp.type_name], n_members, bounds, device=self._device)
                 ensembles[comp.type_name] = ens
                 ens.set_stream(stream.value)
@@ -746,7 +767,7 @@ class ModelBuilder:
                         src = L.SRC_UPSTREAM if read_end or sources.get((name, owner)) == "UpstreamOutput" else L.SRC_EXOGENOUS
                         ens.link_input(k, ensembles[prod], vid, src)
                         links.append((owner, k))
-                        if position[prod] > position[owner]:
+                        if position[owner_of.get(prod, prod)] > position[owner]:
                             # lagged feedback, or -- the breadth-first order is not a topological one -- a
                             # component that runs before the producer of what it reads at n+1 and, like
                             # in the reference, finds NaN there
@@ -766,6 +787,23 @@ class ModelBuilder:
 
             model.param_home = {k: v for k, v in model.param_home.items() if v[1] >= 0}
             for comp in self._components:
+                if getattr(comp, "is_python", False):
+                    node = model._host_nodes[comp.type_name]
+                    for name in comp.input_names():
+                        node.sources[name] = sources.get((name, comp.type_name), "Exogenous")
+                        node.series[name] = np.full((T, n_members), NAN)
+                        if name in var_home:
+                            node.device_reads[name] = var_home[name]
+                            if name in self._initial:
+                                node.series[name][0] = self._initial[name]
+                        else:
+                            if name in endogenous:
+                                raise NotImplementedError(f"{name!r} is a FourBox variable: it cannot feed the scalar input of {comp.type_name}")
+                            vals = self._exogenous_on_axis(name, exo_names + [name])
+                            if vals is not None:
+                                node.series[name][:] = vals[:, None]
+                            exogenous[name] = node.series[name][:, 0].copy()
+                    continue
                 ens = ensembles[comp.type_name]
                 rows = ens.input_rows or [n for n, v in ens.var_ids.items() if v == 0]
                 wire(comp.type_name, list(rows), ens.kind == L.KIND_UDEB)
@@ -796,6 +834,8 @@ class ModelBuilder:
         value it reads at the end of the step (it then reads NaN, which an aggregate skips);
         "topological" is the order in which that cannot happen."""
         endogenous, sources, exo_names, aggregates = self._resolve()
+        if any(getattr(c, "is_python", False) for c in self._components):
+            return self._build_graph(n_members, endogenous, sources, exo_names, aggregates, execution_order)
         types = [c.type_name for c in self._components]
         erf = "Effective Radiative Forcing"
         if types == ["TwoLayer"] and not aggregates:
@@ -952,6 +992,17 @@ def _component_params(comp) -> List[float]:
     return list(comp.param_vector())
 
 
+class _HostNode:
+    """A Python component inside a GraphModel: the series it reads (host copies, refreshed row by
+    row from the device), where those come from, and the source classification of each."""
+
+    def __init__(self, comp):
+        self.comp = comp
+        self.series: Dict[str, np.ndarray] = {}
+        self.device_reads: Dict[str, Tuple[str, int]] = {}
+        self.sources: Dict[str, str] = {}
+
+
 class GraphModel:
     """A component graph the fused kernels do not cover, run as one ensemble per component (and per
     schema aggregate) whose inputs are linked on the device (``rscm_ens_link_input``) and which are
@@ -973,6 +1024,7 @@ class GraphModel:
         self._stream = stream
         self._device = device
         self._feed_forward = feed_forward
+        self._host_nodes: Dict[str, "_HostNode"] = {}  # Python components, stepped on the host
         self._reads_unwritten = False  # some component reads index n+1 of a producer that runs after it
         self._fourbox: Dict[str, Tuple[str, int, bool]] = {}  # FourBox variable -> (producer, first id, stored as scalar)
         self.time_index = 0
@@ -1018,6 +1070,8 @@ class GraphModel:
         the same builder: per ensemble the current row of every stored variable (linked consumers
         read outputs as well as states), the rows the chemistry looks back at, the internal
         component states (runtime.rs:270-282)."""
+        if self._host_nodes:
+            raise NotImplementedError("checkpoints of graphs with Python components are not available")
         for ens in self.ensembles.values():
             ens.sync()
         return {"time_index": self.time_index, "order": list(self._order),
@@ -1065,23 +1119,53 @@ class GraphModel:
     def current_time_bounds(self) -> Tuple[float, float]:
         return self._axis.at_bounds(self.time_index)
 
+    def _sync(self) -> None:
+        next(iter(self.ensembles.values())).sync()  # one stream for all
+
+    def _host_step(self, name: str, n: int) -> None:
+        """One step of a Python component: the rows it may read come back from the device, ``solve`` runs
+        per member, the new rows go into the component's storage series on the device."""
+        node = self._host_nodes[name]
+        T = len(self._axis)
+        for var, (owner, vid) in node.device_reads.items():
+            hi = min(n + 2, T)
+            node.series[var][n:hi] = self.ensembles[owner].get_series(vid, n, hi)
+        t0, t1 = self._axis.at_bounds(n)
+        outs = {v: np.full(self.n_members, NAN) for v in node.comp.output_names()}
+        for m in range(self.n_members):
+            for var, value in node.comp.solve_member(t0, t1, node.series, m, n, node.sources).items():
+                if var not in outs:
+                    raise KeyError(f"{name}.solve returned {var!r}, which it does not declare as an output")
+                outs[var][m] = value
+        for var, row in outs.items():
+            store = self.ensembles[f"{name}:{var}"]
+            store.set_state(1, n + 1, row)
+            store.set_time_index(n + 1)
+
     def step(self) -> None:
         if not self.time_index < len(self._axis) - 1:
             raise RuntimeError("assertion failed: self.time_index < self.time_axis.len() - 1")
         for name in self._order:
-            self.ensembles[name].run(self.time_index + 1, sync=False)
+            if name in self._host_nodes:
+                self._host_step(name, self.time_index)
+            else:
+                self.ensembles[name].run(self.time_index + 1, sync=False)
         self.time_index += 1
-        self.ensembles[self._order[-1]].sync()
+        self._sync()
 
     def run(self) -> None:
         last = len(self._axis) - 1
+        if self._host_nodes:  # Python components: the host takes part in every step
+            while self.time_index < last:
+                self.step()
+            return
         if self._feed_forward:  # no edge points backwards: every producer can finish before its consumers start
             for name in self._order:
                 self.ensembles[name].run(last, sync=False)
         else:
             run_lockstep([self.ensembles[name] for name in self._order], last, sync=False)
         self.time_index = last
-        self.ensembles[self._order[-1]].sync()
+        self._sync()
 
     def finished(self) -> bool:
         return self.time_index == len(self._axis) - 1

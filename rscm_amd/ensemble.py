@@ -138,6 +138,9 @@ class Ensemble:
         v = np.atleast_1d(L.f64(values))
         L.check(self._lib.rscm_ens_set_state(self._h, self._var(var), int(time_index), L.dptr(v), v.size))
 
+    def set_time_index(self, time_index: int) -> None:
+        L.check(self._lib.rscm_ens_set_time_index(self._h, int(time_index)))
+
     def set_stream(self, hip_stream: Optional[int]) -> None:
         L.check(self._lib.rscm_ens_set_stream(self._h, C.c_void_p(hip_stream)))
 

@@ -1070,3 +1070,123 @@ def test_ssp245_emissions_driven_against_magicc7(ra):
     assert abs(fixed["Effective Radiative Forcing"][-1] / V["Effective Radiative Forcing"][-2] - 1.0) < 0.03
     assert abs(fixed["T"][-1] - V["Surface Temperature"][-2]) < 0.25
     assert np.isfinite(fixed["T"]).all()
+
+
+def test_python_components_in_a_gpu_graph(ra):
+    """Components written in Python (rscm_amd.component, the reference's rscm.component surface) inside
+    a graph of GPU components: their solve() runs on the host between the launches, their outputs
+    live in device series the GPU components link to.
+
+    1. the reference's own example (tests/test_typed_python_component.py::test_typed_component_in_model):
+       280 + 10 * 0.5 = 285 ppm and 5 GtC after one step; the history window example runs.
+    2. CO2ERF rewritten in Python between the GPU CarbonCycle and the GPU TwoLayer, plus a Python
+       diagnostic that reads the GPU temperature: the same series as the all-GPU graph (host log vs
+       device log: 1e-12), same execution order, lagged temperature feedback intact, three members."""
+    import math
+    import rscm_amd.core as core
+    from rscm_amd.component import Component, Input, Output, PythonComponent, State
+    from rscm_amd.components import CarbonCycleBuilder, CO2ERFBuilder
+    from rscm_amd.two_layer import TwoLayerBuilder
+
+    class SimpleCarbonCycle(Component, register=False):
+        emissions = Input("Emissions|CO2", unit="GtCO2")
+        concentration = State("Atmospheric Concentration|CO2", unit="ppm")
+        uptake = Output("Carbon Uptake", unit="GtC")
+
+        def __init__(self, sensitivity):
+            self.sensitivity = sensitivity
+
+        def solve(self, t_current, t_next, inputs):
+            e = inputs.emissions.at_start()
+            return self.Outputs(concentration=inputs.concentration.at_start() + e * self.sensitivity, uptake=e * 0.5)
+
+    axis3 = core.TimeAxis.from_values(np.array([2020.0, 2021.0, 2022.0]))
+    model = (core.ModelBuilder().with_py_component(PythonComponent.build(SimpleCarbonCycle(0.5))).with_time_axis(axis3)
+             .with_exogenous_variable("Emissions|CO2", core.Timeseries(np.array([10.0, 10.0, 10.0]), axis3, "GtCO2", core.InterpolationStrategy.Previous))
+             .with_initial_values({"Atmospheric Concentration|CO2": 280.0}).build())
+    model.step()
+    coll = model.timeseries()
+    assert abs(coll.get_timeseries_by_name("Atmospheric Concentration|CO2").at(1) - 285.0) < 1e-3
+    assert abs(coll.get_timeseries_by_name("Carbon Uptake").at(1) - 5.0) < 1e-3
+    model.run()
+    assert model.finished() and coll.get_timeseries_by_name("Atmospheric Concentration|CO2").at(0) == 280.0
+    assert model.timeseries().get_timeseries_by_name("Atmospheric Concentration|CO2").at(2) == 290.0
+    model.close()
+
+    class Delta(Component, register=False):
+        temperature = Input("Temperature", unit="K")
+        output = Output("Output", unit="")
+
+        def solve(self, t_current, t_next, inputs):
+            try:
+                return self.Outputs(output=inputs.temperature.at_start() - inputs.temperature.previous)
+            except ValueError:
+                return self.Outputs(output=0.0)
+
+    axis4 = core.TimeAxis.from_values(np.array([2020.0, 2021.0, 2022.0, 2023.0]))
+    m = (core.ModelBuilder().with_py_component(PythonComponent.build(Delta())).with_time_axis(axis4)
+         .with_exogenous_variable("Temperature", core.Timeseries(np.array([288.0, 289.0, 290.5, 291.0]), axis4, "K", core.InterpolationStrategy.Previous))
+         .build())
+    m.run()
+    out = m.timeseries().get_timeseries_by_name("Output").values()
+    assert np.isnan(out[0]) and list(out[1:]) == [0.0, 1.0, 1.5]
+    m.close()
+
+    class PyCO2ERF(Component, register=False):
+        conc = Input("Atmospheric Concentration|CO2", unit="ppm")
+        erf = Output("Effective Radiative Forcing|CO2", unit="W/m^2")
+
+        def solve(self, t_current, t_next, inputs):
+            c = inputs.conc.get()   # UpstreamOutput: the concentration CarbonCycle has just written
+            return self.Outputs(erf=3.7 / math.log(2.0) * math.log(1.0 + (c - 278.0) / 278.0))
+
+    class Anomaly(Component, register=False):
+        ts = Input("Surface Temperature", unit="K")
+        td = Input("Deep Ocean Temperature", unit="K")
+        gap = Output("Surface minus Deep", unit="K")
+
+        def solve(self, t_current, t_next, inputs):
+            return self.Outputs(gap=inputs.ts.get() - inputs.td.get())
+
+    t = np.arange(1750.0, 1801.0)
+    axis = core.TimeAxis.from_values(t)
+    tl = dict(lambda0=1.1, a=0.0, efficacy=1.3, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+
+    def graph(python_erf):
+        schema = core.VariableSchema()
+        for n in ("Emissions|CO2|Anthropogenic", "Surface Temperature", "Deep Ocean Temperature", "Atmospheric Concentration|CO2",
+                  "Cumulative Land Uptake", "Cumulative Emissions|CO2", "Effective Radiative Forcing|CO2", "Surface minus Deep"):
+            schema.add_variable(n, "")
+        schema.add_aggregate("Effective Radiative Forcing", "", "Sum", ["Effective Radiative Forcing|CO2"])
+        b = (core.ModelBuilder().with_time_axis(axis).with_schema(schema)
+             .with_rust_component(CarbonCycleBuilder.from_parameters(dict(tau=25.0, conc_pi=278.0, alpha_temperature=0.1)).build()))
+        if python_erf:
+            b.with_py_component(PythonComponent.build(PyCO2ERF()))
+        else:
+            b.with_rust_component(CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build())
+        b.with_rust_component(TwoLayerBuilder.from_parameters(tl).build())
+        if python_erf:
+            b.with_py_component(PythonComponent.build(Anomaly()))
+        b.with_exogenous_variable("Emissions|CO2|Anthropogenic", core.Timeseries(emissions_syn(t) + 2.0, axis, "", core.InterpolationStrategy.Linear))
+        b.with_initial_values({"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
+                               "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0})
+        return b.build(n_members=3)
+
+    gpu, mixed = graph(False), graph(True)
+    assert isinstance(gpu, core.Model) and isinstance(mixed, core.GraphModel)   # all-GPU: the fused coupled kernel
+    assert list(mixed._order) == ["CarbonCycle", "PyCO2ERF", "Aggregator:Effective Radiative Forcing", "TwoLayer", "Anomaly"]
+    assert mixed.variable_sources()[("Atmospheric Concentration|CO2", "PyCO2ERF")] == "UpstreamOutput"
+    gpu.run()
+    mixed.run()
+    for name in ("Surface Temperature", "Atmospheric Concentration|CO2", "Effective Radiative Forcing|CO2", "Effective Radiative Forcing"):
+        g, w = mixed.get_series(name), gpu.ensemble.get_series(name)
+        assert (np.isnan(g) == np.isnan(w)).all(), name
+        ok = ~np.isnan(w)
+        assert (np.abs(g[ok] - w[ok]) <= 1e-12 * np.maximum(1.0, np.abs(w[ok]))).all(), name
+    gap = mixed.get_series("Surface minus Deep")
+    assert np.isnan(gap[0]).all() and np.array_equal(gap[1:], mixed.get_series("Surface Temperature")[1:] - mixed.get_series("Deep Ocean Temperature")[1:])
+    assert mixed.get_series("Surface Temperature")[-1, 0] > 0.05
+    with pytest.raises(NotImplementedError, match="Python components"):
+        mixed.checkpoint()
+    gpu.close()
+    mixed.close()

@@ -391,3 +391,53 @@ def test_variable_schema_api_and_validation():
         core.ModelBuilder().with_grid_weights(core.GridType.FourBox, [0.5, 0.5, 0.5, 0.5])
     with pytest.raises(ValueError, match="does not match FourBox grid size"):
         core.ModelBuilder().with_grid_weights(core.GridType.FourBox, [0.5, 0.5])
+
+
+def test_python_component_declarations_registry_and_outputs():
+    """rscm_amd.component mirrors the behaviour the reference's tests/test_typed_python_component.py
+    expects of rscm.component: definitions from the declarations, generated Inputs / Outputs with
+    validation, the class registry with opt-out, inheritance of declarations."""
+    from rscm_amd.component import Component, Input, Output, PythonComponent, State, TimeseriesWindow
+    Component._registry.clear()
+
+    class Cycle(Component):
+        emissions = Input("Emissions|CO2", unit="GtCO2")
+        concentration = State("Atmospheric Concentration|CO2", unit="ppm")
+        uptake = Output("Carbon Uptake", unit="GtC")
+
+        def __init__(self, sensitivity):
+            self.sensitivity = sensitivity
+
+        def solve(self, t_current, t_next, inputs):
+            e = inputs.emissions.at_start()
+            return self.Outputs(concentration=inputs.concentration.at_start() + e * self.sensitivity, uptake=e * 0.5)
+
+    class Hidden(Component, register=False):
+        value = Output("Value", unit="")
+
+    class Derived(Cycle, register=False):
+        extra = Output("Extra", unit="")
+
+    defs = Cycle(0.5).definitions()
+    assert {d.name for d in defs} == {"Emissions|CO2", "Atmospheric Concentration|CO2", "Carbon Uptake"} and len(defs) == 3
+    assert {d.name: d.requirement_type for d in defs}["Atmospheric Concentration|CO2"] == "State"
+    assert Component.get_registered_components() == {"Cycle": Cycle} and Component.get_component("Cycle") is Cycle
+    with pytest.raises(KeyError, match="No component registered with name"):
+        Component.get_component("Hidden")
+    assert isinstance(Cycle(0.5).Outputs(concentration=1.0, uptake=2.0), Cycle.Outputs)
+    with pytest.raises(TypeError, match="Missing required output fields: uptake"):
+        Cycle(0.5).Outputs(concentration=1.0)
+    assert {d.name for d in Derived(1.0).definitions()} == {"Emissions|CO2", "Atmospheric Concentration|CO2", "Carbon Uptake", "Extra"}
+    py = PythonComponent.build(Cycle(0.5))
+    assert py.type_name == "Cycle" and py.definitions == [("Emissions|CO2", "GtCO2", "Input"), ("Carbon Uptake", "GtC", "Output"),
+                                                          ("Atmospheric Concentration|CO2", "ppm", "State")]
+    series = {"Emissions|CO2": np.array([[10.0], [10.0], [10.0]]), "Atmospheric Concentration|CO2": np.array([[280.0], [np.nan], [np.nan]])}
+    out = py.solve_member(2020.0, 2021.0, series, 0, 0, {})
+    assert out == {"Atmospheric Concentration|CO2": 285.0, "Carbon Uptake": 5.0}
+    w = TimeseriesWindow(np.array([1.0, 2.0, 3.0]), 1, "UpstreamOutput")
+    assert (w.at_start(), w.at_end(), w.get(), w.previous, w.current, w.at_offset(-1), w.at_offset(5)) == (2.0, 3.0, 3.0, 1.0, 2.0, 1.0, None)
+    with pytest.raises(ValueError, match="no previous value"):
+        TimeseriesWindow(np.array([1.0, 2.0]), 0, "Exogenous").previous
+    assert TimeseriesWindow(np.array([1.0, 2.0]), 1, "UpstreamOutput").get() == 2.0   # at_end() is None at the last index
+    with pytest.raises(TypeError, match="PythonComponent.build takes"):
+        PythonComponent.build(object())
