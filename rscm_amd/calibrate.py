@@ -314,6 +314,52 @@ class GaussianLikelihood:
 
 
 # ------------------------------------------------------------------------------------ runner
+class FactoryModelRunner:
+    """``ModelRunner(model_factory=...)`` of the reference's Python front (crates/rscm-calibrate/src/python/
+    model_runner.rs): any Python callable ``param_dict -> {variable: {time: value}}`` as the model, run on
+    the host, one call per member.  The slow, general path -- e.g. the tutorial's quadratic toy model;
+    models built from components go through the GPU ``ModelRunner(model_builder, ...)``."""
+
+    def __init__(self, model_factory: Callable[[Dict[str, float]], Dict[str, Dict[float, float]]],
+                 param_names: Sequence[str], output_variables: Sequence[str]):
+        self._factory = model_factory
+        self._param_names = list(param_names)
+        self._outputs = list(output_variables)
+
+    @property
+    def param_names(self) -> List[str]:
+        return list(self._param_names)
+
+    @property
+    def output_variables(self) -> List[str]:
+        return list(self._outputs)
+
+    def run(self, params: Sequence[float]) -> Dict[str, Dict[float, float]]:
+        if len(params) != len(self._param_names):
+            raise ValueError(f"Expected {len(self._param_names)} parameters, got {len(params)}")  # model_runner.rs:225-231
+        out = self._factory(dict(zip(self._param_names, (float(x) for x in params))))
+        missing = [v for v in self._outputs if v not in out]
+        if missing:
+            raise KeyError(f"Model output missing variable: {missing[0]}")
+        return {v: {float(t): float(x) for t, x in out[v].items()} for v in self._outputs}
+
+    def run_batch(self, param_sets) -> List[Dict[str, Dict[float, float]]]:
+        return [self.run(list(p)) for p in param_sets]
+
+    def log_likelihood_batch(self, param_sets, target: "Target", likelihood: "GaussianLikelihood") -> np.ndarray:
+        out = np.full(len(param_sets), -np.inf)
+        for k, p in enumerate(param_sets):
+            try:  # a member that fails is -inf, the batch goes on (sampler/ensemble.rs:163-172)
+                out[k] = likelihood.ln_likelihood(self.run(list(p)), target)
+            except (KeyError, ValueError, ArithmeticError):
+                pass
+        out[np.isnan(out)] = -np.inf
+        return out
+
+    def close(self) -> None:
+        pass
+
+
 class ModelRunner:
     """GPU-batched ``ModelRunner`` (trait: model_runner.rs:38-85).
 
@@ -322,6 +368,11 @@ class ModelRunner:
     that vary per member, in the order of the parameter vectors; every other parameter keeps the
     value of the builder's components.  One device ensemble is kept per batch size.
     """
+
+    def __new__(cls, model=None, param_names=None, output_variables=None, *args, model_factory=None, **kwargs):
+        if model_factory is not None or (model is not None and callable(model) and not isinstance(model, ModelBuilder)):
+            return FactoryModelRunner(model_factory if model_factory is not None else model, param_names, output_variables)
+        return super().__new__(cls)
 
     def __init__(self, model: ModelBuilder, param_names: Sequence[str],
                  output_variables: Sequence[str], mode: int = L.MODE_EXACT, execution_order: str = "reference"):
@@ -497,6 +548,21 @@ class ModelRunner:
 
 
 # ------------------------------------------------------------------------------------ sampler
+class ProgressTracker:
+    """A progress callback that keeps the history (python/rscm/calibrate/progress.py of the reference):
+    ``iterations``, ``acceptance_rates``, ``mean_log_probs``."""
+
+    def __init__(self) -> None:
+        self.iterations: List[int] = []
+        self.acceptance_rates: List[float] = []
+        self.mean_log_probs: List[float] = []
+
+    def __call__(self, iteration: int, acceptance_rate: float, mean_log_prob: float) -> None:
+        self.iterations.append(int(iteration))
+        self.acceptance_rates.append(float(acceptance_rate))
+        self.mean_log_probs.append(float(mean_log_prob))
+
+
 class WalkerInit:
     """sampler/init.rs:40-98."""
 
@@ -559,6 +625,13 @@ class Chain:
         if not self._samples or discard >= len(self):
             return np.zeros(0)
         return np.concatenate(self._log_probs[discard:])
+
+    def to_dataframe(self, discard: int = 0):
+        """One row per kept sample (walker-major within a sweep): the parameters and ``log_prob``."""
+        import pandas as pd
+        df = pd.DataFrame(self.flat_samples(discard), columns=self.param_names)
+        df["log_prob"] = self.flat_log_probs(discard)
+        return df
 
     def to_param_dict(self, discard: int = 0) -> Dict[str, np.ndarray]:
         flat = self.flat_samples(discard)
@@ -768,6 +841,11 @@ class EnsembleSampler:
 
     def acceptance_rate(self) -> float:
         return float(self.n_accepted.sum() / max(1, self.n_proposed.sum()))
+
+    def run_with_progress(self, n_iterations: int, init: WalkerInit, thin: int = 1, progress_callback=None,
+                          n_walkers: Optional[int] = None, rng: Optional[np.random.Generator] = None) -> Chain:
+        """``run`` reporting ``(iteration, acceptance rate so far, mean log probability)`` after every sweep."""
+        return self.run(n_iterations, init, thin, n_walkers=n_walkers, rng=rng, progress=progress_callback)
 
     # -- checkpointed runs (ensemble.rs:272-410, 548-660) -----------------------------------------
     def run_with_checkpoint(self, n_iterations: int, init: WalkerInit, thin: int, checkpoint_every: int,

@@ -135,3 +135,47 @@ def test_checkpointed_run_and_resume(problem, tmp_path):
     assert abs(x[:, 0].mean() - 2.0) < 0.1 and abs(x[:, 1].mean() - 1.0) < 0.4  # y = 2x + 1 recovered
     with pytest.raises(ValueError, match="must be even"):
         problem.run_with_checkpoint(1, cal.WalkerInit.from_prior(), 1, 0, base, n_walkers=31)
+
+
+def test_tutorial_quadratic_model_through_a_python_factory():
+    """docs/notebooks/calibration_tutorial.py part 1 of the reference: a Python callable as the model
+    (ModelRunner(model_factory=...)), random-search point estimate, stretch-move sampling with a
+    progress tracker, the chain as a DataFrame."""
+    rng = np.random.default_rng(42)
+    true = dict(a=0.5, b=-1.0, c=2.0)
+    x_obs = np.linspace(-3.0, 3.0, 15)
+    y_obs = true["a"] * x_obs ** 2 + true["b"] * x_obs + true["c"] + rng.normal(0.0, 0.2, x_obs.size)
+
+    def model_factory(p):
+        return {"y": {float(x): float(p["a"] * x ** 2 + p["b"] * x + p["c"]) for x in x_obs}}
+
+    runner = cal.ModelRunner(model_factory=model_factory, param_names=["a", "b", "c"], output_variables=["y"])
+    assert isinstance(runner, cal.FactoryModelRunner) and runner.param_names == ["a", "b", "c"]
+    assert runner.run([0.5, -1.0, 2.0])["y"][3.0] == 0.5 * 9 - 3 + 2
+    with pytest.raises(ValueError, match="Expected 3 parameters, got 2"):
+        runner.run([1.0, 2.0])
+    params = cal.ParameterSet().add("a", cal.Uniform(-2.0, 2.0)).add("b", cal.Uniform(-3.0, 3.0)).add("c", cal.Uniform(0.0, 4.0))
+    target = cal.Target()
+    for x, y in zip(x_obs, y_obs):
+        target.add_observation("y", float(x), float(y), 0.2)
+    lik = cal.GaussianLikelihood()
+    est = cal.PointEstimator(params, runner, lik, target)
+    res = est.optimize(cal.Optimizer.random_search(), n_samples=600, rng=np.random.default_rng(1))
+    assert est.n_evaluations == 600 and np.isfinite(res.best_log_likelihood)
+    sampler = cal.EnsembleSampler(params, runner, lik, target)
+    tracker = cal.ProgressTracker()
+    chain = sampler.run_with_progress(300, cal.WalkerInit.from_prior(), thin=1, progress_callback=tracker,
+                                      n_walkers=32, rng=np.random.default_rng(2))
+    assert tracker.iterations == list(range(300)) and 0.1 < tracker.acceptance_rates[-1] < 0.9
+    assert tracker.mean_log_probs[-1] > tracker.mean_log_probs[0]
+    df = chain.to_dataframe(discard=150)
+    assert list(df.columns) == ["a", "b", "c", "log_prob"] and df.shape == (150 * 32, 4)
+    med = df[["a", "b", "c"]].median()
+    assert abs(med["a"] - true["a"]) < 0.1 and abs(med["b"] - true["b"]) < 0.1 and abs(med["c"] - true["c"]) < 0.2
+    # a failing member is -inf, the batch goes on
+    def flaky(p):
+        if p["a"] > 1.0:
+            raise ValueError("diverged")
+        return model_factory(p)
+    ll = cal.ModelRunner(flaky, ["a", "b", "c"], ["y"]).log_likelihood_batch(np.array([[0.5, -1.0, 2.0], [1.5, 0.0, 0.0]]), target, lik)
+    assert np.isfinite(ll[0]) and ll[1] == -np.inf
