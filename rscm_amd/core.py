@@ -1065,6 +1065,11 @@ class GraphModel:
         from . import serialise
         return serialise.as_dot(self._builder)
 
+    def debug_info(self, format: str = "plain") -> str:
+        """Execution order, variable flow and source classification (Model::debug_info)."""
+        from . import serialise
+        return serialise.debug_info(self._builder, self, format)
+
     def checkpoint(self) -> Dict[str, object]:
         """Everything needed to continue from the current step in another model object built from
         the same builder: per ensemble the current row of every stored variable (linked consumers
@@ -1254,6 +1259,11 @@ class Model:
     def as_dot(self) -> str:
         from . import serialise
         return serialise.as_dot(self._builder)
+
+    def debug_info(self, format: str = "plain") -> str:
+        """Execution order, variable flow and source classification (Model::debug_info)."""
+        from . import serialise
+        return serialise.debug_info(self._builder, self, format)
 
     def variable_sources(self) -> Dict[Tuple[str, str], str]:
         return dict(self._sources)

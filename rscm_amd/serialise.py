@@ -228,3 +228,60 @@ def as_dot(builder) -> str:
         lines.append(f"    {a} -> {b_} [ label = {_scalar(label)} ]")
     lines.append("}")
     return "\n".join(lines) + "\n"
+
+
+# ------------------------------------------------------------------------------- debug_info
+def debug_info(builder, model, fmt: str = "plain") -> str:
+    """Model::debug_info of the reference (crates/rscm-core/src/python/model.rs:207-218): the execution
+    order with, per component, its inputs tagged with their source (exo / upstream / own_state), its
+    states and outputs, grid tags for FourBox variables.  ``fmt``: "plain", "rich" (ANSI colours) or
+    "json" ({"components": [{"order", "name", "inputs", "states", "outputs"}]})."""
+    import json
+    if fmt not in ("plain", "rich", "json"):
+        raise ValueError(f"Unknown format '{fmt}'. Expected 'rich', 'plain', or 'json'.")
+    from .core import GridType
+    aggregates = builder._schema.aggregates if builder._schema else {}
+    order = list(getattr(model, "_order", None) or builder._graph_order(aggregates))
+    sources = model.variable_sources()
+    tag = {"Exogenous": "exo", "UpstreamOutput": "upstream", "OwnState": "own_state"}
+    by_name = {c.type_name: c for c in builder._components}
+    fourbox = {name for c in builder._components for name, _, _ in c.definitions
+               if builder._schema is not None and builder._schema.grid_types.get(name) == GridType.FourBox}
+    comps = []
+    for k, node in enumerate(order):
+        entry = {"order": k, "name": node, "inputs": [], "states": [], "outputs": []}
+        if node in by_name:
+            for name, unit, kind in by_name[node].definitions:
+                item = {"name": name, "unit": unit, "grid": "FourBox" if name in fourbox else "Scalar"}
+                if kind == "Input":
+                    entry["inputs"].append({**item, "source": tag.get(sources.get((name, node), "Exogenous"), "exo")})
+                elif kind == "State":
+                    entry["states"].append(item)
+                else:
+                    entry["outputs"].append(item)
+        elif node.startswith("Aggregator:"):
+            agg = aggregates[node[len("Aggregator:"):]]
+            entry["operation"] = agg.operation_type
+            entry["inputs"] = [{"name": c, "unit": agg.unit, "grid": "Scalar", "source": "upstream"} for c in agg.contributors]
+            entry["outputs"] = [{"name": agg.name, "unit": agg.unit, "grid": "Scalar"}]
+        elif node.startswith("Transform:"):
+            var = node[len("Transform:"):]
+            entry["inputs"] = [{"name": var, "unit": "", "grid": "FourBox", "source": "upstream"}]
+            entry["outputs"] = [{"name": var, "unit": "", "grid": "Scalar"}]
+        comps.append(entry)
+    if fmt == "json":
+        return json.dumps({"time_index": int(model.time_index), "n_members": int(model.n_members), "components": comps})
+    colour = (lambda code, s: f"\x1b[{code}m{s}\x1b[0m") if fmt == "rich" else (lambda code, s: s)
+    lines = [f"Model at time index {model.time_index} ({model.n_members} member(s)); execution order:"]
+    for e in comps:
+        lines.append(f"[{e['order']}] {e['name']}" + (f" ({e['operation']})" if "operation" in e else ""))
+        for i in e["inputs"]:
+            grid = colour(33, " [FourBox]") if i["grid"] == "FourBox" else ""
+            lines.append("    " + colour(32, "<-") + f" {i['name']} ({i['source']}){grid}")
+        for s_ in e["states"]:
+            grid = colour(33, " [FourBox]") if s_["grid"] == "FourBox" else ""
+            lines.append("    " + colour(35, "<>") + f" {s_['name']}{grid}")
+        for o in e["outputs"]:
+            grid = colour(33, " [FourBox]") if o["grid"] == "FourBox" else ""
+            lines.append("    " + colour(34, "->") + f" {o['name']}{grid}")
+    return "\n".join(lines) + "\n"

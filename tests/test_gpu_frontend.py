@@ -311,3 +311,29 @@ def test_model_toml_round_trip_like_the_reference(api):
         c.Model.from_toml("[model]\nformat = \"something else\"\n")
     g.close()
     h.close()
+
+
+def test_debug_info_shows_the_execution_order_and_sources(api):
+    """Model::debug_info (docs/notebooks/debugging_inspection.py of the reference): plain / rich / json."""
+    import json
+    c = api.core
+    t = np.arange(1750.0, 1756.0)
+    b, _, _, _ = _coupled_builder(api, t)
+    fused = b.build()
+    info = json.loads(fused.debug_info("json"))
+    assert [e["name"] for e in info["components"]] == ["CarbonCycle", "CO2ERF", "Aggregator:Effective Radiative Forcing", "TwoLayer"]
+    cc = info["components"][0]
+    assert {i["name"]: i["source"] for i in cc["inputs"]} == {"Emissions|CO2|Anthropogenic": "exo", "Surface Temperature": "exo"}
+    assert len(cc["states"]) == 3 and info["components"][3]["inputs"][0]["source"] == "upstream"
+    plain = fused.debug_info()
+    assert "[3] TwoLayer" in plain and "<- Effective Radiative Forcing (upstream)" in plain and "<> Surface Temperature" in plain
+    assert "\x1b[" in fused.debug_info("rich") and "\x1b[" not in plain
+    with pytest.raises(ValueError, match="Unknown format"):
+        fused.debug_info("yaml")
+    fused.close()
+    b._schema.add_aggregate("Diagnostic", "K", "Mean", ["Surface Temperature", "Deep Ocean Temperature"])
+    g = b.build()
+    names = [e["name"] for e in json.loads(g.debug_info("json"))["components"]]
+    assert names == list(g._order) and "Aggregator:Diagnostic" in names
+    assert "(Mean)" in g.debug_info("plain")
+    g.close()
