@@ -165,11 +165,11 @@ hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    if (a.kind == 9) {
+    if (a.kind == kKindCo2Budget) {
         RSCM_LAUNCH_BY_SOURCE(co2_budget_kernel, a, grid, dim3(kBlock), s, a);
-    } else if (a.kind == 10) {
+    } else if (a.kind == kKindTerrestrialCarbon) {
         RSCM_LAUNCH_BY_SOURCE(terrestrial_kernel, a, grid, dim3(kBlock), s, a);
-    } else if (a.kind == 15) {
+    } else if (a.kind == kKindCarbonCycle) {
         RSCM_LAUNCH_BY_SOURCE(carbon_cycle_kernel, a, grid, dim3(kBlock), s, a);
     } else {
         return hipErrorInvalidValue;

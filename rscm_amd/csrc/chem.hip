@@ -132,9 +132,9 @@ hipError_t launch_chem(const ChemArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    if (a.kind == 7) {
+    if (a.kind == kKindCh4Chemistry) {
         RSCM_LAUNCH_BY_SOURCE(ch4_kernel, a, grid, dim3(kBlock), s, a);
-    } else if (a.kind == 8) {
+    } else if (a.kind == kKindN2oChemistry) {
         RSCM_LAUNCH_BY_SOURCE(n2o_kernel, a, grid, dim3(kBlock), s, a);
     } else {
         return hipErrorInvalidValue;

@@ -27,19 +27,19 @@ namespace {
 template <int KIND>
 struct Shape;
 template <>
-struct Shape<4> { static constexpr int P = 13, NI = 6, NO = 3; };
+struct Shape<kKindOzoneForcing> { static constexpr int P = 13, NI = 6, NO = 3; };
 template <>
-struct Shape<5> { static constexpr int P = 27, NI = 4, NO = 4; };
+struct Shape<kKindAerosolDirect> { static constexpr int P = 27, NI = 4, NO = 4; };
 template <>
-struct Shape<6> { static constexpr int P = 9, NI = 2, NO = 1; };
+struct Shape<kKindAerosolIndirect> { static constexpr int P = 9, NI = 2, NO = 1; };
 template <>
-struct Shape<13> { static constexpr int P = 4, NI = 1, NO = 4; };
+struct Shape<kKindFourBoxOhu> { static constexpr int P = 4, NI = 1, NO = 4; };
 template <>
-struct Shape<14> { static constexpr int P = 13, NI = 2, NO = 1; };
+struct Shape<kKindOspp> { static constexpr int P = 13, NI = 2, NO = 1; };
 template <>
-struct Shape<16> { static constexpr int P = 2, NI = 1, NO = 1; };   // CO2ERF
+struct Shape<kKindCo2Erf> { static constexpr int P = 2, NI = 1, NO = 1; };   // CO2ERF
 template <>
-struct Shape<17> { static constexpr int P = 9, NI = 8, NO = 1; };   // schema aggregate
+struct Shape<kKindAggregate> { static constexpr int P = 9, NI = 8, NO = 1; };   // schema aggregate
 
 constexpr double kLn2 = 0.693147180559945309417;  // 2.0_f64.ln()
 
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void pointwise_kernel(PointwiseArgs a)
 #pragma unroll
     for (int j = 0; j < S::P; ++j) {
         // the aggregate's eight weight rows matter to the Weighted operation only
-        if (KIND == 17 && j > 0 && p[0] != 2.0) p[j] = 0.0;
+        if (KIND == kKindAggregate && j > 0 && p[0] != 2.0) p[j] = 0.0;
         else p[j] = a.params[(size_t)j * N + i];
     }
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void pointwise_kernel(PointwiseArgs a)
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         double in[S::NI], out[S::NO];
 #pragma unroll
-        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, KIND == 17 ? n + 1 : n);  // AggregatorComponent reads at_end() (schema.rs:886-901)
+        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, KIND == kKindAggregate ? n + 1 : n);  // AggregatorComponent reads at_end() (schema.rs:886-901)
         eval(p, in, out);
         const size_t r = (a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i;
 #pragma unroll
@@ -176,13 +176,13 @@ hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     switch (a.kind) {
-        case 4: return launch_kind<4>(a, s);
-        case 5: return launch_kind<5>(a, s);
-        case 6: return launch_kind<6>(a, s);
-        case 13: return launch_kind<13>(a, s);
-        case 14: return launch_kind<14>(a, s);
-        case 16: return launch_kind<16>(a, s);
-        case 17: return launch_kind<17>(a, s);
+        case kKindOzoneForcing: return launch_kind<kKindOzoneForcing>(a, s);
+        case kKindAerosolDirect: return launch_kind<kKindAerosolDirect>(a, s);
+        case kKindAerosolIndirect: return launch_kind<kKindAerosolIndirect>(a, s);
+        case kKindFourBoxOhu: return launch_kind<kKindFourBoxOhu>(a, s);
+        case kKindOspp: return launch_kind<kKindOspp>(a, s);
+        case kKindCo2Erf: return launch_kind<kKindCo2Erf>(a, s);
+        case kKindAggregate: return launch_kind<kKindAggregate>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -10,6 +10,14 @@ namespace rscm {
 #ifndef RSCM_BLOCK
 #define RSCM_BLOCK 256
 #endif
+// The RSCM_KIND_* values of include/rscm_gpu.h that the kernels dispatch on (the device code does not
+// include the public header; rscm_gpu.cpp static_asserts that the two agree).
+enum Kind : int {
+    kKindOzoneForcing = 4, kKindAerosolDirect = 5, kKindAerosolIndirect = 6, kKindCh4Chemistry = 7, kKindN2oChemistry = 8,
+    kKindCo2Budget = 9, kKindTerrestrialCarbon = 10, kKindFourBoxOhu = 13, kKindOspp = 14, kKindCarbonCycle = 15,
+    kKindCo2Erf = 16, kKindAggregate = 17
+};
+
 constexpr int kBlock = RSCM_BLOCK;           // 256 = 4 wavefronts of 64: one per SIMD of a CU
 constexpr int kMaxStaticLds = 64 * 1024;     // above this the launcher raises the dynamic limit
 constexpr int kMaxLds = 160 * 1024;          // CDNA4: 160 KiB per CU

@@ -141,6 +141,14 @@ static std::vector<double> ocean_irf_table(int model, double irf_scale, double s
     return tab;
 }
 
+static_assert(rscm::kKindOzoneForcing == RSCM_KIND_OZONE_FORCING && rscm::kKindAerosolDirect == RSCM_KIND_AEROSOL_DIRECT &&
+                  rscm::kKindAerosolIndirect == RSCM_KIND_AEROSOL_INDIRECT && rscm::kKindCh4Chemistry == RSCM_KIND_CH4_CHEMISTRY &&
+                  rscm::kKindN2oChemistry == RSCM_KIND_N2O_CHEMISTRY && rscm::kKindCo2Budget == RSCM_KIND_CO2_BUDGET &&
+                  rscm::kKindTerrestrialCarbon == RSCM_KIND_TERRESTRIAL_CARBON && rscm::kKindFourBoxOhu == RSCM_KIND_FOURBOX_OHU &&
+                  rscm::kKindOspp == RSCM_KIND_OSPP && rscm::kKindCarbonCycle == RSCM_KIND_CARBON_CYCLE &&
+                  rscm::kKindCo2Erf == RSCM_KIND_CO2_ERF && rscm::kKindAggregate == RSCM_KIND_AGGREGATE,
+              "rscm_device.hpp and include/rscm_gpu.h disagree on a kind value");
+
 struct rscm_ens {
     int32_t kind = 0;
     int64_t N = 0;
