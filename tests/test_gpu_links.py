@@ -1190,3 +1190,33 @@ def test_python_components_in_a_gpu_graph(ra):
         mixed.checkpoint()
     gpu.close()
     mixed.close()
+
+
+def test_chain_members_are_independent(ra):
+    """Every member of an ensemble run of the ten-component graph equals the one-member model with that
+    member's parameters, bit for bit (no cross-member coupling anywhere in the linked kernels)."""
+    import importlib.util
+    import os
+    from rscm_amd import _lib as L
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    years, N = 40, 5
+    big = mod.build_chain(N, years, "topological")
+    P_ud = big.ensembles["ClimateUDEB"].get_params()
+    P_tc = big.ensembles["TerrestrialCarbon"].get_params()
+    assert len(set(P_ud[L.UD_PARAM_NAMES.index("ecs")])) == N      # the members really differ
+    big.run()
+    names = ["Atmospheric Concentration|CO2", "Atmospheric Concentration|CH4", "Sea Surface Temperature", "Cumulative Ocean Uptake",
+             "Carbon Pool|Humus", "Effective Radiative Forcing"]
+    want = {n: big.get_series(n) for n in names}
+    big.close()
+    for k in range(N):
+        one = mod.build_chain(1, years, "topological")
+        one.ensembles["ClimateUDEB"].set_params(P_ud[:, k:k + 1].copy())
+        one.ensembles["TerrestrialCarbon"].set_params(P_tc[:, k:k + 1].copy())
+        one.run()
+        for n in names:
+            assert_bit_equal(one.get_series(n)[:, 0], want[n][:, k], f"member {k} {n}")
+        one.close()
