@@ -1220,3 +1220,37 @@ def test_chain_members_are_independent(ra):
         for n in names:
             assert_bit_equal(one.get_series(n)[:, 0], want[n][:, k], f"member {k} {n}")
         one.close()
+
+
+def test_chain_full_size_properties(ra):
+    """BASELINE configs[3] size (1e5 members; 150 years to keep the test short): a second run of the
+    same model object gives the same bits (launch order, split ocean tiles and the cleared series are
+    deterministic), and the first 777 members equal a 777-member ensemble with their parameters (the
+    result of a member does not depend on the ensemble it sits in, its block or its lane)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    years, N, n_small = 150, 100_000, 777
+    big = mod.build_chain(N, years, "topological")
+    big.run()
+    names = ["Atmospheric Concentration|CO2", "Sea Surface Temperature", "Cumulative Ocean Uptake", "Effective Radiative Forcing"]
+    first = {n: big.get_series(n, t_begin=years - 1, m_end=2048) for n in names}
+    head = {n: big.get_series(n, m_end=n_small) for n in names}
+    assert big.ensembles["CO2Budget"].summary(1, years)["count"] == N
+    big.rewind()
+    big.run()
+    for n in names:
+        assert_bit_equal(big.get_series(n, t_begin=years - 1, m_end=2048), first[n], f"rerun {n}")
+    P_ud = big.ensembles["ClimateUDEB"].get_params()[:, :n_small].copy()
+    P_tc = big.ensembles["TerrestrialCarbon"].get_params()[:, :n_small].copy()
+    big.close()
+    small = mod.build_chain(n_small, years, "topological")
+    small.ensembles["ClimateUDEB"].set_params(P_ud)
+    small.ensembles["TerrestrialCarbon"].set_params(P_tc)
+    small.run()
+    for n in names:
+        assert_bit_equal(small.get_series(n), head[n], f"sub-ensemble {n}")
+    small.close()
