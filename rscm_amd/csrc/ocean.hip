@@ -62,12 +62,12 @@ __device__ __forceinline__ double mac(double acc, double f, double r)
 
 // YEARS consecutive model steps starting at n: one pass over the old pulses feeds the
 // STEPS*YEARS running sums of all their sub-steps.
-// PHASE splits a two-year tile over two launches, for callers that advance one step at a time
-// (linked graphs: next year's CO2 depends on this year's flux): 1 = the pass over the old pulses
-// and the first year, the second year's running sums parked in a.partial; 2 = the second year,
-// resumed from them.  The same sums in the same order as PHASE 0, half the history traffic of two
-// one-year tiles.
-template <int STEPS, int YEARS, bool FUSED, int PHASE, class Inputs>
+// PART splits a tile over YEARS launches, for callers that advance one step at a time (linked
+// graphs: next year's CO2 depends on this year's flux): part 0 = the pass over the old pulses and
+// the first year, the later years' running sums parked in a.partial; part p > 0 = year p, resumed
+// from its parked sums and the tile's earlier pulses.  The same sums in the same order as a whole
+// tile (PART -1), a YEARS-th of the history traffic of one-year tiles.
+template <int STEPS, int YEARS, bool FUSED, int PART, class Inputs>
 __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember& m, const Inputs& in,
                                            const double* __restrict__ irf, double* __restrict__ hist, int64_t i, int32_t n)
 {
@@ -85,10 +85,10 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     // ---- the old pulses, oldest first.  Head: the first K-1 of them are still outside the
     // window of the later sub-steps (bounded history), so each term is predicated.
     int64_t j = lo(0);
-    if constexpr (PHASE == 2) {
-        j = m0;  // the old pulses were summed by the PHASE 1 launch
+    if constexpr (PART > 0) {
+        j = m0;  // the old pulses were summed by the launch of part 0
 #pragma unroll
-        for (int k = STEPS; k < K; ++k) A[k] = a.partial[(size_t)(k - STEPS) * N + i];
+        for (int k = PART * STEPS; k < (PART + 1) * STEPS; ++k) A[k] = a.partial[(size_t)(k - STEPS) * N + i];
     }
     const int64_t head_end = (j + K - 1 < m0) ? j + K - 1 : m0;
     for (; j < head_end; ++j) {
@@ -122,11 +122,11 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     // ---- the tile's own sub-steps (solve_ocean, carbon/ocean.rs:116-160), its pulses in registers
     double fy[K];
     const size_t r0 = (size_t)n * N + i;
-    constexpr int Y0 = PHASE == 2 ? 1 : 0, Y1 = PHASE == 1 ? 1 : YEARS;
+    constexpr int Y0 = PART > 0 ? PART : 0, Y1 = PART >= 0 ? PART + 1 : YEARS;
     double pco2 = a.series[r0 + (size_t)Y0 * N], cumulative = a.series[vs + r0 + (size_t)Y0 * N];
-    if constexpr (PHASE == 2) {
+    if constexpr (PART > 0) {
 #pragma unroll
-        for (int q = 0; q < STEPS; ++q) fy[q] = hist[(size_t)(m0 + q) * N];  // the first year's pulses
+        for (int q = 0; q < PART * STEPS; ++q) fy[q] = hist[(size_t)(m0 + q) * N];  // the tile's earlier pulses
     }
 #pragma unroll
     for (int y = Y0; y < Y1; ++y) {
@@ -156,7 +156,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
         a.series[vs + r1] = cumulative;
         a.series[2 * vs + r1] = total;
     }
-    if constexpr (PHASE == 1) {
+    if constexpr (PART == 0 && YEARS > 1) {
 #pragma unroll
         for (int k = STEPS; k < K; ++k) a.partial[(size_t)(k - STEPS) * N + i] = A[k];
     }
@@ -184,18 +184,24 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
     double* __restrict__ hist = a.hist + i;   // [months][N]
     a.status[i] = 0;
     int32_t n = a.step_begin;
-    // two model steps per pass over the history while two remain: half the HBM traffic, the same
-    // sums in the same order
-    if (a.phase == 1) {
-        ocean_tile<STEPS, 2, FUSED, 1>(a, m, in, irf, hist, i, n);
+    // Several model steps per pass over the history: a fraction of the HBM traffic, the same sums in
+    // the same order.  Four-year tiles pay off where the multiply-adds are fused (FAST: 570 -> 450 ms
+    // at 262144 members) and cost more than they save where each is two instructions (EXACT: 887 ms,
+    // 48 running sums and their response window crowd the registers); three-year tiles are the
+    // best EXACT gets (750 -> 720 ms).
+    constexpr int YS = kOceanTileYears<FUSED>;
+    if (a.part >= 0) {
+        // one step of a tile split over kOceanSplitYears launches (rscm_gpu.cpp groups the steps).
+        // Two years: split tiles of three or four measured no faster in a lock-step graph (the
+        // launch of part 0 is issue-bound, not traffic-bound: 343 vs 352 us per step, EXACT).
+        static_assert(kOceanSplitYears == 2, "the dispatch below lists the parts of a two-year tile");
+        if (a.part == 0) ocean_tile<STEPS, kOceanSplitYears, FUSED, 0>(a, m, in, irf, hist, i, n);
+        else ocean_tile<STEPS, kOceanSplitYears, FUSED, 1>(a, m, in, irf, hist, i, n - 1);
         return;
     }
-    if (a.phase == 2) {
-        ocean_tile<STEPS, 2, FUSED, 2>(a, m, in, irf, hist, i, n - 1);
-        return;
-    }
-    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2, FUSED, 0>(a, m, in, irf, hist, i, n);
-    if (n < a.step_end) ocean_tile<STEPS, 1, FUSED, 0>(a, m, in, irf, hist, i, n);
+    for (; n + YS <= a.step_end; n += YS) ocean_tile<STEPS, YS, FUSED, -1>(a, m, in, irf, hist, i, n);
+    for (; n + 2 <= a.step_end; n += 2) ocean_tile<STEPS, 2, FUSED, -1>(a, m, in, irf, hist, i, n);
+    if (n < a.step_end) ocean_tile<STEPS, 1, FUSED, -1>(a, m, in, irf, hist, i, n);
 }
 
 }  // namespace

@@ -230,6 +230,11 @@ struct CarbonArgs {
     uint8_t* status;
 };
 
+// OceanCarbon (csrc/ocean.hip): model steps per pass over the flux history
+template <bool FUSED>
+constexpr int kOceanTileYears = FUSED ? 4 : 3;
+constexpr int kOceanSplitYears = 2;  // years of a tile that is split over one-step launches
+
 // OceanCarbon (csrc/ocean.hip)
 struct OceanArgs {
     int64_t n_members;
@@ -246,8 +251,8 @@ struct OceanArgs {
     const double* bounds;    // [T+1]
     const double* irf;       // [max(max_hist, 1)] scaled impulse response at lag k/12 yr
     double* hist;            // [(T-1)*steps][N] flux history, ppm/month
-    double* partial;         // [steps][N] running sums parked between the two launches of a split tile
-    int32_t phase;           // 0: whole tiles; 1 / 2: first / second year of a two-year tile (one-step launches)
+    double* partial;         // [(tile years - 1) * steps][N] running sums parked between the launches of a split tile
+    int32_t part;            // -1: whole tiles; p >= 0: year p of a tile split over one-step launches
     double* series;          // [3][T][N]: pCO2, cumulative uptake, flux
     uint8_t* status;
 };

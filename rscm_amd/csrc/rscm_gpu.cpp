@@ -173,8 +173,9 @@ struct rscm_ens {
     // OceanCarbon: flux history (internal state) and the tabulated impulse response
     double* d_ocean_hist = nullptr;  // [(T-1)*steps][N]
     double* d_ocean_irf = nullptr;   // [max(max_hist, 1)]
-    double* d_ocean_partial = nullptr;  // [steps][N] split-tile running sums (one-step launches)
-    int32_t ocean_partial_step = -1;    // the step whose sums d_ocean_partial holds, -1: none
+    double* d_ocean_partial = nullptr;  // [(tile years - 1) * steps][N] split-tile running sums (one-step launches)
+    int32_t ocean_tile_base = -1;       // first step of the split tile d_ocean_partial belongs to, -1: none
+    int32_t ocean_tile_years = 0;       // its length (depends on the arithmetic mode it was started in)
     int32_t ocean_steps = 0;
     int64_t ocean_max_hist = 0;
     bool ocean_ready = false;
@@ -304,12 +305,12 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
                         "flux history of %lld members x %d months: %s", (long long)h->N, (h->T - 1) * 12, hipGetErrorString(e));
     }
     if (!h->d_ocean_partial) {
-        const hipError_t e = hipMalloc(&h->d_ocean_partial, (size_t)12 * h->N * sizeof(double));
+        const hipError_t e = hipMalloc(&h->d_ocean_partial, (size_t)(rscm::kOceanSplitYears - 1) * 12 * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "split-tile sums of %lld members: %s",
                         (long long)h->N, hipGetErrorString(e));
     }
-    h->ocean_partial_step = -1;  // sums parked under another response table are void
+    h->ocean_tile_base = -1;  // sums parked under another response table are void
     h->ocean_steps = 12;
     h->ocean_max_hist = (int64_t)max_hist;
     h->ocean_ready = true;
@@ -824,7 +825,7 @@ int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;  // a restored checkpoint carries its own state rows
     h->time_index = tidx;
-    h->ocean_partial_step = -1;
+    h->ocean_tile_base = -1;
     return RSCM_OK;
 }
 
@@ -896,7 +897,7 @@ int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;
     h->time_index = time_index;
-    h->ocean_partial_step = -1;
+    h->ocean_tile_base = -1;
     return RSCM_OK;
     GUARD_END
 }
@@ -905,7 +906,7 @@ int rscm_ens_rewind(rscm_ens* h)
 {
     NEED(h);
     h->time_index = 0;
-    h->ocean_partial_step = -1;
+    h->ocean_tile_base = -1;
     return RSCM_OK;
 }
 
@@ -1026,15 +1027,23 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         // one step at a time (linked graphs, Model::step): pair the steps up so that the history is
         // read once per two steps, as the two-year tiles of a whole run do
         a.partial = h->d_ocean_partial;
-        a.phase = 0;
+        a.part = -1;
+        const int32_t tile_years = rscm::kOceanSplitYears;
         if (step_end - step_begin == 1 && h->d_ocean_partial) {
-            if (h->ocean_partial_step == step_begin) {
-                a.phase = 2;
-            } else if (step_begin + 1 < h->T - 1) {
-                a.phase = 1;
+            const int32_t p = step_begin - h->ocean_tile_base;
+            if (h->ocean_tile_base >= 0 && h->ocean_tile_years == tile_years && p > 0 && p < tile_years) {
+                a.part = p;                                   // the next year of the tile in flight
+                if (p == tile_years - 1) h->ocean_tile_base = -1;
+            } else if (step_begin + tile_years <= h->T - 1) {  // all its steps exist: start a tile here
+                a.part = 0;
+                h->ocean_tile_base = step_begin;
+                h->ocean_tile_years = tile_years;
+            } else {
+                h->ocean_tile_base = -1;
             }
+        } else {
+            h->ocean_tile_base = -1;
         }
-        h->ocean_partial_step = a.phase == 1 ? step_begin + 1 : -1;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ocean(a, h->stream));
@@ -1167,7 +1176,7 @@ int rscm_ens_clear_series(rscm_ens* h)
             HIPCHK(rscm::launch_fill(h->series(v) + h->N, (int64_t)(h->rows - 1) * h->N,
                                      std::numeric_limits<double>::quiet_NaN(), h->stream));
     h->time_index = 0;
-    h->ocean_partial_step = -1;
+    h->ocean_tile_base = -1;
     return RSCM_OK;
     GUARD_END
 }
