@@ -255,6 +255,7 @@ struct YearGeom {
     double dt_dz, dt_dzmix, dt_cmix;        // dt/dz, dt/dz_mix, dt/c_mix
     double dt_dz2, dt_dzdz1, dt_dzmixdz1;   // dt/(dz*dz), dt/(dz*dz/2), dt/(dz_mix*dz/2)
     double kC, kdC, kminC;                  // kappa, dkappa/dT, kappa_min in m^2/yr
+    double kC2, kdC2, kminC2;               // the same times dt/(dz*dz): the interior rows want kappa_l * dt/dz^2
     double fb[2];                           // (lambda_o + lambda_l*k_lo*amp*f_l/den) * dt/c_mix
     double famp[2];                         // 1 + k_lo*f_l/den
     double lhc[2];                          // k_lg * dt / (c_mix * f_o), land heat capacity only
@@ -287,6 +288,10 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
     const double t_top = dp[0];
     const double kslope = y.kdC * (t_top - dp[NL - 1]);
     auto kappa_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope, y.kC), y.kminC); };
+    // kappa_l * dt/dz^2 with the (positive) factor folded into the three constants: one multiply
+    // less per interior row, the same value to rounding
+    const double kslope2 = y.kdC2 * (t_top - dp[NL - 1]);
+    auto tdd_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope2, y.kC2), y.kminC2); };
     const double delta_w = w - p.w0;
     // |delta_w| <= 1e-15: the reference skips the profile-advection terms; adding exact zeros is
     // the same thing without a branch per row
@@ -320,7 +325,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
         const double tdu_aft = tdu * af_top[i];
         double bi, di;
         if (i < NL - 1) {
-            const double tdd = kappa_at(i) * y.dt_dz2;
+            const double tdd = tdd_at(i);
             bi = __builtin_fma(tdu + tul, af_top[i], __builtin_fma(tdd, af_bot[i], 1.0));
             di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_diff[i], t_i));
             const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
@@ -512,6 +517,9 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
             y.kC = p.kappa * kDiffCm2sToM2yr;
             y.kdC = p.kappa_dkdt * kDiffCm2sToM2yr;
             y.kminC = p.kappa_min * kDiffCm2sToM2yr;
+            y.kC2 = y.kC * y.dt_dz2;
+            y.kdC2 = y.kdC * y.dt_dz2;
+            y.kminC2 = y.kminC * y.dt_dz2;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const double f_l = (h == 0 ? p.nh_land : p.sh_land) / 2.0;
