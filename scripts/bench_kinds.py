@@ -40,8 +40,9 @@ def timed(e, passes=3):
     return min(ms)
 
 
-def case(kind, members, defaults, ranges, names, inputs, initial, bytes_per_my, note):
+def case(kind, members, defaults, ranges, names, inputs, initial, bytes_per_my, note, mode=0):
     with rscm_amd.Ensemble(kind, members, b) as e:
+        e.set_mode(mode)
         lhs(e, defaults, ranges, names)
         e.set_forcing(inputs)
         for v, x in initial.items():
@@ -75,8 +76,18 @@ out["terrestrial_carbon"] = case(L.KIND_TERRESTRIAL_CARBON, 1_000_000, L.TC_DEFA
                                  "1 log + 5 exp + 4 divisions per member-year")
 out["ocean_carbon"] = case(L.KIND_OCEAN_CARBON, 262_144, L.OC_PRESETS["3D-GFDL"], dict(gas_exchange_tau=(6.0, 10.0), mixed_layer_depth=(45.0, 60.0)),
                            L.OC_PARAM_NAMES, np.stack([np.minimum(ramp(278.0, 1.003), 1100.0), np.minimum(0.006 * yr, 4.0)]), {1: 278.0, 2: 0.0},
-                           3.0e6 * 8 / 2 / years + 24 + 96, "6000-month IRF convolution: 3.0e6 pulse reads (8 B, once per two years) and 7.2e7 f64 ops per member over 750 years")
+                           3.0e6 * 8 / 3 / years + 24 + 96, "6000-month IRF convolution: 3.0e6 pulse reads (8 B, once per three years) and 7.2e7 f64 ops per member over 750 years")
+out["ocean_carbon_fast"] = case(L.KIND_OCEAN_CARBON, 262_144, L.OC_PRESETS["3D-GFDL"], dict(gas_exchange_tau=(6.0, 10.0), mixed_layer_depth=(45.0, 60.0)),
+                                L.OC_PARAM_NAMES, np.stack([np.minimum(ramp(278.0, 1.003), 1100.0), np.minimum(0.006 * yr, 4.0)]), {1: 278.0, 2: 0.0},
+                                3.0e6 * 8 / 4 / years + 24 + 96, "RSCM_MODE_FAST: fused multiply-adds, four years per pass over the history", mode=1)
 out["halocarbon"] = case(L.KIND_HALOCARBON, 100_000, L.HC_DEFAULTS, {"CFC-11.lifetime": (45.0, 60.0), "br_multiplier": (45.0, 75.0)}, L.HC_PARAM_NAMES,
                          np.tile(20.0 + 0.05 * yr, (41, 1)), {v: 10.0 for v in range(1, 42)}, 41 * 8 * 2 + 32,
                          "41 species: series written once, read once for the aggregates")
+out["carbon_cycle"] = case(L.KIND_CARBON_CYCLE, 1_000_000, (25.0, 278.0, 0.05), dict(tau=(15.0, 40.0), alpha_temperature=(0.0, 0.1)), L.CC_PARAM_NAMES,
+                           np.stack([0.02 * yr, 0.004 * yr]), {1: 278.0, 2: 0.0, 3: 0.0}, 24, "RK4, 10 sub-steps: 1 exp + 40 divisions per member-year")
+out["co2_erf"] = case(L.KIND_CO2_ERF, 1_000_000, (3.7, 278.0), dict(erf_2xco2=(3.0, 4.5)), L.CE_PARAM_NAMES, ramp(278.0, 1.001)[None], {}, 8,
+                      "one log per member-year")
+agg_in = np.full((8, T), np.nan)
+agg_in[:3] = np.stack([0.004 * yr, 0.002 * yr, -0.001 * yr])
+out["aggregate_sum"] = case(L.KIND_AGGREGATE, 1_000_000, (0.0,) + (1.0,) * 8, {}, L.AG_PARAM_NAMES, agg_in, {}, 8, "Sum of three contributors, five NaN rows skipped")
 print(json.dumps(out, indent=1))
