@@ -44,16 +44,19 @@ __global__ __launch_bounds__(kBlock) void carbon_cycle_kernel(CarbonArgs a)
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
         const double emis = in.at(0, n), temperature = in.at(1, n);
         const double lifetime = tau * exp(alpha * temperature);
+        // forty divisions by the year's lifetime: the hoisted-reciprocal quotient of rk4_device.hpp
+        // (IEEE-identical inside its exponent windows, the compiler's division outside them)
+        const ConstDiv dl = make_const_div(lifetime);
         const double e_ppm = emis / kGtcPerPpm;
         const int32_t m = a.nsub[n];
         for (int32_t s = 0; s < m; ++s) {
-            const double up1 = (conc - conc_pi) / lifetime;
+            const double up1 = div_const(conc - conc_pi, dl);
             const double k1c = e_ppm - up1, k1u = up1 * kGtcPerPpm;
-            const double up2 = ((conc + k1c * half_c) - conc_pi) / lifetime;
+            const double up2 = div_const((conc + k1c * half_c) - conc_pi, dl);
             const double k2c = e_ppm - up2, k2u = up2 * kGtcPerPpm;
-            const double up3 = ((conc + k2c * half_c) - conc_pi) / lifetime;
+            const double up3 = div_const((conc + k2c * half_c) - conc_pi, dl);
             const double k3c = e_ppm - up3, k3u = up3 * kGtcPerPpm;
-            const double up4 = ((conc + k3c * hc) - conc_pi) / lifetime;
+            const double up4 = div_const((conc + k3c * hc) - conc_pi, dl);
             const double k4c = e_ppm - up4, k4u = up4 * kGtcPerPpm;
             conc = rk4_combine(conc, k1c, k2c, k3c, k4c, sixth_c);
             cum_u = rk4_combine(cum_u, k1u, k2u, k3u, k4u, sixth_c);
