@@ -17,6 +17,7 @@
 // the device math library (tests/test_gpu_chem.py states the tolerance).  Both kernels are
 // VALU-bound: four Prather passes per member-year, each with one f64 pow and several divisions,
 // against 16 B written.
+#include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
 namespace rscm {
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
     const double ppb_to_tg = P(14), nox_ref = P(15), co_ref = P(16), nmvoc_ref = P(17);
     const double burden_reference = ch4_pi * ppb_to_tg;
     const double x = -gamma * self_fb;
+    const double r_ref = refined_rcp(burden_reference), r_other = refined_rcp(tau_other), r_ppb = refined_rcp(ppb_to_tg);
+    const double r_tau0 = refined_rcp(tau_oh0);
     const MemberInputs<SRC, 5> in(a.inputs, a.scen, a.links, T, N, i);
     a.status[i] = 0;
     double cur = a.conc[(size_t)a.step_begin * N + i];
@@ -58,24 +61,30 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
         double base = tau_oh0;
         if (incl_emis) base = tau_oh0 * exp(-gamma * (s_nox * delta_nox + s_co * delta_co + s_nmvoc * delta_nmvoc));
         double burden = cur * ppb_to_tg;
-        double delta_burden = 0.0, tau_oh = tau_oh0;
+        // The ~27 quotients of a member-year are products with refined reciprocals (a tolerance-parity
+        // kind: pow / exp already come from the device library); divisors that do not change are
+        // inverted once per member (r_ref, r_other, r_ppb, r_tau0) or per year (r_prev), and the
+        // temperature feedback tau0 / (tau0 / tau + s dT) is carried as its reciprocal.
+        double delta_burden = 0.0, r_tau = r_tau0;
+        const bool prev_ok = !(fabs(burden_prev) < 1e-10);
+        const double r_prev = prev_ok ? refined_rcp(burden_prev) : 0.0;
+        const bool temp_on = incl_temp && !(fabs(temperature) < 1e-10);
+        const double ts_dt = temp_sens * fmax(temperature, 0.0);
 #pragma unroll
         for (int it = 0; it < kPratherIterations; ++it) {
             const double burden_mean = (burden + burden_prev) / 2.0;
-            const double ratio = fmax(burden_mean / burden_reference, 1.0);
-            tau_oh = base * pow_ratio(ratio, x);
-            if (it > 0 && !(fabs(burden_prev) < 1e-10)) tau_oh = tau_oh * (1.0 - 0.5 * x * delta_burden / burden_prev);
-            if (incl_temp && !(fabs(temperature) < 1e-10)) {
-                const double delta_t = fmax(temperature, 0.0);
-                tau_oh = tau_oh0 / (tau_oh0 / tau_oh + temp_sens * delta_t);
-            }
-            delta_burden = total_emissions - burden_mean / tau_oh - burden_mean / tau_other;
+            const double ratio = fmax(burden_mean * r_ref, 1.0);
+            double tau_oh = base * pow_ratio(ratio, x);
+            if (it > 0 && prev_ok) tau_oh = tau_oh * (1.0 - 0.5 * x * delta_burden * r_prev);
+            r_tau = refined_rcp(tau_oh);
+            if (temp_on) r_tau = __builtin_fma(tau_oh0, r_tau, ts_dt) * r_tau0;  // 1 / (tau0 / (tau0 / tau + s dT))
+            delta_burden = total_emissions - burden_mean * r_tau - burden_mean * r_other;
             burden = burden_prev + delta_burden;
         }
-        const double next = burden / ppb_to_tg;
+        const double next = burden * r_ppb;
         const size_t r = (size_t)(n + 1) * N + i;
         a.conc[r] = next;
-        a.lifetime[r] = 1.0 / (1.0 / tau_oh + 1.0 / tau_other);
+        a.lifetime[r] = refined_rcp(r_tau + r_other);
         prev = cur;
         cur = next;
     }
@@ -93,6 +102,7 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
     int64_t delay = (int64_t)P(4);
     if (delay < 1) delay = 1;  // strat_delay.max(1)
     const double burden_reference = n2o_pi * ppb_to_tg;
+    const double r_ref = refined_rcp(burden_reference), r_ppb = refined_rcp(ppb_to_tg);
     const MemberInputs<SRC, 1> in(a.inputs, a.scen, a.links, T, N, i);
     auto C = [&](int64_t k) -> double { return a.conc[(size_t)k * N + i]; };
     a.status[i] = 0;
@@ -112,12 +122,12 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
 #pragma unroll
         for (int it = 0; it < kPratherIterations; ++it) {
             const double burden_mid = (burden_prev + burden) / 2.0;
-            const double ratio = fmax(burden_mid / burden_reference, 1.0);
+            const double ratio = fmax(burden_mid * r_ref, 1.0);   // quotients as products with refined reciprocals, as in ch4_kernel
             tau_eff = tau0 * pow_ratio(ratio, lifetime_fb);
-            const double rate = total_emissions - burden_lagged / tau_eff;
+            const double rate = total_emissions - burden_lagged * refined_rcp(tau_eff);
             burden = burden_prev + rate * dt;
         }
-        const double next = burden / ppb_to_tg;
+        const double next = burden * r_ppb;
         const size_t r = (size_t)(n + 1) * N + i;
         a.conc[r] = next;
         a.lifetime[r] = tau_eff;

@@ -454,7 +454,8 @@ def test_graph_model_magicc_lite_chain_with_feedback(ra, aerosol_first):
     m2.run()
     ch4_b = m2.timeseries().get_timeseries_by_name("Atmospheric Concentration|CH4").values()
     diff = np.abs(ch4_b - got.get_timeseries_by_name("Atmospheric Concentration|CH4").values())[-1]
-    assert diff > 1e-3 if aerosol_first else diff == 0.0  # the feedback acts on warming only (delta_t = max(T, 0))
+    # the feedback acts on warming only (delta_t = max(T, 0)): under cooling it is tau0 / (tau0 / tau + 0), tau to rounding
+    assert diff > 1e-3 if aerosol_first else diff < 1e-9
     m2.close()
     model.close()
     del cbind
@@ -1257,8 +1258,11 @@ def test_chain_full_size_properties(ra):
 
 
 def test_graph_models_release_what_they_allocate(ra):
-    """Thirty build / run / close cycles of the thirteen-ensemble graph (handles, linked references,
-    the shared stream, split-tile scratch, internal states) leave the free device memory where it was."""
+    """Build / run / close cycles of the thirteen-ensemble graph (handles, linked references, the
+    shared stream, split-tile scratch, internal states) do not eat device memory: after the
+    runtime's own pools (code objects, queue scratch -- a one-off few hundred MB) have settled over
+    the first cycles, 24 more cycles leave the free memory where it was.  A leak of one ensemble's
+    buffers per cycle would show as > 300 MB here."""
     import importlib.util
     import os
     from rscm_amd import _lib as L
@@ -1266,19 +1270,19 @@ def test_graph_models_release_what_they_allocate(ra):
         "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for order in ("reference", "topological"):   # warm-up: the runtime's own pools (code objects, queue scratch) reach
-        m = mod.build_chain(2000, 20, order)     # their steady state -- a one-off ~235 MB that does not grow with cycles
-        m.run()
-        m.rewind()
-        m.run()
-        m.close()
-    free0, _ = L.mem_info(0)
-    for k in range(30):
-        m = mod.build_chain(2000, 20, "topological" if k % 2 else "reference")
+
+    def cycle(k):
+        m = mod.build_chain(20_000, 20, "topological" if k % 2 else "reference")
         m.run()
         if k % 3 == 0:
             m.rewind()
             m.run()
         m.close()
+
+    for k in range(12):
+        cycle(k)
+    free0, _ = L.mem_info(0)
+    for k in range(24):
+        cycle(k)
     free1, _ = L.mem_info(0)
-    assert abs(free0 - free1) <= 64 << 20, (free0, free1)
+    assert free0 - free1 <= 128 << 20, (free0, free1)
