@@ -96,12 +96,14 @@ __global__ __launch_bounds__(kBlock) void co2_budget_kernel(CarbonArgs a)
 }
 
 // carbon/terrestrial.rs:82-100
-__device__ __forceinline__ void implicit_pool_step(double pool, double tau, double flux_in, double temp_factor, double dt,
+// r_tau = 1 / tau (inverted once per member); the quotient by 1 + half_k is a product with a refined
+// reciprocal: TerrestrialCarbon is a tolerance-parity kind (its log / exp come from the device library)
+__device__ __forceinline__ void implicit_pool_step(double pool, double r_tau, double flux_in, double temp_factor, double dt,
                                                    double& new_pool, double& turnover)
 {
-    const double k_eff = temp_factor / tau;
+    const double k_eff = temp_factor * r_tau;
     const double half_k = 0.5 * k_eff * dt;
-    double np = ((1.0 - half_k) * pool + flux_in * dt) / (1.0 + half_k);
+    double np = ((1.0 - half_k) * pool + flux_in * dt) * refined_rcp(1.0 + half_k);
     np = fmax(np, 0.0);
     new_pool = np;
     turnover = 0.5 * k_eff * (pool + np);
@@ -129,6 +131,8 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
     const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
     const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
     const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
+    const double r_tau_plant = refined_rcp(tau_plant), r_tau_det = refined_rcp(tau_det), r_tau_soil = refined_rcp(tau_soil),
+                 r_tau_hum = refined_rcp(tau_hum);
     const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)T * N;
     a.status[i] = 0;
@@ -143,13 +147,13 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
         const double respiration = resp_pi * fert * tf(resp_ts);
         const double tf_det = tf(det_ts), tf_soil = tf(soil_ts), tf_hum = tf(hum_ts);
         double n_plant, to_plant, n_det, to_det, n_soil, to_soil, n_hum, to_hum;
-        implicit_pool_step(plant, tau_plant, npp * f_npp_plant - respiration - landuse, 1.0, dt, n_plant, to_plant);
-        implicit_pool_step(det, tau_det, npp * f_npp_det + f_plant_det * to_plant, tf_det, dt, n_det, to_det);
+        implicit_pool_step(plant, r_tau_plant, npp * f_npp_plant - respiration - landuse, 1.0, dt, n_plant, to_plant);
+        implicit_pool_step(det, r_tau_det, npp * f_npp_det + f_plant_det * to_plant, tf_det, dt, n_det, to_det);
         const double npp_to_soil = npp * f_npp_soil;
         const double plant_to_soil = (1.0 - f_plant_det) * to_plant;
         const double det_to_soil = f_det_soil * to_det;
-        implicit_pool_step(soil, tau_soil, npp_to_soil + plant_to_soil + det_to_soil, tf_soil, dt, n_soil, to_soil);
-        implicit_pool_step(hum, tau_hum, f_soil_hum * to_soil, tf_hum, dt, n_hum, to_hum);
+        implicit_pool_step(soil, r_tau_soil, npp_to_soil + plant_to_soil + det_to_soil, tf_soil, dt, n_soil, to_soil);
+        implicit_pool_step(hum, r_tau_hum, f_soil_hum * to_soil, tf_hum, dt, n_hum, to_hum);
         const double det_to_atm = (1.0 - f_det_soil) * to_det;
         const double soil_to_atm = (1.0 - f_soil_hum) * to_soil;
         const double total_resp = respiration + det_to_atm + soil_to_atm + to_hum;
