@@ -461,6 +461,11 @@ RSCM_API int rscm_ens_rewind(rscm_ens* h);
  * previous run in place, which nothing reads before rewriting them -- except a linked consumer that
  * runs ahead of its producer (rscm_ens_set_link_order_check). */
 RSCM_API int rscm_ens_clear_series(rscm_ens* h);
+/* Every stored row after `tidx` NaN again, the time index untouched: what a collection restored from
+ * a checkpoint taken at `tidx` holds there (runtime.rs:270-282 serialises the collection as it was).
+ * Needed when an already advanced model is rolled back and some component reads index n+1 of a
+ * producer that runs after it (see rscm_ens_set_link_order_check). */
+RSCM_API int rscm_ens_clear_rows_after(rscm_ens* h, int32_t tidx);
 /* Device time of the most recent rscm_ens_run* launch sequence, from HIP events recorded on
  * the launch stream (valid after a sync). */
 RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);

@@ -260,6 +260,7 @@ SIGNATURES = {
     "rscm_ens_sync": (C.c_int, [_h]),
     "rscm_ens_time_index": (C.c_int, [_h, _ip]),
     "rscm_ens_clear_series": (C.c_int, [_h]),
+    "rscm_ens_clear_rows_after": (C.c_int, [_h, C.c_int32]),
     "rscm_ens_internal_state_size": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "rscm_ens_get_internal_state": (C.c_int, [_h, _dp]),
     "rscm_ens_set_internal_state": (C.c_int, [_h, _dp, C.c_int64, C.c_int32]),

@@ -1085,8 +1085,11 @@ class GraphModel:
     def restore(self, ck: Dict[str, object]) -> None:
         if ck["order"] != list(self._order) or set(ck["ensembles"]) != set(self.ensembles):
             raise ValueError("checkpoint does not match this graph")
+        # In the reference's execution order a component can read index n+1 of a producer that runs
+        # after it and must find NaN there, as in the collection the checkpoint was taken from: rows
+        # this (already advanced) model wrote beyond the checkpoint must not survive the roll-back.
         for name, ens in self.ensembles.items():
-            ens.restore(ck["ensembles"][name])
+            ens.restore(ck["ensembles"][name], clear_later_rows=self._reads_unwritten)
         self.time_index = int(ck["time_index"])
 
     def variable_home(self, name: str) -> Tuple[Ensemble, int]:

@@ -103,7 +103,7 @@ __device__ __forceinline__ void implicit_pool_step(double pool, double r_tau, do
 {
     const double k_eff = temp_factor * r_tau;
     const double half_k = 0.5 * k_eff * dt;
-    double np = ((1.0 - half_k) * pool + flux_in * dt) * refined_rcp(1.0 + half_k);
+    double np = ((1.0 - half_k) * pool + flux_in * dt) * guarded_rcp(1.0 + half_k);
     np = fmax(np, 0.0);
     new_pool = np;
     turnover = 0.5 * k_eff * (pool + np);
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
     const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
     const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
     const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
-    const double r_tau_plant = refined_rcp(tau_plant), r_tau_det = refined_rcp(tau_det), r_tau_soil = refined_rcp(tau_soil),
-                 r_tau_hum = refined_rcp(tau_hum);
+    const double r_tau_plant = guarded_rcp(tau_plant), r_tau_det = guarded_rcp(tau_det), r_tau_soil = guarded_rcp(tau_soil),
+                 r_tau_hum = guarded_rcp(tau_hum);
     const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)T * N;
     a.status[i] = 0;

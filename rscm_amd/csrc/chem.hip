@@ -46,8 +46,8 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
     const double ppb_to_tg = P(14), nox_ref = P(15), co_ref = P(16), nmvoc_ref = P(17);
     const double burden_reference = ch4_pi * ppb_to_tg;
     const double x = -gamma * self_fb;
-    const double r_ref = refined_rcp(burden_reference), r_other = refined_rcp(tau_other), r_ppb = refined_rcp(ppb_to_tg);
-    const double r_tau0 = refined_rcp(tau_oh0);
+    const double r_ref = guarded_rcp(burden_reference), r_other = guarded_rcp(tau_other), r_ppb = guarded_rcp(ppb_to_tg);
+    const double r_tau0 = guarded_rcp(tau_oh0);
     const MemberInputs<SRC, 5> in(a.inputs, a.scen, a.links, T, N, i);
     a.status[i] = 0;
     double cur = a.conc[(size_t)a.step_begin * N + i];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
         // temperature feedback tau0 / (tau0 / tau + s dT) is carried as its reciprocal.
         double delta_burden = 0.0, r_tau = r_tau0;
         const bool prev_ok = !(fabs(burden_prev) < 1e-10);
-        const double r_prev = prev_ok ? refined_rcp(burden_prev) : 0.0;
+        const double r_prev = prev_ok ? guarded_rcp(burden_prev) : 0.0;
         const bool temp_on = incl_temp && !(fabs(temperature) < 1e-10);
         const double ts_dt = temp_sens * fmax(temperature, 0.0);
 #pragma unroll
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
             const double ratio = fmax(burden_mean * r_ref, 1.0);
             double tau_oh = base * pow_ratio(ratio, x);
             if (it > 0 && prev_ok) tau_oh = tau_oh * (1.0 - 0.5 * x * delta_burden * r_prev);
-            r_tau = refined_rcp(tau_oh);
+            r_tau = guarded_rcp(tau_oh);
             if (temp_on) r_tau = __builtin_fma(tau_oh0, r_tau, ts_dt) * r_tau0;  // 1 / (tau0 / (tau0 / tau + s dT))
             delta_burden = total_emissions - burden_mean * r_tau - burden_mean * r_other;
             burden = burden_prev + delta_burden;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void ch4_kernel(ChemArgs a)
         const double next = burden * r_ppb;
         const size_t r = (size_t)(n + 1) * N + i;
         a.conc[r] = next;
-        a.lifetime[r] = refined_rcp(r_tau + r_other);
+        a.lifetime[r] = guarded_rcp(r_tau + r_other);
         prev = cur;
         cur = next;
     }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
     int64_t delay = (int64_t)P(4);
     if (delay < 1) delay = 1;  // strat_delay.max(1)
     const double burden_reference = n2o_pi * ppb_to_tg;
-    const double r_ref = refined_rcp(burden_reference), r_ppb = refined_rcp(ppb_to_tg);
+    const double r_ref = guarded_rcp(burden_reference), r_ppb = guarded_rcp(ppb_to_tg);
     const MemberInputs<SRC, 1> in(a.inputs, a.scen, a.links, T, N, i);
     auto C = [&](int64_t k) -> double { return a.conc[(size_t)k * N + i]; };
     a.status[i] = 0;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void n2o_kernel(ChemArgs a)
             const double burden_mid = (burden_prev + burden) / 2.0;
             const double ratio = fmax(burden_mid * r_ref, 1.0);   // quotients as products with refined reciprocals, as in ch4_kernel
             tau_eff = tau0 * pow_ratio(ratio, lifetime_fb);
-            const double rate = total_emissions - burden_lagged * refined_rcp(tau_eff);
+            const double rate = total_emissions - burden_lagged * guarded_rcp(tau_eff);
             burden = burden_prev + rate * dt;
         }
         const double next = burden * r_ppb;

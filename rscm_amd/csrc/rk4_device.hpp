@@ -62,6 +62,16 @@ __device__ __forceinline__ double refined_rcp(double d)
     return r;
 }
 
+// 1/d for any d: the refined reciprocal inside the divisor window, IEEE division outside it
+// (rcp(+-inf) = 0 and rcp(0) = inf would turn the refinement's fma(-d, r, 1) into NaN, where
+// the reference's x / d gives 0 or inf).
+__device__ __forceinline__ double guarded_rcp(double d)
+{
+    double r = refined_rcp(d);
+    if (__builtin_expect(!divisor_in_window(d), 0)) r = 1.0 / d;
+    return r;
+}
+
 // The three-instruction quotient; equals n/d bit for bit inside the two windows.
 __device__ __forceinline__ double spec_div(double n, double d, double r)
 {

@@ -1,6 +1,11 @@
 // C-ABI layer of the MI355X ensemble runner: handle management, validation mirroring the
-// reference's error behaviour, host<->device plumbing.  All arithmetic of the hot path lives in
-// the .hip kernels; nothing here computes model values on the host.
+// reference's error behaviour, host<->device plumbing.  The arithmetic of the hot path lives in
+// the .hip kernels.  Two things are tabulated here, once per scenario / parameter set, with the
+// host's libm: the concentration-only factors of GhgForcing (ghg_tables: ln, sqrt, pow of the shared
+// scenario rows) and OceanCarbon's impulse response per lag (ocean_irf_table).  Both kinds are
+// tolerance-parity kinds for that reason among others (tests/test_gpu_ghg.py, tests/test_gpu_ocean.py
+// state the bounds; GhgForcing's linked-input path evaluates the same factors with the device
+// library and is compared with the table path in tests/test_gpu_links.py).
 #include "../../include/rscm_gpu.h"
 
 #include <hip/hip_runtime.h>
@@ -574,6 +579,7 @@ int rscm_ens_set_mode(rscm_ens* h, int32_t mode)
 {
     NEED(h);
     if (mode != RSCM_MODE_EXACT && mode != RSCM_MODE_FAST) return fail(RSCM_ERR_INVALID, "unknown mode %d", mode);
+    if (mode != h->mode) h->ocean_tile_base = -1;  // sums parked by the other arithmetic cannot be resumed
     h->mode = mode;
     return RSCM_OK;
 }
@@ -1177,6 +1183,20 @@ int rscm_ens_clear_series(rscm_ens* h)
                                      std::numeric_limits<double>::quiet_NaN(), h->stream));
     h->time_index = 0;
     h->ocean_tile_base = -1;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_clear_rows_after(rscm_ens* h, int32_t tidx)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (tidx < 0 || tidx > h->T - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (int rc = set_device(h)) return rc;
+    if (h->rows == h->T && tidx < h->T - 1)
+        for (int32_t v = 1; v < h->V; ++v)
+            HIPCHK(rscm::launch_fill(h->series(v) + (size_t)(tidx + 1) * h->N, (int64_t)(h->T - 1 - tidx) * h->N,
+                                     std::numeric_limits<double>::quiet_NaN(), h->stream));
     return RSCM_OK;
     GUARD_END
 }

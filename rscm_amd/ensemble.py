@@ -230,7 +230,10 @@ class Ensemble:
                 "state": {name: self.get_series(v, k, k + 1)[0] for name, v in names.items()},
                 "history": history, "internal": internal}
 
-    def restore(self, ck: Dict[str, object]) -> None:
+    def restore(self, ck: Dict[str, object], clear_later_rows: bool = False) -> None:
+        """``clear_later_rows``: make every stored row after the checkpoint's time index NaN again, as
+        in the collection the checkpoint was taken from -- needed when an already advanced ensemble is
+        rolled back and a linked consumer reads rows its producer has not rewritten yet."""
         if (ck["kind"] != self.kind or ck["n_members"] != self.n_members
                 or not np.array_equal(ck["bounds"], self.bounds)):
             raise ValueError("checkpoint does not match this ensemble (kind, members or time axis)")
@@ -247,6 +250,8 @@ class Ensemble:
             L.check(self._lib.rscm_ens_set_internal_state(self._h, L.dptr(blob), blob.size, k))
         else:
             L.check(self._lib.rscm_ens_set_time_index(self._h, k))
+        if clear_later_rows and self.store_series:
+            L.check(self._lib.rscm_ens_clear_rows_after(self._h, k))
 
     # -- outputs ----------------------------------------------------------------------------
     def get_series(self, var, t_begin: int = 0, t_end: Optional[int] = None, t_stride: int = 1,

@@ -168,3 +168,37 @@ def test_carbon_full_size_properties(ra, orc):
     pick = rng.choice(n, 16, replace=False)
     want = orc.carbon_run(orc.CARBON_TERRESTRIAL, b, Q[:, pick].copy(), tc, PI_POOLS)
     assert np.abs(final[pick] - want[:4, T - 1].sum(axis=0)).max() <= TOL * 4000.0
+
+
+def test_terrestrial_zero_and_infinite_turnover_times(ra, orc):
+    """Pools with a zero pre-industrial size (turnover time 0: k = 1 / 0) and with no inflow (the
+    reference's fall-back lifetimes), and an infinite pool (turnover time inf: k = 0): the hoisted
+    reciprocals must give what IEEE division gives in the reference."""
+    rng = np.random.default_rng(3)
+    n, T = 64, 41
+    b = np.arange(T + 1, dtype=float) + 1850.0
+    yr = np.arange(T, dtype=float)
+    inputs = np.stack([278.0 * 1.004 ** yr, 0.012 * yr, np.where(yr > 10, 1.5, 0.2)])
+    P = np.repeat(orc.carbon_default_params(orc.CARBON_TERRESTRIAL).reshape(-1, 1), n, axis=1)
+    names = orc.CARBON_PARAM_NAMES[orc.CARBON_TERRESTRIAL]
+    P[names.index("humus_pool_pi"), 0:8] = 0.0
+    P[names.index("soil_pool_pi"), 8:16] = 0.0
+    P[names.index("plant_pool_pi"), 16:24] = float("inf")
+    P[names.index("detritus_pool_pi"), 24:32] = float("inf")
+    P[names.index("npp_pi"), 32:40] = 0.0          # no inflow anywhere: the fall-back lifetimes
+    init = [PI_POOLS[k] * rng.uniform(0.9, 1.1, n) for k in range(4)]
+    want = orc.carbon_run(orc.CARBON_TERRESTRIAL, b, P, inputs, np.stack(init))
+    with ra.Ensemble(ra.KIND_TERRESTRIAL_CARBON, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(inputs)
+        for v, x in enumerate(init, start=1):
+            e.set_initial(v, x)
+        e.run()
+        got = np.stack([e.get_series(v) for v in range(1, 6)])
+    assert (np.isnan(got) == np.isnan(want)).all()
+    inf = np.isinf(want)
+    assert np.array_equal(got[inf], want[inf])
+    ok = np.isfinite(want)
+    err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+    assert err.max() <= TOL, f"max deviation {err.max():.3e}"
+    assert np.isfinite(want[:, :, 40:]).all()

@@ -158,3 +158,48 @@ def test_chem_full_size_properties(ra, orc):
     pick = rng.choice(n, 32, replace=False)
     wc, _ = orc.chem_run(orc.CHEM_CH4, bounds, P[:, pick].copy(), inputs, c0[pick])
     assert np.abs(mid[pick] - wc[100]).max() <= TOL * 3000.0
+
+
+def _close_any(got, want, what, tol=TOL):
+    """Tolerance on the finite entries; infinities and NaNs must sit in the same places."""
+    assert (np.isnan(got) == np.isnan(want)).all(), f"{what}: NaN placement"
+    inf = np.isinf(want)
+    assert np.array_equal(got[inf], want[inf]), f"{what}: infinities"
+    ok = np.isfinite(want)
+    err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+    assert not err.size or err.max() <= tol, f"{what}: max deviation {err.max():.3e}"
+
+
+@pytest.mark.parametrize("kind_name", ["CHEM_CH4", "CHEM_N2O"])
+def test_chem_infinite_and_zero_lifetimes(ra, orc, kind_name):
+    """Lifetimes of +inf (a sink switched off: x / inf = 0 in the reference) and of 0 (x / 0 = inf):
+    the hoisted reciprocals must give what IEEE division gives (rcp(inf) = 0 and rcp(0) = inf would
+    otherwise turn the refinement step into NaN)."""
+    kind = getattr(orc, kind_name)
+    rng = np.random.default_rng(77)
+    n, T = 64, 41
+    bounds = np.arange(T + 1, dtype=float) + 1850.0
+    P, inputs, c0 = (_ch4_case if kind == orc.CHEM_CH4 else _n2o_case)(orc, n, T, rng)
+    names = orc.CHEM_PARAM_NAMES[kind]
+    inf = float("inf")
+    if kind == orc.CHEM_CH4:
+        for m in range(0, 16):   # no soil / stratospheric / chlorine sink at all: tau_other = inf
+            for k in ("tau_soil", "tau_strat", "tau_trop_cl"):
+                P[names.index(k), m] = inf
+        P[names.index("tau_soil"), 16:24] = inf          # one sink off, the others on
+        P[names.index("tau_oh"), 24:32] = inf            # no OH sink
+        P[names.index("tau_strat"), 32:36] = 0.0         # instantaneous sink: burden / 0
+        P[names.index("tau_oh"), 36:40] = 0.0
+    else:
+        P[names.index("tau_n2o"), 0:16] = inf
+        P[names.index("tau_n2o"), 16:24] = 0.0
+    wc, wl = orc.chem_run(kind, bounds, P, inputs[:1], c0)
+    with ra.Ensemble(kind, n, bounds) as e:
+        e.set_params(P)
+        e.set_forcing(inputs[:1])
+        e.set_initial(1, c0)
+        e.run()
+        gc, gl = e.get_series(1), e.get_series(2)
+    assert np.isfinite(wc[:, :16]).all()  # the switched-off sinks give ordinary trajectories
+    _close_any(gc, wc, f"{kind_name} concentration")
+    _close_any(gl, wl, f"{kind_name} lifetime")

@@ -455,7 +455,11 @@ def test_graph_model_magicc_lite_chain_with_feedback(ra, aerosol_first):
     ch4_b = m2.timeseries().get_timeseries_by_name("Atmospheric Concentration|CH4").values()
     diff = np.abs(ch4_b - got.get_timeseries_by_name("Atmospheric Concentration|CH4").values())[-1]
     # the feedback acts on warming only (delta_t = max(T, 0)): under cooling it is tau0 / (tau0 / tau + 0), tau to rounding
-    assert diff > 1e-3 if aerosol_first else diff < 1e-9
+    # -- the kernel carries 1/tau and forms fma(tau0, 1/tau, 0) * (1/tau0): one rounding per factor, i.e. a
+    # relative difference of a few ulp in the lifetime, which the contractive recurrence does not amplify:
+    # bounded here by 256 ulp of the concentration (6e-11 ppb at 1e3 ppb; measured 0 - 2 ulp)
+    print(f"CH4 no-warming feedback difference: {diff:.3e} ({diff / np.spacing(ch4_b[-1]):.1f} ulp)")
+    assert diff > 1e-3 if aerosol_first else diff <= 256 * np.spacing(ch4_b[-1])
     m2.close()
     model.close()
     del cbind
@@ -917,6 +921,38 @@ def test_graph_checkpoint_resumes_the_full_chain_bit_identically(ra, tmp_path):
     b2.close()
 
 
+def test_graph_rollback_into_the_same_model_in_reference_order(ra):
+    """Roll an already finished model back to an earlier checkpoint of itself, in the reference's
+    breadth-first order (where the forcing aggregate runs before some of its producers and must find
+    NaN at n+1): the rows the first pass wrote beyond the checkpoint must not be seen by the second.
+    The continuation carries the bits of the uninterrupted run."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    years, N = 40, 64
+    m = mod.build_chain(N, years, "reference")
+    assert m._reads_unwritten
+    names = ["Effective Radiative Forcing", "Atmospheric Concentration|CO2", "Atmospheric Concentration|CH4", "Sea Surface Temperature",
+             "Carbon Flux|Ocean", "Effective Radiative Forcing|CO2"]
+    for _ in range(17):
+        m.step()
+    ck = m.checkpoint()
+    m.run()
+    want = {n: m.get_series(n) for n in names}
+    m.restore(ck)          # the same model object, all rows up to the end already written once
+    assert m.time_index == 17
+    erf, _ = m.variable_home("Effective Radiative Forcing")
+    assert np.isnan(erf.get_series(1, 18, 19)).all()
+    m.step()
+    m.run()
+    for n in names:
+        assert_bit_equal(m.get_series(n), want[n], f"rolled back {n}")
+    m.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_graph_model_random_registration_orders(ra, seed):
     """The five-component chain of test_graph_model_magicc_lite_chain_with_feedback registered in a
@@ -1285,4 +1321,8 @@ def test_graph_models_release_what_they_allocate(ra):
     for k in range(24):
         cycle(k)
     free1, _ = L.mem_info(0)
-    assert free0 - free1 <= 128 << 20, (free0, free1)
+    print(f"free-memory change over 24 build/run/close cycles: {(free0 - free1) / 2**20:.1f} MiB")
+    # one cycle allocates ~0.6 GB (20 000 members x 13 ensembles); a leak of any one ensemble's series
+    # per cycle would be > 24 x 3 MB x (its variables).  The runtime returns freed blocks to the
+    # device in 2 MiB granules and keeps a few cached: the bound is 32 MiB either way.
+    assert abs(free0 - free1) <= 32 << 20, (free0, free1)
