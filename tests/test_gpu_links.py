@@ -641,6 +641,163 @@ def test_full_emissions_driven_magicc_graph_closed_loop(ra, execution_order):
     model.close()
 
 
+def _load_chain_module():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _closed_loop_member(model, exo, init, contributors, b, member, series=None):
+    """The closed-loop check of test_full_emissions_driven_magicc_graph_closed_loop for one member of
+    an ensemble of chains (topological or reference order alike): every component's outputs
+    recomputed by its CPU oracle, with that member's parameters, from the inputs the component saw on
+    the device.  `series(name)` -> [T] overrides how a stored series of the member is fetched."""
+    from oracle import cbind as orc
+    from rscm_amd import _lib as L
+    T = len(b) - 1
+    order = list(model._order)
+    pos = {n: k for k, n in enumerate(order)}
+    get = series or (lambda name: model.get_series(name, m_begin=member, m_end=member + 1)[:, 0])
+    names = [n for n in model._var_home if n != "Surface Temperature"]
+    S = {n: get(n) for n in names}
+    ud = model.ensembles["ClimateUDEB"]
+    boxes = np.stack([ud.get_series(v, m_begin=member, m_end=member + 1)[:, 0] for v in range(1, 5)], axis=1)
+    ad = model.ensembles["AerosolDirect"]
+    ad_boxes = np.stack([ad.get_series(v, m_begin=member, m_end=member + 1)[:, 0] for v in range(1, 5)], axis=1)
+
+    def scalar_of(bx):
+        s = np.zeros(len(bx))
+        for k in range(4):
+            s = s + bx[:, k] * 0.25
+        return s
+
+    S["Surface Temperature"] = scalar_of(boxes)
+    assert_bit_equal(S["Effective Radiative Forcing|Aerosol|Direct"][1:], scalar_of(ad_boxes)[1:], "write transform of the aerosol forcing")
+    producer = {}
+    for c in model._chain_components:
+        for name, _, kind in c.definitions:
+            if kind in ("Output", "State"):
+                producer[name] = c.type_name
+    producer["Effective Radiative Forcing"] = "Aggregator:Effective Radiative Forcing"
+    sources = model.variable_sources()
+
+    def seen(name, consumer, force_end=False):
+        out = np.full(T, np.nan)
+        if name not in producer:
+            return np.asarray(exo[name], dtype=np.float64).copy()
+        if force_end or sources.get((name, consumer)) == "UpstreamOutput":
+            if pos[producer[name]] < pos[consumer]:
+                out[:-1] = S[name][1:]
+            return out
+        out[:-1] = S[name][:-1]
+        return out
+
+    worst = {}
+
+    def check(name, got, want, tol):
+        assert (np.isnan(got) == np.isnan(want)).all(), (name, member, np.isnan(got).sum(), np.isnan(want).sum())
+        ok = ~np.isnan(want)
+        err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+        worst[name] = float(err.max()) if err.size else 0.0
+        assert err.size == 0 or err.max() <= tol, (name, member, err.max())
+
+    def P(c):
+        return np.ascontiguousarray(model.ensembles[c].get_params()[:, member])
+
+    def block(c, rows):
+        return np.stack([seen(r, c) for r in rows])
+
+    conc, life = orc.chem_run(orc.CHEM_CH4, b, P("CH4Chemistry"), block("CH4Chemistry", L.CH4_INPUTS), init["Atmospheric Concentration|CH4"])
+    check("CH4", S["Atmospheric Concentration|CH4"], conc[:, 0], 1e-12)
+    check("Lifetime|CH4", S["Lifetime|CH4"], life[:, 0], 1e-12)
+    conc, life = orc.chem_run(orc.CHEM_N2O, b, P("N2OChemistry"), block("N2OChemistry", L.N2O_INPUTS), init["Atmospheric Concentration|N2O"])
+    check("N2O", S["Atmospheric Concentration|N2O"], conc[:, 0], 1e-12)
+    g = orc.ghg_run(T, P("GhgForcing"), block("GhgForcing", L.GH_INPUTS))
+    for key, name in zip(orc.GHG_VARS, contributors[:3]):
+        check(name, S[name], g[key][:, 0], 1e-12)
+    o = orc.pointwise_run(orc.PW_OZONE, T, P("OzoneForcing"), block("OzoneForcing", L.OZ_INPUTS))
+    for k, name in enumerate(contributors[3:6]):
+        check(name, S[name], o[k, :, 0], 1e-12)
+    o = orc.pointwise_run(orc.PW_AEROSOL_DIRECT, T, P("AerosolDirect"), block("AerosolDirect", L.AD_INPUTS))
+    check("aerosol direct boxes", ad_boxes, o[:, :, 0].T, 1e-12)
+    o = orc.pointwise_run(orc.PW_AEROSOL_INDIRECT, T, P("AerosolIndirect"), block("AerosolIndirect", L.AI_INPUTS))
+    check(contributors[7], S[contributors[7]], o[0, :, 0], 1e-12)
+    agg = np.full(T, np.nan)
+    agg[0] = init["Effective Radiative Forcing"]
+    rows = [seen(c, "Aggregator:Effective Radiative Forcing", force_end=True) for c in contributors]
+    for n in range(T - 1):
+        acc, cnt = 0.0, 0
+        for r in rows:
+            if not np.isnan(r[n]):
+                acc, cnt = acc + r[n], cnt + 1
+        agg[n + 1] = acc if cnt else np.nan
+    assert_bit_equal(S["Effective Radiative Forcing"], agg, "Sum of eight forcings")
+    u, st = orc.udeb_run(b, P("ClimateUDEB"), S["Effective Radiative Forcing"])
+    assert st[0] == 0
+    for k, key in enumerate(("st0", "st1", "st2", "st3")):
+        check(f"Surface Temperature box {k}", boxes[:, k], u[key][:, 0], 1e-9)
+    check("Sea Surface Temperature", S["Sea Surface Temperature"], u["sst"][:, 0], 1e-9)
+    check("Heat Uptake", S["Heat Uptake"], u["heat_uptake"][:, 0], 1e-9)
+    tc = orc.carbon_run(orc.CARBON_TERRESTRIAL, b, P("TerrestrialCarbon"), block("TerrestrialCarbon", L.TC_INPUTS),
+                        [init[k] for k in ("Carbon Pool|Plant", "Carbon Pool|Detritus", "Carbon Pool|Soil", "Carbon Pool|Humus")])
+    for k, name in enumerate(("Carbon Pool|Plant", "Carbon Pool|Detritus", "Carbon Pool|Soil", "Carbon Pool|Humus", "Carbon Flux|Terrestrial")):
+        check(name, S[name], tc[k, :, 0], 1e-12)
+    oc = orc.ocean_run(b, P("OceanCarbon"), block("OceanCarbon", L.OC_INPUTS), init["Ocean Surface pCO2"], init["Cumulative Ocean Uptake"])
+    for k, name in enumerate(("Ocean Surface pCO2", "Cumulative Ocean Uptake", "Carbon Flux|Ocean")):
+        check(name, S[name], oc[k, :, 0], 1e-9)
+    cb = orc.carbon_run(orc.CARBON_BUDGET, b, P("CO2Budget"), block("CO2Budget", L.CB_INPUTS), [init["Atmospheric Concentration|CO2"]])
+    for k, name in enumerate(("Atmospheric Concentration|CO2", "Emissions|CO2|Net", "Airborne Fraction|CO2")):
+        check(name, S[name], cb[k, :, 0], 1e-12)
+    return S, worst
+
+
+def test_magicc_graph_on_a_monthly_axis_closed_loop(ra):
+    """BASELINE.json configs[3] shape: the emissions-driven MAGICC graph on a MONTHLY model axis
+    (288 steps of 1/12 year from 1750; ClimateUDEB and OceanCarbon still take their 12 sub-steps per
+    model step, as the reference does whatever the step length: climate/udeb/mod.rs:399-656,
+    carbon/ocean.rs:151-190), 10 240 members that differ in ECS, ocean diffusivity and the
+    fertilisation factor.  Members spread over the ensemble (first and last lane of a wavefront, the
+    last member) pass the closed-loop check against all ten component oracles at the single-component
+    tolerances; the other members are compared through ensemble-level properties."""
+    mod = _load_chain_module()
+    years, spy, N = 24, 12, 10_240
+    t, exo, init, contributors = mod.chain_inputs(years, spy)
+    b = np.append(t, t[-1] + (t[-1] - t[-2]))
+    model = mod.build_chain(N, years, "topological", steps_per_year=spy)
+    assert len(t) == 289 and np.allclose(np.diff(t), 1.0 / 12.0)
+    model.run()
+    ud_status = model.ensembles["ClimateUDEB"].status()
+    assert not ud_status.any()
+    worst = {}
+    for member in (0, 63, 64, 5000, N - 1):
+        S, w = _closed_loop_member(model, exo, init, contributors, b, member)
+        for k, v in w.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        assert S["Atmospheric Concentration|CO2"][-1] > 278.0 and S["Cumulative Ocean Uptake"][-1] > 0.0
+    print("monthly axis, worst relative deviation per variable:", {k: f"{v:.1e}" for k, v in worst.items() if v > 0})
+    # members with equal parameters agree bit for bit wherever they sit; different ECS gives different warming
+    ud = model.ensembles["ClimateUDEB"]
+    P = ud.get_params()
+    sst_end = model.get_series("Sea Surface Temperature", t_begin=len(t) - 1)[0]
+    assert np.isfinite(sst_end).all() and np.unique(sst_end).size > N // 2
+    model.rewind()
+    P[:, 1::2] = P[:, 0::2]
+    ud.set_params(P)
+    tc = model.ensembles["TerrestrialCarbon"]
+    Q = tc.get_params()
+    Q[:, 1::2] = Q[:, 0::2]
+    tc.set_params(Q)
+    model.run()
+    for name in ("Sea Surface Temperature", "Atmospheric Concentration|CO2", "Carbon Flux|Ocean", "Effective Radiative Forcing"):
+        row = model.get_series(name, t_begin=len(t) - 1)[0]
+        assert_bit_equal(row[1::2], row[0::2], f"paired members: {name}")
+    model.close()
+
+
 def test_calibrating_a_linked_graph(ra):
     """rscm-calibrate over a graph without a fused kernel: ModelRunner batches the members through
     the linked ensembles, the Gaussian log-likelihood is reduced on the device per owning ensemble.

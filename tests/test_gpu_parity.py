@@ -472,6 +472,58 @@ def test_full_size_properties(ra, orc, n_members):
         assert np.isfinite(base).all()
 
 
+def test_coupled_full_size_properties(ra, orc):
+    """BASELINE.json configs[2]: the coupled chain CarbonCycle -> CO2ERF -> Sum -> TwoLayer at
+    1e6 members x 751 points (42 GB of series on the device), through properties plus an oracle
+    spot check:
+      * determinism: a second run gives identical bits;
+      * sub-ensemble equality: members 0..776 equal a 777-member run with the same parameters, bit for
+        bit (nothing depends on the ensemble size or on the position inside a wavefront / workgroup);
+      * 256 random members against the CPU oracle at 1e-11 on all seven series (bounded members);
+      * `Cumulative Emissions|CO2` involves no transcendental: bit-exact against the oracle."""
+    n = 1_000_000
+    t = axis_values()
+    b = np.append(t, t[-1] + 1.0)
+    P = coupled_params(n)
+    E = emissions_syn(t)
+    rows = [1, 250, 500, 750]
+    rng = np.random.default_rng(23)
+    pick = np.sort(rng.choice(n, 256, replace=False))
+    with ra.Ensemble(ra.KIND_COUPLED, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(E)
+        for k, v in CP_INIT.items():
+            e.set_initial(k, v)
+        e.run()
+        first = {(name, r): e.get_series(name, r, r + 1)[0] for name in CP_NAMES.values() for r in rows}
+        picked = {name: np.stack([e.get_series(name, 0, 751, 1, int(m), int(m) + 1)[:, 0] for m in pick[:32]], axis=1)
+                  for name in CP_NAMES.values()}
+        head = {name: e.get_series(name, 0, 751, 1, 0, 777) for name in CP_NAMES.values()}
+        status = e.status()
+        e.rewind()
+        e.run()
+        for (name, r), want_row in first.items():
+            assert_bit_equal(e.get_series(name, r, r + 1)[0], want_row, f"second run {name} row {r}")
+    assert status.mean() < 0.5
+    small, _ = _cp_gpu(ra, t, np.ascontiguousarray(P[:, :777]), E, CP_INIT)
+    for name in CP_NAMES.values():
+        assert_bit_equal(head[name], small[name], f"first 777 members of 1e6 vs a 777-member run: {name}")
+    want = orc.coupled_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), E,
+                           dict(ts=0.0, td=0.0, conc=278.0, cum_uptake=0.0, cum_emis=0.0), threads=8)
+    bounded = _bounded(want["ts"])
+    assert bounded.mean() > 0.5
+    for k, name in CP_NAMES.items():
+        for r in rows:
+            g, w = first[(name, r)][pick], want[k][r]
+            assert _close(g[bounded], w[bounded], FAST_RTOL).all(), f"{name} row {r}"
+        g, w = picked[name], want[k][:, :32]
+        assert (np.isnan(g[0]) == np.isnan(w[0])).all(), name
+        assert _close(g[1:, bounded[:32]], w[1:, bounded[:32]], FAST_RTOL).all(), f"{name}, whole series of 32 members"
+    for r in rows:
+        assert_bit_equal(first[("Cumulative Emissions|CO2", r)][pick], want["cum_emis"][r], f"cumulative emissions row {r}")
+    assert_bit_equal(picked["Cumulative Emissions|CO2"], want["cum_emis"][:, :32], "cumulative emissions series")
+
+
 def test_checkpoint_restore_resumes_bit_identically(ra):
     """Aux subsystem: checkpoint/resume (reference: Model::checkpoint / from_checkpoint,
     crates/rscm-core/src/model/runtime.rs:270-282).  A fresh handle restored from

@@ -217,3 +217,55 @@ def test_device_sampler_groups_are_independent(setup):
     with pytest.raises(Exception, match="do not split"):
         dev.run(1, cal.WalkerInit.explicit(pos), n_walkers=G * Wg, seed=8, n_groups=3)
     runner.close()
+
+
+def test_device_sampler_full_size_1e5_walkers():
+    """BASELINE.json configs[4] on one GPU: 1e5 walkers, the 751-point axis, six two-layer
+    parameters, 18 `Surface Temperature` observations (1850 ... 2020 step 10, sigma 0.1 K, values
+    from the default-parameter run: SURVEY 8d, C5), three stretch-move sweeps.
+      * walkers that did not move keep the score the fused run+likelihood launch gives their
+        position, bit for bit (checked against ModelRunner.log_likelihood_batch + the host prior);
+      * accepted walkers carry the exact score of their new position;
+      * the acceptance fraction of a prior-wide ensemble against a tight likelihood is small but not
+        zero, every walker was proposed to exactly once per sweep, and the run is reproducible."""
+    import rscm_amd  # noqa: F401
+    from rscm_amd import calibrate as cal
+    from rscm_amd import core
+    from rscm_amd.two_layer import TwoLayerBuilder
+    from tests.helpers import TL_RANGES, axis_values, f_syn
+    t = axis_values()
+    axis = core.TimeAxis.from_values(t)
+    defaults = dict(lambda0=1.0, a=0.0, efficacy=1.0, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    b = (core.ModelBuilder().with_time_axis(axis).with_rust_component(TwoLayerBuilder.from_parameters(defaults).build())
+         .with_exogenous_variable("Effective Radiative Forcing", core.Timeseries(f_syn(t), axis, "W/m^2", core.InterpolationStrategy.Linear))
+         .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    runner = cal.ModelRunner(b, NAMES, ["Surface Temperature"])
+    truth = runner.run([defaults[k] for k in NAMES])["Surface Temperature"]
+    target = cal.Target()
+    for yr in range(1850, 2021, 10):
+        target.add_observation("Surface Temperature", float(yr), truth[float(yr)], 0.1)
+    params = cal.ParameterSet()
+    for k, (lo, hi) in zip(NAMES, TL_RANGES):
+        params.add(k, cal.Uniform(lo, hi))
+    lik = cal.GaussianLikelihood()
+    W = 100_000
+    pos = params.sample_random(W, np.random.default_rng(2026))
+    dev = cal.DeviceEnsembleSampler(params, runner, lik, target)
+    chain = dev.run(3, cal.WalkerInit.explicit(pos), thin=3, n_walkers=W, seed=17)   # keeps sweep 1 only
+    assert len(chain) == 1 and chain.total_iterations == 3
+    host = cal.EnsembleSampler(params, runner, lik, target)
+    want0 = host.log_posterior_batch(pos)
+    assert np.isfinite(want0).all()
+    p1, lp1 = chain._samples[0], chain._log_probs[0]
+    same = (p1 == pos).all(axis=1)
+    assert 0.02 < (~same).mean() < 0.9
+    assert np.array_equal(lp1[same], want0[same])
+    assert np.array_equal(lp1[~same], host.log_posterior_batch(p1[~same]))
+    assert (dev.n_proposed == 3).all() and 0.02 < dev.acceptance_rate() < 0.9
+    assert (lp1[~same] > -np.inf).all()
+    # detailed balance in expectation: accepted moves raise the mean score of a far-from-equilibrium ensemble
+    assert lp1.mean() > want0.mean()
+    again = dev.run(3, cal.WalkerInit.explicit(pos), thin=3, n_walkers=W, seed=17)
+    assert np.array_equal(again._samples[0], p1) and np.array_equal(again._log_probs[0], lp1)
+    print(f"1e5 walkers x 3 sweeps: {dev.device_ms:.2f} ms on the device, acceptance {dev.acceptance_rate():.3f}")
+    runner.close()
