@@ -488,6 +488,15 @@ RSCM_API int rscm_ens_status(rscm_ens* h, uint8_t* out);
 RSCM_API int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
                     const double* obs_value, const double* obs_sigma, int32_t normalize,
                     double* out);
+/* As rscm_ens_loglik, the result left on the device: *out_dev is the device address of the [N] doubles
+ * (owned by the handle, valid until its next likelihood call; the work has completed on return).  For
+ * callers that reduce or all-gather the per-member values without a host round trip (RCCL all-gather
+ * of 8 B per member in the sharded calibration loop). */
+RSCM_API int rscm_ens_loglik_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                                    const double* obs_value, const double* obs_sigma, int32_t normalize,
+                                    void** out_dev);
+/* Device address of the [N] status bytes rscm_ens_status copies out. */
+RSCM_API int rscm_ens_status_devptr(rscm_ens* h, void** out);
 /* Fused Model::run + GaussianLikelihood for the calibration loop (two-layer kind): steps every
  * member from time index 0 to the end of the axis and accumulates ln L on the fly, writing no
  * series (the time index stays 0, status is updated).  Same value as rscm_ens_run followed by
@@ -496,6 +505,10 @@ RSCM_API int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var,
 RSCM_API int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var,
                                  const int32_t* obs_tidx, const double* obs_value,
                                  const double* obs_sigma, int32_t normalize, double* out);
+/* rscm_ens_run_loglik with the result left on the device (see rscm_ens_loglik_device). */
+RSCM_API int rscm_ens_run_loglik_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var,
+                                        const int32_t* obs_tidx, const double* obs_value,
+                                        const double* obs_sigma, int32_t normalize, void** out_dev);
 /* ---- device stretch-move sampler ------------------------------------------------------------
  * EnsembleSampler::run (crates/rscm-calibrate/src/sampler/ensemble.rs:496-547) with StretchMove
  * (sampler/moves.rs:40-125) and the ParameterSet prior kept on the GPU: per half-ensemble update
@@ -573,6 +586,9 @@ RSCM_API int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, 
  * (measured 601 MB of Ts: 11 GB/s into a fresh pageable buffer vs the pinned rate quoted in
  * DESIGN.md section 6). */
 RSCM_API int rscm_gpu_host_alloc(int64_t n_bytes, void** out);
+/* Blocking copy of n_bytes from a device address handed out by this library (rscm_ens_*_devptr,
+ * rscm_ens_loglik_device) into host memory, for callers without a HIP runtime of their own. */
+RSCM_API int rscm_gpu_copy_to_host(int32_t device_id, void* host, const void* device_ptr, int64_t n_bytes);
 RSCM_API int rscm_gpu_host_free(void* p);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */

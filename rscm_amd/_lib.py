@@ -273,6 +273,9 @@ SIGNATURES = {
     "rscm_ens_status": (C.c_int, [_h, _bp]),
     "rscm_ens_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
     "rscm_ens_run_loglik": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, _dp]),
+    "rscm_ens_loglik_device": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rscm_ens_run_loglik_device": (C.c_int, [_h, C.c_int32, _ip, _ip, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rscm_ens_status_devptr": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "rscm_ens_quantile_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "rscm_ens_summary_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rscm_sampler_create": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp, _dp, C.c_int32, _ip, _ip,
@@ -288,6 +291,7 @@ SIGNATURES = {
     "rscm_ens_sample_lhs": (C.c_int, [_h, C.c_uint64, _dp, _dp, C.c_int64, C.c_int64]),
     "rscm_gpu_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
     "rscm_gpu_host_free": (C.c_int, [C.c_void_p]),
+    "rscm_gpu_copy_to_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "rscm_gpu_selftest_div": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, _dp, _dp, _bp]),
 }
 

@@ -522,7 +522,7 @@ class ModelRunner:
         elif fused:  # run + likelihood in one kernel, nothing written to HBM but ln L
             m = self._lik_model(p.shape[0])
             self._load(m, p)
-            local = m.ensemble.run_loglik(ov, ot, val, sig, likelihood.normalize)
+            local = m.ensemble.run_loglik(ov, ot, val, sig, likelihood.normalize, on_device=is_distributed())
         elif self._graph:
             # observations grouped by the ensemble that holds their variable, in the target's order;
             # a member that fails anywhere is -inf (-inf + finite)
@@ -537,7 +537,7 @@ class ModelRunner:
                 local = local + ens.loglik(list(v), list(t_), list(x), list(s), likelihood.normalize)
         else:
             m = self._run(p)
-            local = m.ensemble.loglik(ov, ot, val, sig, likelihood.normalize)
+            local = m.ensemble.loglik(ov, ot, val, sig, likelihood.normalize, on_device=is_distributed())
         return gather_members(local, n_total) if is_distributed() else local
 
     def close(self) -> None:

@@ -1317,12 +1317,11 @@ int rscm_ens_status(rscm_ens* h, uint8_t* out)
     GUARD_END
 }
 
-int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
-                    const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
+// Gaussian log-likelihood of every member into h->d_loglik (device), synchronised before return.
+static int loglik_on_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                            const double* obs_value, const double* obs_sigma, int32_t normalize)
 {
-    GUARD_BEGIN
-    NEED(h);
-    if (n_obs < 0 || !out || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
+    if (n_obs < 0 || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
         return fail(RSCM_ERR_INVALID, "bad observation arrays");
     bool uncomputed = false;
     for (int32_t j = 0; j < n_obs; ++j) {
@@ -1334,12 +1333,13 @@ int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const in
                 if (obs_var[k] == obs_var[j])
                     return fail(RSCM_ERR_INVALID, "observations must be grouped by variable");
     }
-    if (uncomputed) {
-        for (int64_t i = 0; i < h->N; ++i) out[i] = -std::numeric_limits<double>::infinity();
-        return RSCM_OK;
-    }
     if (int rc = set_device(h)) return rc;
     if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+    if (uncomputed) {
+        HIPCHK(rscm::launch_fill(h->d_loglik, h->N, -std::numeric_limits<double>::infinity(), h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return RSCM_OK;
+    }
     std::vector<const double*> ptrs(n_obs);
     for (int32_t j = 0; j < n_obs; ++j) ptrs[j] = h->series(obs_var[j]) + (size_t)obs_tidx[j] * h->N;
     void* d_blob = nullptr;
@@ -1365,12 +1365,43 @@ int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const in
     a.obs_group = (const int32_t*)((char*)d_blob + off_grp);
     a.out = h->d_loglik;
     if (e == hipSuccess) e = rscm::launch_loglik(a, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d_blob);
     if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "loglik: %s", hipGetErrorString(e));
     return RSCM_OK;
+}
+
+int rscm_ens_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                    const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    if (int rc = loglik_on_device(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    HIPCHK(hipMemcpy(out, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    return RSCM_OK;
     GUARD_END
+}
+
+int rscm_ens_loglik_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                           const double* obs_value, const double* obs_sigma, int32_t normalize, void** out_dev)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out_dev) return fail(RSCM_ERR_INVALID, "out_dev is NULL");
+    *out_dev = nullptr;
+    if (int rc = loglik_on_device(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    *out_dev = h->d_loglik;
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_status_devptr(rscm_ens* h, void** out)
+{
+    NEED(h);
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    *out = h->d_status;
+    return RSCM_OK;
 }
 
 namespace {
@@ -1476,21 +1507,41 @@ hipError_t launch_loglik(rscm_ens* h)
 
 }  // namespace
 
+static int run_loglik_impl(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                           const double* obs_value, const double* obs_sigma, int32_t normalize, double* out_host)
+{
+    if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+    if (int rc = check_loglik_ready(h)) return rc;
+    hipError_t e = hipEventRecord(h->ev0, h->stream);
+    if (e == hipSuccess) e = launch_loglik(h);
+    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess && out_host)
+        e = hipMemcpyAsync(out_host, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "run_loglik: %s", hipGetErrorString(e));
+    h->timed = true;
+    return RSCM_OK;
+}
+
 int rscm_ens_run_loglik(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
                         const double* obs_value, const double* obs_sigma, int32_t normalize, double* out)
 {
     GUARD_BEGIN
     NEED(h);
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
-    if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
-    if (int rc = check_loglik_ready(h)) return rc;
-    hipError_t e = hipEventRecord(h->ev0, h->stream);
-    if (e == hipSuccess) e = launch_loglik(h);
-    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, h->d_loglik, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "run_loglik: %s", hipGetErrorString(e));
-    h->timed = true;
+    return run_loglik_impl(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize, out);
+    GUARD_END
+}
+
+int rscm_ens_run_loglik_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                               const double* obs_value, const double* obs_sigma, int32_t normalize, void** out_dev)
+{
+    GUARD_BEGIN
+    NEED(h);
+    if (!out_dev) return fail(RSCM_ERR_INVALID, "out_dev is NULL");
+    *out_dev = nullptr;
+    if (int rc = run_loglik_impl(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize, nullptr)) return rc;
+    *out_dev = h->d_loglik;
     return RSCM_OK;
     GUARD_END
 }
@@ -1962,6 +2013,17 @@ int rscm_ens_get_params(rscm_ens* h, double* out_soa)
     if (int rc = set_device(h)) return rc;
     HIPCHK(hipMemcpyAsync(out_soa, h->d_params, (size_t)h->P * h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_gpu_copy_to_host(int32_t device_id, void* host, const void* device_ptr, int64_t n_bytes)
+{
+    GUARD_BEGIN
+    if (n_bytes < 0 || (n_bytes > 0 && (!host || !device_ptr))) return fail(RSCM_ERR_INVALID, "bad arguments");
+    if (n_bytes == 0) return RSCM_OK;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipMemcpy(host, device_ptr, (size_t)n_bytes, hipMemcpyDeviceToHost));
     return RSCM_OK;
     GUARD_END
 }

@@ -61,14 +61,22 @@ def _device_for_backend():
     return torch.device("cpu")
 
 
-def gather_members(local: np.ndarray, n_total: int, group=None) -> np.ndarray:
+def gather_members(local, n_total: int, group=None) -> np.ndarray:
     """All-gather a per-member vector sharded by ``shard_bounds`` into the global order.
-    Every rank returns the full ``[n_total]`` array."""
-    local = np.ascontiguousarray(local)
+    Every rank returns the full ``[n_total]`` array on the host.
+
+    ``local`` is a numpy array or a ``DeviceVector`` (``Ensemble.loglik(..., on_device=True)``,
+    ``status_device()``).  With the ``nccl`` backend a device vector is gathered where it lies: one
+    device-to-device copy into the padded send buffer, the RCCL all-gather, one copy of the gathered
+    vector to the host -- no host round trip of the shard.  With ``gloo`` (CPU rehearsals) the shard
+    comes to the host first."""
+    from .ensemble import DeviceVector
+    on_device = isinstance(local, DeviceVector)
     if not is_distributed():
-        if len(local) != n_total:
+        host = local.to_host() if on_device else np.ascontiguousarray(local).copy()
+        if len(host) != n_total:
             raise ValueError("single process: local shard must be the whole ensemble")
-        return local.copy()
+        return host
     import torch
     d = _dist()
     world, rank = d.get_world_size(group), d.get_rank(group)
@@ -77,15 +85,22 @@ def gather_members(local: np.ndarray, n_total: int, group=None) -> np.ndarray:
         raise ValueError(f"rank {rank}: shard has {len(local)} members, expected {cnt}")
     dev = _device_for_backend()
     max_cnt = shard_bounds(n_total, 0, world)[1]
-    pad = np.zeros(max_cnt, dtype=local.dtype)
-    pad[:cnt] = local
-    mine = torch.from_numpy(pad).to(dev)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    d.all_gather(parts, mine, group=group)
-    out = np.empty(n_total, dtype=local.dtype)
-    for r, p in enumerate(parts):
+    if on_device and dev.type == "cuda":
+        src = torch.as_tensor(local, device=dev)            # zero-copy view of the library's buffer
+        mine = torch.zeros(max_cnt, dtype=src.dtype, device=dev)
+        mine[:cnt].copy_(src)
+    else:
+        host = local.to_host() if on_device else np.ascontiguousarray(local)
+        pad = np.zeros(max_cnt, dtype=host.dtype)
+        pad[:cnt] = host
+        mine = torch.from_numpy(pad).to(dev)
+    gathered = torch.empty(world * max_cnt, dtype=mine.dtype, device=dev)
+    d.all_gather_into_tensor(gathered, mine, group=group)
+    parts = gathered.cpu().numpy().reshape(world, max_cnt)
+    out = np.empty(n_total, dtype=parts.dtype)
+    for r in range(world):
         o, c = shard_bounds(n_total, r, world)
-        out[o:o + c] = p[:c].cpu().numpy()
+        out[o:o + c] = parts[r, :c]
     return out
 
 
@@ -137,11 +152,16 @@ class ShardedEnsemble:
         self.ensemble.run()
 
     def loglik_global(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize=False) -> np.ndarray:
-        local = self.ensemble.loglik(obs_var, obs_tidx, obs_value, obs_sigma, normalize)
+        local = self.ensemble.loglik(obs_var, obs_tidx, obs_value, obs_sigma, normalize, on_device=True)
         return gather_members(local, self.n_total)
 
     def status_global(self) -> np.ndarray:
-        return gather_members(self.ensemble.status(), self.n_total)
+        return gather_members(self.ensemble.status_device(), self.n_total)
+
+    def params_global(self) -> np.ndarray:
+        """The global ``[P][n_total]`` parameter matrix (one gather per row)."""
+        P = self.ensemble.get_params()
+        return np.stack([gather_members(np.ascontiguousarray(row), self.n_total) for row in P])
 
     def summary_global(self, var, tidx: int) -> Dict[str, float]:
         return reduce_summary(self.ensemble.summary(var, tidx))

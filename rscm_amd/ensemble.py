@@ -16,6 +16,31 @@ import numpy as np
 from . import _lib as L
 
 
+class DeviceVector:
+    """A per-member vector left in device memory by an ensemble (``loglik(..., on_device=True)``,
+    ``status_device()``): owned by the handle and valid until its next call of the same kind.  It
+    carries ``__cuda_array_interface__``, so ``torch.as_tensor(v, device="cuda")`` is a zero-copy
+    view -- what the RCCL all-gather of ``rscm_amd.distributed`` sends -- and ``to_host()`` copies it
+    out through the library."""
+
+    def __init__(self, ptr: int, n: int, dtype, owner: "Ensemble"):
+        self.ptr, self.n, self.dtype, self.owner = int(ptr), int(n), np.dtype(dtype), owner
+
+    def __len__(self) -> int:
+        return self.n
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.n,), "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2,
+                "strides": None}
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=self.dtype)
+        L.check(L.load().rscm_gpu_copy_to_host(self.owner.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                               out.nbytes))
+        return out
+
+
 class Ensemble:
     def __init__(self, kind: int, n_members: int, time_bounds: Sequence[float], device: int = 0,
                  store_series: bool = True):
@@ -280,24 +305,42 @@ class Ensemble:
         L.check(self._lib.rscm_ens_status(self._h, L.bptr(out)))
         return out
 
-    def loglik(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize: bool = False) -> np.ndarray:
+    def status_device(self) -> DeviceVector:
+        p = C.c_void_p()
+        L.check(self._lib.rscm_ens_status_devptr(self._h, C.byref(p)))
+        self.sync()
+        return DeviceVector(p.value, self.n_members, np.uint8, self)
+
+    def loglik(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize: bool = False, on_device: bool = False):
+        """Gaussian log-likelihood per member, ``[N]``; ``on_device`` leaves it in device memory (a
+        ``DeviceVector``) for a reduction or all-gather without a host round trip."""
         ov = np.ascontiguousarray([self._var(v) for v in np.atleast_1d(obs_var)], dtype=np.int32)
         ot = np.ascontiguousarray(obs_tidx, dtype=np.int32)
         val, sig = L.f64(obs_value), L.f64(obs_sigma)
         if not (len(ov) == len(ot) == len(val) == len(sig)):
             raise ValueError("observation arrays differ in length")
+        if on_device:
+            p = C.c_void_p()
+            L.check(self._lib.rscm_ens_loglik_device(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
+                                                     L.dptr(sig), int(normalize), C.byref(p)))
+            return DeviceVector(p.value, self.n_members, np.float64, self)
         out = np.empty(self.n_members)
         L.check(self._lib.rscm_ens_loglik(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
                                           L.dptr(sig), int(normalize), L.dptr(out)))
         return out
 
-    def run_loglik(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize: bool = False) -> np.ndarray:
+    def run_loglik(self, obs_var, obs_tidx, obs_value, obs_sigma, normalize: bool = False, on_device: bool = False):
         """Fused run + Gaussian log-likelihood: no series is written (see rscm_ens_run_loglik)."""
         ov = np.ascontiguousarray([self._var(v) for v in np.atleast_1d(obs_var)], dtype=np.int32)
         ot = np.ascontiguousarray(obs_tidx, dtype=np.int32)
         val, sig = L.f64(obs_value), L.f64(obs_sigma)
         if not (len(ov) == len(ot) == len(val) == len(sig)):
             raise ValueError("observation arrays differ in length")
+        if on_device:
+            p = C.c_void_p()
+            L.check(self._lib.rscm_ens_run_loglik_device(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
+                                                         L.dptr(sig), int(normalize), C.byref(p)))
+            return DeviceVector(p.value, self.n_members, np.float64, self)
         out = np.empty(self.n_members)
         L.check(self._lib.rscm_ens_run_loglik(self._h, len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
                                               L.dptr(sig), int(normalize), L.dptr(out)))

@@ -42,6 +42,12 @@ class FakeEnsemble:
     def status(self):
         return (self.gid % 7 == 0).astype(np.uint8)
 
+    def status_device(self):  # the stand-in has no device: the gather takes host arrays as well
+        return self.status()
+
+    def get_params(self):
+        return self.params
+
     def summary(self, var, tidx):
         x = self.gid.astype(np.float64)
         if len(x) == 0:
