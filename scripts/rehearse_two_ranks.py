@@ -100,8 +100,8 @@ def main():
     checks["own_block_series_bit_equal"] = same_bits(own_rows, rows_one[se.offset:se.offset + se.count])
     checks["summary_count_min_max_equal"] = bool(sm_sharded["count"] == sm_one["count"] and sm_sharded["min"] == sm_one["min"]
                                                  and sm_sharded["max"] == sm_one["max"])
-    checks["summary_mean_rel_diff"] = abs(sm_sharded["mean"] - sm_one["mean"]) / abs(sm_one["mean"])
-    checks["summary_mean_ok"] = checks["summary_mean_rel_diff"] < 1e-13
+    checks["summary_mean_rel_diff"] = float(abs(sm_sharded["mean"] - sm_one["mean"]) / abs(sm_one["mean"]))
+    checks["summary_mean_ok"] = bool(checks["summary_mean_rel_diff"] < 1e-13)
     checks["finite_members"] = int(np.isfinite(ll_one).sum())
     se.ensemble.close()
 
@@ -126,7 +126,7 @@ def main():
     ref.close()
     checks["calibrate_batch_bit_equal"] = same_bits(ll_batch, ll_ref)
 
-    ok = all(v for k, v in checks.items() if isinstance(v, bool))
+    ok = bool(all(v for k, v in checks.items() if isinstance(v, bool)))
     res = {"rank": rank, "world": world, "backend": dist.get_backend(), "n_total": n_total, "shard": [se.offset, se.count],
            "ok": ok, "checks": checks}
     os.makedirs(args.out, exist_ok=True)

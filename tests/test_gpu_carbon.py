@@ -201,4 +201,4 @@ def test_terrestrial_zero_and_infinite_turnover_times(ra, orc):
     ok = np.isfinite(want)
     err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
     assert err.max() <= TOL, f"max deviation {err.max():.3e}"
-    assert np.isfinite(want[:, :, 40:]).all()
+    assert np.isfinite(want[:, 1:, 40:]).all() and np.isfinite(want[:4, 0]).all()

@@ -457,9 +457,9 @@ def test_graph_model_magicc_lite_chain_with_feedback(ra, aerosol_first):
     # the feedback acts on warming only (delta_t = max(T, 0)): under cooling it is tau0 / (tau0 / tau + 0), tau to rounding
     # -- the kernel carries 1/tau and forms fma(tau0, 1/tau, 0) * (1/tau0): one rounding per factor, i.e. a
     # relative difference of a few ulp in the lifetime, which the contractive recurrence does not amplify:
-    # bounded here by 256 ulp of the concentration (6e-11 ppb at 1e3 ppb; measured 0 - 2 ulp)
+    # bounded here by 16 ulp of the concentration (measured on an MI355X: 1 ulp)
     print(f"CH4 no-warming feedback difference: {diff:.3e} ({diff / np.spacing(ch4_b[-1]):.1f} ulp)")
-    assert diff > 1e-3 if aerosol_first else diff <= 256 * np.spacing(ch4_b[-1])
+    assert diff > 1e-3 if aerosol_first else diff <= 16 * np.spacing(ch4_b[-1])
     m2.close()
     model.close()
     del cbind
@@ -1480,6 +1480,6 @@ def test_graph_models_release_what_they_allocate(ra):
     free1, _ = L.mem_info(0)
     print(f"free-memory change over 24 build/run/close cycles: {(free0 - free1) / 2**20:.1f} MiB")
     # one cycle allocates ~0.6 GB (20 000 members x 13 ensembles); a leak of any one ensemble's series
-    # per cycle would be > 24 x 3 MB x (its variables).  The runtime returns freed blocks to the
-    # device in 2 MiB granules and keeps a few cached: the bound is 32 MiB either way.
-    assert abs(free0 - free1) <= 32 << 20, (free0, free1)
+    # per cycle would be > 24 x 3 MB x (its variables).  Measured on an MI355X after the 12 warm-up
+    # cycles: 0.0 MiB; the bound leaves room for a few of the runtime's 2 MiB granules either way.
+    assert abs(free0 - free1) <= 8 << 20, (free0, free1)
