@@ -360,6 +360,22 @@ RSCM_API int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, c
 RSCM_API int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times,
                                 const double* time_bounds, int32_t device_id, uint32_t flags,
                                 rscm_ens** out);
+/* RSCM_FLAG_WINDOWED (any kind): keep only a sliding window of `window_rows` rows of every series
+ * -- enough for what a step and its linked consumers read (indices n and n+1, plus the rows a
+ * chemistry kind looks back at) -- instead of all n_times rows, and, if out_stride > 0, every
+ * out_stride-th row (t = 0, out_stride, 2 out_stride, ...) of the `out_vars` (n_out_vars < 0: every stored
+ * variable) in an output store.  This is what lets a graph of linked ensembles run a long axis: 36
+ * series x 9001 monthly points are 2.6 MB per member stored whole, 4.6 KB in a 16-row window plus 216 KB
+ * of annual outputs.  Semantics are unchanged: outputs of step n are written at index n+1, consumers
+ * read n or n+1 (state/windows.rs:229-234), rows never written read as NaN.  A windowed handle is stepped
+ * in ranges shorter than its window (lock-step graphs: one step per launch); rscm_ens_get_series,
+ * rscm_ens_loglik and rscm_ens_summary serve the rows that are resident (output store or window) and
+ * fail with RSCM_ERR_STATE for the others; rscm_ens_rewind puts the initial rows back.
+ * window_rows >= 4 and >= 2 x (look-back + 1); window_rows >= n_times gives plain full storage. */
+#define RSCM_FLAG_WINDOWED 2u
+RSCM_API int rscm_ens_create_windowed(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
+                                      int32_t device_id, uint32_t flags, int32_t window_rows, int32_t out_stride,
+                                      int32_t n_out_vars, const int32_t* out_vars, rscm_ens** out);
 RSCM_API int rscm_ens_destroy(rscm_ens* h);
 
 RSCM_API int rscm_ens_n_params(const rscm_ens* h, int32_t* out);

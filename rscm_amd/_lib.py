@@ -27,6 +27,7 @@ SRC_EXOGENOUS, SRC_UPSTREAM = 0, 1
 COMP_TWO_LAYER, COMP_CARBON_CYCLE = 0, 1
 MODE_EXACT, MODE_FAST = 0, 1
 FLAG_NO_SERIES = 1
+FLAG_WINDOWED = 2
 
 TL_VARS = {"Effective Radiative Forcing": 0, "Surface Temperature": 1, "Deep Ocean Temperature": 2}
 CP_VARS = {"Emissions|CO2|Anthropogenic": 0, "Surface Temperature": 1, "Deep Ocean Temperature": 2,
@@ -234,6 +235,8 @@ SIGNATURES = {
     "rscm_ens_create": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.POINTER(_h)]),
     "rscm_ens_create_ex": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_uint32,
                                      C.POINTER(_h)]),
+    "rscm_ens_create_windowed": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                           C.c_int32, _ip, C.POINTER(_h)]),
     "rscm_ens_destroy": (C.c_int, [_h]),
     "rscm_ens_n_params": (C.c_int, [_h, _ip]),
     "rscm_ens_n_vars": (C.c_int, [_h, _ip]),

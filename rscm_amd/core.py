@@ -667,7 +667,8 @@ class ModelBuilder:
         return topo
 
     def _build_graph(self, n_members: int, endogenous, sources, exo_names, aggregates,
-                     execution_order: str = "reference") -> "GraphModel":
+                     execution_order: str = "reference", series_window: Optional[int] = None, output_stride: int = 0,
+                     outputs: Optional[Sequence[str]] = None) -> "GraphModel":
         T, bounds = len(self._axis), self._axis.bounds()
         types = [c.type_name for c in self._components]
         if len(set(types)) != len(types):
@@ -690,6 +691,25 @@ class ModelBuilder:
         model = GraphModel(self._axis, order, ensembles, var_home, links, exogenous, sources, stream, self._device, True)
         model._builder = self
         model._execution_order = execution_order
+        windowed = series_window is not None and series_window < T
+        model._windowed = windowed
+        model._output_stride = int(output_stride) if windowed else 1
+        want_out = None if outputs is None else set(outputs)
+
+        def make(kind: int, out_names=None) -> Ensemble:
+            """One ensemble of the graph; windowed graphs keep `series_window` rows of every series and
+            every `output_stride`-th row of the requested outputs (all variables if none were named)."""
+            if not windowed:
+                return Ensemble(kind, n_members, bounds, device=self._device)
+            ids = L.KIND_TABLE[kind][0]
+            keep = None
+            if want_out is not None:
+                names = out_names if out_names is not None else [n for n, v in ids.items() if v > 0]
+                fb = L.FOURBOX_VARS.get(kind)
+                keep = [ids[n] for n in names if n in want_out or (fb and fb[0] in want_out and fb[1] <= ids[n] < fb[1] + 4)]
+            return Ensemble(kind, n_members, bounds, device=self._device, window_rows=series_window,
+                            output_stride=output_stride if keep is None or keep else 0, output_vars=keep)
+
         try:
             def params_of(values) -> np.ndarray:
                 return np.repeat(np.array(values, dtype=np.float64)[:, None], n_members, axis=1)
@@ -710,7 +730,7 @@ class ModelBuilder:
                     model._host_nodes[comp.type_name] = _HostNode(comp)
                     model._feed_forward = False
                     continue
-                ens = Ensemble(COMPONENT_KINDS[comp.type_name], n_members, bounds, device=self._device)
+                ens = make(COMPONENT_KINDS[comp.type_name])
                 ensembles[comp.type_name] = ens
                 ens.set_stream(stream.value)
                 base = _component_params(comp)
@@ -732,7 +752,9 @@ class ModelBuilder:
                             # 162-176) -- gets sum(value * weight) over the boxes, formed by a Weighted
                             # aggregate ensemble that runs right after the producer, index by index.
                             tname = f"Transform:{name}"
-                            tr = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device)
+                            tr = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
+                                          window_rows=series_window if windowed else None,
+                                          output_stride=output_stride if (want_out is None or name in want_out) else 0)
                             ensembles[tname] = tr
                             tr.set_stream(stream.value)
                             w = self._grid_weights.get(GridType.FourBox, [0.25, 0.25, 0.25, 0.25])
@@ -749,7 +771,9 @@ class ModelBuilder:
             for agg, (_, op, contributors, weights) in aggregates.items():
                 if len(contributors) > L.AG_NINPUTS:
                     raise NotImplementedError(f"aggregate {agg!r}: more than {L.AG_NINPUTS} contributors")
-                ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device)
+                ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
+                               window_rows=series_window if windowed else None,
+                               output_stride=output_stride if (want_out is None or agg in want_out) else 0)
                 ensembles[f"Aggregator:{agg}"] = ens
                 ens.set_stream(stream.value)
                 w = list(weights or []) + [0.0] * (L.AG_NINPUTS - len(weights or []))
@@ -828,12 +852,26 @@ class ModelBuilder:
             raise
         return model
 
-    def build(self, n_members: int = 1, store_series: bool = True, execution_order: str = "reference") -> "Model":
+    def build(self, n_members: int = 1, store_series: bool = True, execution_order: str = "reference",
+              series_window: Optional[int] = None, output_stride: int = 0,
+              outputs: Optional[Sequence[str]] = None) -> "Model":
         """``execution_order`` (graphs without a fused kernel only): "reference" steps the components
         in the reference's breadth-first order, which can run a component before the producer of a
         value it reads at the end of the step (it then reads NaN, which an aggregate skips);
-        "topological" is the order in which that cannot happen."""
+        "topological" is the order in which that cannot happen.
+
+        ``series_window`` (an extension, for long axes and large ensembles): run the model as a graph of
+        linked ensembles that keep only a sliding window of that many rows of every series -- what a
+        step and its consumers read -- plus every ``output_stride``-th row of ``outputs`` (variable
+        names; None: every variable).  The reference holds whole collections, one member at a time
+        (model/builder.rs:735-830); 1e5 members x 9001 monthly points x 36 series do not fit a GPU that
+        way.  ``get_series(name, t_stride=output_stride)`` reads the kept rows."""
         endogenous, sources, exo_names, aggregates = self._resolve()
+        if series_window is not None:
+            if any(getattr(c, "is_python", False) for c in self._components):
+                raise NotImplementedError("Python components read whole host series: no series_window for such graphs")
+            return self._build_graph(n_members, endogenous, sources, exo_names, aggregates, execution_order,
+                                     series_window, output_stride, outputs)
         if any(getattr(c, "is_python", False) for c in self._components):
             return self._build_graph(n_members, endogenous, sources, exo_names, aggregates, execution_order)
         types = [c.type_name for c in self._components]
@@ -1027,6 +1065,8 @@ class GraphModel:
         self._host_nodes: Dict[str, "_HostNode"] = {}  # Python components, stepped on the host
         self._reads_unwritten = False  # some component reads index n+1 of a producer that runs after it
         self._fourbox: Dict[str, Tuple[str, int, bool]] = {}  # FourBox variable -> (producer, first id, stored as scalar)
+        self._windowed = False      # ensembles keep a sliding window of rows + strided outputs (build(series_window=...))
+        self._output_stride = 1
         self.time_index = 0
         # component parameters: "Type.name" -> (owner, row); bare names too where they are unique
         self.param_home: Dict[str, Tuple[str, int]] = {}
@@ -1167,7 +1207,7 @@ class GraphModel:
             while self.time_index < last:
                 self.step()
             return
-        if self._feed_forward:  # no edge points backwards: every producer can finish before its consumers start
+        if self._feed_forward and not self._windowed:  # no edge points backwards: every producer can finish before its consumers start
             for name in self._order:
                 self.ensembles[name].run(last, sync=False)
         else:
@@ -1179,6 +1219,9 @@ class GraphModel:
         return self.time_index == len(self._axis) - 1
 
     def timeseries(self, member: int = 0) -> TimeseriesCollection:
+        if self._windowed:
+            raise NotImplementedError("a windowed model keeps every output_stride-th row only: read them with "
+                                      "get_series(name, t_stride=output_stride)")
         coll = TimeseriesCollection()
         for name, vals in self._exogenous.items():
             coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Exogenous)

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void carbon_cycle_kernel(CarbonArgs a)
     const int32_t T = a.n_times;
     const double tau = a.params[i], conc_pi = a.params[(size_t)N + i], alpha = a.params[(size_t)2 * N + i];
     const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)T * N;
+    const size_t vs = (size_t)a.rows * N;
     const size_t r0 = (size_t)a.step_begin * N + i;
     double conc = a.series[r0], cum_u = a.series[vs + r0], cum_e = a.series[2 * vs + r0];
     const double hc = a.h, half_c = hc / 2.0, sixth_c = hc / 6.0;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void co2_budget_kernel(CarbonArgs a)
     const int32_t T = a.n_times;
     const double gtc_per_ppm = a.params[i];
     const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)T * N;
+    const size_t vs = (size_t)a.rows * N;
     a.status[i] = 0;
     double co2 = a.series[(size_t)a.step_begin * N + i];
     for (int32_t n = a.step_begin; n < a.step_end; ++n) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
     const double r_tau_plant = guarded_rcp(tau_plant), r_tau_det = guarded_rcp(tau_det), r_tau_soil = guarded_rcp(tau_soil),
                  r_tau_hum = guarded_rcp(tau_hum);
     const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)T * N;
+    const size_t vs = (size_t)a.rows * N;
     a.status[i] = 0;
     const size_t r0 = (size_t)a.step_begin * N + i;
     double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];

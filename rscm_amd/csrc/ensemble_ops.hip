@@ -4,6 +4,8 @@
 //   * counter-based Latin hypercube          crates/rscm-calibrate/src/parameter_set.rs:207-233
 //   * fills / row broadcast for collection initialisation (builder.rs:772-780)
 //   * the division self-test behind rscm_gpu_selftest_div
+#include <algorithm>
+
 #include "philox.hpp"
 #include "rk4_device.hpp"
 #include "rscm_device.hpp"
@@ -24,6 +26,61 @@ __global__ __launch_bounds__(kBlock) void broadcast_row_kernel(double* row, int6
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
         row[i] = src[n_src == 1 ? 0 : i];
+}
+
+// ---- windowed series (RSCM_FLAG_WINDOWED) -------------------------------------------------------
+// buf is [n_vars][R][N].  Slide: rows [shift, shift + keep) of every variable move to rows [0, keep)
+// (shift >= keep: source and destination rows are disjoint).
+__global__ __launch_bounds__(kBlock) void slide_rows_kernel(double* buf, int64_t N, int32_t R, int32_t n_vars, int32_t shift,
+                                                            int32_t keep)
+{
+    const int64_t per_var = (int64_t)keep * N, total = per_var * n_vars;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x; x < total; x += stride) {
+        const int64_t v = x / per_var, o = x - v * per_var;
+        double* var = buf + (size_t)v * R * N;
+        var[o] = var[(size_t)shift * N + o];
+    }
+}
+
+// rows [row_begin, R) of every variable = value
+__global__ __launch_bounds__(kBlock) void fill_rows_kernel(double* buf, int64_t N, int32_t R, int32_t n_vars, int32_t row_begin,
+                                                           double value)
+{
+    const int64_t per_var = (int64_t)(R - row_begin) * N, total = per_var * n_vars;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x; x < total; x += stride) {
+        const int64_t v = x / per_var, o = x - v * per_var;
+        buf[(size_t)v * R * N + (size_t)row_begin * N + o] = value;
+    }
+}
+
+// dst[k][dst_row][:] = src[vars[k] - 1][src_row][:] for k < n_out (or vars == nullptr: k-th variable)
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const double* src, int64_t N, int32_t src_rows, int32_t src_row,
+                                                             const int32_t* vars, int32_t n_out, double* dst, int32_t dst_rows,
+                                                             int32_t dst_row)
+{
+    const int64_t total = (int64_t)n_out * N;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x; x < total; x += stride) {
+        const int64_t k = x / N, i = x - k * N;
+        const int64_t v = vars ? vars[k] - 1 : k;
+        dst[((size_t)k * dst_rows + dst_row) * N + i] = src[((size_t)v * src_rows + src_row) * N + i];
+    }
+}
+
+// the reverse: src[vars[k] - 1][src_row][:] = dst[k][dst_row][:]
+__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(double* src, int64_t N, int32_t src_rows, int32_t src_row,
+                                                              const int32_t* vars, int32_t n_out, const double* dst, int32_t dst_rows,
+                                                              int32_t dst_row)
+{
+    const int64_t total = (int64_t)n_out * N;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t x = (int64_t)blockIdx.x * kBlock + threadIdx.x; x < total; x += stride) {
+        const int64_t k = x / N, i = x - k * N;
+        const int64_t v = vars ? vars[k] - 1 : k;
+        src[((size_t)v * src_rows + src_row) * N + i] = dst[((size_t)k * dst_rows + dst_row) * N + i];
+    }
 }
 
 // ---- Gaussian log-likelihood ----------------------------------------------------------------
@@ -230,6 +287,52 @@ inline unsigned grid_for(int64_t n, int64_t cap = 2048)
 }
 
 }  // namespace
+
+static unsigned stream_grid(int64_t total)
+{
+    return (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 8192);
+}
+
+hipError_t launch_slide_rows(double* buf, int64_t N, int32_t R, int32_t n_vars, int32_t shift, int32_t keep, hipStream_t s)
+{
+    if (n_vars <= 0 || keep <= 0 || shift <= 0) return hipSuccess;
+    if (shift >= keep) {
+        hipLaunchKernelGGL(slide_rows_kernel, dim3(stream_grid((int64_t)keep * N * n_vars)), dim3(kBlock), 0, s, buf, N, R, n_vars, shift, keep);
+        return hipGetLastError();
+    }
+    // overlapping move: row by row in ascending order, each launch ordered after the one before
+    for (int32_t r = 0; r < keep; ++r) {
+        hipLaunchKernelGGL(slide_rows_kernel, dim3(stream_grid(N * n_vars)), dim3(kBlock), 0, s, buf + (size_t)r * N, N, R, n_vars, shift, 1);
+        if (hipError_t e = hipGetLastError()) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_fill_rows(double* buf, int64_t N, int32_t R, int32_t n_vars, int32_t row_begin, double value, hipStream_t s)
+{
+    if (n_vars <= 0 || row_begin >= R) return hipSuccess;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(stream_grid((int64_t)(R - row_begin) * N * n_vars)), dim3(kBlock), 0, s, buf, N, R, n_vars,
+                       row_begin, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const double* src, int64_t N, int32_t src_rows, int32_t src_row, const int32_t* vars, int32_t n_out,
+                              double* dst, int32_t dst_rows, int32_t dst_row, hipStream_t s)
+{
+    if (n_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid((int64_t)n_out * N)), dim3(kBlock), 0, s, src, N, src_rows, src_row, vars, n_out,
+                       dst, dst_rows, dst_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_rows(double* src, int64_t N, int32_t src_rows, int32_t src_row, const int32_t* vars, int32_t n_out,
+                               const double* dst, int32_t dst_rows, int32_t dst_row, hipStream_t s)
+{
+    if (n_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(stream_grid((int64_t)n_out * N)), dim3(kBlock), 0, s, src, N, src_rows, src_row, vars, n_out,
+                       dst, dst_rows, dst_row);
+    return hipGetLastError();
+}
 
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s)
 {

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void halo_species_kernel(HaloArgs a)
     const double atm_mass_g = P(4) * 1e12;
     const double conv = (P(3) / mol_weight) * (1e9 / atm_mass_g) * 1e12 / P(5);
     const double* __restrict__ e = a.emissions + ((HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * kSpecies + s) * T;
-    double* __restrict__ c_series = a.series + (size_t)s * T * N + i;
+    double* __restrict__ c_series = a.series + (size_t)s * a.rows * N + i;
     if (s == 0) a.status[i] = 0;
     double c = c_series[(size_t)a.step_begin * N];
     double dt_prev = __builtin_nan(""), decay = 0.0;
@@ -63,13 +63,12 @@ __global__ __launch_bounds__(kBlock) void halo_aggregate_kernel(HaloArgs a)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
     const int64_t N = a.n_members;
-    const int32_t T = a.n_times;
     const int32_t row0 = a.step_begin + 1 + (int32_t)blockIdx.y * kChunk;  // first output row of this chunk
     if (row0 > a.step_end) return;
     const int32_t rows = (a.step_end - row0 + 1) < kChunk ? (a.step_end - row0 + 1) : kChunk;
     auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
     const double br_mult = P(0), cfc11_norm = P(1);
-    const size_t vs = (size_t)T * N;
+    const size_t vs = (size_t)a.rows * N;
     double total[kChunk], fgas[kChunk], montreal[kChunk], eesc[kChunk];
 #pragma unroll
     for (int y = 0; y < kChunk; ++y) total[y] = fgas[y] = montreal[y] = eesc[y] = 0.0;

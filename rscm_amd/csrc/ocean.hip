@@ -73,9 +73,8 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
 {
     constexpr int K = STEPS * YEARS;
     const int64_t N = a.n_members;
-    const int32_t T = a.n_times;
     const int64_t H = a.max_hist;
-    const size_t vs = (size_t)T * N;
+    const size_t vs = (size_t)a.rows * N;
     const int64_t m0 = (int64_t)n * STEPS;  // months already in the history
     // sub-step k of the tile convolves the pulses j in [lo(k), m0 + k]
     auto lo = [&](int k) -> int64_t { const int64_t v = m0 + k + 1 - H; return v > 0 ? v : 0; };

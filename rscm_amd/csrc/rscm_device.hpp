@@ -226,7 +226,8 @@ struct CarbonArgs {
     const double* bounds;    // [T+1]
     const int32_t* nsub;     // CarbonCycle: [T-1] RK4 sub-steps per model step
     double h;                // CarbonCycle: RK4 step
-    double* series;          // [n_states + n_outputs][T][N], states first
+    int32_t rows;            // stored rows per series (T, or the window length)
+    double* series;          // [n_states + n_outputs][rows][N], states first
     uint8_t* status;
 };
 
@@ -253,7 +254,8 @@ struct OceanArgs {
     double* hist;            // [(T-1)*steps][N] flux history, ppm/month
     double* partial;         // [(tile years - 1) * steps][N] running sums parked between the launches of a split tile
     int32_t part;            // -1: whole tiles; p >= 0: year p of a tile split over one-step launches
-    double* series;          // [3][T][N]: pCO2, cumulative uptake, flux
+    int32_t rows;            // stored rows per series (T, or the window length)
+    double* series;          // [3][rows][N]: pCO2, cumulative uptake, flux
     uint8_t* status;
 };
 
@@ -266,7 +268,8 @@ struct HaloArgs {
     const double* emissions;  // [S][41][T]
     const int32_t* scen;      // [N] or null
     const double* bounds;     // [T+1]
-    double* series;           // [41 + 4][T][N]: concentrations, then total / F-gas / Montreal forcing, EESC
+    int32_t rows;             // stored rows per series (T, or the window length)
+    double* series;           // [41 + 4][rows][N]: concentrations, then total / F-gas / Montreal forcing, EESC
     uint8_t* status;
 };
 
@@ -324,6 +327,14 @@ hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,
                                 hipStream_t s);
+// windowed series buffers [n_vars][R][N] (RSCM_FLAG_WINDOWED): move rows [shift, shift+keep) to the
+// front, fill rows [row_begin, R), copy one row of chosen variables into / out of a row store
+hipError_t launch_slide_rows(double* buf, int64_t N, int32_t R, int32_t n_vars, int32_t shift, int32_t keep, hipStream_t s);
+hipError_t launch_fill_rows(double* buf, int64_t N, int32_t R, int32_t n_vars, int32_t row_begin, double value, hipStream_t s);
+hipError_t launch_gather_rows(const double* src, int64_t N, int32_t src_rows, int32_t src_row, const int32_t* vars, int32_t n_out,
+                              double* dst, int32_t dst_rows, int32_t dst_row, hipStream_t s);
+hipError_t launch_scatter_rows(double* src, int64_t N, int32_t src_rows, int32_t src_row, const int32_t* vars, int32_t n_out,
+                               const double* dst, int32_t dst_rows, int32_t dst_row, hipStream_t s);
 // partial[4*n_blocks] then reduced into out[4] = {count_finite, sum, min, max}
 hipError_t launch_summary(const double* row, int64_t n, double* partial, int32_t n_blocks,
                           double* out, hipStream_t s);

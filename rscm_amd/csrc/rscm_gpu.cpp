@@ -225,7 +225,38 @@ struct rscm_ens {
     bool params_set = false, forcing_set = false;
     std::vector<uint8_t> initial_set;  // per variable id
 
-    double* series(int32_t var) const { return d_series + (size_t)(var - 1) * (size_t)rows * (size_t)N; }
+    // Windowed storage (RSCM_FLAG_WINDOWED): d_series holds rows [win0, win0 + rows) of every series.
+    bool windowed = false;
+    int32_t win0 = 0;            // absolute time index of the first stored row
+    int32_t lookback = 0;        // own rows before the current one that a step reads (chemistry kinds)
+    bool read_ahead = false;     // a linked consumer may read index n+1 before this producer wrote it: rows after a slide must be NaN
+    double* d_row0 = nullptr;    // [V-1][N] the initial rows, saved when step 0 starts (rewind restores them)
+    bool row0_saved = false;
+    int32_t out_stride = 0;      // > 0: every out_stride-th row of the output variables is kept in d_out
+    int32_t n_out = 0, out_rows = 0;
+    std::vector<int32_t> out_vars;      // variable ids kept
+    std::vector<int32_t> out_slot;      // per variable id: slot in d_out or -1
+    int32_t* d_out_vars = nullptr;
+    double* d_out = nullptr;     // [n_out][out_rows][N]
+    int32_t keep_rows() const { return std::max(lookback + 1, 2); }
+
+    // Base of series[var] such that row t lives at base + t * N (for a windowed handle the address of
+    // the virtual row 0: only rows [win0, win0 + rows) exist).
+    double* series(int32_t var) const
+    {
+        return d_series + ((int64_t)(var - 1) * (int64_t)rows - (int64_t)win0) * N;
+    }
+    // Device address of row t of a stored variable where it is resident: the output store (every
+    // out_stride-th row of the output variables, up to the current index), else the window; nullptr
+    // if the row is not held any more.
+    const double* row_ptr(int32_t var, int32_t t) const
+    {
+        if (!windowed) return (rows == T || t == 0) ? series(var) + (size_t)t * N : nullptr;
+        if (out_stride > 0 && out_slot[var] >= 0 && t % out_stride == 0 && t <= time_index)
+            return d_out + ((size_t)out_slot[var] * out_rows + (size_t)(t / out_stride)) * N;
+        if (t >= win0 && t < win0 + rows) return series(var) + (size_t)t * N;
+        return nullptr;
+    }
     bool is_state(int32_t var) const
     {
         if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
@@ -383,6 +414,55 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
     return RSCM_OK;
 }
 
+// ---- windowed series -----------------------------------------------------------------------
+// Back to the start of the axis: window at row 0, the saved initial rows put back, the rest NaN if
+// asked (a fresh collection) or if a consumer may read rows this producer has not written yet.
+int window_reset(rscm_ens* h, bool clear)
+{
+    if (!h->windowed) return RSCM_OK;
+    h->win0 = 0;
+    if (h->row0_saved)
+        HIPCHK(rscm::launch_scatter_rows(h->d_series, h->N, h->rows, 0, nullptr, h->V - 1, h->d_row0, 1, 0, h->stream));
+    if (clear || h->read_ahead)
+        HIPCHK(rscm::launch_fill_rows(h->d_series, h->N, h->rows, h->V - 1, 1, std::numeric_limits<double>::quiet_NaN(), h->stream));
+    return RSCM_OK;
+}
+
+// Move the window forward to start at new_win0, keeping the rows both windows share.
+int window_slide(rscm_ens* h, int32_t new_win0)
+{
+    const int32_t shift = new_win0 - h->win0;
+    if (!h->windowed || shift <= 0) return RSCM_OK;
+    const int32_t cnt = std::max(0, h->rows - shift);  // rows still inside the new window
+    HIPCHK(rscm::launch_slide_rows(h->d_series, h->N, h->rows, h->V - 1, shift, cnt, h->stream));
+    if (h->read_ahead || cnt == 0)
+        HIPCHK(rscm::launch_fill_rows(h->d_series, h->N, h->rows, h->V - 1, cnt, std::numeric_limits<double>::quiet_NaN(), h->stream));
+    h->win0 = new_win0;
+    return RSCM_OK;
+}
+
+// Re-position the window for a stepper that is put at time index k from outside (checkpoint restore):
+// the contents are the caller's to fill in (rscm_ens_set_state); everything is NaN until then.
+int window_seek(rscm_ens* h, int32_t k)
+{
+    if (!h->windowed) return RSCM_OK;
+    if (k == 0) return window_reset(h, true);
+    const int32_t w0 = std::max(0, k - h->keep_rows() + 1);
+    if (k >= h->win0 && k < h->win0 + h->rows - 1 && w0 >= h->win0) return window_slide(h, w0);
+    HIPCHK(rscm::launch_fill_rows(h->d_series, h->N, h->rows, h->V - 1, 0, std::numeric_limits<double>::quiet_NaN(), h->stream));
+    h->win0 = w0;
+    return RSCM_OK;
+}
+
+// every out_stride-th row into the output store
+int window_store_row(rscm_ens* h, int32_t t)
+{
+    if (!h->windowed || h->n_out == 0 || t % h->out_stride != 0) return RSCM_OK;
+    HIPCHK(rscm::launch_gather_rows(h->d_series, h->N, h->rows, t - h->win0, h->d_out_vars, h->n_out, h->d_out, h->out_rows,
+                                    t / h->out_stride, h->stream));
+    return RSCM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -430,10 +510,22 @@ int rscm_ens_create(int32_t kind, int64_t n_members, int32_t n_times, const doub
 int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
                        int32_t device_id, uint32_t flags, rscm_ens** out)
 {
+    return rscm_ens_create_windowed(kind, n_members, n_times, time_bounds, device_id, flags, 16, 0, -1, nullptr, out);
+}
+
+int rscm_ens_create_windowed(int32_t kind, int64_t n_members, int32_t n_times, const double* time_bounds,
+                             int32_t device_id, uint32_t flags, int32_t window_rows, int32_t out_stride,
+                             int32_t n_out_vars, const int32_t* out_vars, rscm_ens** out)
+{
     GUARD_BEGIN
-    if (flags & ~(uint32_t)RSCM_FLAG_NO_SERIES) return fail(RSCM_ERR_INVALID, "unknown flags 0x%x", flags);
+    if (flags & ~(uint32_t)(RSCM_FLAG_NO_SERIES | RSCM_FLAG_WINDOWED)) return fail(RSCM_ERR_INVALID, "unknown flags 0x%x", flags);
     if ((flags & RSCM_FLAG_NO_SERIES) && kind != RSCM_KIND_TWO_LAYER)
         return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES is only available for the two-layer kind");
+    if ((flags & RSCM_FLAG_NO_SERIES) && (flags & RSCM_FLAG_WINDOWED))
+        return fail(RSCM_ERR_INVALID, "RSCM_FLAG_NO_SERIES and RSCM_FLAG_WINDOWED exclude each other");
+    const bool windowed = (flags & RSCM_FLAG_WINDOWED) != 0;
+    if (windowed && (window_rows < 4 || out_stride < 0 || (n_out_vars > 0 && !out_vars)))
+        return fail(RSCM_ERR_INVALID, "a windowed ensemble needs window_rows >= 4, out_stride >= 0 and a variable list if n_out_vars > 0");
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (kind < RSCM_KIND_TWO_LAYER || kind > RSCM_KIND_AGGREGATE)
@@ -452,6 +544,10 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->N = n_members;
     h->T = n_times;
     h->rows = (flags & RSCM_FLAG_NO_SERIES) ? 1 : n_times;
+    if (windowed && window_rows < n_times) {  // a window as long as the axis is plain full storage
+        h->windowed = true;
+        h->rows = window_rows;
+    }
     h->device = device_id;
     static const int32_t kP[] = {RSCM_TL_NPARAMS, RSCM_CP_NPARAMS, RSCM_UD_NPARAMS, RSCM_GH_NPARAMS,
                                  RSCM_OZ_NPARAMS, RSCM_AD_NPARAMS, RSCM_AI_NPARAMS, RSCM_CH4_NPARAMS,
@@ -468,6 +564,26 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     h->n_inputs = kInputs[kind];
     h->bounds.assign(time_bounds, time_bounds + n_times + 1);
     h->initial_set.assign(h->V, 0);
+    h->out_slot.assign(h->V, -1);
+    if (kind == RSCM_KIND_CH4_CHEMISTRY) h->lookback = 1;   // previous()
+    if (kind == RSCM_KIND_N2O_CHEMISTRY) h->lookback = 2;   // at_offset(-(strat_delay + 1)), refreshed by set_params
+    if (h->windowed && out_stride > 0) {
+        h->out_stride = out_stride;
+        h->out_rows = (n_times - 1) / out_stride + 1;
+        if (n_out_vars < 0)
+            for (int32_t v = 1; v < h->V; ++v) h->out_vars.push_back(v);
+        else
+            for (int32_t k = 0; k < n_out_vars; ++k) {
+                if (out_vars[k] < 1 || out_vars[k] >= h->V || h->out_slot[out_vars[k]] >= 0) {
+                    delete h;
+                    return fail(RSCM_ERR_INVALID, "output variable %d: not a stored variable of this kind, or listed twice", out_vars[k]);
+                }
+                h->out_slot[out_vars[k]] = k;
+                h->out_vars.push_back(out_vars[k]);
+            }
+        h->n_out = (int32_t)h->out_vars.size();
+        for (int32_t k = 0; k < h->n_out; ++k) h->out_slot[h->out_vars[k]] = k;
+    }
 
     auto cleanup = [&](int rc) {
         rscm_ens_destroy(h);
@@ -493,6 +609,16 @@ int rscm_ens_create_ex(int32_t kind, int64_t n_members, int32_t n_times, const d
     CK(hipMalloc(&h->d_params, (size_t)h->P * h->N * sizeof(double)));
     CK(hipMalloc(&h->d_series, series_elems * sizeof(double)));
     CK(hipMalloc(&h->d_status, (size_t)h->N));
+    if (h->windowed) {
+        CK(hipMalloc(&h->d_row0, (size_t)(h->V - 1) * h->N * sizeof(double)));
+        if (h->n_out > 0) {
+            const size_t out_elems = (size_t)h->n_out * h->out_rows * h->N;
+            CK(hipMalloc(&h->d_out, out_elems * sizeof(double)));
+            CK(hipMalloc(&h->d_out_vars, (size_t)h->n_out * sizeof(int32_t)));
+            CK(hipMemcpy(h->d_out_vars, h->out_vars.data(), (size_t)h->n_out * sizeof(int32_t), hipMemcpyHostToDevice));
+            CK(rscm::launch_fill(h->d_out, (int64_t)out_elems, std::numeric_limits<double>::quiet_NaN(), h->stream));
+        }
+    }
     CK(hipMalloc(&h->d_nsub_tl, (size_t)(h->T - 1) * sizeof(int32_t)));
     CK(hipMalloc(&h->d_nsub_cc, (size_t)(h->T - 1) * sizeof(int32_t)));
     CK(hipMalloc(&h->d_partial, 4 * 1024 * sizeof(double)));
@@ -558,6 +684,9 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_out4);
     (void)hipFree(h->d_loglik);
     (void)hipFree(h->d_obs);
+    (void)hipFree(h->d_row0);
+    (void)hipFree(h->d_out);
+    (void)hipFree(h->d_out_vars);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -659,6 +788,11 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
                 return fail(RSCM_ERR_INVALID, "GhgForcing parameter row %d (method) must be the same for every member", RSCM_GH_P_METHOD);
         h->ghg_method = (int32_t)m;
     }
+    if (h->kind == RSCM_KIND_N2O_CHEMISTRY) {  // rows the stratospheric delay looks back (n2o.rs:203-218)
+        double d = 1.0;
+        for (int64_t i = 0; i < h->N; ++i) d = std::max(d, soa[(size_t)4 * h->N + i]);
+        h->lookback = (int32_t)std::min(d, 1e6) + 1;
+    }
     HIPCHK(hipMemcpyAsync(h->d_params, soa, (size_t)h->P * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -745,8 +879,9 @@ int rscm_ens_link_input(rscm_ens* h, int32_t input_row, rscm_ens* src, int32_t s
     if (src->N != h->N || src->T != h->T || src->device != h->device)
         return fail(RSCM_ERR_INVALID, "linked ensembles need the same members, time points and device (%lld x %d on %d vs %lld x %d on %d)",
                     (long long)src->N, src->T, src->device, (long long)h->N, h->T, h->device);
-    if (src->rows != src->T || h->rows != h->T)
+    if ((!src->windowed && src->rows != src->T) || (!h->windowed && h->rows != h->T))
         return fail(RSCM_ERR_INVALID, "linked ensembles must store their series (no RSCM_FLAG_NO_SERIES)");
+    if (!h->link_order_check) src->read_ahead = true;
     auto& l = h->links[input_row];
     if (l.src) --l.src->link_refs;
     else ++h->n_linked;
@@ -762,6 +897,9 @@ int rscm_ens_set_link_order_check(rscm_ens* h, int32_t enabled)
 {
     NEED(h);
     h->link_order_check = enabled != 0;
+    if (!h->link_order_check)  // the producers' rows beyond what they have written must read as NaN
+        for (auto& l : h->links)
+            if (l.src) l.src->read_ahead = true;
     return RSCM_OK;
 }
 
@@ -787,6 +925,11 @@ int rscm_ens_set_initial(rscm_ens* h, int32_t var_id, const double* values, int6
     if (!values || (n_values != 1 && n_values != h->N))
         return fail(RSCM_ERR_INVALID, "initial values: need 1 or n_members values, got %lld", (long long)n_values);
     if (int rc = set_device(h)) return rc;
+    if (h->windowed) {
+        if (h->win0 != 0)
+            if (int rc = window_reset(h, false)) return rc;
+        h->row0_saved = false;  // saved again when step 0 starts
+    }
     if (n_values == 1)
         HIPCHK(rscm::launch_fill(h->series(var_id), h->N, values[0], h->stream));
     else
@@ -803,10 +946,13 @@ int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* 
     GUARD_BEGIN
     NEED(h);
     if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
-    if (tidx < 0 || tidx >= h->rows) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (h->windowed ? (tidx < h->win0 || tidx >= h->win0 + h->rows) : (tidx < 0 || tidx >= h->rows))
+        return fail(RSCM_ERR_INVALID, h->windowed ? "time index %d is outside the stored window (move the stepper there first: rscm_ens_set_time_index)"
+                                                   : "time index %d out of range", tidx);
     if (!values || (n_values != 1 && n_values != h->N))
         return fail(RSCM_ERR_INVALID, "state values: need 1 or n_members values, got %lld", (long long)n_values);
     if (int rc = set_device(h)) return rc;
+    if (h->windowed && tidx == 0) h->row0_saved = false;
     double* row = h->series(var_id) + (size_t)tidx * h->N;
     if (n_values == 1)
         HIPCHK(rscm::launch_fill(row, h->N, values[0], h->stream));
@@ -820,8 +966,9 @@ int rscm_ens_set_state(rscm_ens* h, int32_t var_id, int32_t tidx, const double* 
 
 int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
 {
+    GUARD_BEGIN
     NEED(h);
-    if (tidx < 0 || tidx > h->rows - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
+    if (tidx < 0 || tidx > (h->windowed ? h->T : h->rows) - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
     // kinds whose components keep internal state in the reference (ComponentState: the UDEB ocean
     // columns, the OceanCarbon flux history) can only continue from where that state stands
     if ((h->kind == RSCM_KIND_UDEB || h->kind == RSCM_KIND_OCEAN_CARBON) && tidx != 0 && tidx != h->time_index)
@@ -830,9 +977,14 @@ int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
     if (tidx > 0)
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;  // a restored checkpoint carries its own state rows
+    if (h->windowed && tidx != h->time_index) {
+        if (int rc = set_device(h)) return rc;
+        if (int rc = window_seek(h, tidx)) return rc;
+    }
     h->time_index = tidx;
     h->ocean_tile_base = -1;
     return RSCM_OK;
+    GUARD_END
 }
 
 typedef std::vector<std::pair<double*, int64_t>> StatePieces;
@@ -883,7 +1035,7 @@ int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles
 {
     GUARD_BEGIN
     NEED(h);
-    if (time_index < 0 || time_index > h->rows - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", time_index);
+    if (time_index < 0 || time_index > (h->windowed ? h->T : h->rows) - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", time_index);
     if ((h->kind == RSCM_KIND_UDEB && !h->udeb_ready) || (h->kind == RSCM_KIND_OCEAN_CARBON && !h->ocean_ready))
         return fail(RSCM_ERR_STATE, "set the parameters first: they size the internal state");
     StatePieces pieces;
@@ -902,6 +1054,8 @@ int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles
     if (time_index > 0)
         for (int32_t v = 1; v < h->V; ++v)
             if (h->is_state(v)) h->initial_set[v] = 1;
+    if (h->windowed && time_index != h->time_index)
+        if (int rc = window_seek(h, time_index)) return rc;
     h->time_index = time_index;
     h->ocean_tile_base = -1;
     return RSCM_OK;
@@ -910,10 +1064,16 @@ int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles
 
 int rscm_ens_rewind(rscm_ens* h)
 {
+    GUARD_BEGIN
     NEED(h);
+    if (h->windowed) {
+        if (int rc = set_device(h)) return rc;
+        if (int rc = window_reset(h, false)) return rc;
+    }
     h->time_index = 0;
     h->ocean_tile_base = -1;
     return RSCM_OK;
+    GUARD_END
 }
 
 // One launch of the kind's kernel over [step_begin, step_end).  `timed` brackets it with the events
@@ -926,8 +1086,17 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
                     step_begin, step_end, h->T - 1);
     if (step_begin != h->time_index)
         return fail(RSCM_ERR_STATE, "step_begin %d != current time index %d", step_begin, h->time_index);
-    if (h->rows != h->T && step_end > step_begin)
+    if (!h->windowed && h->rows != h->T && step_end > step_begin)
         return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES): use rscm_ens_run_loglik");
+    const int32_t keep = h->keep_rows();
+    if (h->windowed && step_end > step_begin) {
+        if (h->rows < 2 * keep)
+            return fail(RSCM_ERR_STATE, "a window of %d rows is too short for a component that reads %d of its own earlier rows (need >= %d)",
+                        h->rows, h->lookback, 2 * keep);
+        if (step_end - step_begin + keep > h->rows)
+            return fail(RSCM_ERR_STATE, "steps [%d, %d) do not fit a window of %d rows (%d are kept for look-back): step in shorter ranges",
+                        step_begin, step_end, h->rows, keep);
+    }
     if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
     if (!h->forcing_set && h->n_linked < h->n_inputs) return fail(RSCM_ERR_STATE, "shared input series not set");
     for (int32_t v = 1; v < h->V; ++v)
@@ -947,11 +1116,32 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         if (h->link_order_check && step_end > step_begin && l.src->time_index < need)
             return fail(RSCM_ERR_STATE, "input row %d reads index %d of its source, which has only been stepped to %d", k, need,
                         l.src->time_index);
+        if (l.src->windowed && step_end > step_begin) {  // the rows this launch reads must be resident in the producer's window
+            const int32_t lo = step_begin + (h->kind == RSCM_KIND_UDEB ? 0 : (reads_end ? 1 : l.off));
+            const int32_t hi = step_end - 1 + (reads_end ? 1 : l.off);
+            if (lo < l.src->win0 || hi >= l.src->win0 + l.src->rows)
+                return fail(RSCM_ERR_STATE, "input row %d reads indices [%d, %d] of its source, whose window holds [%d, %d): step the graph in lock-step",
+                            k, lo, hi, l.src->win0, l.src->win0 + l.src->rows);
+        }
         links.row[k] = l.src->series(l.var);
         links.off[k] = h->kind == RSCM_KIND_AGGREGATE ? 0 : l.off;
     }
     if (int rc = set_device(h)) return rc;
     if (int rc = refresh_schedule(h)) return rc;
+    if (h->windowed && step_end > step_begin) {
+        if (step_begin == 0) {
+            if (h->win0 != 0)
+                if (int rc = window_reset(h, false)) return rc;
+            if (!h->row0_saved) {  // the initial rows, for rewind
+                HIPCHK(rscm::launch_gather_rows(h->d_series, h->N, h->rows, 0, nullptr, h->V - 1, h->d_row0, 1, 0, h->stream));
+                h->row0_saved = true;
+            }
+            if (int rc = window_store_row(h, 0)) return rc;
+        }
+        if (step_end >= h->win0 + h->rows)
+            if (int rc = window_slide(h, step_begin - keep + 1)) return rc;
+        // the links of h were resolved against the producers' windows above; h's own base moved with the slide
+    }
 
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
@@ -1009,6 +1199,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.emissions = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
+        a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_halocarbon(a, h->stream));
@@ -1050,6 +1241,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         } else {
             h->ocean_tile_base = -1;
         }
+        a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_ocean(a, h->stream));
@@ -1068,6 +1260,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.bounds = h->d_bounds;
         a.nsub = h->d_nsub_cc;
         a.h = h->h_cc;
+        a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
         HIPCHK(rscm::launch_carbon(a, h->stream));
@@ -1164,11 +1357,20 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.status = h->d_status;
         HIPCHK(rscm::launch_coupled(a, h->mode, h->stream));
     }
+    h->time_index = step_end;
+    if (h->windowed && step_end > step_begin) {
+        if (h->n_out > 0)
+            for (int32_t t = step_begin + 1; t <= step_end; ++t)
+                if (int rc = window_store_row(h, t)) return rc;
+        // make room for the next step now: consumers that run before this producer in the next step
+        // resolve their links against the window as it will be when they read
+        if (step_end + 1 >= h->win0 + h->rows && step_end < h->T - 1)
+            if (int rc = window_slide(h, step_end - keep + 1)) return rc;
+    }
     if (timed) {
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
     }
-    h->time_index = step_end;
     return RSCM_OK;
 }
 
@@ -1177,7 +1379,11 @@ int rscm_ens_clear_series(rscm_ens* h)
     GUARD_BEGIN
     NEED(h);
     if (int rc = set_device(h)) return rc;
-    if (h->rows > 1)
+    if (h->windowed) {
+        if (int rc = window_reset(h, true)) return rc;
+        if (h->d_out)
+            HIPCHK(rscm::launch_fill(h->d_out, (int64_t)h->n_out * h->out_rows * h->N, std::numeric_limits<double>::quiet_NaN(), h->stream));
+    } else if (h->rows > 1)
         for (int32_t v = 1; v < h->V; ++v)
             HIPCHK(rscm::launch_fill(h->series(v) + h->N, (int64_t)(h->rows - 1) * h->N,
                                      std::numeric_limits<double>::quiet_NaN(), h->stream));
@@ -1193,7 +1399,10 @@ int rscm_ens_clear_rows_after(rscm_ens* h, int32_t tidx)
     NEED(h);
     if (tidx < 0 || tidx > h->T - 1) return fail(RSCM_ERR_INVALID, "time index %d out of range", tidx);
     if (int rc = set_device(h)) return rc;
-    if (h->rows == h->T && tidx < h->T - 1)
+    if (h->windowed) {
+        const int32_t first = std::max(0, tidx + 1 - h->win0);
+        HIPCHK(rscm::launch_fill_rows(h->d_series, h->N, h->rows, h->V - 1, first, std::numeric_limits<double>::quiet_NaN(), h->stream));
+    } else if (h->rows == h->T && tidx < h->T - 1)
         for (int32_t v = 1; v < h->V; ++v)
             HIPCHK(rscm::launch_fill(h->series(v) + (size_t)(tidx + 1) * h->N, (int64_t)(h->T - 1 - tidx) * h->N,
                                      std::numeric_limits<double>::quiet_NaN(), h->stream));
@@ -1263,13 +1472,30 @@ int rscm_ens_get_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_t t_
     if (var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
     if (t_begin < 0 || t_end > h->T || t_begin > t_end || t_stride < 1)
         return fail(RSCM_ERR_INVALID, "bad time range [%d, %d) stride %d", t_begin, t_end, t_stride);
-    if (h->rows != h->T && t_end > 1)
+    if (!h->windowed && h->rows != h->T && t_end > 1)
         return fail(RSCM_ERR_STATE, "this handle stores only the initial row (RSCM_FLAG_NO_SERIES)");
     if (m_begin < 0 || m_end > h->N || m_begin > m_end || !out)
         return fail(RSCM_ERR_INVALID, "bad member range [%lld, %lld)", (long long)m_begin, (long long)m_end);
     const int64_t width = m_end - m_begin;
     if (width == 0 || t_begin == t_end) return RSCM_OK;
     if (int rc = set_device(h)) return rc;
+    if (h->windowed) {  // row by row from wherever each row is resident: the output store or the window
+        int64_t r = 0;
+        for (int32_t t = t_begin; t < t_end; t += t_stride, ++r) {
+            double* dst = out + r * width;
+            if (t > h->time_index) {
+                for (int64_t m = 0; m < width; ++m) dst[m] = std::numeric_limits<double>::quiet_NaN();
+                continue;
+            }
+            const double* src = h->row_ptr(var_id, t);
+            if (!src)
+                return fail(RSCM_ERR_STATE, "row %d of variable %d is not resident: the window holds [%d, %d) and the output store every %d-th row%s",
+                            t, var_id, h->win0, h->win0 + h->rows, h->out_stride, h->out_slot[var_id] < 0 ? " of other variables" : "");
+            HIPCHK(hipMemcpyAsync(dst, src + m_begin, (size_t)width * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return RSCM_OK;
+    }
     // rows beyond the current time index were never computed by this model instance: NaN
     int64_t n_rows = 0, n_valid = 0;
     for (int32_t t = t_begin; t < t_end; t += t_stride) {
@@ -1292,6 +1518,7 @@ int rscm_ens_series_devptr(rscm_ens* h, int32_t var_id, void** out)
 {
     NEED(h);
     if (!out || var_id < 1 || var_id >= h->V) return fail(RSCM_ERR_INVALID, "variable %d has no stored series", var_id);
+    if (h->windowed) return fail(RSCM_ERR_STATE, "a windowed ensemble has no contiguous [T][N] series: read rows with rscm_ens_get_series");
     *out = h->series(var_id);
     return RSCM_OK;
 }
@@ -1341,7 +1568,12 @@ static int loglik_on_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, 
         return RSCM_OK;
     }
     std::vector<const double*> ptrs(n_obs);
-    for (int32_t j = 0; j < n_obs; ++j) ptrs[j] = h->series(obs_var[j]) + (size_t)obs_tidx[j] * h->N;
+    for (int32_t j = 0; j < n_obs; ++j) {
+        ptrs[j] = h->row_ptr(obs_var[j], obs_tidx[j]);
+        if (!ptrs[j])
+            return fail(RSCM_ERR_STATE, "observation %d: row %d of variable %d is not resident (NO_SERIES handle, or outside the window and the output stride)",
+                        j, obs_tidx[j], obs_var[j]);
+    }
     void* d_blob = nullptr;
     const size_t sz_ptr = (size_t)n_obs * sizeof(double*), sz_i = (size_t)n_obs * sizeof(int32_t),
                  sz_d = (size_t)n_obs * sizeof(double);
@@ -1412,6 +1644,7 @@ int prepare_obs(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_
                 const double* obs_value, const double* obs_sigma, int32_t normalize)
 {
     if (h->kind != RSCM_KIND_TWO_LAYER) return fail(RSCM_ERR_INVALID, "run_loglik supports the two-layer kind");
+    if (h->windowed) return fail(RSCM_ERR_INVALID, "run_loglik writes no series: use a plain or RSCM_FLAG_NO_SERIES handle, not a windowed one");
     if (n_obs < 0 || (n_obs > 0 && (!obs_var || !obs_tidx || !obs_value || !obs_sigma)))
         return fail(RSCM_ERR_INVALID, "bad observation arrays");
     const int32_t first_var = n_obs > 0 ? obs_var[0] : RSCM_TL_VAR_TS;
@@ -1642,6 +1875,7 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
     *out = nullptr;
     rscm_ens* h = evaluator;
     NEED(h);
+    if (h->windowed) return fail(RSCM_ERR_INVALID, "the sampler's evaluator must not be a windowed ensemble");
     if (n_walkers < 2) return fail(RSCM_ERR_INVALID, "Must have at least 2 walkers");          // ensemble.rs:120-127
     if (n_walkers % 2) return fail(RSCM_ERR_INVALID, "Number of walkers must be even");
     if (h->N != n_walkers / 2)
@@ -1871,7 +2105,7 @@ int rscm_ens_summary_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_
     NEED(h);
     if (var_id < 1 || var_id >= h->V || t_begin < 0 || t_end > h->T || t_begin > t_end || !out)
         return fail(RSCM_ERR_INVALID, "bad variable / time range");
-    if (h->rows != h->T) return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES)");
+    if (h->windowed || h->rows != h->T) return fail(RSCM_ERR_STATE, "this handle does not store whole series (RSCM_FLAG_NO_SERIES / RSCM_FLAG_WINDOWED): use rscm_ens_summary row by row");
     const int32_t n_rows = t_end - t_begin;
     // rows beyond the current time index have not been computed: empty summaries, as rscm_ens_summary
     const int32_t computed = std::max(0, std::min(t_end, h->time_index + 1) - t_begin);
@@ -1907,7 +2141,7 @@ int rscm_ens_quantile_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32
         return fail(RSCM_ERR_INVALID, "bad variable / time range / quantile list");
     for (int32_t k = 0; k < n_q; ++k)
         if (!(q[k] >= 0.0 && q[k] <= 1.0)) return fail(RSCM_ERR_INVALID, "Quantiles must be in the range [0, 1], got %g", q[k]);
-    if (h->rows != h->T) return fail(RSCM_ERR_STATE, "this handle stores no series (RSCM_FLAG_NO_SERIES)");
+    if (h->windowed || h->rows != h->T) return fail(RSCM_ERR_STATE, "this handle does not store whole series (RSCM_FLAG_NO_SERIES / RSCM_FLAG_WINDOWED)");
     const int32_t n_rows = t_end - t_begin;
     const int32_t computed = std::max(0, std::min(t_end, h->time_index + 1) - t_begin);
     for (int32_t r = computed; r < n_rows; ++r) {
@@ -1951,7 +2185,9 @@ int rscm_ens_summary(rscm_ens* h, int32_t var_id, int32_t tidx, double out[4])
     }
     if (int rc = set_device(h)) return rc;
     const int32_t nb = rscm::summary_blocks(h->N);
-    HIPCHK(rscm::launch_summary(h->series(var_id) + (size_t)tidx * h->N, h->N, h->d_partial, nb, h->d_out4, h->stream));
+    const double* row = h->row_ptr(var_id, tidx);
+    if (!row) return fail(RSCM_ERR_STATE, "row %d of variable %d is not resident on this handle", tidx, var_id);
+    HIPCHK(rscm::launch_summary(row, h->N, h->d_partial, nb, h->d_out4, h->stream));
     HIPCHK(hipMemcpyAsync(out, h->d_out4, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RSCM_OK;
@@ -1986,6 +2222,7 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
                 return fail(RSCM_ERR_INVALID, "OceanCarbon parameter row %d is structural: low must equal high", j);
         if (int rc = configure_ocean(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
     }
+    if (h->kind == RSCM_KIND_N2O_CHEMISTRY) h->lookback = (int32_t)std::min(std::max(1.0, high[4]), 1e6) + 1;
     if (h->kind == RSCM_KIND_GHG_FORCING) {
         const double m = low[RSCM_GH_P_METHOD];
         if (m != high[RSCM_GH_P_METHOD] || (m != 0.0 && m != 1.0))

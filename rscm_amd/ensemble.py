@@ -43,7 +43,11 @@ class DeviceVector:
 
 class Ensemble:
     def __init__(self, kind: int, n_members: int, time_bounds: Sequence[float], device: int = 0,
-                 store_series: bool = True):
+                 store_series: bool = True, window_rows: Optional[int] = None, output_stride: int = 0,
+                 output_vars: Optional[Sequence] = None):
+        """``window_rows``: keep only a sliding window of that many rows of every series
+        (``RSCM_FLAG_WINDOWED``) plus, with ``output_stride`` > 0, every ``output_stride``-th row of
+        ``output_vars`` (names or ids; None: all) -- for long axes stepped in lock-step."""
         self._lib = L.load()
         b = L.f64(time_bounds)
         if b.ndim != 1 or len(b) < 3:
@@ -59,8 +63,19 @@ class Ensemble:
         self.n_inputs = len(input_rows) if input_rows else 1
         h = C.c_void_p()
         self.store_series = bool(store_series)
-        L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
-                                             0 if store_series else L.FLAG_NO_SERIES, C.byref(h)))
+        self.window_rows = None if window_rows is None or window_rows >= self.n_times else int(window_rows)
+        self.output_stride = int(output_stride) if self.window_rows else 0
+        if self.window_rows:
+            ov = None
+            if output_vars is not None:
+                ov = np.ascontiguousarray([self._var(v) for v in output_vars], dtype=np.int32)
+            self.output_vars = None if ov is None else [int(v) for v in ov]
+            L.check(self._lib.rscm_ens_create_windowed(kind, self.n_members, self.n_times, L.dptr(b), device, L.FLAG_WINDOWED,
+                                                       self.window_rows, self.output_stride, -1 if ov is None else len(ov),
+                                                       L.iptr(ov), C.byref(h)))
+        else:
+            L.check(self._lib.rscm_ens_create_ex(kind, self.n_members, self.n_times, L.dptr(b), device,
+                                                 0 if store_series else L.FLAG_NO_SERIES, C.byref(h)))
         self._h = h
         # the library and the tables of this package must agree on the shape of the kind
         got = [C.c_int32() for _ in range(3)]
@@ -264,18 +279,19 @@ class Ensemble:
             raise ValueError("checkpoint does not match this ensemble (kind, members or time axis)")
         self.set_params(ck["params"])
         k = int(ck["time_index"])
-        for name, row in ck["state"].items():
-            self.set_state(name, k, row)
-        for name, rows in ck.get("history", {}).items():
-            for d, row in enumerate(rows):
-                self.set_state(name, k - len(rows) + d, row)
+        # the stepper first: a windowed ensemble positions its window at k, then the rows go in
         internal = ck.get("internal")
         if internal is not None:
             blob = L.f64(internal)
             L.check(self._lib.rscm_ens_set_internal_state(self._h, L.dptr(blob), blob.size, k))
         else:
             L.check(self._lib.rscm_ens_set_time_index(self._h, k))
-        if clear_later_rows and self.store_series:
+        for name, row in ck["state"].items():
+            self.set_state(name, k, row)
+        for name, rows in ck.get("history", {}).items():
+            for d, row in enumerate(rows):
+                self.set_state(name, k - len(rows) + d, row)
+        if clear_later_rows and self.store_series and not self.window_rows:
             L.check(self._lib.rscm_ens_clear_rows_after(self._h, k))
 
     # -- outputs ----------------------------------------------------------------------------
