@@ -252,9 +252,9 @@ struct rscm_ens {
     const double* row_ptr(int32_t var, int32_t t) const
     {
         if (!windowed) return (rows == T || t == 0) ? series(var) + (size_t)t * N : nullptr;
+        if (t >= win0 && t < win0 + rows) return series(var) + (size_t)t * N;  // the window is the live copy
         if (out_stride > 0 && out_slot[var] >= 0 && t % out_stride == 0 && t <= time_index)
             return d_out + ((size_t)out_slot[var] * out_rows + (size_t)(t / out_stride)) * N;
-        if (t >= win0 && t < win0 + rows) return series(var) + (size_t)t * N;
         return nullptr;
     }
     bool is_state(int32_t var) const

