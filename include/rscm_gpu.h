@@ -551,6 +551,37 @@ RSCM_API int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t
                                  int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
                                  const double* obs_value, const double* obs_sigma, int32_t normalize,
                                  double stretch_a, uint64_t seed, rscm_sampler** out);
+/* The same sampler sharded over n_ranks processes (one per GPU): every rank holds a replica of the walker
+ * positions and owns the half-walkers [rank * n, (rank + 1) * n), n = n_walkers / 2 / n_ranks, of BOTH
+ * halves; `evaluator` has n members.  Per half-step a rank proposes, evaluates and accepts its block and
+ * packs the block's new positions and log probabilities ([n_dims + 1][n] doubles); the ranks all-gather
+ * the blocks (RCCL over xGMI: 2.8 MB in all at 1e5 walkers x 6 dimensions) and unpack them into their
+ * replicas.  Proposals, complementary walkers and acceptance draws are keyed on the global walker index,
+ * so the chain is the same for every n_ranks, bit for bit.  The driver loop
+ * (rscm_amd.calibrate.DeviceEnsembleSampler):
+ *     rscm_sampler_set_positions(s, pos)                    -- the same positions on every rank
+ *     for half in 0, 1: rscm_sampler_half_step(s, half, 1); all-gather; rscm_sampler_apply_exchange(s, half)
+ *     per iteration: rscm_sampler_begin_iteration(s);
+ *         for half in 0, 1: rscm_sampler_half_step(s, half, 0); all-gather; rscm_sampler_apply_exchange(s, half)
+ * with the all-gather from *send into *recv of rscm_sampler_exchange_buffers (device memory, on the
+ * evaluator's stream: call rscm_sampler_sync first unless the collective runs on that stream).
+ * rscm_sampler_get then returns all positions and log probabilities on every rank and this rank's
+ * acceptance counters (zero for walkers of other ranks).  n_groups must be 1. */
+RSCM_API int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims,
+                                         const int32_t* param_rows, const double* base_params,
+                                         const int32_t* prior_kind, const double* prior_a, const double* prior_b,
+                                         const double* prior_low, const double* prior_high,
+                                         int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                                         const double* obs_value, const double* obs_sigma, int32_t normalize,
+                                         double stretch_a, uint64_t seed, int32_t rank, int32_t n_ranks,
+                                         rscm_sampler** out);
+RSCM_API int rscm_sampler_begin_iteration(rscm_sampler* s);
+/* One half-ensemble update of this rank's block, enqueued: propose (identity != 0: score the walkers where
+ * they stand), evaluate, accept, pack.  Also usable on an unsharded sampler (no pack). */
+RSCM_API int rscm_sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity);
+RSCM_API int rscm_sampler_exchange_buffers(rscm_sampler* s, void** send, void** recv, int64_t* doubles_per_rank);
+RSCM_API int rscm_sampler_apply_exchange(rscm_sampler* s, int32_t half);
+RSCM_API int rscm_sampler_sync(rscm_sampler* s);
 RSCM_API int rscm_sampler_destroy(rscm_sampler* s);
 /* Split the walkers into n_groups independent ensembles of n_walkers / n_groups walkers each
  * (consecutive blocks of the walker index): every group is a sampler of its own -- its own two
@@ -605,6 +636,7 @@ RSCM_API int rscm_gpu_host_alloc(int64_t n_bytes, void** out);
 /* Blocking copy of n_bytes from a device address handed out by this library (rscm_ens_*_devptr,
  * rscm_ens_loglik_device) into host memory, for callers without a HIP runtime of their own. */
 RSCM_API int rscm_gpu_copy_to_host(int32_t device_id, void* host, const void* device_ptr, int64_t n_bytes);
+RSCM_API int rscm_gpu_copy_to_device(int32_t device_id, void* device_ptr, const void* host, int64_t n_bytes);
 RSCM_API int rscm_gpu_host_free(void* p);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */

@@ -283,6 +283,13 @@ SIGNATURES = {
     "rscm_ens_summary_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rscm_sampler_create": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp, _dp, C.c_int32, _ip, _ip,
                                       _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.POINTER(_h)]),
+    "rscm_sampler_create_sharded": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp, _dp, C.c_int32, _ip, _ip,
+                                              _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(_h)]),
+    "rscm_sampler_begin_iteration": (C.c_int, [_h]),
+    "rscm_sampler_half_step": (C.c_int, [_h, C.c_int32, C.c_int32]),
+    "rscm_sampler_exchange_buffers": (C.c_int, [_h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "rscm_sampler_apply_exchange": (C.c_int, [_h, C.c_int32]),
+    "rscm_sampler_sync": (C.c_int, [_h]),
     "rscm_sampler_destroy": (C.c_int, [_h]),
     "rscm_sampler_set_groups": (C.c_int, [_h, C.c_int32]),
     "rscm_sampler_set_positions": (C.c_int, [_h, _dp]),
@@ -295,6 +302,7 @@ SIGNATURES = {
     "rscm_gpu_host_alloc": (C.c_int, [C.c_int64, C.POINTER(C.c_void_p)]),
     "rscm_gpu_host_free": (C.c_int, [C.c_void_p]),
     "rscm_gpu_copy_to_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "rscm_gpu_copy_to_device": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "rscm_gpu_selftest_div": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, _dp, _dp, _bp]),
 }
 

@@ -944,9 +944,12 @@ class DeviceEnsembleSampler:
         return np.array(ov, dtype=np.int32), np.array(ot, dtype=np.int32), L.f64(val), L.f64(sig)
 
     def run(self, n_iterations: int, init: "WalkerInit", thin: int = 1, n_walkers: Optional[int] = None,
-            rng: Optional[np.random.Generator] = None, seed: int = 0, n_groups: int = 1) -> "Chain":
+            rng: Optional[np.random.Generator] = None, seed: int = 0, n_groups: int = 1,
+            shard: Optional[bool] = None) -> "Chain":
         """``n_groups`` > 1 runs that many independent ensembles of ``n_walkers / n_groups`` walkers
-        side by side (consecutive blocks of the walker index), each a sampler of its own."""
+        side by side (consecutive blocks of the walker index), each a sampler of its own.
+        ``shard``: split the walkers over the ranks of the initialised ``torch.distributed`` group
+        (default: whenever there is one); the chain is the same for any number of ranks."""
         import ctypes as C
         n_walkers = n_walkers or self.default_n_walkers * n_groups
         if n_walkers < 2:
@@ -955,8 +958,21 @@ class DeviceEnsembleSampler:
             raise ValueError("Number of walkers must be even")
         rng = rng or np.random.default_rng(seed)
         pos = L.f64(init.initialize(n_walkers, self.params, rng))
+        # One process per GPU (torch.distributed initialised): every rank holds a replica of the walkers and
+        # owns a block of both halves; the blocks are all-gathered after every half-step.  All ranks must be
+        # given the same initial positions (the same `rng` / `seed`), as with the host sampler.
+        from .distributed import is_distributed
+        rank, world = 0, 1
+        if is_distributed() and shard is not False:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+            if (n_walkers // 2) % world:
+                raise ValueError(f"half the walkers ({n_walkers // 2}) must split evenly over {world} ranks")
+            if n_groups != 1:
+                raise ValueError("a sharded sampler runs one ensemble (n_groups = 1)")
+        n_eval = n_walkers // 2 // world
         two_layer = self.runner._model(1).ensemble.kind == L.KIND_TWO_LAYER
-        model = self.runner._lik_model(n_walkers // 2) if two_layer else self.runner._model(n_walkers // 2)
+        model = self.runner._lik_model(n_eval) if two_layer else self.runner._model(n_eval)
         ens, lib = model.ensemble, model.ensemble._lib
         ens.rewind()
         ov, ot, val, sig = self._observations(model)
@@ -964,11 +980,13 @@ class DeviceEnsembleSampler:
         kinds, pa, pb, plo, phi = self._prior
         base = L.f64(model.base_params)
         h = C.c_void_p()
-        L.check(lib.rscm_sampler_create(ens._h, n_walkers, len(rows), L.iptr(rows), L.dptr(base), L.iptr(kinds),
-                                        L.dptr(pa), L.dptr(pb), L.dptr(plo), L.dptr(phi), len(ov), L.iptr(ov), L.iptr(ot), L.dptr(val),
-                                        L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
-                                        C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.byref(h)))
+        L.check(lib.rscm_sampler_create_sharded(ens._h, n_walkers, len(rows), L.iptr(rows), L.dptr(base), L.iptr(kinds),
+                                                L.dptr(pa), L.dptr(pb), L.dptr(plo), L.dptr(phi), len(ov), L.iptr(ov), L.iptr(ot),
+                                                L.dptr(val), L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
+                                                C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), rank, world, C.byref(h)))
         try:
+            if world > 1:
+                return self._run_sharded(lib, h, ens, pos, n_iterations, thin, n_walkers, world)
             if n_groups != 1:
                 L.check(lib.rscm_sampler_set_groups(h, n_groups))
             L.check(lib.rscm_sampler_set_positions(h, L.dptr(pos)))
@@ -999,6 +1017,69 @@ class DeviceEnsembleSampler:
             self.n_accepted, self.n_proposed = acc, prop
         finally:
             lib.rscm_sampler_destroy(h)
+        return chain
+
+    def _run_sharded(self, lib, h, ens, pos, n_iterations: int, thin: int, n_walkers: int, world: int) -> "Chain":
+        """The sweep loop of a sharded sampler (rscm_sampler_create_sharded): per half-step the
+        rank's block is updated on its GPU, the blocks are all-gathered (RCCL: device to device on the
+        evaluator's stream order; gloo rehearsals: through the host) and unpacked into every replica."""
+        import ctypes as C
+        import time
+        import torch
+        import torch.distributed as dist
+        send, recv, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        L.check(lib.rscm_sampler_exchange_buffers(h, C.byref(send), C.byref(recv), C.byref(n)))
+        per = n.value
+        on_device = dist.get_backend() == "nccl"
+        if on_device:
+            from .ensemble import DeviceVector
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t_send = torch.as_tensor(DeviceVector(send.value, per, np.float64, ens), device=dev)
+            t_recv = torch.as_tensor(DeviceVector(recv.value, per * world, np.float64, ens), device=dev)
+        else:
+            h_send, h_recv = np.empty(per), np.empty(per * world)
+            t_send, t_recv = torch.from_numpy(h_send), torch.from_numpy(h_recv)
+
+        def half_step(half: int, identity: int) -> None:
+            L.check(lib.rscm_sampler_half_step(h, half, identity))
+            L.check(lib.rscm_sampler_sync(h))        # the packed block is complete before the collective reads it
+            if not on_device:
+                L.check(lib.rscm_gpu_copy_to_host(ens.device, h_send.ctypes.data_as(C.c_void_p), send, h_send.nbytes))
+            dist.all_gather_into_tensor(t_recv, t_send)
+            if on_device:
+                torch.cuda.current_stream().synchronize()   # the gathered blocks have landed before the unpack launch
+            else:
+                L.check(lib.rscm_gpu_copy_to_device(ens.device, recv, h_recv.ctypes.data_as(C.c_void_p), h_recv.nbytes))
+            L.check(lib.rscm_sampler_apply_exchange(h, half))
+
+        L.check(lib.rscm_sampler_set_positions(h, L.dptr(pos)))
+        for half in (0, 1):
+            half_step(half, 1)
+        chain = Chain(self.params.param_names, thin)
+        logp = np.empty(n_walkers)
+        t0 = time.perf_counter()
+        for it in range(1, n_iterations + 1):
+            L.check(lib.rscm_sampler_begin_iteration(h))
+            for half in (0, 1):
+                half_step(half, 0)
+            if (it - 1) % chain.thin == 0:  # Chain.push keeps sweeps 1, 1 + thin, ...
+                L.check(lib.rscm_sampler_get(h, L.dptr(pos), L.dptr(logp), None, None))
+                chain._samples.append(pos.copy())
+                chain._log_probs.append(logp.copy())
+        L.check(lib.rscm_sampler_sync(h))
+        self.device_ms = (time.perf_counter() - t0) * 1e3   # wall time of the sweeps incl. the exchanges
+        chain.total_iterations = n_iterations
+        acc = np.empty(n_walkers, dtype=np.int64)
+        prop = np.empty(n_walkers, dtype=np.int64)
+        L.check(lib.rscm_sampler_get(h, None, None, acc.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     prop.ctypes.data_as(C.POINTER(C.c_int64))))
+        # every rank counted its own walkers only: the sum over ranks is the whole ensemble's record
+        counts = torch.from_numpy(np.stack([acc, prop]))
+        if on_device:
+            counts = counts.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        counts = counts.cpu().numpy()
+        self.n_accepted, self.n_proposed = counts[0], counts[1]
         return chain
 
     def acceptance_rate(self) -> float:

@@ -278,6 +278,8 @@ struct SamplerArgs {
     int32_t n_walkers, n_dims, n_params;
     int32_t n_groups;    // independent ensembles of n_walkers / n_groups walkers each
     int32_t half;        // 0 / 1: the half (of every group) being updated
+    int32_t k_offset;    // this rank's block of the half: half-walker indices [k_offset, k_offset + n_local)
+    int32_t n_local;     // = members of the evaluating ensemble (n_walkers / 2 when not sharded)
     int32_t iteration;
     int32_t identity;    // score the walkers where they stand (initialisation)
     uint64_t seed;
@@ -291,11 +293,13 @@ struct SamplerArgs {
     const double* prior_hi;
     double* pos;         // [D][W]
     double* logp;        // [W]
-    double* proposal;    // [D][W/2]
-    double* z;           // [W/2]
-    double* lp;          // [W/2] log prior of the proposals
-    const double* loglik;  // [W/2] written by the evaluator's fused run+likelihood launch
-    double* eval_params;   // [P][W/2] the evaluator's parameter block
+    double* proposal;    // [D][n_local]
+    double* z;           // [n_local]
+    double* lp;          // [n_local] log prior of the proposals
+    const double* loglik;  // [n_local] written by the evaluator's fused run+likelihood launch
+    double* eval_params;   // [P][n_local] the evaluator's parameter block
+    double* exchange;      // pack: [D + 1][n_local] out; unpack: [n_ranks][D + 1][n_local] in (positions, then log prob)
+    int32_t n_ranks;
     int64_t* n_accepted;   // [W]
     int64_t* n_proposed;   // [W]
 };
@@ -323,6 +327,9 @@ hipError_t launch_ocean(const OceanArgs& a, hipStream_t s);
 hipError_t launch_halocarbon(const HaloArgs& a, hipStream_t s);
 hipError_t launch_sampler_propose(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_sampler_accept(const SamplerArgs& a, hipStream_t s);
+// sharded sampler: this rank's block of the updated half into a.exchange / every rank's block out of it
+hipError_t launch_sampler_pack(const SamplerArgs& a, hipStream_t s);
+hipError_t launch_sampler_unpack(const SamplerArgs& a, hipStream_t s);
 hipError_t launch_loglik(const LoglikArgs& a, hipStream_t s);
 hipError_t launch_fill(double* p, int64_t n, double v, hipStream_t s);
 hipError_t launch_broadcast_row(double* row, int64_t n, const double* src, int64_t n_src,

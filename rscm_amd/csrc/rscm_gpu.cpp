@@ -1785,6 +1785,10 @@ int rscm_ens_run_loglik_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_va
 struct rscm_sampler {
     rscm_ens* ev = nullptr;  // evaluates one half-ensemble per launch; not owned
     int32_t W = 0, D = 0, groups = 1;
+    int32_t rank = 0, n_ranks = 1;   // sharded: this rank owns half-walkers [rank * n_local, (rank + 1) * n_local) of both halves
+    int32_t n_local = 0;             // = members of the evaluator
+    double* d_send = nullptr;        // [D + 1][n_local]
+    double* d_recv = nullptr;        // [n_ranks][D + 1][n_local]
     double stretch_a = 2.0;
     uint64_t seed = 0;
     int32_t iteration = 0;
@@ -1821,6 +1825,10 @@ rscm::SamplerArgs sampler_args(const rscm_sampler* s, int32_t half, int32_t iden
     a.n_params = s->ev->P;
     a.n_groups = s->groups;
     a.half = half;
+    a.k_offset = s->rank * s->n_local;
+    a.n_local = s->n_local;
+    a.n_ranks = s->n_ranks;
+    a.exchange = nullptr;
     a.iteration = s->iteration;
     a.identity = identity;
     a.seed = s->seed;
@@ -1858,6 +1866,11 @@ int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
         HIPCHK(rscm::launch_loglik(s->lik, s->ev->stream));
     }
     HIPCHK(rscm::launch_sampler_accept(a, s->ev->stream));
+    if (s->n_ranks > 1) {  // this rank's block of the updated half, ready for the all-gather
+        rscm::SamplerArgs p = a;
+        p.exchange = s->d_send;
+        HIPCHK(rscm::launch_sampler_pack(p, s->ev->stream));
+    }
     return RSCM_OK;
 }
 
@@ -1870,17 +1883,32 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
                         const double* obs_value, const double* obs_sigma, int32_t normalize, double stretch_a,
                         uint64_t seed, rscm_sampler** out)
 {
+    return rscm_sampler_create_sharded(evaluator, n_walkers, n_dims, param_rows, base_params, prior_kind, prior_a, prior_b,
+                                       prior_low, prior_high, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize,
+                                       stretch_a, seed, 0, 1, out);
+}
+
+int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, const int32_t* param_rows,
+                        const double* base_params, const int32_t* prior_kind, const double* prior_a,
+                        const double* prior_b, const double* prior_low, const double* prior_high,
+                        int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx,
+                        const double* obs_value, const double* obs_sigma, int32_t normalize, double stretch_a,
+                        uint64_t seed, int32_t rank, int32_t n_ranks, rscm_sampler** out)
+{
     GUARD_BEGIN
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = nullptr;
     rscm_ens* h = evaluator;
     NEED(h);
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RSCM_ERR_INVALID, "bad rank %d of %d", rank, n_ranks);
     if (h->windowed) return fail(RSCM_ERR_INVALID, "the sampler's evaluator must not be a windowed ensemble");
     if (n_walkers < 2) return fail(RSCM_ERR_INVALID, "Must have at least 2 walkers");          // ensemble.rs:120-127
     if (n_walkers % 2) return fail(RSCM_ERR_INVALID, "Number of walkers must be even");
-    if (h->N != n_walkers / 2)
-        return fail(RSCM_ERR_INVALID, "the evaluating ensemble must have n_walkers/2 = %d members, it has %lld",
-                    n_walkers / 2, (long long)h->N);
+    if ((n_walkers / 2) % n_ranks)
+        return fail(RSCM_ERR_INVALID, "half the walkers (%d) must split evenly over %d ranks", n_walkers / 2, n_ranks);
+    if (h->N != n_walkers / 2 / n_ranks)
+        return fail(RSCM_ERR_INVALID, "the evaluating ensemble must have n_walkers / 2 / n_ranks = %d members, it has %lld",
+                    n_walkers / 2 / n_ranks, (long long)h->N);
     if (!(stretch_a > 1.0)) return fail(RSCM_ERR_INVALID, "Stretch move scale parameter must be > 1.0, got %g", stretch_a);  // moves.rs:40-48
     if (n_dims < 1 || n_dims > h->P || !param_rows || !base_params || !prior_kind || !prior_a || !prior_b)
         return fail(RSCM_ERR_INVALID, "bad parameter description");
@@ -1922,13 +1950,16 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
     s->fused = fused;
     s->W = n_walkers;
     s->D = n_dims;
+    s->rank = rank;
+    s->n_ranks = n_ranks;
+    s->n_local = (int32_t)h->N;
     s->stretch_a = stretch_a;
     s->seed = seed;
     auto cleanup = [&](int rc) {
         rscm_sampler_destroy(s);
         return rc;
     };
-    const size_t W = (size_t)n_walkers, H = W / 2, D = (size_t)n_dims;
+    const size_t W = (size_t)n_walkers, H = (size_t)h->N, D = (size_t)n_dims;  // H: this rank's block of a half
 #define CK(expr)                                                                               \
     do {                                                                                       \
         hipError_t e2_ = (expr);                                                               \
@@ -1948,6 +1979,10 @@ int rscm_sampler_create(rscm_ens* evaluator, int32_t n_walkers, int32_t n_dims, 
     CK(hipMalloc(&s->d_prop, D * H * sizeof(double)));
     CK(hipMalloc(&s->d_z, H * sizeof(double)));
     CK(hipMalloc(&s->d_lp, H * sizeof(double)));
+    if (n_ranks > 1) {
+        CK(hipMalloc(&s->d_send, (D + 1) * H * sizeof(double)));
+        CK(hipMalloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));
+    }
     CK(hipMalloc(&s->d_nacc, W * sizeof(int64_t)));
     CK(hipMalloc(&s->d_nprop, W * sizeof(int64_t)));
     CK(hipMemcpy(s->d_rows, param_rows, D * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -2004,6 +2039,8 @@ int rscm_sampler_destroy(rscm_sampler* s)
     (void)hipFree(s->d_pb); (void)hipFree(s->d_plo); (void)hipFree(s->d_phi); (void)hipFree(s->d_pos); (void)hipFree(s->d_logp); (void)hipFree(s->d_prop);
     (void)hipFree(s->d_z); (void)hipFree(s->d_lp); (void)hipFree(s->d_nacc); (void)hipFree(s->d_nprop);
     (void)hipFree(s->d_sobs);
+    (void)hipFree(s->d_send);
+    (void)hipFree(s->d_recv);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -2016,6 +2053,7 @@ int rscm_sampler_set_groups(rscm_sampler* s, int32_t n_groups)
     if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
     if (n_groups < 1 || s->W % n_groups != 0 || (s->W / n_groups) % 2 != 0 || s->W / n_groups < 2)
         return fail(RSCM_ERR_INVALID, "%d walkers do not split into %d groups of an even number (>= 2) of walkers", s->W, n_groups);
+    if (s->n_ranks > 1 && n_groups != 1) return fail(RSCM_ERR_INVALID, "a sharded sampler runs one ensemble (n_groups = 1)");
     s->groups = n_groups;
     s->positions_set = false;  // positions are scored per group layout: set them again
     return RSCM_OK;
@@ -2040,10 +2078,15 @@ int rscm_sampler_set_positions(rscm_sampler* s, const double* positions)
     HIPCHK(hipMemset(s->d_nacc, 0, W * sizeof(int64_t)));
     HIPCHK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
     s->iteration = 0;
+    s->positions_set = true;
+    if (s->n_ranks > 1) {  // scored half by half through rscm_sampler_half_step(identity = 1) + the exchange
+        HIPCHK(rscm::launch_fill(s->d_logp, (int64_t)W, -std::numeric_limits<double>::infinity(), h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return RSCM_OK;
+    }
     for (int32_t half = 0; half < 2; ++half)
         if (int rc = sampler_half_step(s, half, 1)) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    s->positions_set = true;
     return RSCM_OK;
     GUARD_END
 }
@@ -2054,6 +2097,9 @@ int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations)
     if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
     if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
     if (n_iterations < 0) return fail(RSCM_ERR_INVALID, "n_iterations must be >= 0");
+    if (s->n_ranks > 1)
+        return fail(RSCM_ERR_STATE, "a sharded sampler is driven half-step by half-step (rscm_sampler_half_step, all-gather, "
+                                    "rscm_sampler_apply_exchange)");
     rscm_ens* h = s->ev;
     h->time_index = 0;
     if (int rc = check_loglik_ready(h)) return rc;
@@ -2066,6 +2112,70 @@ int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations)
     }
     HIPCHK(hipEventRecord(s->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_sampler_begin_iteration(rscm_sampler* s)
+{
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
+    s->iteration += 1;
+    return RSCM_OK;
+}
+
+int rscm_sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
+{
+    GUARD_BEGIN
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
+    if (half != 0 && half != 1) return fail(RSCM_ERR_INVALID, "half must be 0 or 1");
+    rscm_ens* h = s->ev;
+    h->time_index = 0;
+    if (int rc = check_loglik_ready(h)) return rc;
+    return sampler_half_step(s, half, identity ? 1 : 0);
+    GUARD_END
+}
+
+int rscm_sampler_exchange_buffers(rscm_sampler* s, void** send, void** recv, int64_t* doubles_per_rank)
+{
+    if (!s || !send || !recv || !doubles_per_rank) return fail(RSCM_ERR_INVALID, "NULL argument");
+    if (s->n_ranks < 2) return fail(RSCM_ERR_STATE, "this sampler is not sharded");
+    *send = s->d_send;
+    *recv = s->d_recv;
+    *doubles_per_rank = (int64_t)(s->D + 1) * s->n_local;
+    return RSCM_OK;
+}
+
+int rscm_sampler_apply_exchange(rscm_sampler* s, int32_t half)
+{
+    GUARD_BEGIN
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    if (s->n_ranks < 2) return fail(RSCM_ERR_STATE, "this sampler is not sharded");
+    if (half != 0 && half != 1) return fail(RSCM_ERR_INVALID, "half must be 0 or 1");
+    rscm::SamplerArgs a = sampler_args(s, half, 0);
+    a.exchange = s->d_recv;
+    HIPCHK(rscm::launch_sampler_unpack(a, s->ev->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_sampler_sync(rscm_sampler* s)
+{
+    GUARD_BEGIN
+    if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
+    HIPCHK(hipStreamSynchronize(s->ev->stream));
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_gpu_copy_to_device(int32_t device_id, void* device_ptr, const void* host, int64_t n_bytes)
+{
+    GUARD_BEGIN
+    if (n_bytes < 0 || (n_bytes > 0 && (!host || !device_ptr))) return fail(RSCM_ERR_INVALID, "bad arguments");
+    if (n_bytes == 0) return RSCM_OK;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipMemcpy(device_ptr, host, (size_t)n_bytes, hipMemcpyHostToDevice));
     return RSCM_OK;
     GUARD_END
 }
