@@ -20,6 +20,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_ranks: starts torch.distributed.run children that share the GPU; run as its own "
+                                       "pytest process (tests/test_multirank_gpu.py)")
 
 
 def _denan(x):
