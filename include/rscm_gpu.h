@@ -640,6 +640,17 @@ RSCM_API int rscm_gpu_copy_to_device(int32_t device_id, void* device_ptr, const 
 RSCM_API int rscm_gpu_host_free(void* p);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */
+/* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an
+ * O(T) recurrence: lags below `near_lags` months explicitly, the rest through decaying modes fitted to the
+ * scaled impulse response (parameters/ocean_carbon.rs:85-216) by the host.  This runs that fit alone (no
+ * GPU): the largest deviation of the fitted response from the tabulated one over the window (negative: the
+ * parameters do not allow the recurrence and FAST keeps the tiled convolution), the number of modes, of
+ * modes that still weigh when a pulse leaves the window, and the largest amplitude. */
+RSCM_API int rscm_gpu_ocean_fit_selftest(int32_t model, double irf_scale, double irf_switch_time,
+                                         int64_t max_history_months, double* max_error, int32_t* n_modes,
+                                         int32_t* near_lags, int32_t* n_exit, double* max_abs_coefficient);
+/* Whether this OceanCarbon ensemble's RSCM_MODE_FAST runs the recurrence, and the fit's deviation. */
+RSCM_API int rscm_ens_ocean_fast_info(rscm_ens* h, int32_t* uses_recurrence, double* fit_error);
 /* Element-wise num[i]/den[i] on the device through (a) the compiler's IEEE f64 division and
  * (b) the three-instruction hoisted-reciprocal quotient of rk4_device.hpp with no fallback;
  * used_fast[i] = 1 where both operands are inside the windows in which the kernels trust (b).

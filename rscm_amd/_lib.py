@@ -303,6 +303,8 @@ SIGNATURES = {
     "rscm_gpu_host_free": (C.c_int, [C.c_void_p]),
     "rscm_gpu_copy_to_host": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "rscm_gpu_copy_to_device": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "rscm_gpu_ocean_fit_selftest": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_int64, _dp, _ip, _ip, _ip, _dp]),
+    "rscm_ens_ocean_fast_info": (C.c_int, [_h, _ip, _dp]),
     "rscm_gpu_selftest_div": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, _dp, _dp, _bp]),
 }
 

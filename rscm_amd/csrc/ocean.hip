@@ -203,12 +203,136 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
     if (n < a.step_end) ocean_tile<STEPS, 1, FUSED, -1>(a, m, in, irf, hist, i, n);
 }
 
+// ---------------------------------------------------------------------------------------------
+// RSCM_MODE_FAST: O(T) instead of O(T^2).  The convolution of sub-step m splits at lag NEAR:
+//   lags 0 .. NEAR-1   explicit, with the tabulated response (whatever its form: the first-year
+//                      polynomial of 3D-GFDL, the early exponential sums of 2D-BERN / HILDA), the last
+//                      NEAR pulses kept in registers;
+//   lags NEAR .. H-1   through the host-fitted decaying modes (OceanModes), one running sum S_q per
+//                      mode and member: S_q <- d_q S_q + f(m - NEAR) - e_q f(m - H).
+// The scaled response is s raw / (s raw + 1 - raw) with raw a sum of six exponentials: not itself a
+// finite exponential sum, but its expansion in powers of (1 - s) raw converges fast; rates up to
+// pairwise sums, amplitudes by least squares over the whole window, reproduce the table to a few 1e-12
+// (checked by the host at configuration, which otherwise keeps the tiled kernel above).  The results
+// differ from the EXACT mode by that fit and by the summation order: tests/test_gpu_ocean.py states
+// the tolerance.  Per member-year: 12 x (NEAR + 2 x 21 + exits + ~25) f64 operations and 216 B of HBM
+// traffic (12 pulses written, 12 leaving pulses read, 3 output rows) against 144 k operations and 24 KB.
+template <int NEAR, int SRC>
+__global__ __launch_bounds__(kBlock) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table)
+{
+    constexpr int STEPS = 12, M = kOceanModes;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    const int32_t T = a.n_times;
+    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    OceanMember m;
+    m.pco2_pi = P(2);
+    m.k_gas = P(3) / (P(4) * 12.0);
+    m.temp_sens = P(5);
+    m.dic_conv = kMicromolPerPpmM3PerKg / (P(7) * P(8));
+    const double sst_pi = P(9);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
+    m.temp_on = P(23) != 0.0;
+    const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
+    const double* __restrict__ irf = irf_table;
+    double* __restrict__ hist = a.hist + i;
+    a.status[i] = 0;
+    const int64_t H = a.max_hist;
+    const size_t vs = (size_t)a.rows * N;
+    // ---- state at the start of the launch
+    int64_t m0 = (int64_t)a.step_begin * STEPS;
+    double S[M];
+    if (a.rebuild) {
+        // S_q(m0 - 1) = sum over the pulses j with lag m0 - 1 - j in [NEAR, H): Horner in d_q, oldest pulse first
+#pragma unroll
+        for (int q = 0; q < M; ++q) S[q] = 0.0;
+        const int64_t j_lo = m0 - H > 0 ? m0 - H : 0;
+        for (int64_t j = j_lo; j <= m0 - 1 - NEAR; ++j) {
+            const double f = hist[(size_t)j * N];
+#pragma unroll
+            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], a.modes.d[q], f);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < M; ++q) S[q] = a.mode_state[(size_t)q * N + i];
+    }
+    double w[NEAR + STEPS];  // w[x] = f(m0 - NEAR + x): the last NEAR pulses, then this step's
+#pragma unroll
+    for (int x = 0; x < NEAR; ++x) {
+        const int64_t j = m0 - NEAR + x;
+        w[x] = j >= 0 ? hist[(size_t)j * N] : 0.0;
+    }
+    const size_t r0 = (size_t)a.step_begin * N + i;
+    double pco2 = a.series[r0], cumulative = a.series[vs + r0];
+    for (int32_t n = a.step_begin; n < a.step_end; ++n, m0 += STEPS) {
+        const double co2 = in.at(0, n), delta_sst = in.at(1, n);
+        const double dt = a.bounds[n + 1] - a.bounds[n];
+        const double dt_month = dt / (double)STEPS;
+        const double temp_factor = m.temp_on ? exp(m.temp_sens * delta_sst) : 1.0;
+        double total = 0.0;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int64_t mm = m0 + s;
+            const double flux_ppm = m.k_gas * (co2 - pco2);
+            w[NEAR + s] = flux_ppm;
+            hist[(size_t)mm * N] = flux_ppm;
+            const double flux_gtc_yr = flux_ppm * 12.0 * kPpmToGtc;
+            total += flux_gtc_yr / (double)STEPS;
+            cumulative += flux_gtc_yr * dt_month;
+            // the far lags: the pulse that is NEAR months old enters, the one H months old leaves
+            const double f_in = w[s];
+#pragma unroll
+            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], a.modes.d[q], f_in);
+            if (mm >= H) {  // uniform over the launch grid
+                const double f_out = hist[(size_t)(mm - H) * N];
+#pragma unroll
+                for (int q = 0; q < M; ++q)
+                    if (q < a.modes.n_exit) S[q] = __builtin_fma(-a.modes.e[q], f_out, S[q]);
+            }
+            double integral = 0.0;
+#pragma unroll
+            for (int q = M - 1; q >= 0; --q) integral = __builtin_fma(a.modes.c[q], S[q], integral);  // fastest-decaying (smallest) first
+            // the near lags, oldest first
+#pragma unroll
+            for (int lag = NEAR - 1; lag >= 0; --lag) integral = __builtin_fma(w[NEAR + s - lag], irf[lag], integral);
+            const double delta_dic = integral * m.dic_conv;
+            pco2 = pco2_from_dic(m, delta_dic, temp_factor);
+        }
+#pragma unroll
+        for (int x = 0; x < NEAR; ++x) w[x] = w[x + STEPS];
+        const size_t r1 = (size_t)(n + 1) * N + i;
+        a.series[r1] = pco2;
+        a.series[vs + r1] = cumulative;
+        a.series[2 * vs + r1] = total;
+    }
+#pragma unroll
+    for (int q = 0; q < M; ++q) a.mode_state[(size_t)q * N + i] = S[q];
+}
+
+template <int NEAR>
+static hipError_t launch_recur(const OceanArgs& a, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
+    const int src = a.linked ? 2 : a.scen ? 1 : 0;
+    void (*kern)(OceanArgs, const double*) =
+        src == 2 ? ocean_recur_kernel<NEAR, 2> : src == 1 ? ocean_recur_kernel<NEAR, 1> : ocean_recur_kernel<NEAR, 0>;
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, a, a.irf);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_ocean(const OceanArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     if (a.steps != 12) return hipErrorInvalidValue;  // the sub-step loop is unrolled for monthly steps
+    if (a.recur) {
+        if (a.near == 60) return launch_recur<60>(a, s);
+        if (a.near == 120) return launch_recur<120>(a, s);
+        return hipErrorInvalidValue;
+    }
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     const int src = a.linked ? 2 : a.scen ? 1 : 0;
     void (*kern)(OceanArgs, const double*) =

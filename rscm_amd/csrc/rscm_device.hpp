@@ -236,6 +236,18 @@ template <bool FUSED>
 constexpr int kOceanTileYears = FUSED ? 4 : 3;
 constexpr int kOceanSplitYears = 2;  // years of a tile that is split over one-step launches
 
+// OceanCarbon, RSCM_MODE_FAST: the far part of the impulse response (lags >= near, all in the late
+// exponential-sum regime) as a sum of decaying modes  r(lag) ~ sum_q c[q] d[q]^(lag - near)  fitted by the
+// host (rscm_gpu.cpp, ocean_fit_modes).  Each mode carries one running sum per member:
+//   S_q(m) = d[q] S_q(m-1) + f(m - near) - e[q] f(m - H),   e[q] = d[q]^(H - near)
+// so a sub-step costs O(modes + near) instead of O(H) multiply-adds.  Modes are sorted by rate; only the
+// first n_exit of them still have a non-negligible weight when a pulse leaves the H-month window.
+constexpr int kOceanModes = 21;   // constant + five rates + their fifteen pairwise sums (six-term late forms)
+struct OceanModes {
+    double d[kOceanModes], c[kOceanModes], e[kOceanModes];
+    int32_t n_modes, n_exit;
+};
+
 // OceanCarbon (csrc/ocean.hip)
 struct OceanArgs {
     int64_t n_members;
@@ -255,6 +267,11 @@ struct OceanArgs {
     double* partial;         // [(tile years - 1) * steps][N] running sums parked between the launches of a split tile
     int32_t part;            // -1: whole tiles; p >= 0: year p of a tile split over one-step launches
     int32_t rows;            // stored rows per series (T, or the window length)
+    int32_t recur;           // RSCM_MODE_FAST with fitted modes: the O(T) recurrence kernel (near = 60 or 120 lags explicit)
+    int32_t near;
+    int32_t rebuild;         // the mode sums do not stand at step_begin: re-form them from the flux history first
+    double* mode_state;      // [kOceanModes][N] the running sums S_q between launches
+    OceanModes modes;
     double* series;          // [3][rows][N]: pCO2, cumulative uptake, flux
     uint8_t* status;
 };

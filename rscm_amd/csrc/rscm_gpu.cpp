@@ -111,9 +111,11 @@ static std::vector<double> ghg_tables(const double* conc, int32_t n_scen, int32_
 // (OceanCarbonParameters::irf + scale_irf, parameters/ocean_carbon.rs:202-216, with the IrfForm
 // coefficient sets of the gfdl_3d / bern_2d / hilda presets, :88-196).  The expressions are the
 // reference's, evaluated once per lag instead of once per (pulse, sub-step) pair.
-static std::vector<double> ocean_irf_table(int model, double irf_scale, double switch_time, int64_t n)
+struct OceanIrfForm { bool poly; int n; double c[8]; double tau[8]; };
+
+static void ocean_forms(int model, const OceanIrfForm** early_out, const OceanIrfForm** late_out)
 {
-    struct Form { bool poly; int n; double c[8]; double tau[8]; };
+    typedef OceanIrfForm Form;
     static const Form gfdl_e = {true, 7, {1.0, -2.2617, 14.002, -48.770, 82.986, -67.527, 21.037}, {0}};
     static const Form gfdl_l = {false, 6, {0.01481, 0.019439, 0.038344, 0.066485, 0.24966, 0.70367},
                                 {1.0e10, 347.55, 65.359, 15.281, 2.3488, 0.70177}};
@@ -125,8 +127,16 @@ static std::vector<double> ocean_irf_table(int model, double irf_scale, double s
                                  {1.0e10, 4.9792, 0.96083, 0.26936, 0.034569}};
     static const Form hilda_l = {false, 6, {0.022936, 0.035549, 0.037820, 0.089318, 0.13963, 0.24278},
                                  {1.0e10, 232.30, 68.736, 18.601, 5.2528, 1.2679}};
-    const Form& early = model == 1 ? bern_e : model == 2 ? hilda_e : gfdl_e;
-    const Form& late = model == 1 ? bern_l : model == 2 ? hilda_l : gfdl_l;
+    *early_out = model == 1 ? &bern_e : model == 2 ? &hilda_e : &gfdl_e;
+    *late_out = model == 1 ? &bern_l : model == 2 ? &hilda_l : &gfdl_l;
+}
+
+static std::vector<double> ocean_irf_table(int model, double irf_scale, double switch_time, int64_t n)
+{
+    typedef OceanIrfForm Form;
+    const Form *early_p, *late_p;
+    ocean_forms(model, &early_p, &late_p);
+    const Form &early = *early_p, &late = *late_p;
     auto eval = [](const Form& f, double t) {
         if (f.poly) {
             double r = 0.0;
@@ -145,6 +155,99 @@ static std::vector<double> ocean_irf_table(int model, double irf_scale, double s
     }
     return tab;
 }
+
+// RSCM_MODE_FAST for OceanCarbon: fit  tab[lag] ~ sum_q c_q d_q^(lag - near)  for lag in [near, H) with
+// d_q = exp(-rate_q / 12) and rate_q in {1/tau_i} u {1/tau_i + 1/tau_j} of the late form (the scaled
+// response s raw / (s raw + 1 - raw) expands in powers of (1 - s) raw; first and second order carry it to
+// ~1e-11).  Linear least squares for the amplitudes by Householder QR in long double (the columns are
+// strongly correlated: condition numbers of 1e8 and more).  Returns the largest deviation from the table
+// over the window, or a negative number if the parameters do not allow the recurrence.
+static double ocean_fit_modes(const std::vector<double>& tab, int model, double switch_time, int64_t H, int32_t* near_out,
+                              rscm::OceanModes* out)
+{
+    const OceanIrfForm *early, *late;
+    ocean_forms(model, &early, &late);
+    if (late->poly) return -1.0;
+    const int64_t sw = (int64_t)std::ceil(switch_time * 12.0 - 1e-9);   // first lag of the late regime
+    const int32_t near = sw <= 60 ? 60 : sw <= 120 ? 120 : 0;
+    if (!near || H < 4 * (int64_t)near) return -1.0;   // short windows: the tiled convolution is cheap already
+    std::vector<double> rates;
+    auto add = [&](double r) {
+        for (double x : rates)
+            if (std::fabs(x - r) <= 1e-7 * (1.0 + std::fabs(r))) return;
+        rates.push_back(r);
+    };
+    for (int i = 0; i < late->n; ++i) add(1.0 / late->tau[i]);
+    for (int i = 0; i < late->n; ++i)
+        for (int j = i; j < late->n; ++j) add(1.0 / late->tau[i] + 1.0 / late->tau[j]);
+    std::sort(rates.begin(), rates.end());
+    const int M = (int)rates.size();
+    if (M > rscm::kOceanModes) return -1.0;
+    const int64_t rows = std::min<int64_t>(H, 24000) - near;   // beyond 2000 years only the constant mode is left
+    typedef long double ld;
+    std::vector<ld> A((size_t)rows * M), b((size_t)rows);
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int q = 0; q < M; ++q) A[(size_t)r * M + q] = std::exp(-(ld)rates[q] * (ld)r / 12.0L);
+        b[(size_t)r] = tab[(size_t)(near + r)];
+    }
+    // Householder QR, applied to b on the fly
+    std::vector<ld> R((size_t)M * M, 0.0L), v((size_t)rows);
+    for (int k = 0; k < M; ++k) {
+        ld norm = 0.0L;
+        for (int64_t r = k; r < rows; ++r) norm += A[(size_t)r * M + k] * A[(size_t)r * M + k];
+        norm = std::sqrt(norm);
+        if (norm == 0.0L) return -1.0;
+        const ld akk = A[(size_t)k * M + k];
+        const ld alpha = akk > 0 ? -norm : norm;
+        ld vnorm = 0.0L;
+        for (int64_t r = k; r < rows; ++r) {
+            v[(size_t)r] = A[(size_t)r * M + k] - (r == k ? alpha : 0.0L);
+            vnorm += v[(size_t)r] * v[(size_t)r];
+        }
+        if (vnorm == 0.0L) return -1.0;
+        for (int c = k; c < M; ++c) {
+            ld dot = 0.0L;
+            for (int64_t r = k; r < rows; ++r) dot += v[(size_t)r] * A[(size_t)r * M + c];
+            const ld f = 2.0L * dot / vnorm;
+            for (int64_t r = k; r < rows; ++r) A[(size_t)r * M + c] -= f * v[(size_t)r];
+        }
+        ld dot = 0.0L;
+        for (int64_t r = k; r < rows; ++r) dot += v[(size_t)r] * b[(size_t)r];
+        const ld f = 2.0L * dot / vnorm;
+        for (int64_t r = k; r < rows; ++r) b[(size_t)r] -= f * v[(size_t)r];
+        for (int c = k; c < M; ++c) R[(size_t)k * M + c] = A[(size_t)k * M + c];
+    }
+    std::vector<ld> x((size_t)M);
+    for (int k = M - 1; k >= 0; --k) {
+        ld acc = b[(size_t)k];
+        for (int c = k + 1; c < M; ++c) acc -= R[(size_t)k * M + c] * x[(size_t)c];
+        if (R[(size_t)k * M + k] == 0.0L) return -1.0;
+        x[(size_t)k] = acc / R[(size_t)k * M + k];
+    }
+    *out = rscm::OceanModes{};
+    for (int q = 0; q < M; ++q) {
+        out->d[q] = (double)std::exp(-(ld)rates[q] / 12.0L);
+        out->c[q] = (double)x[(size_t)q];
+        out->e[q] = (double)std::exp(-(ld)rates[q] * (ld)(H - near) / 12.0L);
+        if (!std::isfinite(out->c[q])) return -1.0;
+    }
+    out->n_modes = M;
+    // rates ascend, so the exit weights e_q descend: the first n_exit modes still matter at lag H
+    out->n_exit = 0;
+    for (int q = 0; q < M; ++q)
+        if (std::fabs(out->c[q]) * out->e[q] >= 1e-19) out->n_exit = q + 1;
+    // the fit as the device will evaluate it (double coefficients), against the whole window
+    double worst = 0.0;
+    for (int64_t lag = near; lag < H; ++lag) {
+        ld acc = 0.0L;
+        for (int q = 0; q < M; ++q) acc += (ld)out->c[q] * std::exp(-(ld)rates[q] * (ld)(lag - near) / 12.0L);
+        worst = std::max(worst, std::fabs((double)acc - tab[(size_t)lag]));
+    }
+    *near_out = near;
+    return worst;
+}
+
+constexpr double kOceanFitTolerance = 5e-10;  // largest deviation of the fitted far response accepted for RSCM_MODE_FAST
 
 static_assert(rscm::kKindOzoneForcing == RSCM_KIND_OZONE_FORCING && rscm::kKindAerosolDirect == RSCM_KIND_AEROSOL_DIRECT &&
                   rscm::kKindAerosolIndirect == RSCM_KIND_AEROSOL_INDIRECT && rscm::kKindCh4Chemistry == RSCM_KIND_CH4_CHEMISTRY &&
@@ -184,6 +287,13 @@ struct rscm_ens {
     int32_t ocean_steps = 0;
     int64_t ocean_max_hist = 0;
     bool ocean_ready = false;
+    // RSCM_MODE_FAST: the far response as decaying modes (ocean_fit_modes) and their running sums
+    rscm::OceanModes ocean_modes{};
+    bool ocean_recur_ok = false;
+    int32_t ocean_near = 0;
+    double ocean_fit_error = 0.0;
+    double* d_ocean_mode_state = nullptr;  // [kOceanModes][N]
+    int32_t ocean_modes_at = -1;           // time index the running sums stand at (-1: re-form them from the history)
     int32_t* d_scen = nullptr;   // [N] or null
     int32_t n_scen = 0;
     int32_t source = RSCM_SRC_EXOGENOUS;
@@ -349,6 +459,14 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
     h->ocean_tile_base = -1;  // sums parked under another response table are void
     h->ocean_steps = 12;
     h->ocean_max_hist = (int64_t)max_hist;
+    h->ocean_modes_at = -1;
+    h->ocean_fit_error = ocean_fit_modes(tab, (int)model, row(RSCM_OC_P_IRF_SWITCH_TIME, 0), (int64_t)max_hist, &h->ocean_near, &h->ocean_modes);
+    h->ocean_recur_ok = h->ocean_fit_error >= 0.0 && h->ocean_fit_error <= kOceanFitTolerance;
+    if (h->ocean_recur_ok && !h->d_ocean_mode_state) {
+        const hipError_t e = hipMalloc(&h->d_ocean_mode_state, (size_t)rscm::kOceanModes * h->N * sizeof(double));
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "mode sums of %lld members: %s", (long long)h->N, hipGetErrorString(e));
+    }
     h->ocean_ready = true;
     return RSCM_OK;
 }
@@ -673,6 +791,7 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_ocean_hist);
     (void)hipFree(h->d_ocean_irf);
     (void)hipFree(h->d_ocean_partial);
+    (void)hipFree(h->d_ocean_mode_state);
     (void)hipFree(h->d_ocean);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
@@ -708,7 +827,10 @@ int rscm_ens_set_mode(rscm_ens* h, int32_t mode)
 {
     NEED(h);
     if (mode != RSCM_MODE_EXACT && mode != RSCM_MODE_FAST) return fail(RSCM_ERR_INVALID, "unknown mode %d", mode);
-    if (mode != h->mode) h->ocean_tile_base = -1;  // sums parked by the other arithmetic cannot be resumed
+    if (mode != h->mode) {  // sums parked / carried by the other arithmetic cannot be resumed
+        h->ocean_tile_base = -1;
+        h->ocean_modes_at = -1;
+    }
     h->mode = mode;
     return RSCM_OK;
 }
@@ -983,6 +1105,7 @@ int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx)
     }
     h->time_index = tidx;
     h->ocean_tile_base = -1;
+    h->ocean_modes_at = -1;
     return RSCM_OK;
     GUARD_END
 }
@@ -1058,6 +1181,7 @@ int rscm_ens_set_internal_state(rscm_ens* h, const double* in, int64_t n_doubles
         if (int rc = window_seek(h, time_index)) return rc;
     h->time_index = time_index;
     h->ocean_tile_base = -1;
+    h->ocean_modes_at = -1;
     return RSCM_OK;
     GUARD_END
 }
@@ -1072,6 +1196,7 @@ int rscm_ens_rewind(rscm_ens* h)
     }
     h->time_index = 0;
     h->ocean_tile_base = -1;
+    h->ocean_modes_at = -1;
     return RSCM_OK;
     GUARD_END
 }
@@ -1225,8 +1350,20 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         // read once per two steps, as the two-year tiles of a whole run do
         a.partial = h->d_ocean_partial;
         a.part = -1;
+        a.recur = (h->mode == RSCM_MODE_FAST && h->ocean_recur_ok) ? 1 : 0;
+        if (a.recur) {
+            a.near = h->ocean_near;
+            a.modes = h->ocean_modes;
+            a.mode_state = h->d_ocean_mode_state;
+            a.rebuild = h->ocean_modes_at == step_begin ? 0 : 1;
+            h->ocean_modes_at = step_end;
+        } else {
+            h->ocean_modes_at = -1;  // this launch does not advance the running sums
+        }
         const int32_t tile_years = rscm::kOceanSplitYears;
-        if (step_end - step_begin == 1 && h->d_ocean_partial) {
+        if (a.recur) {
+            h->ocean_tile_base = -1;
+        } else if (step_end - step_begin == 1 && h->d_ocean_partial) {
             const int32_t p = step_begin - h->ocean_tile_base;
             if (h->ocean_tile_base >= 0 && h->ocean_tile_years == tile_years && p > 0 && p < tile_years) {
                 a.part = p;                                   // the next year of the tile in flight
@@ -1389,6 +1526,7 @@ int rscm_ens_clear_series(rscm_ens* h)
                                      std::numeric_limits<double>::quiet_NaN(), h->stream));
     h->time_index = 0;
     h->ocean_tile_base = -1;
+    h->ocean_modes_at = -1;
     return RSCM_OK;
     GUARD_END
 }
@@ -2391,6 +2529,37 @@ int rscm_gpu_host_free(void* p)
     if (p) HIPCHK(hipHostFree(p));
     return RSCM_OK;
     GUARD_END
+}
+
+int rscm_gpu_ocean_fit_selftest(int32_t model, double irf_scale, double irf_switch_time, int64_t max_history_months,
+                                double* max_error, int32_t* n_modes, int32_t* near_lags, int32_t* n_exit, double* max_abs_coefficient)
+{
+    GUARD_BEGIN
+    if (!max_error || !n_modes || !near_lags || !n_exit) return fail(RSCM_ERR_INVALID, "NULL output");
+    if (model < 0 || model > 2 || max_history_months < 1 || max_history_months > 10000000)
+        return fail(RSCM_ERR_INVALID, "bad model or history length");
+    const std::vector<double> tab = ocean_irf_table(model, irf_scale, irf_switch_time, max_history_months);
+    rscm::OceanModes m{};
+    int32_t near = 0;
+    *max_error = ocean_fit_modes(tab, model, irf_switch_time, max_history_months, &near, &m);
+    *n_modes = m.n_modes;
+    *near_lags = near;
+    *n_exit = m.n_exit;
+    if (max_abs_coefficient) {
+        *max_abs_coefficient = 0.0;
+        for (int q = 0; q < m.n_modes; ++q) *max_abs_coefficient = std::max(*max_abs_coefficient, std::fabs(m.c[q]));
+    }
+    return RSCM_OK;
+    GUARD_END
+}
+
+int rscm_ens_ocean_fast_info(rscm_ens* h, int32_t* uses_recurrence, double* fit_error)
+{
+    NEED(h);
+    if (h->kind != RSCM_KIND_OCEAN_CARBON || !h->ocean_ready) return fail(RSCM_ERR_STATE, "not a configured OceanCarbon ensemble");
+    if (uses_recurrence) *uses_recurrence = h->ocean_recur_ok ? 1 : 0;
+    if (fit_error) *fit_error = h->ocean_fit_error;
+    return RSCM_OK;
 }
 
 int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const double* den,

@@ -202,29 +202,90 @@ def test_internal_state_kinds_refuse_time_jumps(ra, orc):
         assert np.array_equal(e.get_series(1), first)
 
 
-def test_ocean_fast_mode_tolerance(ra, orc):
-    """RSCM_MODE_FAST fuses the multiply-adds of the convolution (half the VALU work): the sums
-    of up to 6000 terms then differ from the reference's by rounding only."""
+FAST_TOL = 2e-8
+
+
+def _fast_info(e):
+    import ctypes as C
+    from rscm_amd import _lib
+    uses, err = C.c_int32(), C.c_double()
+    _lib.check(e._lib.rscm_ens_ocean_fast_info(e._h, C.byref(uses), C.byref(err)))
+    return bool(uses.value), err.value
+
+
+@pytest.mark.parametrize("model", ["3D-GFDL", "2D-BERN", "HILDA"])
+def test_ocean_fast_mode_tolerance(ra, orc, model):
+    """RSCM_MODE_FAST computes the history convolution in O(T): the last 60 (2D-BERN: 120) monthly lags
+    explicitly, the older ones through 21 decaying modes fitted to the scaled impulse response (host fit,
+    deviation from the table <= 5e-10, here ~1e-12) with one running sum each.  Against the EXACT mode
+    (which equals the CPU oracle bit for bit) over 600 years -- the 500-year window fills and pulses leave
+    it -- the outputs agree to FAST_TOL = 2e-8 relative (measured ~1e-10: printed).  Launch boundaries and
+    one-step launches do not change a bit of the FAST result; joining a run that EXACT began re-forms the
+    running sums from the flux history."""
     rng = np.random.default_rng(12)
     n, T = 64, 601
     b = np.arange(T + 1, dtype=float) + 1750.0
-    P, _ = _case(orc, "3D-GFDL", n, T, rng, enable_temp_feedback=0.0)
+    P, _ = _case(orc, model, n, T, rng, enable_temp_feedback=0.0)
+    P[orc.OCEAN_PARAM_NAMES.index("enable_temp_feedback"), ::2] = 1.0
     # a bounded pathway: beyond ~1500 ppm the fifth-order Joos polynomial leaves its fitted range
     # and amplifies any rounding difference
-    inputs = np.stack([np.minimum(278.0 + 0.9 * np.arange(T), 700.0), np.zeros(T)])[None]
-    with ra.Ensemble(ra.KIND_OCEAN_CARBON, n, b) as e:
-        e.set_params(P)
-        e.set_forcing(inputs[:1])
-        e.set_initial(1, 278.0)
-        e.set_initial(2, 0.0)
-        e.run()
-        exact = np.stack([e.get_series(v) for v in (1, 2, 3)])
-        e.set_mode(ra.MODE_FAST)
-        e.rewind()
-        e.run()
-        fast = np.stack([e.get_series(v) for v in (1, 2, 3)])
-    want = orc.ocean_run(b, P[:, :2].copy(), inputs[:1], 278.0, 0.0, threads=2)
-    assert np.array_equal(exact[:, :, :2], want, equal_nan=True)
+    yr = np.arange(T)
+    inputs = np.stack([np.minimum(278.0 + 0.9 * yr, 700.0) - np.where(yr > 500, 0.5 * (yr - 500), 0.0), 0.004 * np.minimum(yr, 400)])[None]
+
+    def run(mode, chunks=(), switch_at=None):
+        with ra.Ensemble(ra.KIND_OCEAN_CARBON, n, b) as e:
+            e.set_params(P)
+            e.set_forcing(inputs[:1])
+            e.set_initial(1, 278.0)
+            e.set_initial(2, 0.0)
+            e.set_mode(ra.MODE_EXACT if switch_at else mode)
+            uses, fit = _fast_info(e)
+            assert uses and 0.0 <= fit <= 5e-10
+            for c in chunks:
+                e.run(c)
+            if switch_at:
+                e.run(switch_at)
+                e.set_mode(mode)
+            e.run()
+            return np.stack([e.get_series(v) for v in (1, 2, 3)]), fit
+
+    exact, fit = run(ra.MODE_EXACT)
+    fast, _ = run(ra.MODE_FAST)
+    want = orc.ocean_run(b, P[:, 1:3].copy(), inputs[:1], 278.0, 0.0, threads=2)   # member 1: no temperature feedback
+    assert np.array_equal(exact[:, :, 1:2], want[:, :, :1], equal_nan=True)
     ok = ~np.isnan(exact)
     err = np.abs(fast[ok] - exact[ok]) / np.maximum(1.0, np.abs(exact[ok]))
-    assert 0.0 < err.max() <= 1e-12, err.max()
+    print(f"{model}: fit deviation {fit:.2e}, FAST vs EXACT over {T - 1} years: max relative deviation {err.max():.2e}")
+    assert 0.0 < err.max() <= FAST_TOL, err.max()
+    assert (np.isnan(fast) == np.isnan(exact)).all()
+    # launch boundaries / one step per launch: the running sums and the last pulses are carried exactly
+    assert np.array_equal(run(ra.MODE_FAST, chunks=(1, 2, 17, 300, 301, 555))[0], fast, equal_nan=True)
+    assert np.array_equal(run(ra.MODE_FAST, chunks=range(1, 90))[0], fast, equal_nan=True)
+    # EXACT for 520 years (pulses have started leaving the window), then FAST: the sums are re-formed from the history
+    joined, _ = run(ra.MODE_FAST, switch_at=520)
+    assert np.array_equal(joined[:, :521], exact[:, :521], equal_nan=True)
+    errj = np.abs(joined[ok] - exact[ok]) / np.maximum(1.0, np.abs(exact[ok]))
+    assert errj.max() <= FAST_TOL
+
+
+def test_ocean_fast_mode_falls_back_when_the_window_is_short(ra, orc):
+    """max_history_months below four times the explicit part: nothing to gain, FAST keeps the tiled
+    convolution with fused multiply-adds (<= 1e-12 from EXACT)."""
+    rng = np.random.default_rng(5)
+    n, T = 64, 81
+    b = np.arange(T + 1, dtype=float) + 1750.0
+    P, inputs = _case(orc, "3D-GFDL", n, T, rng, enable_temp_feedback=0.0, max_history_months=100.0)
+    out = {}
+    for mode in (ra.MODE_EXACT, ra.MODE_FAST):
+        with ra.Ensemble(ra.KIND_OCEAN_CARBON, n, b) as e:
+            e.set_params(P)
+            e.set_forcing(inputs[:1])
+            e.set_initial(1, 278.0)
+            e.set_initial(2, 0.0)
+            e.set_mode(mode)
+            assert not _fast_info(e)[0]
+            e.run()
+            out[mode] = np.stack([e.get_series(v) for v in (1, 2, 3)])
+    ok = ~np.isnan(out[ra.MODE_EXACT])
+    err = np.abs(out[ra.MODE_FAST][ok] - out[ra.MODE_EXACT][ok]) / np.maximum(1.0, np.abs(out[ra.MODE_EXACT][ok]))
+    assert 0.0 < err.max() <= 1e-12
