@@ -218,7 +218,8 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
 // the tolerance.  Per member-year: 12 x (NEAR + 2 x 21 + exits + ~25) f64 operations and 216 B of HBM
 // traffic (12 pulses written, 12 leaving pulses read, 3 output rows) against 144 k operations and 24 KB.
 template <int NEAR, int SRC>
-__global__ __launch_bounds__(kBlock) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table)
+__global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table,
+                                                             const double* __restrict__ mode_table)
 {
     constexpr int STEPS = 12, M = kOceanModes;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void ocean_recur_kernel(OceanArgs a, const 
         for (int64_t j = j_lo; j <= m0 - 1 - NEAR; ++j) {
             const double f = hist[(size_t)j * N];
 #pragma unroll
-            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], a.modes.d[q], f);
+            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], mode_table[q], f);
         }
     } else {
 #pragma unroll
@@ -266,46 +267,67 @@ __global__ __launch_bounds__(kBlock) void ocean_recur_kernel(OceanArgs a, const 
     }
     const size_t r0 = (size_t)a.step_begin * N + i;
     double pco2 = a.series[r0], cumulative = a.series[vs + r0];
+    double* __restrict__ hp = hist + (size_t)m0 * N;                 // where this sub-step's pulse goes
+    const double* __restrict__ hp_out = hist + (size_t)(m0 - H) * N;   // the pulse that leaves the window (valid once m >= H)
+    double* __restrict__ out = a.series + r0;
+    const bool few_exits = a.modes.n_exit <= 10;                     // the modes whose weight at lag H is not negligible come first
     for (int32_t n = a.step_begin; n < a.step_end; ++n, m0 += STEPS) {
         const double co2 = in.at(0, n), delta_sst = in.at(1, n);
         const double dt = a.bounds[n + 1] - a.bounds[n];
         const double dt_month = dt / (double)STEPS;
         const double temp_factor = m.temp_on ? exp(m.temp_sens * delta_sst) : 1.0;
+        const bool leaving = m0 >= H;   // sub-steps of a step that straddles m = H take the general path below
+        const bool straddle = !leaving && m0 + STEPS > H;
         double total = 0.0;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            const int64_t mm = m0 + s;
             const double flux_ppm = m.k_gas * (co2 - pco2);
             w[NEAR + s] = flux_ppm;
-            hist[(size_t)mm * N] = flux_ppm;
+            *hp = flux_ppm;
             const double flux_gtc_yr = flux_ppm * 12.0 * kPpmToGtc;
             total += flux_gtc_yr / (double)STEPS;
             cumulative += flux_gtc_yr * dt_month;
+            // The 60-120 response values and 3 x 21 mode constants of a sub-step are wave-uniform and read with
+            // scalar loads.  They do not fit the 102 SGPRs of a wave at once: an opaque zero offset per sub-step
+            // keeps the compiler from hoisting all of them out of the loops (and then spilling them into VGPR
+            // lanes, one v_readlane pair per use) -- they are re-read from the scalar cache where they are used.
+            int32_t opaque = 0;
+            asm volatile("" : "+s"(opaque));
+            const double* __restrict__ rt = irf + opaque;
+            const double* __restrict__ md = mode_table + opaque;           // d_q
+            const double* __restrict__ mc = mode_table + M + opaque;       // c_q
+            const double* __restrict__ me = mode_table + 2 * M + opaque;   // e_q
             // the far lags: the pulse that is NEAR months old enters, the one H months old leaves
             const double f_in = w[s];
 #pragma unroll
-            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], a.modes.d[q], f_in);
-            if (mm >= H) {  // uniform over the launch grid
-                const double f_out = hist[(size_t)(mm - H) * N];
+            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], md[q], f_in);
+            if (leaving || (straddle && m0 + s >= H)) {  // wave-uniform
+                const double f_out = *hp_out;
+                if (few_exits) {
 #pragma unroll
-                for (int q = 0; q < M; ++q)
-                    if (q < a.modes.n_exit) S[q] = __builtin_fma(-a.modes.e[q], f_out, S[q]);
+                    for (int q = 0; q < 10; ++q) S[q] = __builtin_fma(-me[q], f_out, S[q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < M; ++q) S[q] = __builtin_fma(-me[q], f_out, S[q]);   // e_q = 0 beyond n_exit
+                }
             }
+            hp += N;
+            hp_out += N;
             double integral = 0.0;
 #pragma unroll
-            for (int q = M - 1; q >= 0; --q) integral = __builtin_fma(a.modes.c[q], S[q], integral);  // fastest-decaying (smallest) first
+            for (int q = M - 1; q >= 0; --q) integral = __builtin_fma(mc[q], S[q], integral);  // fastest-decaying (smallest) first
             // the near lags, oldest first
 #pragma unroll
-            for (int lag = NEAR - 1; lag >= 0; --lag) integral = __builtin_fma(w[NEAR + s - lag], irf[lag], integral);
+            for (int lag = NEAR - 1; lag >= 0; --lag) integral = __builtin_fma(w[NEAR + s - lag], rt[lag], integral);
             const double delta_dic = integral * m.dic_conv;
             pco2 = pco2_from_dic(m, delta_dic, temp_factor);
         }
 #pragma unroll
         for (int x = 0; x < NEAR; ++x) w[x] = w[x + STEPS];
-        const size_t r1 = (size_t)(n + 1) * N + i;
-        a.series[r1] = pco2;
-        a.series[vs + r1] = cumulative;
-        a.series[2 * vs + r1] = total;
+        out += N;
+        out[0] = pco2;
+        out[vs] = cumulative;
+        out[2 * vs] = total;
     }
 #pragma unroll
     for (int q = 0; q < M; ++q) a.mode_state[(size_t)q * N + i] = S[q];
@@ -316,9 +338,9 @@ static hipError_t launch_recur(const OceanArgs& a, hipStream_t s)
 {
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     const int src = a.linked ? 2 : a.scen ? 1 : 0;
-    void (*kern)(OceanArgs, const double*) =
+    void (*kern)(OceanArgs, const double*, const double*) =
         src == 2 ? ocean_recur_kernel<NEAR, 2> : src == 1 ? ocean_recur_kernel<NEAR, 1> : ocean_recur_kernel<NEAR, 0>;
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, a, a.irf);
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, a, a.irf, a.mode_table);
     return hipGetLastError();
 }
 

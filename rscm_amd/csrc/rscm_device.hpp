@@ -271,7 +271,8 @@ struct OceanArgs {
     int32_t near;
     int32_t rebuild;         // the mode sums do not stand at step_begin: re-form them from the flux history first
     double* mode_state;      // [kOceanModes][N] the running sums S_q between launches
-    OceanModes modes;
+    const double* mode_table; // [3][kOceanModes] on the device: d_q, c_q, e_q (read with scalar loads)
+    OceanModes modes;        // the same by value (n_exit; the constants for host-side use)
     double* series;          // [3][rows][N]: pCO2, cumulative uptake, flux
     uint8_t* status;
 };

@@ -236,6 +236,7 @@ static double ocean_fit_modes(const std::vector<double>& tab, int model, double 
     out->n_exit = 0;
     for (int q = 0; q < M; ++q)
         if (std::fabs(out->c[q]) * out->e[q] >= 1e-19) out->n_exit = q + 1;
+    for (int q = out->n_exit; q < rscm::kOceanModes; ++q) out->e[q] = 0.0;  // the kernel applies a fixed number of exit terms
     // the fit as the device will evaluate it (double coefficients), against the whole window
     double worst = 0.0;
     for (int64_t lag = near; lag < H; ++lag) {
@@ -293,6 +294,7 @@ struct rscm_ens {
     int32_t ocean_near = 0;
     double ocean_fit_error = 0.0;
     double* d_ocean_mode_state = nullptr;  // [kOceanModes][N]
+    double* d_ocean_mode_table = nullptr;  // [3][kOceanModes]: d_q, c_q, e_q
     int32_t ocean_modes_at = -1;           // time index the running sums stand at (-1: re-form them from the history)
     int32_t* d_scen = nullptr;   // [N] or null
     int32_t n_scen = 0;
@@ -466,6 +468,16 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
         const hipError_t e = hipMalloc(&h->d_ocean_mode_state, (size_t)rscm::kOceanModes * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "mode sums of %lld members: %s", (long long)h->N, hipGetErrorString(e));
+    }
+    if (h->ocean_recur_ok) {
+        if (!h->d_ocean_mode_table) HIPCHK(hipMalloc(&h->d_ocean_mode_table, (size_t)3 * rscm::kOceanModes * sizeof(double)));
+        double t3[3 * rscm::kOceanModes];
+        for (int q = 0; q < rscm::kOceanModes; ++q) {
+            t3[q] = h->ocean_modes.d[q];
+            t3[rscm::kOceanModes + q] = h->ocean_modes.c[q];
+            t3[2 * rscm::kOceanModes + q] = h->ocean_modes.e[q];
+        }
+        HIPCHK(hipMemcpy(h->d_ocean_mode_table, t3, sizeof t3, hipMemcpyHostToDevice));
     }
     h->ocean_ready = true;
     return RSCM_OK;
@@ -792,6 +804,7 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_ocean_irf);
     (void)hipFree(h->d_ocean_partial);
     (void)hipFree(h->d_ocean_mode_state);
+    (void)hipFree(h->d_ocean_mode_table);
     (void)hipFree(h->d_ocean);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
@@ -1355,6 +1368,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
             a.near = h->ocean_near;
             a.modes = h->ocean_modes;
             a.mode_state = h->d_ocean_mode_state;
+            a.mode_table = h->d_ocean_mode_table;
             a.rebuild = h->ocean_modes_at == step_begin ? 0 : 1;
             h->ocean_modes_at = step_end;
         } else {
