@@ -288,7 +288,7 @@ def linked_graph_extra(members, device, stream, years):
             "note": "CarbonCycle, CO2ERF, Sum, TwoLayer as four linked ensembles, 4 launches per model step"}
 
 
-def magicc_chain_extra(members, years):
+def magicc_chain_extra(members, years, fast=False):
     import importlib.util
     import time
     spec = importlib.util.spec_from_file_location(
@@ -296,6 +296,9 @@ def magicc_chain_extra(members, years):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     model = mod.build_chain(members, years, "topological")
+    if fast:  # RSCM_MODE_FAST: OceanCarbon's O(T) recurrence, fused two-layer style arithmetic where a kind has it
+        from rscm_amd import _lib as L
+        model.set_mode(L.MODE_FAST)
     t0 = time.perf_counter()
     model.run()
     dt = time.perf_counter() - t0
@@ -447,6 +450,7 @@ def main():
         # BASELINE.json configs[3]: the emissions-driven MAGICC graph (ten rscm-magicc components, Sum of
         # eight forcings, FourBox transforms) as linked ensembles, ClimateUDEB / OceanCarbon at 12 sub-steps
         side("magicc_chain_1e5", lambda: magicc_chain_extra(100_000, years))
+        side("magicc_chain_1e5_fast", lambda: magicc_chain_extra(100_000, years, fast=True))
 
         # SURVEY 8d asks for the end-to-end figure beside the resident one: host parameters in,
         # run, full Ts and Td series out into page-locked buffers (never reported as `value`)

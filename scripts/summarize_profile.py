@@ -18,7 +18,7 @@ for f in glob.glob(f"{d}/trace/runc/*_kernel_stats.csv"):
     for l in open(f):
         lines.append(l.rstrip())
     for r in csv.DictReader(open(f)):
-        if any(k in r["Name"] for k in ("two_layer_kernel", "coupled_kernel", "udeb_kernel", "ghg_kernel", "ocean_kernel")):
+        if any(k in r["Name"] for k in ("two_layer_kernel", "coupled_kernel", "udeb_kernel", "ghg_kernel", "ocean_kernel", "ocean_recur_kernel", "group_kernel")):
             avg_ns = float(r["AverageNs"])
 lines += ["", "## driver output under --kernel-trace (HIP events on the launch stream)"]
 lines += [l for l in open(f"{d}/trace.log").read().splitlines() if l.startswith(("kind=", "member-years"))]
@@ -29,7 +29,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
         continue
     acc, meta, dur = collections.defaultdict(list), {}, []
     for r in csv.DictReader(open(fs[0])):
-        if any(k in r["Kernel_Name"] for k in ("two_layer_kernel", "coupled_kernel", "udeb_kernel", "ghg_kernel", "ocean_kernel")):
+        if any(k in r["Kernel_Name"] for k in ("two_layer_kernel", "coupled_kernel", "udeb_kernel", "ghg_kernel", "ocean_kernel", "ocean_recur_kernel", "group_kernel")):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = r
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
