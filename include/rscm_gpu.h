@@ -467,6 +467,15 @@ RSCM_API int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_en
  * rscm_ens_sync on any of them.  If a launch is refused part-way (a state error of one handle), the
  * handles before it in the order have advanced one step further than those after it. */
 RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end);
+/* rscm_ens_run_lockstep issues one launch per step for every run of consecutive light components (chemistry,
+ * forcing formulas, budgets, aggregates, grid transforms, the RK4 box models) instead of one per component:
+ * each thread runs the components' per-member bodies in graph order -- every graph edge is per member, so this
+ * is the same computation, bit for bit.  ClimateUDEB, OceanCarbon and HalocarbonChemistry keep their own
+ * launches.  enabled = 0 switches the fusion off for the process (A/B tests); default on. */
+RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
+/* Step launches issued by rscm_ens_run_lockstep (component kernels + fused groups; HalocarbonChemistry counts
+ * as one) and the component steps they carried, since the last call; resets both counters. */
+RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps);
 RSCM_API int rscm_ens_sync(rscm_ens* h);
 RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
 /* Rewind to time index 0 keeping parameters, forcing and initial values (outputs are

@@ -1193,11 +1193,14 @@ class GraphModel:
     def step(self) -> None:
         if not self.time_index < len(self._axis) - 1:
             raise RuntimeError("assertion failed: self.time_index < self.time_axis.len() - 1")
-        for name in self._order:
-            if name in self._host_nodes:
-                self._host_step(name, self.time_index)
-            else:
-                self.ensembles[name].run(self.time_index + 1, sync=False)
+        if self._host_nodes:
+            for name in self._order:
+                if name in self._host_nodes:
+                    self._host_step(name, self.time_index)
+                else:
+                    self.ensembles[name].run(self.time_index + 1, sync=False)
+        else:  # one native call: consecutive light components share a launch (rscm_ens_run_lockstep)
+            run_lockstep([self.ensembles[name] for name in self._order], self.time_index + 1, sync=False)
         self.time_index += 1
         self._sync()
 

@@ -14,60 +14,18 @@
 // library (tests/test_gpu_carbon.py states the tolerance).  Both stream their state rows to HBM
 // (24 / 40 B per member-year); CO2Budget is bound by that write stream, TerrestrialCarbon by
 // the transcendental VALU work.
-#include "rk4_device.hpp"
-#include "rscm_device.hpp"
+#include "carbon_body.hpp"
 
 namespace rscm {
 
 namespace {
 
-constexpr double kGtcPerPpm = 2.13;  // crates/rscm-components/src/constants.rs:37
-
-// rscm-components' CarbonCycle on its own (carbon_cycle.rs:102-159): y = (C, cumulative uptake,
-// cumulative emissions) integrated with RK4 over the model step, emissions and temperature
-// constant over it (get() ignores t).  The arithmetic is that of the fused coupled chain
-// (csrc/coupled.hip, year<false>), so a graph assembled from linked ensembles reproduces the
-// fused kind bit for bit.  in = {Emissions|CO2|Anthropogenic, Surface Temperature}.
 template <int SRC>
 __global__ __launch_bounds__(kBlock) void carbon_cycle_kernel(CarbonArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    const int64_t N = a.n_members;
-    const int32_t T = a.n_times;
-    const double tau = a.params[i], conc_pi = a.params[(size_t)N + i], alpha = a.params[(size_t)2 * N + i];
-    const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)a.rows * N;
-    const size_t r0 = (size_t)a.step_begin * N + i;
-    double conc = a.series[r0], cum_u = a.series[vs + r0], cum_e = a.series[2 * vs + r0];
-    const double hc = a.h, half_c = hc / 2.0, sixth_c = hc / 6.0;
-    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-        const double emis = in.at(0, n), temperature = in.at(1, n);
-        const double lifetime = tau * exp(alpha * temperature);
-        // forty divisions by the year's lifetime: the hoisted-reciprocal quotient of rk4_device.hpp
-        // (IEEE-identical inside its exponent windows, the compiler's division outside them)
-        const ConstDiv dl = make_const_div(lifetime);
-        const double e_ppm = emis / kGtcPerPpm;
-        const int32_t m = a.nsub[n];
-        for (int32_t s = 0; s < m; ++s) {
-            const double up1 = div_const(conc - conc_pi, dl);
-            const double k1c = e_ppm - up1, k1u = up1 * kGtcPerPpm;
-            const double up2 = div_const((conc + k1c * half_c) - conc_pi, dl);
-            const double k2c = e_ppm - up2, k2u = up2 * kGtcPerPpm;
-            const double up3 = div_const((conc + k2c * half_c) - conc_pi, dl);
-            const double k3c = e_ppm - up3, k3u = up3 * kGtcPerPpm;
-            const double up4 = div_const((conc + k3c * hc) - conc_pi, dl);
-            const double k4c = e_ppm - up4, k4u = up4 * kGtcPerPpm;
-            conc = rk4_combine(conc, k1c, k2c, k3c, k4c, sixth_c);
-            cum_u = rk4_combine(cum_u, k1u, k2u, k3u, k4u, sixth_c);
-            cum_e = rk4_combine(cum_e, emis, emis, emis, emis, sixth_c);
-        }
-        const size_t r = (size_t)(n + 1) * N + i;
-        a.series[r] = conc;
-        a.series[vs + r] = cum_u;
-        a.series[2 * vs + r] = cum_e;
-    }
-    a.status[i] = (is_finite(conc) && is_finite(cum_u) && is_finite(cum_e)) ? 0 : 1;
+    carbon::carbon_cycle_body<SRC>(a, i, a.step_begin, a.step_end);
 }
 
 template <int SRC>
@@ -75,38 +33,7 @@ __global__ __launch_bounds__(kBlock) void co2_budget_kernel(CarbonArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    const int64_t N = a.n_members;
-    const int32_t T = a.n_times;
-    const double gtc_per_ppm = a.params[i];
-    const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)a.rows * N;
-    a.status[i] = 0;
-    double co2 = a.series[(size_t)a.step_begin * N + i];
-    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-        const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double total_emissions = in.at(0, n) + in.at(1, n);
-        const double total_uptake = in.at(2, n) + in.at(3, n);
-        const double net_to_atm = total_emissions - total_uptake;
-        co2 = co2 + (net_to_atm * dt) / gtc_per_ppm;
-        const size_t r = (size_t)(n + 1) * N + i;
-        a.series[r] = co2;
-        a.series[vs + r] = net_to_atm;
-        a.series[2 * vs + r] = total_emissions > 0.0 ? net_to_atm / total_emissions : 0.0;
-    }
-}
-
-// carbon/terrestrial.rs:82-100
-// r_tau = 1 / tau (inverted once per member); the quotient by 1 + half_k is a product with a refined
-// reciprocal: TerrestrialCarbon is a tolerance-parity kind (its log / exp come from the device library)
-__device__ __forceinline__ void implicit_pool_step(double pool, double r_tau, double flux_in, double temp_factor, double dt,
-                                                   double& new_pool, double& turnover)
-{
-    const double k_eff = temp_factor * r_tau;
-    const double half_k = 0.5 * k_eff * dt;
-    double np = ((1.0 - half_k) * pool + flux_in * dt) * guarded_rcp(1.0 + half_k);
-    np = fmax(np, 0.0);
-    new_pool = np;
-    turnover = 0.5 * k_eff * (pool + np);
+    carbon::co2_budget_body<SRC>(a, i, a.step_begin, a.step_end);
 }
 
 template <int SRC>
@@ -114,56 +41,7 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    const int64_t N = a.n_members;
-    const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
-    const double npp_pi = P(0), co2_pi = P(1), beta = P(2), npp_ts = P(3), resp_ts = P(4), det_ts = P(5), soil_ts = P(6),
-                 hum_ts = P(7), plant_pi = P(8), det_pi = P(9), soil_pi = P(10), hum_pi = P(11), resp_pi = P(12),
-                 f_npp_plant = P(13), f_npp_det = P(14), f_plant_det = P(15), f_det_soil = P(16), f_soil_hum = P(17);
-    const bool fert_on = P(18) != 0.0, temp_on = P(19) != 0.0;
-    // parameters/terrestrial_carbon.rs:103-168, once per member
-    const double f_npp_soil = fmax(1.0 - f_npp_plant - f_npp_det, 0.0);
-    const double net_plant = f_npp_plant * npp_pi - resp_pi;
-    const double tau_plant = net_plant > 1e-10 ? plant_pi / net_plant : 100.0;
-    const double flux_det = f_npp_det * npp_pi + f_plant_det * net_plant;
-    const double tau_det = flux_det > 1e-10 ? det_pi / flux_det : 3.0;
-    const double flux_soil = f_npp_soil * npp_pi + (1.0 - f_plant_det) * net_plant + f_det_soil * (det_pi / tau_det);
-    const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
-    const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
-    const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
-    const double r_tau_plant = guarded_rcp(tau_plant), r_tau_det = guarded_rcp(tau_det), r_tau_soil = guarded_rcp(tau_soil),
-                 r_tau_hum = guarded_rcp(tau_hum);
-    const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)a.rows * N;
-    a.status[i] = 0;
-    const size_t r0 = (size_t)a.step_begin * N + i;
-    double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];
-    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
-        const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double co2 = in.at(0, n), temperature = in.at(1, n), landuse = in.at(2, n);
-        const double fert = (!fert_on || co2 <= 0.0) ? 1.0 : fmax(1.0 + beta * log(co2 / co2_pi), 0.1);
-        auto tf = [&](double sens) -> double { return temp_on ? exp(sens * temperature) : 1.0; };
-        const double npp = npp_pi * fert * tf(npp_ts);
-        const double respiration = resp_pi * fert * tf(resp_ts);
-        const double tf_det = tf(det_ts), tf_soil = tf(soil_ts), tf_hum = tf(hum_ts);
-        double n_plant, to_plant, n_det, to_det, n_soil, to_soil, n_hum, to_hum;
-        implicit_pool_step(plant, r_tau_plant, npp * f_npp_plant - respiration - landuse, 1.0, dt, n_plant, to_plant);
-        implicit_pool_step(det, r_tau_det, npp * f_npp_det + f_plant_det * to_plant, tf_det, dt, n_det, to_det);
-        const double npp_to_soil = npp * f_npp_soil;
-        const double plant_to_soil = (1.0 - f_plant_det) * to_plant;
-        const double det_to_soil = f_det_soil * to_det;
-        implicit_pool_step(soil, r_tau_soil, npp_to_soil + plant_to_soil + det_to_soil, tf_soil, dt, n_soil, to_soil);
-        implicit_pool_step(hum, r_tau_hum, f_soil_hum * to_soil, tf_hum, dt, n_hum, to_hum);
-        const double det_to_atm = (1.0 - f_det_soil) * to_det;
-        const double soil_to_atm = (1.0 - f_soil_hum) * to_soil;
-        const double total_resp = respiration + det_to_atm + soil_to_atm + to_hum;
-        const size_t r = (size_t)(n + 1) * N + i;
-        a.series[r] = plant = n_plant;
-        a.series[vs + r] = det = n_det;
-        a.series[2 * vs + r] = soil = n_soil;
-        a.series[3 * vs + r] = hum = n_hum;
-        a.series[4 * vs + r] = npp - total_resp - landuse;
-    }
+    carbon::terrestrial_body<SRC>(a, i, a.step_begin, a.step_end);
 }
 
 }  // namespace

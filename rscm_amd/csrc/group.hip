@@ -1,0 +1,76 @@
+// Fused lock-step launches for graphs of linked ensembles (gfx950).
+//
+// Model::step walks the component graph (crates/rscm-core/src/model/runtime.rs:368-527); as linked
+// ensembles that is one launch per component and model step.  Most components of a MAGICC-style graph
+// are a few dozen operations per member and step -- chemistry, the forcing formulas, aggregates, grid
+// transforms -- and their launches are bound by the dependent-kernel boundary (~2 us each) and by the
+// tail of a grid that lives for 5-10 us, not by arithmetic or bandwidth.  This kernel runs a whole run
+// of consecutive such components of one model step in ONE launch: thread i executes, in graph order,
+// the per-member body of every op in the table for member i.
+//
+// Why that is the same computation: every edge of the graph is per member -- a linked input of member
+// i is row n or n+1 of the SAME member i of the producer (rscm_ens_link_input) -- so thread i reads
+// only what thread i wrote earlier in this launch (program order, same address, same work-item) or
+// what earlier launches wrote.  The bodies are the very functions the stand-alone kernels call
+// (*_body.hpp), instantiated with the same template arguments, so a fused step carries the bits of the
+// unfused one (tests/test_gpu_links.py, tests/test_gpu_group.py).
+//
+// The op table (kind + the argument struct each kernel would have received) sits in device memory; its
+// address is wave-uniform and the table is read-only for the launch, so the fields arrive through the
+// scalar cache.  Heavy components -- ClimateUDEB (two 50-layer columns in registers and LDS),
+// OceanCarbon (history convolution), HalocarbonChemistry (species-parallel grid) -- keep their own
+// launches; rscm_gpu.cpp cuts the step's component list into segments accordingly.
+#include "carbon_body.hpp"
+#include "chem_body.hpp"
+#include "ghg_body.hpp"
+#include "pointwise_body.hpp"
+#include "two_layer_body.hpp"
+
+namespace rscm {
+
+namespace {
+
+__global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members, int32_t step)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_members) return;
+    const int32_t b = step, e = step + 1;
+    for (int32_t k = 0; k < n_ops; ++k) {
+        const GroupOp& op = ops[k];
+        switch (op.kind) {
+            case 0:  // RSCM_KIND_TWO_LAYER (forcing through L2: a linked series or the scenario table)
+                if (op.variant == 0) tl::two_layer_body<0, false, true>(op.u.tl, nullptr, i, b, e);
+                else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, b, e);
+                break;
+            case 3:  // RSCM_KIND_GHG_FORCING, linked concentrations
+                if (op.variant == 0) ghg::ghg_body<0, false, true>(op.u.ghg, nullptr, i, b, e);
+                else ghg::ghg_body<1, false, true>(op.u.ghg, nullptr, i, b, e);
+                break;
+            case kKindOzoneForcing: pw::pointwise_body<kKindOzoneForcing, 2>(op.u.pw, i, b, e); break;
+            case kKindAerosolDirect: pw::pointwise_body<kKindAerosolDirect, 2>(op.u.pw, i, b, e); break;
+            case kKindAerosolIndirect: pw::pointwise_body<kKindAerosolIndirect, 2>(op.u.pw, i, b, e); break;
+            case kKindFourBoxOhu: pw::pointwise_body<kKindFourBoxOhu, 2>(op.u.pw, i, b, e); break;
+            case kKindOspp: pw::pointwise_body<kKindOspp, 2>(op.u.pw, i, b, e); break;
+            case kKindCo2Erf: pw::pointwise_body<kKindCo2Erf, 2>(op.u.pw, i, b, e); break;
+            case kKindAggregate: pw::pointwise_body<kKindAggregate, 2>(op.u.pw, i, b, e); break;
+            case kKindCh4Chemistry: chem::ch4_body<2>(op.u.chem, i, b, e); break;
+            case kKindN2oChemistry: chem::n2o_body<2>(op.u.chem, i, b, e); break;
+            case kKindCo2Budget: carbon::co2_budget_body<2>(op.u.carbon, i, b, e); break;
+            case kKindTerrestrialCarbon: carbon::terrestrial_body<2>(op.u.carbon, i, b, e); break;
+            case kKindCarbonCycle: carbon::carbon_cycle_body<2>(op.u.carbon, i, b, e); break;
+            default: break;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step, hipStream_t s)
+{
+    if (n_ops <= 0 || n_members <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(group_kernel, grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step);
+    return hipGetLastError();
+}
+
+}  // namespace rscm

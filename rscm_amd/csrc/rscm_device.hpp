@@ -333,6 +333,25 @@ struct LoglikArgs {
     double* out;                      // [N]
 };
 
+// One component of a fused lock-step launch (csrc/group.hip): the arguments its own kernel would get;
+// the step range comes with the launch.  The table of ops lives in device memory and is read with
+// scalar loads.
+struct GroupOp {
+    int32_t kind;      // RSCM_KIND_* of a kind the group kernel knows, -1: not fusable
+    int32_t variant;   // two-layer: arithmetic mode; GhgForcing: method
+    union Args {
+        TwoLayerArgs tl;
+        GhgArgs ghg;
+        PointwiseArgs pw;
+        ChemArgs chem;
+        CarbonArgs carbon;
+        Args() : pw() {}
+    } u;
+    GroupOp() : kind(-1), variant(0), u() {}
+};
+constexpr int kMaxGroupOps = 16;
+hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step, hipStream_t s);
+
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);

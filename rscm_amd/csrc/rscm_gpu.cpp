@@ -258,6 +258,18 @@ static_assert(rscm::kKindOzoneForcing == RSCM_KIND_OZONE_FORCING && rscm::kKindA
                   rscm::kKindCo2Erf == RSCM_KIND_CO2_ERF && rscm::kKindAggregate == RSCM_KIND_AGGREGATE,
               "rscm_device.hpp and include/rscm_gpu.h disagree on a kind value");
 
+// Cached state of rscm_ens_run_lockstep for one list of handles (kept by the first of them): the device
+// table of fused-launch operations (csrc/group.hip) and what it currently holds.
+struct LockstepPlan {
+    std::vector<rscm_ens*> handles;
+    rscm::GroupOp* d_ops = nullptr;          // [handles.size()]
+    std::vector<rscm::GroupOp> cached;       // the table's contents (step fields zeroed)
+    std::vector<uint8_t> valid;
+    rscm::GroupOp* staging = nullptr;        // page-locked ring the uploads are sourced from
+    int32_t ring_pos = 0;
+    static constexpr int32_t kRing = 128;
+};
+
 struct rscm_ens {
     int32_t kind = 0;
     int64_t N = 0;
@@ -332,6 +344,8 @@ struct rscm_ens {
     int32_t n_linked = 0;
     bool link_order_check = true;
     int32_t link_refs = 0;  // links of other ensembles into this one's series
+
+    LockstepPlan* plan = nullptr;  // rscm_ens_run_lockstep with this handle first
 
     int32_t time_index = 0;
     bool params_set = false, forcing_set = false;
@@ -816,6 +830,12 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_out4);
     (void)hipFree(h->d_loglik);
     (void)hipFree(h->d_obs);
+    if (h->plan) {
+        (void)hipFree(h->plan->d_ops);
+        if (h->plan->staging) (void)hipHostFree(h->plan->staging);
+        delete h->plan;
+        h->plan = nullptr;
+    }
     (void)hipFree(h->d_row0);
     (void)hipFree(h->d_out);
     (void)hipFree(h->d_out_vars);
@@ -1214,9 +1234,9 @@ int rscm_ens_rewind(rscm_ens* h)
     GUARD_END
 }
 
-// One launch of the kind's kernel over [step_begin, step_end).  `timed` brackets it with the events
-// rscm_ens_last_run_ms reads; the lock-step loop of rscm_ens_run_lockstep leaves them out.
-static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
+// ---- one launch range of one handle, in pieces (rscm_ens_run_lockstep fuses the launches of several handles) ----
+// (1) what must hold before anything is enqueued
+static int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     NEED(h);
     if (step_begin < 0 || step_end > h->T - 1 || step_begin > step_end)
@@ -1240,9 +1260,40 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
     for (int32_t v = 1; v < h->V; ++v)
         if (h->is_state(v) && !h->initial_set[v])  // builder.rs:704-717 MissingInitialValue
             return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
+    return RSCM_OK;
+}
+
+// (2) schedule tables and the handle's own window: room for the rows this range writes
+static int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end)
+{
+    const int32_t keep = h->keep_rows();
+    if (int rc = set_device(h)) return rc;
+    if (int rc = refresh_schedule(h)) return rc;
+    if (h->windowed && step_end > step_begin) {
+        if (step_begin == 0) {
+            if (h->win0 != 0)
+                if (int rc = window_reset(h, false)) return rc;
+            if (!h->row0_saved) {  // the initial rows, for rewind
+                HIPCHK(rscm::launch_gather_rows(h->d_series, h->N, h->rows, 0, nullptr, h->V - 1, h->d_row0, 1, 0, h->stream));
+                h->row0_saved = true;
+            }
+            if (int rc = window_store_row(h, 0)) return rc;
+        }
+        if (step_end >= h->win0 + h->rows)
+            if (int rc = window_slide(h, step_begin - keep + 1)) return rc;
+        // the links of h were resolved against the producers' windows above; h's own base moved with the slide
+    }
+
+    return RSCM_OK;
+}
+
+// (3) the producing ensembles' series as they stand now (after every window of the graph has been moved)
+static int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out)
+{
     // linked inputs: the producing ensembles' series, in launch order on one stream
-    rscm::InputLinks links{};
+    links = rscm::InputLinks{};
     const int32_t linked = h->n_linked > 0 ? 1 : 0;
+    linked_out = linked;
     for (int32_t k = 0; k < rscm::kMaxLinks && k < h->n_inputs; ++k) {
         const auto& l = h->links[k];
         if (!l.src) continue;
@@ -1264,26 +1315,16 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         links.row[k] = l.src->series(l.var);
         links.off[k] = h->kind == RSCM_KIND_AGGREGATE ? 0 : l.off;
     }
-    if (int rc = set_device(h)) return rc;
-    if (int rc = refresh_schedule(h)) return rc;
-    if (h->windowed && step_end > step_begin) {
-        if (step_begin == 0) {
-            if (h->win0 != 0)
-                if (int rc = window_reset(h, false)) return rc;
-            if (!h->row0_saved) {  // the initial rows, for rewind
-                HIPCHK(rscm::launch_gather_rows(h->d_series, h->N, h->rows, 0, nullptr, h->V - 1, h->d_row0, 1, 0, h->stream));
-                h->row0_saved = true;
-            }
-            if (int rc = window_store_row(h, 0)) return rc;
-        }
-        if (step_end >= h->win0 + h->rows)
-            if (int rc = window_slide(h, step_begin - keep + 1)) return rc;
-        // the links of h were resolved against the producers' windows above; h's own base moved with the slide
-    }
+    return RSCM_OK;
+}
 
+// (4) the launch itself -- or, with op_out, its arguments for the group kernel (csrc/group.hip) if the kind can
+// be fused with its neighbours (op_out->kind = -1 otherwise; nothing is launched either way)
+static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
+                       rscm::GroupOp* op_out)
+{
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
-    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (h->kind == RSCM_KIND_TWO_LAYER) {
         rscm::TwoLayerArgs a{};
         a.n_members = h->N;
@@ -1307,6 +1348,14 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.ts = h->series(RSCM_TL_VAR_TS);
         a.td = h->series(RSCM_TL_VAR_TD);
         a.status = h->d_status;
+        if (op_out && (true)) {
+            a.lds_forcing = 0;
+            op_out->kind = h->kind;
+            op_out->variant = h->mode;
+            op_out->u.tl = a;
+            return RSCM_OK;
+        }
+        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
     } else if (h->kind == RSCM_KIND_GHG_FORCING) {
         rscm::GhgArgs a{};
@@ -1326,6 +1375,13 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.erf_ch4 = h->series(RSCM_GH_VAR_ERF_CH4);
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
         a.status = h->d_status;
+        if (op_out && (linked)) {
+            op_out->kind = h->kind;
+            op_out->variant = h->ghg_method;
+            op_out->u.ghg = a;
+            return RSCM_OK;
+        }
+        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_ghg(a, h->stream));
     } else if (h->kind == RSCM_KIND_HALOCARBON) {
         rscm::HaloArgs a{};
@@ -1340,6 +1396,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
+        if (op_out) { op_out->kind = -1; return RSCM_OK; }
         HIPCHK(rscm::launch_halocarbon(a, h->stream));
     } else if (h->kind == RSCM_KIND_OCEAN_CARBON) {
         if (!h->ocean_ready) return fail(RSCM_ERR_STATE, "OceanCarbon parameters not configured");
@@ -1395,6 +1452,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
+        if (op_out) { op_out->kind = -1; return RSCM_OK; }
         HIPCHK(rscm::launch_ocean(a, h->stream));
     } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON || h->kind == RSCM_KIND_CARBON_CYCLE) {
         rscm::CarbonArgs a{};
@@ -1414,6 +1472,13 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
+        if (op_out && (true)) {
+            op_out->kind = h->kind;
+            op_out->variant = 0;
+            op_out->u.carbon = a;
+            return RSCM_OK;
+        }
+        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_carbon(a, h->stream));
     } else if (h->kind == RSCM_KIND_CH4_CHEMISTRY || h->kind == RSCM_KIND_N2O_CHEMISTRY) {
         rscm::ChemArgs a{};
@@ -1431,6 +1496,13 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.conc = h->series(RSCM_CHEM_VAR_CONC);
         a.lifetime = h->series(RSCM_CHEM_VAR_LIFETIME);
         a.status = h->d_status;
+        if (op_out && (true)) {
+            op_out->kind = h->kind;
+            op_out->variant = 0;
+            op_out->u.chem = a;
+            return RSCM_OK;
+        }
+        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_chem(a, h->stream));
     } else if ((h->kind >= RSCM_KIND_OZONE_FORCING && h->kind <= RSCM_KIND_AEROSOL_INDIRECT) ||
                h->kind == RSCM_KIND_FOURBOX_OHU || h->kind == RSCM_KIND_OSPP || h->kind == RSCM_KIND_CO2_ERF ||
@@ -1449,6 +1521,13 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.linked = linked;
         a.out = h->series(1);
         a.status = h->d_status;
+        if (op_out && (true)) {
+            op_out->kind = h->kind;
+            op_out->variant = 0;
+            op_out->u.pw = a;
+            return RSCM_OK;
+        }
+        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_pointwise(a, h->stream));
     } else if (h->kind == RSCM_KIND_UDEB) {
         if (!h->udeb_ready) return fail(RSCM_ERR_STATE, "ClimateUDEB parameters not configured");
@@ -1482,6 +1561,7 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.ohc = h->series(RSCM_UD_VAR_OHC);
         a.sst = h->series(RSCM_UD_VAR_SST);
         a.status = h->d_status;
+        if (op_out) { op_out->kind = -1; return RSCM_OK; }
         HIPCHK(rscm::launch_udeb(a, h->stream));
     } else {
         rscm::CoupledArgs a{};
@@ -1506,8 +1586,16 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         a.erf_co2 = h->series(RSCM_CP_VAR_ERF_CO2);
         a.erf_total = h->series(RSCM_CP_VAR_ERF);
         a.status = h->d_status;
+        if (op_out) { op_out->kind = -1; return RSCM_OK; }
         HIPCHK(rscm::launch_coupled(a, h->mode, h->stream));
     }
+    return RSCM_OK;
+}
+
+// (5) bookkeeping after the launch: time index, strided outputs, room for the next step
+static int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end)
+{
+    const int32_t keep = h->keep_rows();
     h->time_index = step_end;
     if (h->windowed && step_end > step_begin) {
         if (h->n_out > 0)
@@ -1518,6 +1606,22 @@ static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool tim
         if (step_end + 1 >= h->win0 + h->rows && step_end < h->T - 1)
             if (int rc = window_slide(h, step_end - keep + 1)) return rc;
     }
+    return RSCM_OK;
+}
+
+// One launch of the kind's kernel over [step_begin, step_end).  `timed` brackets it with the events
+// rscm_ens_last_run_ms reads; the lock-step loop of rscm_ens_run_lockstep leaves them out.
+static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
+{
+    NEED(h);
+    if (int rc = step_check(h, step_begin, step_end)) return rc;
+    if (int rc = step_window_pre(h, step_begin, step_end)) return rc;
+    rscm::InputLinks links{};
+    int32_t linked = 0;
+    if (int rc = step_links(h, step_begin, step_end, links, linked)) return rc;
+    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (int rc = step_launch(h, step_begin, step_end, links, linked, nullptr)) return rc;
+    if (int rc = step_finish(h, step_begin, step_end)) return rc;
     if (timed) {
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
@@ -1569,6 +1673,91 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
     GUARD_END
 }
 
+static bool g_fuse_lockstep = true;
+static int64_t g_lockstep_launches = 0, g_lockstep_component_steps = 0;  // since the last rscm_gpu_lockstep_stats
+
+int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
+{
+    if (launches) *launches = g_lockstep_launches;
+    if (component_steps) *component_steps = g_lockstep_component_steps;
+    g_lockstep_launches = g_lockstep_component_steps = 0;
+    return RSCM_OK;
+}
+
+int rscm_gpu_set_lockstep_fusion(int32_t enabled)
+{
+    g_fuse_lockstep = enabled != 0;
+    return RSCM_OK;
+}
+
+// Kinds whose one-step launch the group kernel can absorb (csrc/group.hip): the light per-member
+// components.  ClimateUDEB, OceanCarbon, HalocarbonChemistry and the fused coupled chain keep their own
+// launches; GhgForcing joins only with linked concentrations (its table path uses host-built rows).
+static bool fusable(const rscm_ens* h)
+{
+    switch (h->kind) {
+        case RSCM_KIND_TWO_LAYER: case RSCM_KIND_OZONE_FORCING: case RSCM_KIND_AEROSOL_DIRECT: case RSCM_KIND_AEROSOL_INDIRECT:
+        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON:
+        case RSCM_KIND_FOURBOX_OHU: case RSCM_KIND_OSPP: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE:
+            return true;
+        case RSCM_KIND_GHG_FORCING: return h->n_linked > 0;
+        default: return false;
+    }
+}
+
+// the step range is an argument of the fused launch, not part of the table
+static void clear_step_fields(rscm::GroupOp& op)
+{
+    switch (op.kind) {
+        case RSCM_KIND_TWO_LAYER: op.u.tl.step_begin = op.u.tl.step_end = 0; break;
+        case RSCM_KIND_GHG_FORCING: op.u.ghg.step_begin = op.u.ghg.step_end = 0; break;
+        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: op.u.chem.step_begin = op.u.chem.step_end = 0; break;
+        case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON: case RSCM_KIND_CARBON_CYCLE:
+            op.u.carbon.step_begin = op.u.carbon.step_end = 0; break;
+        default: op.u.pw.step_begin = op.u.pw.step_end = 0; break;
+    }
+}
+
+// One model step of handles [first, first + count) of the plan as ONE launch.
+static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n)
+{
+    rscm_ens* lead = plan->handles[first];
+    for (int32_t k = first; k < first + count; ++k) {
+        rscm_ens* h = plan->handles[k];
+        if (int rc = step_check(h, n, n + 1)) return rc;
+        if (int rc = step_window_pre(h, n, n + 1)) return rc;
+    }
+    for (int32_t k = first; k < first + count; ++k) {
+        rscm_ens* h = plan->handles[k];
+        rscm::InputLinks links{};
+        int32_t linked = 0;
+        if (int rc = step_links(h, n, n + 1, links, linked)) return rc;
+        rscm::GroupOp op;
+        memset((void*)&op, 0, sizeof op);
+        if (int rc = step_launch(h, n, n + 1, links, linked, &op)) return rc;
+        if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", k, h->kind);
+        clear_step_fields(op);
+        if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
+            if (plan->ring_pos == LockstepPlan::kRing) {  // every slot may still be the source of a queued copy
+                HIPCHK(hipStreamSynchronize(lead->stream));
+                plan->ring_pos = 0;
+            }
+            rscm::GroupOp* slot = plan->staging + plan->ring_pos++;
+            memcpy((void*)slot, &op, sizeof op);
+            HIPCHK(hipMemcpyAsync(plan->d_ops + k, slot, sizeof op, hipMemcpyHostToDevice, lead->stream));
+            memcpy((void*)&plan->cached[k], &op, sizeof op);
+            plan->valid[k] = 1;
+        }
+        h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
+    }
+    HIPCHK(rscm::launch_group(plan->d_ops + first, count, lead->N, n, lead->stream));
+    for (int32_t k = first; k < first + count; ++k) {
+        plan->handles[k]->time_index = n;
+        if (int rc = step_finish(plan->handles[k], n, n + 1)) return rc;
+    }
+    return RSCM_OK;
+}
+
 int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end)
 {
     GUARD_BEGIN
@@ -1580,9 +1769,49 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
         if (handles[k]->time_index != step_begin)
             return fail(RSCM_ERR_STATE, "handle %d is at time index %d, not at step_begin %d", k, handles[k]->time_index, step_begin);
     }
+    // Consecutive fusable components become one launch per step (csrc/group.hip); the others, and
+    // fusable ones on their own, keep their kernels.
+    std::vector<std::pair<int32_t, int32_t>> segments;  // (first, count)
+    for (int32_t k = 0; k < n_handles;) {
+        int32_t c = 1;
+        if (g_fuse_lockstep && fusable(handles[k]))
+            while (k + c < n_handles && c < rscm::kMaxGroupOps && fusable(handles[k + c]) && handles[k + c]->N == handles[k]->N &&
+                   handles[k + c]->device == handles[k]->device)
+                ++c;
+        segments.emplace_back(k, c);
+        k += c;
+    }
+    bool any_fused = false;
+    for (const auto& sgm : segments) any_fused = any_fused || sgm.second > 1;
+    LockstepPlan* plan = nullptr;
+    if (any_fused) {
+        rscm_ens* lead = handles[0];
+        if (int rc = set_device(lead)) return rc;
+        plan = lead->plan;
+        const std::vector<rscm_ens*> list(handles, handles + n_handles);
+        if (!plan || plan->handles != list) {
+            if (!plan) plan = lead->plan = new LockstepPlan();
+            HIPCHK(hipStreamSynchronize(lead->stream));
+            HIPCHK(hipFree(plan->d_ops));
+            plan->d_ops = nullptr;
+            plan->handles = list;
+            plan->cached.assign((size_t)n_handles, rscm::GroupOp());
+            plan->valid.assign((size_t)n_handles, 0);
+            plan->ring_pos = 0;
+            HIPCHK(hipMalloc(&plan->d_ops, (size_t)n_handles * sizeof(rscm::GroupOp)));
+            if (!plan->staging) HIPCHK(hipHostMalloc((void**)&plan->staging, LockstepPlan::kRing * sizeof(rscm::GroupOp), hipHostMallocDefault));
+        }
+    }
     for (int32_t n = step_begin; n < step_end; ++n)
-        for (int32_t k = 0; k < n_handles; ++k)
-            if (int rc = run_range(handles[k], n, n + 1, false)) return rc;
+        for (const auto& sgm : segments) {
+            g_lockstep_launches += 1;
+            g_lockstep_component_steps += sgm.second;
+            if (sgm.second > 1) {
+                if (int rc = fused_segment(plan, sgm.first, sgm.second, n)) return rc;
+            } else if (int rc = run_range(handles[sgm.first], n, n + 1, false)) {
+                return rc;
+            }
+        }
     return RSCM_OK;
     GUARD_END
 }

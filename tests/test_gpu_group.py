@@ -1,0 +1,174 @@
+"""Fused lock-step launches (csrc/group.hip, rscm_gpu_set_lockstep_fusion): consecutive light components of
+a model step run in one launch, every thread executing the components' per-member bodies in graph order.
+Model::step (crates/rscm-core/src/model/runtime.rs:368-527) walks the same components one after the other;
+every graph edge is per member, so the fused step must carry the bits of the unfused one -- checked here for
+the coupled chain (against the fused coupled KERNEL as well), the MAGICC graph in both execution orders, a
+windowed graph, and graphs stepped one step at a time."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import assert_bit_equal, axis_values, coupled_params, emissions_syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rscm_amd
+    from rscm_amd import _lib
+    _lib.load()
+    assert _lib.device_count() >= 1
+    return rscm_amd
+
+
+def _fusion(on: bool):
+    from rscm_amd import _lib as L
+    L.check(L.load().rscm_gpu_set_lockstep_fusion(1 if on else 0))
+
+
+def _stats():
+    from rscm_amd import _lib as L
+    a, b = C.c_int64(), C.c_int64()
+    L.check(L.load().rscm_gpu_lockstep_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def _chain():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench_magicc_chain", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "bench_magicc_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(autouse=True)
+def _fusion_back_on():
+    yield
+    _fusion(True)
+
+
+def test_fused_coupled_chain_is_one_launch_per_step_and_keeps_the_bits(ra):
+    from rscm_amd import _lib as L
+    from rscm_amd.ensemble import run_lockstep
+    t = axis_values(1750, 1950)
+    b = np.append(t, t[-1] + 1.0)
+    T, n = len(t), 1000
+    P, E = coupled_params(n), emissions_syn(t)
+    with ra.Ensemble(ra.KIND_COUPLED, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(E)
+        for v, x in ((1, 0.0), (2, 0.0), (3, 278.0), (4, 0.0), (5, 0.0)):
+            e.set_initial(v, x)
+        e.run()
+        want = {v: e.get_series(v) for v in range(1, 8)}
+    stream = C.c_void_p()
+    L.check(L.load().rscm_gpu_stream_create(0, C.byref(stream)))
+    cc, ce, ag, tl = (ra.Ensemble(k, n, b) for k in (ra.KIND_CARBON_CYCLE, ra.KIND_CO2_ERF, ra.KIND_AGGREGATE, ra.KIND_TWO_LAYER))
+    try:
+        for x in (cc, ce, ag, tl):
+            x.set_stream(stream.value)
+        cc.set_params(P[[6, 7, 8]])
+        ce.set_params(P[[9, 7]])
+        ag.set_params(np.zeros((9, n)))
+        tl.set_params(P[:6])
+        cc.set_forcing(np.stack([E, np.full(T, np.nan)]))
+        for v, x in ((1, 278.0), (2, 0.0), (3, 0.0)):
+            cc.set_initial(v, x)
+        tl.set_initial(1, 0.0)
+        tl.set_initial(2, 0.0)
+        cc.link_input(1, tl, 1, ra.SRC_EXOGENOUS)
+        ce.link_input(0, cc, 1, ra.SRC_UPSTREAM)
+        ag.link_input(0, ce, 1, ra.SRC_UPSTREAM)
+        tl.link_input(0, ag, 1, ra.SRC_UPSTREAM)
+
+        def collect():
+            return {1: tl.get_series(1), 2: tl.get_series(2), 3: cc.get_series(1), 4: cc.get_series(2), 5: cc.get_series(3),
+                    6: ce.get_series(1), 7: ag.get_series(1)}
+        _stats()
+        _fusion(True)
+        run_lockstep((cc, ce, ag, tl))
+        launches, steps = _stats()
+        assert (launches, steps) == (T - 1, 4 * (T - 1))     # one launch per model step carries all four components
+        fused = collect()
+        for v in range(1, 8):
+            assert_bit_equal(fused[v], want[v], f"fused lock-step vs the coupled kernel: variable {v}")
+        for x in (cc, ce, ag, tl):
+            x.clear_series()
+        _fusion(False)
+        run_lockstep((cc, ce, ag, tl))
+        assert _stats() == (4 * (T - 1), 4 * (T - 1))
+        plain = collect()
+        for v in range(1, 8):
+            assert_bit_equal(plain[v], fused[v], f"unfused vs fused: variable {v}")
+        # fused again, in pieces, with single ensembles stepped by hand in between (the cached table must follow)
+        for x in (cc, ce, ag, tl):
+            x.clear_series()
+        _fusion(True)
+        run_lockstep((cc, ce, ag, tl), 7)
+        for x in (cc, ce, ag, tl):
+            x.run(8)
+        run_lockstep((cc, ce, ag, tl), 100)
+        tl.set_mode(ra.MODE_EXACT)
+        run_lockstep((cc, ce, ag, tl))
+        again = collect()
+        for v in range(1, 8):
+            assert_bit_equal(again[v], fused[v], f"fused in pieces: variable {v}")
+    finally:
+        cc.unlink_input(1)
+        for x in (tl, ag, ce, cc):
+            x.close()
+        L.check(L.load().rscm_gpu_stream_destroy(0, stream))
+
+
+@pytest.mark.parametrize("execution_order", ["reference", "topological"])
+def test_fused_magicc_graph_keeps_the_bits(ra, execution_order):
+    mod = _chain()
+    years, N = 60, 200
+    _fusion(False)
+    plain = mod.build_chain(N, years, execution_order)
+    _stats()
+    plain.run()
+    unfused_launches, comp_steps = _stats()
+    assert unfused_launches == comp_steps == len(plain._order) * years
+    _fusion(True)
+    fused = mod.build_chain(N, years, execution_order)
+    fused.run()
+    launches, steps = _stats()
+    assert steps == comp_steps
+    per_step = launches / years
+    print(f"{execution_order}: {len(plain._order)} components per step in {per_step:.0f} launches; order {fused._order}")
+    assert per_step <= 6
+    for name in plain._var_home:
+        if name == "Surface Temperature":
+            continue
+        assert_bit_equal(fused.get_series(name), plain.get_series(name), f"{execution_order}: {name}")
+    for v in range(1, 5):
+        assert_bit_equal(fused.ensembles["ClimateUDEB"].get_series(v), plain.ensembles["ClimateUDEB"].get_series(v), f"box {v}")
+    # step by step (Model::step) goes through the same fused launches
+    fused.rewind()
+    for _ in range(years):
+        fused.step()
+    for name in ("Atmospheric Concentration|CO2", "Effective Radiative Forcing", "Sea Surface Temperature", "Atmospheric Concentration|CH4"):
+        assert_bit_equal(fused.get_series(name), plain.get_series(name), f"stepwise {name}")
+    plain.close()
+    fused.close()
+
+
+def test_fused_windowed_graph_keeps_the_bits(ra):
+    mod = _chain()
+    years, N = 70, 128
+    _fusion(False)
+    plain = mod.build_chain(N, years, "reference")
+    plain.run()
+    _fusion(True)
+    win = mod.build_chain(N, years, "reference", series_window=8, output_stride=5)
+    win.run()
+    for name in plain._var_home:
+        if name != "Surface Temperature":
+            assert_bit_equal(win.get_series(name, t_stride=5), plain.get_series(name)[::5], name)
+    plain.close()
+    win.close()
