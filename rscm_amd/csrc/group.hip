@@ -30,11 +30,20 @@ namespace rscm {
 
 namespace {
 
-__global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members, int32_t step)
+// FULL = false leaves out the register-hungry bodies (TerrestrialCarbon 134 VGPRs, CH4 110, GhgForcing 102,
+// OzoneForcing 101, AerosolDirect 92, N2O 87): a segment made of box models, CO2ERF, budgets, aggregates and
+// grid transforms only then runs at <= 80 registers, i.e. six wavefronts per SIMD instead of three -- these
+// launches wait on four dependent memory round trips per step and need the occupancy to hide them.
+template <bool FULL>
+__global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members, int32_t step_begin,
+                                                       int32_t step_end)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_members) return;
-    const int32_t b = step, e = step + 1;
+    // Several model steps in one launch when the table is the WHOLE graph (no heavy component in between):
+    // step after step, component after component, as Model::run does -- the waves never drain between steps.
+    for (int32_t b = step_begin; b < step_end; ++b) {
+    const int32_t e = b + 1;
     for (int32_t k = 0; k < n_ops; ++k) {
         const GroupOp& op = ops[k];
         switch (op.kind) {
@@ -43,33 +52,48 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict
                 else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, b, e);
                 break;
             case 3:  // RSCM_KIND_GHG_FORCING, linked concentrations
-                if (op.variant == 0) ghg::ghg_body<0, false, true>(op.u.ghg, nullptr, i, b, e);
-                else ghg::ghg_body<1, false, true>(op.u.ghg, nullptr, i, b, e);
+                if constexpr (FULL) {
+                    if (op.variant == 0) ghg::ghg_body<0, false, true>(op.u.ghg, nullptr, i, b, e);
+                    else ghg::ghg_body<1, false, true>(op.u.ghg, nullptr, i, b, e);
+                }
                 break;
-            case kKindOzoneForcing: pw::pointwise_body<kKindOzoneForcing, 2>(op.u.pw, i, b, e); break;
-            case kKindAerosolDirect: pw::pointwise_body<kKindAerosolDirect, 2>(op.u.pw, i, b, e); break;
+            case kKindOzoneForcing: if constexpr (FULL) pw::pointwise_body<kKindOzoneForcing, 2>(op.u.pw, i, b, e); break;
+            case kKindAerosolDirect: if constexpr (FULL) pw::pointwise_body<kKindAerosolDirect, 2>(op.u.pw, i, b, e); break;
             case kKindAerosolIndirect: pw::pointwise_body<kKindAerosolIndirect, 2>(op.u.pw, i, b, e); break;
             case kKindFourBoxOhu: pw::pointwise_body<kKindFourBoxOhu, 2>(op.u.pw, i, b, e); break;
             case kKindOspp: pw::pointwise_body<kKindOspp, 2>(op.u.pw, i, b, e); break;
             case kKindCo2Erf: pw::pointwise_body<kKindCo2Erf, 2>(op.u.pw, i, b, e); break;
             case kKindAggregate: pw::pointwise_body<kKindAggregate, 2>(op.u.pw, i, b, e); break;
-            case kKindCh4Chemistry: chem::ch4_body<2>(op.u.chem, i, b, e); break;
-            case kKindN2oChemistry: chem::n2o_body<2>(op.u.chem, i, b, e); break;
+            case kKindCh4Chemistry: if constexpr (FULL) chem::ch4_body<2>(op.u.chem, i, b, e); break;
+            case kKindN2oChemistry: if constexpr (FULL) chem::n2o_body<2>(op.u.chem, i, b, e); break;
             case kKindCo2Budget: carbon::co2_budget_body<2>(op.u.carbon, i, b, e); break;
-            case kKindTerrestrialCarbon: carbon::terrestrial_body<2>(op.u.carbon, i, b, e); break;
+            case kKindTerrestrialCarbon: if constexpr (FULL) carbon::terrestrial_body<2>(op.u.carbon, i, b, e); break;
             case kKindCarbonCycle: carbon::carbon_cycle_body<2>(op.u.carbon, i, b, e); break;
             default: break;
         }
+    }
     }
 }
 
 }  // namespace
 
-hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step, hipStream_t s)
+bool group_kind_is_small(int32_t kind)
 {
-    if (n_ops <= 0 || n_members <= 0) return hipSuccess;
+    switch (kind) {
+        case 0: case kKindAerosolIndirect: case kKindFourBoxOhu: case kKindOspp: case kKindCo2Erf: case kKindAggregate:
+        case kKindCo2Budget: case kKindCarbonCycle:
+            return true;
+        default: return false;
+    }
+}
+
+hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, bool all_small,
+                        hipStream_t s)
+{
+    if (n_ops <= 0 || n_members <= 0 || step_end <= step_begin) return hipSuccess;
     const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(group_kernel, grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step);
+    if (all_small) hipLaunchKernelGGL((group_kernel<false>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
+    else hipLaunchKernelGGL((group_kernel<true>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
     return hipGetLastError();
 }
 

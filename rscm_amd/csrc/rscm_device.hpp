@@ -350,7 +350,10 @@ struct GroupOp {
     GroupOp() : kind(-1), variant(0), u() {}
 };
 constexpr int kMaxGroupOps = 16;
-hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step, hipStream_t s);
+// all_small: every op is one of the kinds group_kind_is_small accepts (the low-register variant of the kernel)
+bool group_kind_is_small(int32_t kind);
+hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, bool all_small,
+                        hipStream_t s);
 
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);

@@ -1718,14 +1718,15 @@ static void clear_step_fields(rscm::GroupOp& op)
     }
 }
 
-// One model step of handles [first, first + count) of the plan as ONE launch.
-static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n)
+// Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
+// the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
+static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
 {
     rscm_ens* lead = plan->handles[first];
     for (int32_t k = first; k < first + count; ++k) {
         rscm_ens* h = plan->handles[k];
-        if (int rc = step_check(h, n, n + 1)) return rc;
-        if (int rc = step_window_pre(h, n, n + 1)) return rc;
+        if (int rc = step_check(h, n, n + len)) return rc;
+        if (int rc = step_window_pre(h, n, n + len)) return rc;
     }
     for (int32_t k = first; k < first + count; ++k) {
         rscm_ens* h = plan->handles[k];
@@ -1750,11 +1751,11 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         }
         h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
     }
-    HIPCHK(rscm::launch_group(plan->d_ops + first, count, lead->N, n, lead->stream));
-    for (int32_t k = first; k < first + count; ++k) {
-        plan->handles[k]->time_index = n;
-        if (int rc = step_finish(plan->handles[k], n, n + 1)) return rc;
-    }
+    bool all_small = true;
+    for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
+    HIPCHK(rscm::launch_group(plan->d_ops + first, count, lead->N, n, n + len, all_small, lead->stream));
+    for (int32_t k = first; k < first + count; ++k)
+        if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
     return RSCM_OK;
 }
 
@@ -1802,12 +1803,28 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
             if (!plan->staging) HIPCHK(hipHostMalloc((void**)&plan->staging, LockstepPlan::kRing * sizeof(rscm::GroupOp), hipHostMallocDefault));
         }
     }
+    if (segments.size() == 1 && segments[0].second > 1) {
+        // The whole graph is one fused segment: many model steps per launch.  A chunk ends where a windowed
+        // handle runs out of rows (its window slides between launches).
+        for (int32_t n = step_begin; n < step_end;) {
+            int32_t len = step_end - n;
+            for (int32_t k = 0; k < n_handles; ++k) {
+                const rscm_ens* h = handles[k];
+                if (h->windowed) len = std::min(len, std::max(1, h->rows - h->keep_rows()));
+            }
+            g_lockstep_launches += 1;
+            g_lockstep_component_steps += (int64_t)n_handles * len;
+            if (int rc = fused_segment(plan, 0, n_handles, n, len)) return rc;
+            n += len;
+        }
+        return RSCM_OK;
+    }
     for (int32_t n = step_begin; n < step_end; ++n)
         for (const auto& sgm : segments) {
             g_lockstep_launches += 1;
             g_lockstep_component_steps += sgm.second;
             if (sgm.second > 1) {
-                if (int rc = fused_segment(plan, sgm.first, sgm.second, n)) return rc;
+                if (int rc = fused_segment(plan, sgm.first, sgm.second, n, 1)) return rc;
             } else if (int rc = run_range(handles[sgm.first], n, n + 1, false)) {
                 return rc;
             }

@@ -1,6 +1,10 @@
 """Linked-ensemble graphs against the fused kernel (run on the GPU box): the coupled chain
 CarbonCycle -> CO2ERF -> Sum -> TwoLayer assembled from four linked ensembles and stepped in
-lock-step (four launches per model step), beside RSCM_KIND_COUPLED (one launch for the whole run)."""
+lock-step, beside RSCM_KIND_COUPLED (one launch for the whole run).  The four components are light,
+so rscm_ens_run_lockstep fuses them into one group launch (csrc/group.hip) that covers every step;
+`--unfused` issues four launches per model step instead.
+
+    python scripts/bench_graph.py [members ...] [--unfused]"""
 import ctypes as C
 import os
 import sys
@@ -19,7 +23,10 @@ b = np.append(t, t[-1] + 1.0)
 E = emissions_syn(t)
 INIT = (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0), ("Cumulative Emissions|CO2", 0.0))
 
-for N in (100_000, 1_000_000):
+ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
+if "--unfused" in sys.argv:
+    L.check(L.load().rscm_gpu_set_lockstep_fusion(0))
+for N in ([int(a) for a in ARGS] or [100_000, 1_000_000]):
     P = coupled_params(N)
     with ra.Ensemble(ra.KIND_COUPLED, N, b) as f:
         f.set_params(P)
@@ -56,9 +63,11 @@ for N in (100_000, 1_000_000):
         best = min(best, time.perf_counter() - t0)
     same = np.array_equal(tl.get_series(1, 750, 751), ts_fused, equal_nan=True)
     my = N * 750
+    nl, ns = C.c_int64(), C.c_int64()
+    L.check(L.load().rscm_gpu_lockstep_stats(C.byref(nl), C.byref(ns)))
     print(f"N={N}: fused coupled kernel {fused*1e3:.1f} ms ({my/fused:.3g} member-years/s); "
           f"four linked ensembles in lock-step {best*1e3:.1f} ms ({my/best:.3g} member-years/s, "
-          f"{3000/best/1e3:.0f}k launches/s); same bits: {same}", flush=True)
+          f"{nl.value // 3} launch(es) per run); same bits: {same}", flush=True)
     cc.unlink_input(1)
     for e in (tl, ag, ce, cc):
         e.close()

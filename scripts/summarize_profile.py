@@ -21,7 +21,7 @@ for f in glob.glob(f"{d}/trace/runc/*_kernel_stats.csv"):
         if any(k in r["Name"] for k in ("two_layer_kernel", "coupled_kernel", "udeb_kernel", "ghg_kernel", "ocean_kernel", "ocean_recur_kernel", "group_kernel")):
             avg_ns = float(r["AverageNs"])
 lines += ["", "## driver output under --kernel-trace (HIP events on the launch stream)"]
-lines += [l for l in open(f"{d}/trace.log").read().splitlines() if l.startswith(("kind=", "member-years"))]
+lines += [l for l in open(f"{d}/trace.log").read().splitlines() if l.startswith(("kind=", "member-years", "N="))]
 C = {}
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     fs = glob.glob(f"{d}/{sub}/runc/*_counter_collection.csv")

@@ -51,7 +51,7 @@ def _fusion_back_on():
     _fusion(True)
 
 
-def test_fused_coupled_chain_is_one_launch_per_step_and_keeps_the_bits(ra):
+def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra):
     from rscm_amd import _lib as L
     from rscm_amd.ensemble import run_lockstep
     t = axis_values(1750, 1950)
@@ -92,7 +92,8 @@ def test_fused_coupled_chain_is_one_launch_per_step_and_keeps_the_bits(ra):
         _fusion(True)
         run_lockstep((cc, ce, ag, tl))
         launches, steps = _stats()
-        assert (launches, steps) == (T - 1, 4 * (T - 1))     # one launch per model step carries all four components
+        # the whole graph is light: ONE launch carries all four components through all steps
+        assert (launches, steps) == (1, 4 * (T - 1))
         fused = collect()
         for v in range(1, 8):
             assert_bit_equal(fused[v], want[v], f"fused lock-step vs the coupled kernel: variable {v}")
