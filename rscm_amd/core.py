@@ -768,17 +768,44 @@ class ModelBuilder:
                             model._fourbox[name] = (comp.type_name, fb[1], stored_scalar)
                             continue
                         var_home[name] = (comp.type_name, ens.var_ids[name])
+            # An aggregate ensemble takes eight contributors.  More are folded left to right through
+            # partial-sum stages -- stage k adds up to seven further contributors to the partial of stage
+            # k-1 -- which keeps compute_aggregate's order of additions (schema.rs:760-802: one running sum
+            # over the contributors in declaration order, NaN skipped, all-NaN -> NaN), so the result
+            # carries the same bits.  Weighted: the partial enters the next stage with weight 1.  Mean would
+            # need the count of non-NaN contributors carried along and is limited to eight.
+            agg_stages: Dict[str, List[Tuple[str, List[str]]]] = {}
             for agg, (_, op, contributors, weights) in aggregates.items():
-                if len(contributors) > L.AG_NINPUTS:
-                    raise NotImplementedError(f"aggregate {agg!r}: more than {L.AG_NINPUTS} contributors")
-                ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
-                               window_rows=series_window if windowed else None,
-                               output_stride=output_stride if (want_out is None or agg in want_out) else 0)
-                ensembles[f"Aggregator:{agg}"] = ens
-                ens.set_stream(stream.value)
-                w = list(weights or []) + [0.0] * (L.AG_NINPUTS - len(weights or []))
-                ens.set_params(params_of([L.AG_OPERATIONS[op]] + w))
-                var_home[agg] = (f"Aggregator:{agg}", 1)
+                contributors = list(contributors)
+                wts = list(weights or [])
+                if len(contributors) > L.AG_NINPUTS and op == "Mean":
+                    raise NotImplementedError(f"aggregate {agg!r}: a Mean of more than {L.AG_NINPUTS} contributors")
+                stages, k = [], 0
+                while True:
+                    first = not stages
+                    take = L.AG_NINPUTS if first else L.AG_NINPUTS - 1
+                    last = len(contributors) - k <= take
+                    chunk = contributors[k:k + take]
+                    wchunk = wts[k:k + take] if wts else []
+                    k += len(chunk)
+                    name = f"Aggregator:{agg}" if last else f"Aggregator:{agg}#{len(stages)}"
+                    rows = chunk if first else [f"{agg}#partial{len(stages) - 1}"] + chunk
+                    wrow = wchunk if first else [1.0] + wchunk
+                    ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
+                                   window_rows=series_window if windowed else None,
+                                   output_stride=output_stride if (last and (want_out is None or agg in want_out)) else 0)
+                    ensembles[name] = ens
+                    ens.set_stream(stream.value)
+                    w = list(wrow) + [0.0] * (L.AG_NINPUTS - len(wrow))
+                    ens.set_params(params_of([L.AG_OPERATIONS[op]] + w))
+                    var_home[agg if last else f"{agg}#partial{len(stages)}"] = (name, 1)
+                    stages.append((name, rows))
+                    if last:
+                        break
+                agg_stages[agg] = stages
+                if len(stages) > 1:  # the partial stages run right before the aggregate itself
+                    at = order.index(f"Aggregator:{agg}")
+                    order[at:at] = [n for n, _ in stages[:-1]]
             position = {name: k for k, name in enumerate(order)}
 
             def wire(owner: str, rows: Sequence[str], read_end: bool) -> None:
@@ -831,8 +858,9 @@ class ModelBuilder:
                 ens = ensembles[comp.type_name]
                 rows = ens.input_rows or [n for n, v in ens.var_ids.items() if v == 0]
                 wire(comp.type_name, list(rows), ens.kind == L.KIND_UDEB)
-            for agg, (_, _, contributors, _) in aggregates.items():
-                wire(f"Aggregator:{agg}", list(contributors), True)
+            for agg in aggregates:
+                for name, rows in agg_stages[agg]:
+                    wire(name, rows, True)
             for name, (owner, vid) in var_home.items():
                 if name in self._initial:
                     ensembles[owner].set_initial(vid, self._initial[name])
@@ -886,12 +914,12 @@ class ModelBuilder:
             h = {L.COMP_TWO_LAYER: 0.1}
         elif (types == ["CarbonCycle", "CO2ERF", "TwoLayer"] and list(aggregates) == [erf]
               and aggregates[erf][1] == "Sum"
-              and aggregates[erf][2] == ["Effective Radiative Forcing|CO2"]):
+              and aggregates[erf][2] == ["Effective Radiative Forcing|CO2"]
+              # the fused coupled kernel carries ONE conc_pi row; two different pre-industrial
+              # concentrations run as the same graph of linked ensembles (one launch as well: all light)
+              and self._components[0].parameters["conc_pi"] == self._components[1].parameters["conc_pi"]):
             kind = L.KIND_COUPLED
             cc, ce, tl = self._components
-            if cc.parameters["conc_pi"] != ce.parameters["conc_pi"]:
-                raise NotImplementedError("CarbonCycle.conc_pi != CO2ERF.conc_pi is not supported "
-                                          "by the fused coupled kernel")
             assert sources[("Surface Temperature", "CarbonCycle")] == "Exogenous"
             assert sources[(erf, "TwoLayer")] == "UpstreamOutput"
             forcing = self._exogenous_on_axis("Emissions|CO2|Anthropogenic", exo_names)
@@ -1237,7 +1265,7 @@ class GraphModel:
             coll.add_fourbox_timeseries(name, FourBoxTimeseries(boxes, self._axis, "K" if ens.kind == L.KIND_UDEB else "W/m^2"))
             skip.add(name)
         for name, (owner, vid) in self._var_home.items():
-            if name in skip:
+            if name in skip or "#partial" in name:  # partial sums of aggregates with more than eight contributors are internal
                 continue
             vals = self.ensembles[owner].get_series(vid, m_begin=member, m_end=member + 1)[:, 0]
             coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Endogenous)

@@ -178,6 +178,95 @@ def test_notebook_coupled_model_vs_generic_stepper(api, rm):
     model.close()
 
 
+def test_coupled_model_with_two_preindustrial_concentrations(api, rm):
+    """CarbonCycle.conc_pi != CO2ERF.conc_pi (builder.rs allows any parameters): the fused coupled kernel
+    carries one conc_pi row, so the model is built as the same graph of linked ensembles -- and has to
+    reproduce the generic stepper like the fused one does."""
+    c = api.core
+    t = np.arange(1750.0, 1901.0)
+    b, (years, vals), tl, cc = _coupled_builder(api, t)
+    b._components[1] = api.CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=285.0)).build()
+    model = b.build()
+    assert isinstance(model, c.GraphModel)
+    model.run()
+    got = model.timeseries()
+    ref = rm.ModelBuilder(
+        axis=rm.TimeAxis.from_values(t),
+        components=[rm.CarbonCycle(cc["tau"], cc["conc_pi"], cc["alpha_temperature"]),
+                    rm.CO2ERF(3.7, 285.0), rm.TwoLayer(*[tl[k] for k in api.core.TL_PARAM_ORDER])],
+        aggregates=[("Effective Radiative Forcing", "Sum", ["Effective Radiative Forcing|CO2"])],
+        exogenous={"Emissions|CO2|Anthropogenic":
+                   rm.ExoSeries(list(vals), rm.TimeAxis.from_bounds(list(years) + [2101.0]), "Linear")},
+        initial_values={"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0,
+                        "Atmospheric Concentration|CO2": 278.0, "Surface Temperature": 0.0,
+                        "Deep Ocean Temperature": 0.0}).build()
+    ref.run()
+    for name, want in ref.data.items():
+        g = got.get_timeseries_by_name(name).values()
+        w = np.array(want)
+        assert (np.isnan(g) == np.isnan(w)).all(), name
+        ok = ~np.isnan(w)
+        assert (np.abs(g[ok] - w[ok]) <= RTOL * np.maximum(1.0, np.abs(w[ok]))).all(), name
+    assert got.get_timeseries_by_name("Effective Radiative Forcing|CO2").values()[1] < 0.0   # 278 ppm against a 285 ppm baseline
+    model.close()
+
+
+@pytest.mark.parametrize("operation", ["Sum", "Weighted"])
+def test_aggregate_of_more_than_eight_contributors(api, operation):
+    """compute_aggregate (schema.rs:760-802) folds any number of contributors; an aggregate ensemble takes
+    eight, so eleven run as two chained stages whose additions keep the declaration order: the same bits
+    as one running sum.  Some contributors are NaN at some times (skipped), one row is NaN throughout."""
+    c = api.core
+    t = np.arange(1850.0, 1881.0)
+    axis = c.TimeAxis.from_values(t)
+    rng = np.random.default_rng(4)
+    names = [f"Effective Radiative Forcing|Part{k}" for k in range(11)]
+    series = {n: rng.normal(0.3, 1.0, len(t)) for n in names}
+    series[names[2]][5:9] = np.nan
+    series[names[9]][:] = np.nan
+    series[names[10]][20] = np.nan
+    weights = list(rng.uniform(0.2, 2.0, 11)) if operation == "Weighted" else None
+    schema = c.VariableSchema()
+    for n in names + ["Surface Temperature", "Deep Ocean Temperature"]:
+        schema.add_variable(n, "")
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", operation, names, weights)
+    fixed = dict(lambda0=1.1, a=0.05, efficacy=1.3, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    b = (c.ModelBuilder().with_time_axis(axis).with_schema(schema)
+         .with_rust_component(api.TwoLayerBuilder.from_parameters(fixed).build())
+         .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    for n in names:
+        b = b.with_exogenous_variable(n, c.Timeseries(series[n], axis, "W/m^2", c.InterpolationStrategy.Previous))
+    model = b.build()
+    assert isinstance(model, c.GraphModel) and "Aggregator:Effective Radiative Forcing#0" in model._order
+    model.run()
+    got = model.timeseries()
+    assert not any("#partial" in n for n in got.names())
+    erf = got.get_timeseries_by_name("Effective Radiative Forcing").values()
+    want = np.full(len(t), np.nan)
+    for n in range(len(t) - 1):      # contributors at n + 1, in declaration order, NaN skipped
+        acc, cnt = 0.0, 0
+        for k, name in enumerate(names):
+            v = series[name][n + 1]
+            if not np.isnan(v):
+                acc = acc + (v * weights[k] if weights else v)
+                cnt += 1
+        want[n + 1] = acc if cnt else np.nan
+    assert_bit_equal(erf, want, f"{operation} of eleven contributors")
+    assert np.isfinite(got.get_timeseries_by_name("Surface Temperature").values()[1:]).all()
+    model.close()
+    with pytest.raises(NotImplementedError, match="Mean of more than"):
+        s2 = c.VariableSchema()
+        for n in names + ["Surface Temperature", "Deep Ocean Temperature"]:
+            s2.add_variable(n, "")
+        s2.add_aggregate("Effective Radiative Forcing", "W/m^2", "Mean", names)
+        b2 = (c.ModelBuilder().with_time_axis(axis).with_schema(s2)
+              .with_rust_component(api.TwoLayerBuilder.from_parameters(fixed).build())
+              .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+        for n in names:
+            b2 = b2.with_exogenous_variable(n, c.Timeseries(series[n], axis, "W/m^2", c.InterpolationStrategy.Previous))
+        b2.build()
+
+
 def _tl_runner(api, t, F, names, outputs=("Surface Temperature",), mode=0):
     c = api.core
     erf = c.Timeseries(F, c.TimeAxis.from_values(t), "W/m^2", c.InterpolationStrategy.Linear)
