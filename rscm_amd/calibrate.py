@@ -985,7 +985,7 @@ class DeviceEnsembleSampler:
                                                 L.dptr(val), L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
                                                 C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), rank, world, C.byref(h)))
         try:
-            if world > 1:
+            if world > 1 or (is_distributed() and shard is not False):
                 return self._run_sharded(lib, h, ens, pos, n_iterations, thin, n_walkers, world)
             if n_groups != 1:
                 L.check(lib.rscm_sampler_set_groups(h, n_groups))
@@ -1028,7 +1028,7 @@ class DeviceEnsembleSampler:
         import torch
         import torch.distributed as dist
         send, recv, n = C.c_void_p(), C.c_void_p(), C.c_int64()
-        L.check(lib.rscm_sampler_exchange_buffers(h, C.byref(send), C.byref(recv), C.byref(n)))
+        L.check(lib.rscm_sampler_exchange_buffers(h, C.byref(send), C.byref(recv), C.byref(n)))   # also switches the sampler to driven mode
         per = n.value
         on_device = dist.get_backend() == "nccl"
         if on_device:

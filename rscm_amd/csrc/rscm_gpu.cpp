@@ -2183,6 +2183,7 @@ int rscm_ens_run_loglik_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_va
 struct rscm_sampler {
     rscm_ens* ev = nullptr;  // evaluates one half-ensemble per launch; not owned
     int32_t W = 0, D = 0, groups = 1;
+    bool sharded = false;            // driven half-step by half-step with an exchange in between
     int32_t rank = 0, n_ranks = 1;   // sharded: this rank owns half-walkers [rank * n_local, (rank + 1) * n_local) of both halves
     int32_t n_local = 0;             // = members of the evaluator
     double* d_send = nullptr;        // [D + 1][n_local]
@@ -2264,7 +2265,7 @@ int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
         HIPCHK(rscm::launch_loglik(s->lik, s->ev->stream));
     }
     HIPCHK(rscm::launch_sampler_accept(a, s->ev->stream));
-    if (s->n_ranks > 1) {  // this rank's block of the updated half, ready for the all-gather
+    if (s->sharded) {  // this rank's block of the updated half, ready for the all-gather
         rscm::SamplerArgs p = a;
         p.exchange = s->d_send;
         HIPCHK(rscm::launch_sampler_pack(p, s->ev->stream));
@@ -2350,6 +2351,7 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
     s->D = n_dims;
     s->rank = rank;
     s->n_ranks = n_ranks;
+    s->sharded = n_ranks > 1;
     s->n_local = (int32_t)h->N;
     s->stretch_a = stretch_a;
     s->seed = seed;
@@ -2377,10 +2379,8 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
     CK(hipMalloc(&s->d_prop, D * H * sizeof(double)));
     CK(hipMalloc(&s->d_z, H * sizeof(double)));
     CK(hipMalloc(&s->d_lp, H * sizeof(double)));
-    if (n_ranks > 1) {
-        CK(hipMalloc(&s->d_send, (D + 1) * H * sizeof(double)));
-        CK(hipMalloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));
-    }
+    CK(hipMalloc(&s->d_send, (D + 1) * H * sizeof(double)));   // 2 x (D + 1) x H doubles: also for one rank (the exchange of
+    CK(hipMalloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));   // a one-rank group is a copy)
     CK(hipMalloc(&s->d_nacc, W * sizeof(int64_t)));
     CK(hipMalloc(&s->d_nprop, W * sizeof(int64_t)));
     CK(hipMemcpy(s->d_rows, param_rows, D * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -2451,7 +2451,7 @@ int rscm_sampler_set_groups(rscm_sampler* s, int32_t n_groups)
     if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
     if (n_groups < 1 || s->W % n_groups != 0 || (s->W / n_groups) % 2 != 0 || s->W / n_groups < 2)
         return fail(RSCM_ERR_INVALID, "%d walkers do not split into %d groups of an even number (>= 2) of walkers", s->W, n_groups);
-    if (s->n_ranks > 1 && n_groups != 1) return fail(RSCM_ERR_INVALID, "a sharded sampler runs one ensemble (n_groups = 1)");
+    if ((s->n_ranks > 1 || s->sharded) && n_groups != 1) return fail(RSCM_ERR_INVALID, "a sharded sampler runs one ensemble (n_groups = 1)");
     s->groups = n_groups;
     s->positions_set = false;  // positions are scored per group layout: set them again
     return RSCM_OK;
@@ -2477,7 +2477,7 @@ int rscm_sampler_set_positions(rscm_sampler* s, const double* positions)
     HIPCHK(hipMemset(s->d_nprop, 0, W * sizeof(int64_t)));
     s->iteration = 0;
     s->positions_set = true;
-    if (s->n_ranks > 1) {  // scored half by half through rscm_sampler_half_step(identity = 1) + the exchange
+    if (s->sharded) {  // scored half by half through rscm_sampler_half_step(identity = 1) + the exchange
         HIPCHK(rscm::launch_fill(s->d_logp, (int64_t)W, -std::numeric_limits<double>::infinity(), h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         return RSCM_OK;
@@ -2495,7 +2495,7 @@ int rscm_sampler_iterate(rscm_sampler* s, int32_t n_iterations)
     if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
     if (!s->positions_set) return fail(RSCM_ERR_STATE, "walker positions not set");
     if (n_iterations < 0) return fail(RSCM_ERR_INVALID, "n_iterations must be >= 0");
-    if (s->n_ranks > 1)
+    if (s->sharded)
         return fail(RSCM_ERR_STATE, "a sharded sampler is driven half-step by half-step (rscm_sampler_half_step, all-gather, "
                                     "rscm_sampler_apply_exchange)");
     rscm_ens* h = s->ev;
@@ -2538,7 +2538,7 @@ int rscm_sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
 int rscm_sampler_exchange_buffers(rscm_sampler* s, void** send, void** recv, int64_t* doubles_per_rank)
 {
     if (!s || !send || !recv || !doubles_per_rank) return fail(RSCM_ERR_INVALID, "NULL argument");
-    if (s->n_ranks < 2) return fail(RSCM_ERR_STATE, "this sampler is not sharded");
+    s->sharded = true;   // from here on the caller drives the half-steps and the exchange
     *send = s->d_send;
     *recv = s->d_recv;
     *doubles_per_rank = (int64_t)(s->D + 1) * s->n_local;
@@ -2549,7 +2549,7 @@ int rscm_sampler_apply_exchange(rscm_sampler* s, int32_t half)
 {
     GUARD_BEGIN
     if (!s) return fail(RSCM_ERR_INVALID, "sampler is NULL");
-    if (s->n_ranks < 2) return fail(RSCM_ERR_STATE, "this sampler is not sharded");
+    if (!s->sharded) return fail(RSCM_ERR_STATE, "this sampler is not sharded (rscm_sampler_exchange_buffers first)");
     if (half != 0 && half != 1) return fail(RSCM_ERR_INVALID, "half must be 0 or 1");
     rscm::SamplerArgs a = sampler_args(s, half, 0);
     a.exchange = s->d_recv;

@@ -46,9 +46,13 @@ def _dist():
 
 
 def is_distributed() -> bool:
+    """An initialised process group of more than one rank -- or of one rank when
+    ``RSCM_FORCE_DISTRIBUTED=1`` (rehearsal of the collective paths, e.g. RCCL on a one-GPU box)."""
     try:
         d = _dist()
-        return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+        if not (d.is_available() and d.is_initialized()):
+            return False
+        return d.get_world_size() > 1 or os.environ.get("RSCM_FORCE_DISTRIBUTED") == "1"
     except Exception:
         return False
 
