@@ -475,6 +475,28 @@ def main():
         side("magicc_chain_1e5", lambda: magicc_chain_extra(100_000, years))
         side("magicc_chain_1e5_fast", lambda: magicc_chain_extra(100_000, years, fast=True))
 
+        # BASELINE.json configs[3], one GPU's share at full size: 125 000 members x 9000 MONTHLY steps of the MAGICC
+        # graph, windowed series + annual outputs (scripts/run_configs3_share.py)
+        def configs3_share():
+            import contextlib
+            import io
+            from scripts import run_configs3_share as prog
+            argv, sys.argv = sys.argv, ["run_configs3_share.py"]
+            buf = io.StringIO()
+            try:
+                with contextlib.redirect_stdout(buf):
+                    try:
+                        prog.main()
+                    except SystemExit as done:
+                        code = done.code
+            finally:
+                sys.argv = argv
+            out = json.loads(buf.getvalue().strip().splitlines()[-1])
+            out["exit_code"] = code
+            return out
+
+        side("configs3_share_125000x9000_fast", configs3_share)
+
         # SURVEY 8d asks for the end-to-end figure beside the resident one: host parameters in,
         # run, full Ts and Td series out into page-locked buffers (never reported as `value`)
         side("end_to_end_1e5", lambda: end_to_end_extra(args.members, local_rank, mode, stream, years))
