@@ -307,3 +307,37 @@ def test_configs3_share_runs_at_full_size(ra):
     assert all(out["first_64_members_equal_a_64_member_run"].values())
     assert out["warming_end_K"]["count"] == 125_000 and 1.0 < out["warming_end_K"]["mean"] < 12.0
     assert out["co2_end_ppm"]["min"] > 278.0
+
+
+def test_windowed_graph_in_fast_mode(ra):
+    """RSCM_MODE_FAST (OceanCarbon's O(T) recurrence with running mode sums as extra internal state) under
+    windowed storage: the kept rows equal the full-storage FAST run bit for bit; a checkpoint restored into a
+    fresh model re-forms the mode sums from the flux history (Horner instead of the incremental recurrence), so
+    the continuation agrees to the FAST tolerance, not to the bit."""
+    from rscm_amd import _lib as L
+    mod = _chain()
+    years, N = 80, 96
+    full = mod.build_chain(N, years, "topological")
+    full.set_mode(L.MODE_FAST)
+    full.run()
+    win = mod.build_chain(N, years, "topological", series_window=12, output_stride=4)
+    win.set_mode(L.MODE_FAST)
+    win.run()
+    names = ["Atmospheric Concentration|CO2", "Carbon Flux|Ocean", "Ocean Surface pCO2", "Sea Surface Temperature", "Effective Radiative Forcing"]
+    for name in names:
+        assert_bit_equal(win.get_series(name, t_stride=4), full.get_series(name)[::4], f"FAST, windowed: {name}")
+    win.rewind()
+    for _ in range(37):
+        win.step()
+    ck = win.checkpoint()
+    win.close()
+    other = mod.build_chain(N, years, "topological", series_window=12, output_stride=4)
+    other.set_mode(L.MODE_FAST)
+    other.restore(ck)
+    other.run()
+    for name in names:
+        got, ref = other.get_series(name, t_begin=40, t_stride=4), full.get_series(name)[40::4]
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert np.isfinite(got).all() and err.max() <= 2e-8, (name, err.max())
+    other.close()
+    full.close()
