@@ -436,7 +436,9 @@ RSCM_API int rscm_ens_set_time_index(rscm_ens* h, int32_t tidx);
 /* The internal ComponentState of the kinds that have one -- what the reference serialises next to the
  * collection in a checkpoint (runtime.rs:270-282): RSCM_KIND_UDEB: ocean layer temperatures
  * [2][n_layers][N], the per-member scalars [11][N] and the temperature history rows 0..time_index;
- * RSCM_KIND_OCEAN_CARBON: the flux history of the time_index * 12 months so far.  One flat block of
+ * RSCM_KIND_OCEAN_CARBON: the flux history of the time_index * 12 months so far, or of the last
+ * max_history_months (+ a few) of them if that is fewer -- the convolution reads no further back, and the
+ * device keeps the history as a ring of that length.  One flat block of
  * doubles whose length depends on the current time index (0 for every other kind).
  * rscm_ens_set_internal_state puts such a block back and moves the stepper to `time_index` (the
  * one it was taken at); the stored series rows are restored with rscm_ens_set_state. */

@@ -52,6 +52,15 @@ __device__ __forceinline__ double pco2_from_dic(const OceanMember& m, double d, 
     return (m.pco2_pi + s) * temp_factor;
 }
 
+// The flux history is a ring of a.hist_rows pulses (>= max_history_months + the pulses of one tile; the
+// whole run's pulses when that is shorter): pulse j lives in row j mod hist_rows.  All pulse indices are
+// wave-uniform, so the ring arithmetic stays on the scalar unit: one modulo per tile, then increments.
+__device__ __forceinline__ int32_t ring_add(int32_t r, int32_t k, int32_t R)
+{
+    const int32_t x = r + k;
+    return x >= R ? x - R : x;
+}
+
 // acc + f*r: one rounded multiply and one rounded add like the reference (EXACT), or fused
 // (RSCM_MODE_FAST: half the instructions, results differ by rounding only)
 template <bool FUSED>
@@ -83,15 +92,18 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     for (int k = 0; k < K; ++k) A[k] = 0.0;
     // ---- the old pulses, oldest first.  Head: the first K-1 of them are still outside the
     // window of the later sub-steps (bounded history), so each term is predicated.
+    const int32_t R = a.hist_rows;
     int64_t j = lo(0);
     if constexpr (PART > 0) {
         j = m0;  // the old pulses were summed by the launch of part 0
 #pragma unroll
         for (int k = PART * STEPS; k < (PART + 1) * STEPS; ++k) A[k] = a.partial[(size_t)(k - STEPS) * N + i];
     }
+    int32_t jr = (int32_t)(j % R);             // ring row of pulse j
+    const int32_t mr0 = (int32_t)(m0 % R);     // ring row of the tile's first own pulse
     const int64_t head_end = (j + K - 1 < m0) ? j + K - 1 : m0;
-    for (; j < head_end; ++j) {
-        const double f = hist[(size_t)j * N];
+    for (; j < head_end; ++j, jr = ring_add(jr, 1, R)) {
+        const double f = hist[(size_t)jr * N];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int64_t lag = m0 + k - j;
@@ -100,21 +112,21 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
         }
     }
     // Bulk: groups of STEPS pulses share a K+STEPS-1 entry window of the response table
-    for (; j + STEPS <= m0; j += STEPS) {
+    for (; j + STEPS <= m0; j += STEPS, jr = ring_add(jr, STEPS, R)) {
         const int64_t base = m0 - j - (STEPS - 1);  // lag of (last pulse of the group, k = 0), >= 1
         double w[K + STEPS - 1], f[STEPS];
 #pragma unroll
         for (int t = 0; t < K + STEPS - 1; ++t) w[t] = irf[base + t];
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) f[u] = hist[(size_t)(j + u) * N];
+        for (int u = 0; u < STEPS; ++u) f[u] = hist[(size_t)ring_add(jr, u, R) * N];
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
 #pragma unroll
             for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f[u], w[STEPS - 1 - u + k]);
         }
     }
-    for (; j < m0; ++j) {  // tail
-        const double f = hist[(size_t)j * N];
+    for (; j < m0; ++j, jr = ring_add(jr, 1, R)) {  // tail
+        const double f = hist[(size_t)jr * N];
 #pragma unroll
         for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f, irf[m0 + k - j]);
     }
@@ -125,7 +137,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
     double pco2 = a.series[r0 + (size_t)Y0 * N], cumulative = a.series[vs + r0 + (size_t)Y0 * N];
     if constexpr (PART > 0) {
 #pragma unroll
-        for (int q = 0; q < PART * STEPS; ++q) fy[q] = hist[(size_t)(m0 + q) * N];  // the tile's earlier pulses
+        for (int q = 0; q < PART * STEPS; ++q) fy[q] = hist[(size_t)ring_add(mr0, q, R) * N];  // the tile's earlier pulses
     }
 #pragma unroll
     for (int y = Y0; y < Y1; ++y) {
@@ -139,7 +151,7 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
             const int k = y * STEPS + s;
             const double flux_ppm = m.k_gas * (co2 - pco2);
             fy[k] = flux_ppm;
-            hist[(size_t)(m0 + k) * N] = flux_ppm;
+            hist[(size_t)ring_add(mr0, k, R) * N] = flux_ppm;
             const double flux_gtc_yr = flux_ppm * 12.0 * kPpmToGtc;
             total += flux_gtc_yr / (double)STEPS;
             cumulative += flux_gtc_yr * dt_month;
@@ -250,8 +262,9 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
 #pragma unroll
         for (int q = 0; q < M; ++q) S[q] = 0.0;
         const int64_t j_lo = m0 - H > 0 ? m0 - H : 0;
-        for (int64_t j = j_lo; j <= m0 - 1 - NEAR; ++j) {
-            const double f = hist[(size_t)j * N];
+        int32_t jr = (int32_t)(j_lo % a.hist_rows);
+        for (int64_t j = j_lo; j <= m0 - 1 - NEAR; ++j, jr = ring_add(jr, 1, a.hist_rows)) {
+            const double f = hist[(size_t)jr * N];
 #pragma unroll
             for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], mode_table[q], f);
         }
@@ -263,12 +276,13 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
 #pragma unroll
     for (int x = 0; x < NEAR; ++x) {
         const int64_t j = m0 - NEAR + x;
-        w[x] = j >= 0 ? hist[(size_t)j * N] : 0.0;
+        w[x] = j >= 0 ? hist[(size_t)(j % a.hist_rows) * N] : 0.0;
     }
     const size_t r0 = (size_t)a.step_begin * N + i;
     double pco2 = a.series[r0], cumulative = a.series[vs + r0];
-    double* __restrict__ hp = hist + (size_t)m0 * N;                 // where this sub-step's pulse goes
-    const double* __restrict__ hp_out = hist + (size_t)(m0 - H) * N;   // the pulse that leaves the window (valid once m >= H)
+    const int32_t R = a.hist_rows;
+    int32_t mr = (int32_t)(m0 % R);                                  // ring row of this sub-step's pulse
+    int32_t mr_out = m0 >= H ? (int32_t)((m0 - H) % R) : 0;          // ... of the pulse that leaves the window (used once m >= H)
     double* __restrict__ out = a.series + r0;
     const bool few_exits = a.modes.n_exit <= 10;                     // the modes whose weight at lag H is not negligible come first
     for (int32_t n = a.step_begin; n < a.step_end; ++n, m0 += STEPS) {
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
         for (int s = 0; s < STEPS; ++s) {
             const double flux_ppm = m.k_gas * (co2 - pco2);
             w[NEAR + s] = flux_ppm;
-            *hp = flux_ppm;
+            hist[(size_t)mr * N] = flux_ppm;
             const double flux_gtc_yr = flux_ppm * 12.0 * kPpmToGtc;
             total += flux_gtc_yr / (double)STEPS;
             cumulative += flux_gtc_yr * dt_month;
@@ -302,7 +316,8 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
 #pragma unroll
             for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], md[q], f_in);
             if (leaving || (straddle && m0 + s >= H)) {  // wave-uniform
-                const double f_out = *hp_out;
+                const double f_out = hist[(size_t)mr_out * N];
+                mr_out = ring_add(mr_out, 1, R);
                 if (few_exits) {
 #pragma unroll
                     for (int q = 0; q < 10; ++q) S[q] = __builtin_fma(-me[q], f_out, S[q]);
@@ -311,8 +326,7 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
                     for (int q = 0; q < M; ++q) S[q] = __builtin_fma(-me[q], f_out, S[q]);   // e_q = 0 beyond n_exit
                 }
             }
-            hp += N;
-            hp_out += N;
+            mr = ring_add(mr, 1, R);
             double integral = 0.0;
 #pragma unroll
             for (int q = M - 1; q >= 0; --q) integral = __builtin_fma(mc[q], S[q], integral);  // fastest-decaying (smallest) first

@@ -263,7 +263,8 @@ struct OceanArgs {
     int32_t linked;
     const double* bounds;    // [T+1]
     const double* irf;       // [max(max_hist, 1)] scaled impulse response at lag k/12 yr
-    double* hist;            // [(T-1)*steps][N] flux history, ppm/month
+    double* hist;            // [hist_rows][N] flux history, ppm/month: a ring, pulse j in row j mod hist_rows
+    int32_t hist_rows;       // min((T-1)*steps, max_hist + ring slack): the whole run's pulses, or the convolution window
     double* partial;         // [(tile years - 1) * steps][N] running sums parked between the launches of a split tile
     int32_t part;            // -1: whole tiles; p >= 0: year p of a tile split over one-step launches
     int32_t rows;            // stored rows per series (T, or the window length)

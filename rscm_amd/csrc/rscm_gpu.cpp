@@ -292,7 +292,8 @@ struct rscm_ens {
     double* d_ghg_tables = nullptr;  // GhgForcing: [S][kGhgRows][T] derived scenario rows
     int32_t ghg_method = 1;
     // OceanCarbon: flux history (internal state) and the tabulated impulse response
-    double* d_ocean_hist = nullptr;  // [(T-1)*steps][N]
+    double* d_ocean_hist = nullptr;  // [ocean_hist_rows][N]: a ring, pulse j in row j mod ocean_hist_rows
+    int64_t ocean_hist_rows = 0;     // min((T-1)*12, max_hist + slack): the convolution never looks further back
     double* d_ocean_irf = nullptr;   // [max(max_hist, 1)]
     double* d_ocean_partial = nullptr;  // [(tile years - 1) * steps][N] split-tile running sums (one-step launches)
     int32_t ocean_tile_base = -1;       // first step of the split tile d_ocean_partial belongs to, -1: none
@@ -460,11 +461,20 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
     h->d_ocean_irf = nullptr;
     HIPCHK(hipMalloc(&h->d_ocean_irf, tab.size() * sizeof(double)));
     HIPCHK(hipMemcpy(h->d_ocean_irf, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (!h->d_ocean_hist) {
-        const hipError_t e = hipMalloc(&h->d_ocean_hist, (size_t)(h->T - 1) * 12 * h->N * sizeof(double));
+    // The flux history is a ring: the convolution reads at most max_history_months pulses back, a tile writes
+    // up to 48 new ones before it is done reading (ocean.hip), the O(T) recurrence reads the pulse that leaves
+    // the window.  On a monthly axis that is 48 KB per member instead of 864 KB (108 000 pulses).
+    const int64_t all_pulses = (int64_t)(h->T - 1) * 12;
+    const int64_t ring = (((int64_t)max_hist + 60 + 11) / 12) * 12;
+    const int64_t rows = std::min(all_pulses, ring);
+    if (!h->d_ocean_hist || rows != h->ocean_hist_rows) {
+        HIPCHK(hipFree(h->d_ocean_hist));
+        h->d_ocean_hist = nullptr;
+        const hipError_t e = hipMalloc(&h->d_ocean_hist, (size_t)rows * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,
-                        "flux history of %lld members x %d months: %s", (long long)h->N, (h->T - 1) * 12, hipGetErrorString(e));
+                        "flux history of %lld members x %lld months: %s", (long long)h->N, (long long)rows, hipGetErrorString(e));
+        h->ocean_hist_rows = rows;
     }
     if (!h->d_ocean_partial) {
         const hipError_t e = hipMalloc(&h->d_ocean_partial, (size_t)(rscm::kOceanSplitYears - 1) * 12 * h->N * sizeof(double));
@@ -1153,7 +1163,12 @@ static void internal_pieces(const rscm_ens* h, int32_t k, StatePieces& p)
         p.emplace_back(h->d_scal, (int64_t)rscm::kUdebScalars * h->N);
         p.emplace_back(h->d_hist, (int64_t)(k + 1) * h->N);
     } else if (h->kind == RSCM_KIND_OCEAN_CARBON && h->d_ocean_hist) {
-        p.emplace_back(h->d_ocean_hist, (int64_t)k * h->ocean_steps * h->N);
+        // the pulses still held, oldest first: the ring unrolled into (at most) two pieces
+        const int64_t total = (int64_t)k * h->ocean_steps, R = h->ocean_hist_rows;
+        const int64_t cnt = std::min(total, R), first = (total - cnt) % R;
+        const int64_t head = std::min(cnt, R - first);
+        if (head > 0) p.emplace_back(h->d_ocean_hist + (size_t)first * h->N, head * h->N);
+        if (cnt > head) p.emplace_back(h->d_ocean_hist, (cnt - head) * h->N);
     }
 }
 
@@ -1416,6 +1431,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.linked = linked;
         a.irf = h->d_ocean_irf;
         a.hist = h->d_ocean_hist;
+        a.hist_rows = (int32_t)h->ocean_hist_rows;
         // one step at a time (linked graphs, Model::step): pair the steps up so that the history is
         // read once per two steps, as the two-year tiles of a whole run do
         a.partial = h->d_ocean_partial;
