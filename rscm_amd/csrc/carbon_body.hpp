@@ -20,7 +20,8 @@ __device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    const double tau = a.params[i], conc_pi = a.params[(size_t)N + i], alpha = a.params[(size_t)2 * N + i];
+    const double tau = param_at(a.params, a.uniform_rows, 0, N, i), conc_pi = param_at(a.params, a.uniform_rows, 1, N, i),
+                 alpha = param_at(a.params, a.uniform_rows, 2, N, i);
     const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
     const size_t r0 = (size_t)step_begin * N + i;
@@ -60,7 +61,7 @@ __device__ __forceinline__ void co2_budget_body(const CarbonArgs& a, int64_t i, 
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    const double gtc_per_ppm = a.params[i];
+    const double gtc_per_ppm = param_at(a.params, a.uniform_rows, 0, N, i);
     const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
     a.status[i] = 0;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     const double npp_pi = P(0), co2_pi = P(1), beta = P(2), npp_ts = P(3), resp_ts = P(4), det_ts = P(5), soil_ts = P(6),
                  hum_ts = P(7), plant_pi = P(8), det_pi = P(9), soil_pi = P(10), hum_pi = P(11), resp_pi = P(12),
                  f_npp_plant = P(13), f_npp_det = P(14), f_plant_det = P(15), f_det_soil = P(16), f_soil_hum = P(17);

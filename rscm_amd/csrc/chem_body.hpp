@@ -20,7 +20,7 @@ __device__ __forceinline__ void ch4_body(const ChemArgs& a, int64_t i, int32_t s
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     const double ch4_pi = P(0), natural = P(1), tau_oh0 = P(2);
     const double tau_other = 1.0 / (1.0 / P(3) + 1.0 / P(4) + 1.0 / P(5));  // parameters/ch4_chemistry.rs tau_other
     const double self_fb = P(6), gamma = P(7), s_nox = P(8), s_co = P(9), s_nmvoc = P(10), temp_sens = P(11);
@@ -77,7 +77,7 @@ __device__ __forceinline__ void n2o_body(const ChemArgs& a, int64_t i, int32_t s
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     const double n2o_pi = P(0), natural = P(1), tau0 = P(2), lifetime_fb = P(3), ppb_to_tg = P(5);
     int64_t delay = (int64_t)P(4);
     if (delay < 1) delay = 1;  // strat_delay.max(1)

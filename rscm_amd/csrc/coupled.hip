@@ -139,16 +139,16 @@ __global__ __launch_bounds__(kBlock) void coupled_kernel(CoupledArgs a)
     const int64_t N = a.n_members;
 
     CPConst p;
-    p.lambda0 = a.params[0 * N + i];
-    p.a = a.params[1 * N + i];
-    p.eff_eta = a.params[2 * N + i] * a.params[3 * N + i];
-    p.eta = a.params[3 * N + i];
-    p.cs = a.params[4 * N + i];
-    p.cd = a.params[5 * N + i];
-    p.tau = a.params[6 * N + i];
-    p.conc_pi = a.params[7 * N + i];
-    p.alpha = a.params[8 * N + i];
-    p.erf_scale = a.params[9 * N + i] / kLn2;
+    p.lambda0 = param_at(a.params, a.uniform_rows, 0, N, i);
+    p.a = param_at(a.params, a.uniform_rows, 1, N, i);
+    p.eff_eta = param_at(a.params, a.uniform_rows, 2, N, i) * param_at(a.params, a.uniform_rows, 3, N, i);
+    p.eta = param_at(a.params, a.uniform_rows, 3, N, i);
+    p.cs = param_at(a.params, a.uniform_rows, 4, N, i);
+    p.cd = param_at(a.params, a.uniform_rows, 5, N, i);
+    p.tau = param_at(a.params, a.uniform_rows, 6, N, i);
+    p.conc_pi = param_at(a.params, a.uniform_rows, 7, N, i);
+    p.alpha = param_at(a.params, a.uniform_rows, 8, N, i);
+    p.erf_scale = param_at(a.params, a.uniform_rows, 9, N, i) / kLn2;
     const ConstDiv dcs = make_const_div(p.cs), dcd = make_const_div(p.cd);
     p.rcs = dcs.r;
     p.rcd = dcd.r;

@@ -23,7 +23,7 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     const double co2_pi = P(1), ch4_pi = P(2), n2o_pi = P(3);
     const double adj_co2 = P(18), adj_ch4 = P(19), adj_n2o = P(20);
     const double ln_c0 = log(co2_pi), sq_m0 = sqrt(ch4_pi), sq_n0 = sqrt(n2o_pi);

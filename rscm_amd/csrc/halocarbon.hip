@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void halo_species_kernel(HaloArgs a)
     const int s = blockIdx.y;
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     const double lifetime = P(kGlobals + s * kFields + 0), mol_weight = P(kGlobals + s * kFields + 3);
     // emission_to_concentration_factor
     const double atm_mass_g = P(4) * 1e12;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void halo_aggregate_kernel(HaloArgs a)
     const int32_t row0 = a.step_begin + 1 + (int32_t)blockIdx.y * kChunk;  // first output row of this chunk
     if (row0 > a.step_end) return;
     const int32_t rows = (a.step_end - row0 + 1) < kChunk ? (a.step_end - row0 + 1) : kChunk;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     const double br_mult = P(0), cfc11_norm = P(1);
     const size_t vs = (size_t)a.rows * N;
     double total[kChunk], fgas[kChunk], montreal[kChunk], eesc[kChunk];

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
     if (i >= a.n_members) return;
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     OceanMember m;
     m.pco2_pi = P(2);
     m.k_gas = P(3) / (P(4) * 12.0);  // gas_exchange_rate()
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
     if (i >= a.n_members) return;
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     OceanMember m;
     m.pco2_pi = P(2);
     m.k_gas = P(3) / (P(4) * 12.0);

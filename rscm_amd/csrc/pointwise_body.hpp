@@ -126,7 +126,7 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
     for (int j = 0; j < S::P; ++j) {
         // the aggregate's eight weight rows matter to the Weighted operation only
         if (KIND == kKindAggregate && j > 0 && p[0] != 2.0) p[j] = 0.0;
-        else p[j] = a.params[(size_t)j * N + i];
+        else p[j] = param_at(a.params, a.uniform_rows, j, N, i);
     }
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;

@@ -34,6 +34,17 @@ struct InputLinks {
 };
 
 #ifdef __HIPCC__
+// Parameter j of member i from the [P][N] block.  Rows the host found to be the same for every member
+// (bit j of `uniform`, rows 0..63) are read from element 0 by every lane: one 64-byte request per
+// wavefront from a line that stays hot in L1/L2 instead of 512 coalesced bytes from HBM -- in a graph
+// of linked ensembles most rows are uniform (a calibration varies a handful), and the light
+// components' launches are bound by exactly this traffic.  The value read is the same either way.
+__device__ __forceinline__ double param_at(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i)
+{
+    const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;
+    return params[(size_t)j * N + (u ? (int64_t)0 : i)];
+}
+
 // The NI input rows of member i.  SRC 0: one shared table [NI][T]; 1: per-member scenario of a
 // table [S][NI][T]; 2: linked rows (coalesced [T][N] reads) mixed with table rows.  SRC < 2
 // compiles to the plain table indexing the kernels had before links existed.
@@ -88,6 +99,7 @@ struct TwoLayerArgs {
     int32_t src_off;         // 0: Exogenous -> F[n]; 1: UpstreamOutput -> F[n+1]
     int32_t lds_forcing;     // 1: forcing slice staged in LDS, 0: read through L2
     const double* params;    // [6][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* forcing;   // [S][T]
     const double* link;      // [T][N] linked forcing (InputLinks, one row) or nullptr
     const int32_t* scen;     // [N] or nullptr
@@ -116,6 +128,7 @@ struct CoupledArgs {
     int32_t n_scen;
     int32_t lds_forcing;
     const double* params;     // [10][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* emissions;  // [S][T]
     const int32_t* scen;
     const int32_t* nsub_tl;   // [T-1]
@@ -138,6 +151,7 @@ struct UdebArgs {
     int32_t n_scen;
     int32_t n_layers, steps_per_year, land_hc, efficacy_apply;  // uniform over the ensemble
     const double* params;   // [37][N], ClimateUDEBParameters order (include/rscm_gpu.h)
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* erf;      // [S][T]
     const int32_t* scen;    // [N] or nullptr
     const double* link;     // [T][N] linked forcing or nullptr
@@ -170,6 +184,7 @@ struct GhgArgs {
     int32_t rows;            // stored rows per series (T)
     int32_t method;          // 0 = IPCCTAR, 1 = OLBL (uniform over the ensemble)
     const double* params;    // [21][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* tables;    // [S][kGhgRows][T]
     const int32_t* scen;     // [N] or null
     const double* conc;      // [S][3][T] the concentrations themselves (linked launches)
@@ -187,6 +202,7 @@ struct PointwiseArgs {
     int32_t rows;            // stored rows per series (T)
     int32_t kind;            // RSCM_KIND_OZONE_FORCING / _AEROSOL_DIRECT / _AEROSOL_INDIRECT / ...
     const double* params;    // [P][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
     InputLinks links;        // used when linked != 0
@@ -202,6 +218,7 @@ struct ChemArgs {
     int32_t step_begin, step_end;
     int32_t kind;            // RSCM_KIND_CH4_CHEMISTRY / RSCM_KIND_N2O_CHEMISTRY
     const double* params;    // [P][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
     InputLinks links;        // used when linked != 0
@@ -219,6 +236,7 @@ struct CarbonArgs {
     int32_t step_begin, step_end;
     int32_t kind;            // RSCM_KIND_CO2_BUDGET / RSCM_KIND_TERRESTRIAL_CARBON
     const double* params;    // [P][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
     InputLinks links;        // used when linked != 0
@@ -257,6 +275,7 @@ struct OceanArgs {
     int32_t fused;           // RSCM_MODE_FAST: fused multiply-add in the convolution
     int64_t max_hist;        // max_history_months
     const double* params;    // [24][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* inputs;    // [S][2][T]: CO2, SST anomaly
     const int32_t* scen;     // [N] or null
     InputLinks links;        // used when linked != 0
@@ -284,6 +303,7 @@ struct HaloArgs {
     int32_t n_times;
     int32_t step_begin, step_end;
     const double* params;     // [293][N]
+    uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* emissions;  // [S][41][T]
     const int32_t* scen;      // [N] or null
     const double* bounds;     // [T+1]

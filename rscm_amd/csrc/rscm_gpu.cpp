@@ -286,6 +286,7 @@ struct rscm_ens {
     int32_t* d_nsub_cc = nullptr;
 
     double* d_params = nullptr;  // [P][N]
+    uint64_t uniform_rows = 0;   // bit j: parameter row j (< 64) holds one value for every member (the kernels then read element 0: param_at)
     double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
     double* d_forcing = nullptr; // [S][n_inputs][T]
     int32_t n_inputs = 1;        // rows per scenario of the shared input block
@@ -959,6 +960,16 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
         h->lookback = (int32_t)std::min(d, 1e6) + 1;
     }
     HIPCHK(hipMemcpyAsync(h->d_params, soa, (size_t)h->P * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    {   // rows that hold the same bits for every member
+        uint64_t uni = 0;
+        for (int32_t j = 0; j < h->P && j < 64; ++j) {
+            const double* row = soa + (size_t)j * h->N;
+            bool same = true;
+            for (int64_t i = 1; i < h->N && same; ++i) same = memcmp(&row[i], &row[0], sizeof(double)) == 0;
+            if (same) uni |= 1ull << j;
+        }
+        h->uniform_rows = uni;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
     return RSCM_OK;
@@ -1350,6 +1361,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.src_off = h->source == RSCM_SRC_UPSTREAM ? 1 : 0;
         a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.forcing = h->d_forcing;
         if (linked) {
             a.link = links.row[0];
@@ -1381,6 +1393,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.rows = h->rows;
         a.method = h->ghg_method;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.tables = h->d_ghg_tables;
         a.scen = h->d_scen;
         a.conc = h->d_forcing;
@@ -1405,6 +1418,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.step_begin = step_begin;
         a.step_end = step_end;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.emissions = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
@@ -1424,6 +1438,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.fused = h->mode == RSCM_MODE_FAST ? 1 : 0;
         a.max_hist = h->ocean_max_hist;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
@@ -1478,6 +1493,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.step_end = step_end;
         a.kind = h->kind;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.links = links;
@@ -1504,6 +1520,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.step_end = step_end;
         a.kind = h->kind;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.bounds = h->d_bounds;
@@ -1531,6 +1548,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.rows = h->rows;
         a.kind = h->kind;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.links = links;
@@ -1558,6 +1576,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.land_hc = h->udeb_land_hc;
         a.efficacy_apply = h->udeb_efficacy;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.erf = h->d_forcing;
         a.link = linked ? links.row[0] : nullptr;
         a.scen = linked ? nullptr : h->d_scen;
@@ -1588,6 +1607,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.n_scen = h->n_scen;
         a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
         a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
         a.emissions = h->d_forcing;
         a.scen = h->d_scen;
         a.nsub_tl = h->d_nsub_tl;
@@ -1942,6 +1962,7 @@ int rscm_ens_params_devptr(rscm_ens* h, void** out)
     NEED(h);
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = h->d_params;
+    h->uniform_rows = 0;   // whatever the caller writes there
     h->params_set = true;  // the caller fills it on the device
     return RSCM_OK;
 }
@@ -2134,6 +2155,7 @@ hipError_t launch_loglik(rscm_ens* h)
     a.src_off = h->source == RSCM_SRC_UPSTREAM ? 1 : 0;
     a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
     a.params = h->d_params;
+        a.uniform_rows = h->uniform_rows;
     a.forcing = h->d_forcing;
     a.scen = h->d_scen;
     a.nsub = h->d_nsub_tl;
@@ -2271,6 +2293,7 @@ rscm::SamplerArgs sampler_args(const rscm_sampler* s, int32_t half, int32_t iden
 int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
 {
     const rscm::SamplerArgs a = sampler_args(s, half, identity);
+    s->ev->uniform_rows = 0;  // the proposal kernel writes the evaluator's parameter block
     HIPCHK(rscm::launch_sampler_propose(a, s->ev->stream));
     if (s->fused) {
         HIPCHK(launch_loglik(s->ev));
@@ -2761,6 +2784,7 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(d_lh);
     if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "sample_lhs: %s", hipGetErrorString(e));
+    h->uniform_rows = 0;   // conservatively: low + u (high - low) need not reproduce low's bits for every u
     h->params_set = true;
     return RSCM_OK;
     GUARD_END

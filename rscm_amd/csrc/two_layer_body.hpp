@@ -112,12 +112,12 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
     const int32_t len = step_end - step_begin;
     const int64_t N = a.n_members;
 
-    const double lambda0 = a.params[0 * N + i];
-    const double pa = a.params[1 * N + i];
-    const double efficacy = a.params[2 * N + i];
-    const double eta = a.params[3 * N + i];
-    const double cs = a.params[4 * N + i];
-    const double cd = a.params[5 * N + i];
+    const double lambda0 = param_at(a.params, a.uniform_rows, 0, N, i);
+    const double pa = param_at(a.params, a.uniform_rows, 1, N, i);
+    const double efficacy = param_at(a.params, a.uniform_rows, 2, N, i);
+    const double eta = param_at(a.params, a.uniform_rows, 3, N, i);
+    const double cs = param_at(a.params, a.uniform_rows, 4, N, i);
+    const double cd = param_at(a.params, a.uniform_rows, 5, N, i);
     const int32_t scen = a.scen ? a.scen[i] : 0;
     // a linked forcing (rscm_ens_link_input, always the non-LDS variant) is another ensemble's
     // [T][N] series: coalesced, one stride of N per year

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     const int64_t i = (int64_t)blockIdx.x * kUdebBlock + threadIdx.x;
     if (i >= a.n_members) return;
     const int64_t N = a.n_members;
-    auto P = [&](int j) -> double { return a.params[(size_t)j * N + i]; };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     UdebP p;
     p.dz_mix = P(1); p.dz = P(2); p.kappa = P(3); p.kappa_min = P(4); p.kappa_dkdt = P(5);
     p.w0 = P(6); p.f_var = P(7); p.t_thresh_nh = P(8); p.t_thresh_sh = P(9);
