@@ -99,36 +99,51 @@ __device__ __forceinline__ void ocean_tile(const OceanArgs& a, const OceanMember
 #pragma unroll
         for (int k = PART * STEPS; k < (PART + 1) * STEPS; ++k) A[k] = a.partial[(size_t)(k - STEPS) * N + i];
     }
-    int32_t jr = (int32_t)(j % R);             // ring row of pulse j
     const int32_t mr0 = (int32_t)(m0 % R);     // ring row of the tile's first own pulse
     const int64_t head_end = (j + K - 1 < m0) ? j + K - 1 : m0;
-    for (; j < head_end; ++j, jr = ring_add(jr, 1, R)) {
-        const double f = hist[(size_t)jr * N];
+    // The old pulses [j, m0) occupy at most two runs of consecutive ring rows (the ring wraps at most once
+    // inside a window): within a run the loops below walk a plain pointer, as they did over the unwrapped history.
+    const int32_t jr0 = (int32_t)(j % R);
+    const int64_t j_wrap = j + (R - jr0);   // the first pulse at or after j that sits in ring row 0
+    int64_t jb = j;
+    int32_t row = jr0;
+#pragma unroll 1
+    for (int seg = 0; seg < 2 && jb < m0; ++seg) {   // one copy of the loops serves both runs
+        const int64_t je = (seg == 0 && j_wrap < m0) ? j_wrap : m0;
+        const double* __restrict__ hp = hist + (size_t)row * N;
+        int64_t jj = jb;
+        // Head: the first K-1 old pulses are still outside the window of the later sub-steps (bounded
+        // history), so each term is predicated.
+        for (; jj < je && jj < head_end; ++jj, hp += N) {
+            const double f = *hp;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int64_t lag = m0 + k - j;
-            const double next = mac<FUSED>(A[k], f, irf[lag < H ? lag : 0]);
-            if (j >= lo(k)) A[k] = next;
+            for (int k = 0; k < K; ++k) {
+                const int64_t lag = m0 + k - jj;
+                const double next = mac<FUSED>(A[k], f, irf[lag < H ? lag : 0]);
+                if (jj >= lo(k)) A[k] = next;
+            }
         }
-    }
-    // Bulk: groups of STEPS pulses share a K+STEPS-1 entry window of the response table
-    for (; j + STEPS <= m0; j += STEPS, jr = ring_add(jr, STEPS, R)) {
-        const int64_t base = m0 - j - (STEPS - 1);  // lag of (last pulse of the group, k = 0), >= 1
-        double w[K + STEPS - 1], f[STEPS];
+        // Bulk: groups of STEPS pulses share a K+STEPS-1 entry window of the response table
+        for (; jj + STEPS <= je; jj += STEPS, hp += (size_t)STEPS * N) {
+            const int64_t base = m0 - jj - (STEPS - 1);  // lag of (last pulse of the group, k = 0), >= 1
+            double w[K + STEPS - 1], f[STEPS];
 #pragma unroll
-        for (int t = 0; t < K + STEPS - 1; ++t) w[t] = irf[base + t];
+            for (int t = 0; t < K + STEPS - 1; ++t) w[t] = irf[base + t];
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) f[u] = hist[(size_t)ring_add(jr, u, R) * N];
+            for (int u = 0; u < STEPS; ++u) f[u] = hp[(size_t)u * N];
 #pragma unroll
-        for (int u = 0; u < STEPS; ++u) {
+            for (int u = 0; u < STEPS; ++u) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f[u], w[STEPS - 1 - u + k]);
+                for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f[u], w[STEPS - 1 - u + k]);
+            }
         }
-    }
-    for (; j < m0; ++j, jr = ring_add(jr, 1, R)) {  // tail
-        const double f = hist[(size_t)jr * N];
+        for (; jj < je; ++jj, hp += N) {  // tail
+            const double f = *hp;
 #pragma unroll
-        for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f, irf[m0 + k - j]);
+            for (int k = 0; k < K; ++k) A[k] = mac<FUSED>(A[k], f, irf[m0 + k - jj]);
+        }
+        jb = je;
+        row = 0;
     }
     // ---- the tile's own sub-steps (solve_ocean, carbon/ocean.rs:116-160), its pulses in registers
     double fy[K];
