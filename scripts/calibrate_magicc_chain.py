@@ -55,7 +55,9 @@ for name, vals in exo.items():
     builder.with_exogenous_variable(name, core.Timeseries(vals, axis, "", core.InterpolationStrategy.Linear))
 
 # the scalar view of the FourBox surface temperature is what MAGICC7's global mean compares with
-runner = cal.ModelRunner(builder, ["ClimateUDEB.ecs", "ClimateUDEB.kappa"], ["Surface Temperature"], execution_order="topological")
+FAST = "--fast" in sys.argv   # RSCM_MODE_FAST: OceanCarbon's O(T) recurrence instead of the literal convolution
+runner = cal.ModelRunner(builder, ["ClimateUDEB.ecs", "ClimateUDEB.kappa"], ["Surface Temperature"], execution_order="topological",
+                         mode=1 if FAST else 0)
 target = cal.Target()
 for year in range(1900, 2100, 10):          # MAGICC7's year n is our index n + 1 (upstream's comparison)
     target.add_observation("Surface Temperature", float(year + 1), float(V["Surface Temperature"][year - 1750]), 0.05)
