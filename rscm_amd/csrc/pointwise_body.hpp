@@ -134,7 +134,12 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
     for (int32_t n = step_begin; n < step_end; ++n) {
         double in[S::NI], out[S::NO];
 #pragma unroll
-        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, KIND == kKindAggregate ? n + 1 : n);  // AggregatorComponent reads at_end() (schema.rs:886-901)
+        for (int k = 0; k < S::NI; ++k) {
+            // AggregatorComponent reads at_end() (schema.rs:886-901).  Rows beyond the last contributor that was
+            // ever linked or set are NaN by construction (the input block starts out all-NaN): not read at all.
+            if (KIND == kKindAggregate) in[k] = k < a.n_inputs_used ? inputs.at(k, n + 1) : __builtin_nan("");
+            else in[k] = inputs.at(k, n);
+        }
         eval(p, in, out);
         const size_t r = (a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i;
 #pragma unroll

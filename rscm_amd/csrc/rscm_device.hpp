@@ -207,6 +207,7 @@ struct PointwiseArgs {
     const int32_t* scen;     // [N] or null
     InputLinks links;        // used when linked != 0
     int32_t linked;
+    int32_t n_inputs_used;   // aggregate kind: 1 + the highest contributor row that is linked or was given a series (the rest is NaN)
     double* out;             // [n_outputs][rows][N]
     uint8_t* status;
 };

@@ -286,6 +286,7 @@ struct rscm_ens {
     int32_t* d_nsub_cc = nullptr;
 
     double* d_params = nullptr;  // [P][N]
+    int32_t ag_rows_set = 0;     // aggregate kind: 1 + the highest contributor row rscm_ens_set_forcing has ever been given data for
     uint64_t uniform_rows = 0;   // bit j: parameter row j (< 64) holds one value for every member (the kernels then read element 0: param_at)
     double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
     double* d_forcing = nullptr; // [S][n_inputs][T]
@@ -1036,6 +1037,14 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
     h->n_scen = n_scen;
     h->source = source;
     h->forcing_set = true;
+    if (h->kind == RSCM_KIND_AGGREGATE) {  // rows after the last non-NaN one of the block stay out of the sums anyway
+        int32_t used = 0;
+        for (int32_t sidx = 0; sidx < n_scen; ++sidx)
+            for (int32_t k = 0; k < h->n_inputs; ++k)
+                for (int32_t t = 0; t < h->T; ++t)
+                    if (!std::isnan(series[((size_t)sidx * h->n_inputs + k) * h->T + t])) used = std::max(used, k + 1);
+        h->ag_rows_set = used;
+    }
     return RSCM_OK;
     GUARD_END
 }
@@ -1553,6 +1562,9 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.scen = h->d_scen;
         a.links = links;
         a.linked = linked;
+        a.n_inputs_used = h->ag_rows_set;
+        for (int32_t k = 0; k < rscm::kMaxLinks && k < h->n_inputs; ++k)
+            if (h->links[k].src) a.n_inputs_used = std::max(a.n_inputs_used, k + 1);
         a.out = h->series(1);
         a.status = h->d_status;
         if (op_out && (true)) {
