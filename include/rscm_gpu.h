@@ -548,7 +548,8 @@ RSCM_API int rscm_ens_run_loglik_device(rscm_ens* h, int32_t n_obs, const int32_
  * configures the structural rows of kinds that have them), forcing and initial values set; it must
  * outlive the sampler and is used exclusively by it while iterating.  A two-layer evaluator whose
  * observations have ascending time indices inside each variable group is scored by the fused
- * run+likelihood kernel (RSCM_FLAG_NO_SERIES is enough); any other kind, or observation order,
+ * run+likelihood kernel (RSCM_FLAG_NO_SERIES is enough), whose launches end at the last observed time index
+ * (later steps cannot change ln L; the evaluator's status then refers to that index); any other kind, or observation order,
  * is run through rscm_ens_run_async and scored from its stored series.  Sampled dimension d drives parameter row param_rows[d]; the other rows hold
  * base_params[P].  prior_kind: 0 = Uniform(low = a, high = b), 1 = Normal(mean = a, std = b),
  * 2 = LogNormal(mu = a, sigma = b); prior_low / prior_high truncate dimension d to [low, high]

@@ -335,6 +335,8 @@ struct rscm_ens {
     void* d_obs = nullptr;
     size_t obs_capacity = 0;
     int32_t obs_n = 0, obs_normalize = 0, obs_first_is_deep = 0;
+    int32_t obs_last_tidx = 0;        // the latest time index any prepared observation refers to
+    bool loglik_stop_at_last_obs = false;  // fused run+likelihood launches end there (the device sampler: only ln L is used)
 
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -2133,6 +2135,8 @@ int prepare_obs(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_
     }
     HIPCHK(hipMemcpy(h->d_obs, blob.data(), blob.size(), hipMemcpyHostToDevice));
     h->obs_n = n_obs;
+    h->obs_last_tidx = 0;
+    for (int32_t j = 0; j < n_obs; ++j) h->obs_last_tidx = std::max(h->obs_last_tidx, obs_tidx[j]);
     h->obs_normalize = normalize ? 1 : 0;
     h->obs_first_is_deep = first_var == RSCM_TL_VAR_TD ? 1 : 0;
     if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
@@ -2156,13 +2160,16 @@ int check_loglik_ready(rscm_ens* h)
 // Asynchronous fused run+likelihood launch with the prepared observations; fills h->d_loglik.
 hipError_t launch_loglik(rscm_ens* h)
 {
-    const int32_t len = h->T - 1;
+    // Steps after the last observed index cannot change ln L (GaussianLikelihood reads the model at the
+    // observation times only, likelihood.rs:206-226): a caller that uses nothing but ln L -- the device
+    // sampler -- lets the launch end there (1850-2020 observations on a 1750-2500 axis: 270 of 750 steps).
+    const int32_t len = h->loglik_stop_at_last_obs ? std::max(1, std::min(h->T - 1, h->obs_last_tidx)) : h->T - 1;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
     rscm::TwoLayerArgs a{};
     a.n_members = h->N;
     a.n_times = h->T;
     a.step_begin = 0;
-    a.step_end = h->T - 1;
+    a.step_end = len;
     a.n_scen = h->n_scen;
     a.src_off = h->source == RSCM_SRC_UPSTREAM ? 1 : 0;
     a.lds_forcing = lds_bytes <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
@@ -2379,6 +2386,7 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
     }
     if (fused) {
         if (int rc = prepare_obs(h, n_obs, obs_var, obs_tidx, obs_value, obs_sigma, normalize)) return rc;
+        h->loglik_stop_at_last_obs = true;   // cleared again by rscm_sampler_destroy
     } else {
         if (h->rows != h->T)
             return fail(RSCM_ERR_INVALID, "this evaluator stores no series: only the fused two-layer likelihood "
@@ -2483,7 +2491,10 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
 int rscm_sampler_destroy(rscm_sampler* s)
 {
     if (!s) return RSCM_OK;
-    if (s->ev) (void)hipStreamSynchronize(s->ev->stream);
+    if (s->ev) {
+        (void)hipStreamSynchronize(s->ev->stream);
+        s->ev->loglik_stop_at_last_obs = false;
+    }
     (void)hipFree(s->d_rows); (void)hipFree(s->d_kind); (void)hipFree(s->d_base); (void)hipFree(s->d_pa);
     (void)hipFree(s->d_pb); (void)hipFree(s->d_plo); (void)hipFree(s->d_phi); (void)hipFree(s->d_pos); (void)hipFree(s->d_logp); (void)hipFree(s->d_prop);
     (void)hipFree(s->d_z); (void)hipFree(s->d_lp); (void)hipFree(s->d_nacc); (void)hipFree(s->d_nprop);
