@@ -56,13 +56,11 @@ def main():
     ap.add_argument("--exact", action="store_true", help="RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) convolution")
     args = ap.parse_args()
     big, rows = run(args.members, args.years, args.exact)
-    # parity anchor: members are independent and their parameters are drawn per member from one seeded stream in
-    # member order?  build_chain draws whole vectors, so a small ensemble has other parameters: compare instead a
-    # 64-member ensemble that is GIVEN the first 64 members' parameters
-    from scripts.bench_magicc_chain import build_chain as bc
-    small = bc(64, args.years, "topological", steps_per_year=12, series_window=16, output_stride=12)
+    # Parity anchor at this size: a 64-member ensemble that is GIVEN the first 64 members' parameters
+    # (build_chain draws whole vectors from one seeded generator: replayed here for the big ensemble's draws)
     import scripts.bench_magicc_chain as mod
-    rng = np.random.default_rng(20260327)   # the generator build_chain uses, replayed for the big ensemble's draws
+    small = build_chain(64, args.years, "topological", steps_per_year=12, series_window=16, output_stride=12)
+    rng = np.random.default_rng(20260327)
     ecs = rng.uniform(2.0, 4.5, args.members)
     kappa = rng.uniform(0.5, 1.2, args.members)
     beta_f = rng.uniform(0.7, 1.3, args.members)

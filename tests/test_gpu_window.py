@@ -284,7 +284,7 @@ def test_configs3_share_runs_at_full_size(ra):
     fused launches).  scripts/run_configs3_share.py is the same thing as a program (profiles/r2_configs3_share_*)."""
     import json
     import os
-    import subprocess  # noqa: F401  (the script is imported, not spawned: a GPU process must not exec)
+    # the script is imported, not spawned: a GPU process must not exec other programs on this pool
     import sys
     import io
     import contextlib
