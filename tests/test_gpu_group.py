@@ -173,3 +173,79 @@ def test_fused_windowed_graph_keeps_the_bits(ra):
             assert_bit_equal(win.get_series(name, t_stride=5), plain.get_series(name)[::5], name)
     plain.close()
     win.close()
+
+
+def test_long_chains_split_into_several_fused_launches(ra):
+    """More light components in a row than one group launch takes (16): the step is cut into several fused
+    launches.  Twenty chained aggregates (each the Weighted image of the one before) feeding a two-layer model,
+    in one-step launches: fused == unfused, bit for bit, and 2 launches per step instead of 21."""
+    from rscm_amd import _lib as L
+    from rscm_amd.ensemble import run_lockstep
+    t = axis_values(1750, 1800)
+    b = np.append(t, t[-1] + 1.0)
+    T, n = len(t), 300
+    rng = np.random.default_rng(8)
+    stream = C.c_void_p()
+    L.check(L.load().rscm_gpu_stream_create(0, C.byref(stream)))
+    P_tl = np.stack([rng.uniform(lo, hi, n) for lo, hi in ((0.8, 1.5), (0.0, 0.1), (1.0, 1.8), (0.5, 1.0), (5.0, 15.0), (50.0, 200.0))])
+    aggs = [ra.Ensemble(ra.KIND_AGGREGATE, n, b) for _ in range(20)]
+    tl = ra.Ensemble(ra.KIND_TWO_LAYER, n, b)
+    # a heavy component between the light ones forces per-step launches (otherwise the whole run would be one launch)
+    ud = ra.Ensemble(ra.KIND_UDEB, n, b)
+    try:
+        for x in aggs + [tl, ud]:
+            x.set_stream(stream.value)
+        F = 3.0 * (1.0 - np.exp(-(t - 1750.0) / 30.0))
+        for k, a in enumerate(aggs):
+            w = np.zeros((9, n))
+            w[0] = 2.0                       # Weighted
+            w[1] = rng.uniform(0.9, 1.1, n)  # per-member weight of the single contributor
+            a.set_params(w)
+            if k == 0:
+                tab = np.full((8, T), np.nan)
+                tab[0] = F
+                a.set_forcing(tab)
+            else:
+                a.link_input(0, aggs[k - 1], 1, ra.SRC_UPSTREAM)
+        tl.set_params(P_tl)
+        tl.set_initial(1, 0.0)
+        tl.set_initial(2, 0.0)
+        tl.link_input(0, aggs[-1], 1, ra.SRC_UPSTREAM)
+        Pu = np.repeat(np.array(L.UD_DEFAULTS, dtype=np.float64)[:, None], n, axis=1)
+        ud.set_params(Pu)
+        for v in (1, 2, 3, 4):
+            ud.set_initial(v, 0.0)
+        ud.link_input(0, aggs[-1], 1, ra.SRC_EXOGENOUS)
+        for a in aggs:
+            a.set_initial(1, 0.0)           # ClimateUDEB reads its forcing at the start of step 0
+        order = aggs + [tl, ud]
+        out = {}
+        for fused in (True, False):
+            for x in order:
+                x.clear_series()
+            for a in aggs:
+                a.set_initial(1, 0.0)
+            tl.set_initial(1, 0.0)
+            tl.set_initial(2, 0.0)
+            for v in (1, 2, 3, 4):
+                ud.set_initial(v, 0.0)
+            _fusion(fused)
+            _stats()
+            run_lockstep(order)
+            launches, steps = _stats()
+            assert steps == 22 * (T - 1)
+            assert launches == (3 if fused else 22) * (T - 1)   # 16 + 5 fused (aggregates + two-layer), ClimateUDEB
+            out[fused] = (tl.get_series(1), aggs[-1].get_series(1), ud.get_series(7))
+        for a_, b_ in zip(out[True], out[False]):
+            assert_bit_equal(a_, b_, "fused in two groups vs unfused")
+        assert np.isfinite(out[True][0][1:]).all()
+    finally:
+        for x in [ud, tl] + aggs[::-1]:
+            for row in range(8):
+                try:
+                    x.unlink_input(row)
+                except Exception:
+                    pass
+        for x in [ud, tl] + aggs[::-1]:
+            x.close()
+        L.check(L.load().rscm_gpu_stream_destroy(0, stream))
