@@ -1386,14 +1386,13 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.ts = h->series(RSCM_TL_VAR_TS);
         a.td = h->series(RSCM_TL_VAR_TD);
         a.status = h->d_status;
-        if (op_out && (true)) {
+        if (op_out) {  // the arguments go into the fused launch's table instead (csrc/group.hip)
             a.lds_forcing = 0;
             op_out->kind = h->kind;
             op_out->variant = h->mode;
             op_out->u.tl = a;
             return RSCM_OK;
         }
-        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
     } else if (h->kind == RSCM_KIND_GHG_FORCING) {
         rscm::GhgArgs a{};
@@ -1414,13 +1413,16 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.erf_ch4 = h->series(RSCM_GH_VAR_ERF_CH4);
         a.erf_n2o = h->series(RSCM_GH_VAR_ERF_N2O);
         a.status = h->d_status;
-        if (op_out && (linked)) {
+        if (op_out) {  // the arguments go into the fused launch's table instead (csrc/group.hip)
+            if (!linked) {  // the table path uses host-built rows: not fused (fusable() keeps such a handle out)
+                op_out->kind = -1;
+                return RSCM_OK;
+            }
             op_out->kind = h->kind;
             op_out->variant = h->ghg_method;
             op_out->u.ghg = a;
             return RSCM_OK;
         }
-        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_ghg(a, h->stream));
     } else if (h->kind == RSCM_KIND_HALOCARBON) {
         rscm::HaloArgs a{};
@@ -1515,13 +1517,12 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
-        if (op_out && (true)) {
+        if (op_out) {  // the arguments go into the fused launch's table instead (csrc/group.hip)
             op_out->kind = h->kind;
             op_out->variant = 0;
             op_out->u.carbon = a;
             return RSCM_OK;
         }
-        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_carbon(a, h->stream));
     } else if (h->kind == RSCM_KIND_CH4_CHEMISTRY || h->kind == RSCM_KIND_N2O_CHEMISTRY) {
         rscm::ChemArgs a{};
@@ -1540,13 +1541,12 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.conc = h->series(RSCM_CHEM_VAR_CONC);
         a.lifetime = h->series(RSCM_CHEM_VAR_LIFETIME);
         a.status = h->d_status;
-        if (op_out && (true)) {
+        if (op_out) {  // the arguments go into the fused launch's table instead (csrc/group.hip)
             op_out->kind = h->kind;
             op_out->variant = 0;
             op_out->u.chem = a;
             return RSCM_OK;
         }
-        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_chem(a, h->stream));
     } else if ((h->kind >= RSCM_KIND_OZONE_FORCING && h->kind <= RSCM_KIND_AEROSOL_INDIRECT) ||
                h->kind == RSCM_KIND_FOURBOX_OHU || h->kind == RSCM_KIND_OSPP || h->kind == RSCM_KIND_CO2_ERF ||
@@ -1569,13 +1569,12 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
             if (h->links[k].src) a.n_inputs_used = std::max(a.n_inputs_used, k + 1);
         a.out = h->series(1);
         a.status = h->d_status;
-        if (op_out && (true)) {
+        if (op_out) {  // the arguments go into the fused launch's table instead (csrc/group.hip)
             op_out->kind = h->kind;
             op_out->variant = 0;
             op_out->u.pw = a;
             return RSCM_OK;
         }
-        if (op_out) op_out->kind = -1;
         HIPCHK(rscm::launch_pointwise(a, h->stream));
     } else if (h->kind == RSCM_KIND_UDEB) {
         if (!h->udeb_ready) return fail(RSCM_ERR_STATE, "ClimateUDEB parameters not configured");
