@@ -535,7 +535,7 @@ class ModelBuilder:
         aggregates = self._schema.aggregates if self._schema else {}
         if self._schema:
             self._schema.validate()
-        for comp in self._components:
+        for comp, node_name in zip(self._components, self._node_names()):
             for name, _, kind in comp.definitions:
                 if kind not in ("Input", "State"):
                     continue
@@ -546,6 +546,7 @@ class ModelBuilder:
                 else:
                     src = "Exogenous"
                 sources[(name, comp.type_name)] = src
+                sources[(name, node_name)] = src  # "<type>#k" for all but the last component of a type
                 kinds.setdefault(name, kind)
                 if name not in endogenous and name not in aggregates and name not in exo_names:
                     exo_names.append(name)
@@ -583,6 +584,25 @@ class ModelBuilder:
             raise NotImplementedError(f"unit conversion is not available on the GPU path: {name!r} is supplied in "
                                       f"{supplied!r}, expected {sorted(wanted)}")
 
+    def _node_names(self) -> List[str]:
+        """One graph-node name per component: its type name, except that all but the LAST registered
+        component of a type are "<type>#<k>".  The reference accepts several components that provide the
+        same variables (builder.rs:531-559: the later one becomes the owner, with an edge from the earlier
+        one); each of them writes index n+1 of the same series every step, so what stands is the write of
+        whichever runs LAST in the execution order (runtime.rs:504-527).  For components of one built-in
+        type -- same variables, same states -- the others' work is never seen: they keep their nodes (the
+        edges shape the breadth-first order) but get no ensemble (_build_graph)."""
+        last = {c.type_name: k for k, c in enumerate(self._components)}
+        seen: Dict[str, int] = {}
+        out = []
+        for k, c in enumerate(self._components):
+            if last[c.type_name] == k:
+                out.append(c.type_name)
+            else:
+                seen[c.type_name] = seen.get(c.type_name, 0) + 1
+                out.append(f"{c.type_name}#{seen[c.type_name]}")
+        return out
+
     def _graph_order(self, aggregates, topological: bool = False) -> List[str]:
         """Execution order of the reference: nodes in registration order (root, components,
         aggregates), edges as ModelBuilder::build adds them, petgraph Bfs from the root (neighbours
@@ -595,13 +615,14 @@ class ModelBuilder:
         edges: Dict[int, List[int]] = {}
         endogenous: Dict[str, int] = {}
         pending: List[Tuple[int, str]] = []
+        node_names = self._node_names()
 
         def add_edge(a: int, b: int) -> None:
             edges.setdefault(a, []).append(b)
 
-        for comp in self._components:
+        for comp, node_name in zip(self._components, node_names):
             node = len(names)
-            names.append(comp.type_name)
+            names.append(node_name)
             has_dep = False
             for name, _, kind in comp.definitions:
                 if kind not in ("Input", "State"):
@@ -670,18 +691,49 @@ class ModelBuilder:
                      execution_order: str = "reference", series_window: Optional[int] = None, output_stride: int = 0,
                      outputs: Optional[Sequence[str]] = None) -> "GraphModel":
         T, bounds = len(self._axis), self._axis.bounds()
-        types = [c.type_name for c in self._components]
-        if len(set(types)) != len(types):
-            raise NotImplementedError(f"two components of the same type in one graph: {types}")
-        for c in self._components:
+        node_names = self._node_names()
+        for c, node in zip(self._components, node_names):
             if c.type_name not in COMPONENT_KINDS and not getattr(c, "is_python", False):
                 raise NotImplementedError(f"component {c.type_name} has no GPU kernel; supported: " + "; ".join(SUPPORTED))
+            if node != c.type_name and getattr(c, "is_python", False):
+                # host components of one class may declare different variables: they would all be live
+                raise NotImplementedError(f"two Python components of the same type in one graph: {c.type_name}")
         if execution_order not in ("reference", "topological"):
             raise ValueError("execution_order must be 'reference' or 'topological'")
         order = self._graph_order(aggregates, topological=execution_order == "topological")
-        missing = [n for n in types + [f"Aggregator:{a}" for a in aggregates] if n not in order]
+        missing = [n for n in node_names + [f"Aggregator:{a}" for a in aggregates] if n not in order]
         if missing:
             raise NotImplementedError(f"components not reachable from the graph root: {missing}")
+        # of several components of one type the one that runs last stands (see _node_names): the others
+        # take part in the ordering only, and the survivor goes by the plain type name from here on
+        runs_last: Dict[str, str] = {}
+        for n in order:
+            if not n.startswith("Aggregator:"):
+                runs_last[n.split("#")[0]] = n
+        by_node = dict(zip(node_names, self._components))
+        for at, n in enumerate(order):
+            if n.startswith("Aggregator:") or runs_last[n.split("#")[0]] == n:
+                continue
+            # an overridden component's values ARE seen by whoever reads index n+1 between it and the survivor
+            provided = {name for name, _, kind in by_node[n].definitions if kind in ("Output", "State")}
+            for reader in order[at + 1:order.index(runs_last[n.split("#")[0]])]:
+                if reader.startswith("Aggregator:"):
+                    reads = set(aggregates[reader[len("Aggregator:"):]][2])
+                else:
+                    reads = {name for name, _, kind in by_node[reader].definitions
+                             if kind == "Input" and sources.get((name, reader)) == "UpstreamOutput"}
+                if provided & reads:
+                    raise NotImplementedError(f"{reader} reads {sorted(provided & reads)} of {n} within the step, before "
+                                              f"{runs_last[n.split('#')[0]]} overrides them")
+        order = [n.split("#")[0] if not n.startswith("Aggregator:") else n for n in order
+                 if n.startswith("Aggregator:") or runs_last[n.split("#")[0]] == n]
+        components = [c for c, node in zip(self._components, node_names) if runs_last[c.type_name] == node]
+        for c, node in zip(self._components, node_names):
+            if runs_last[c.type_name] == node and node != c.type_name:
+                sources = dict(sources)
+                for name, _, kind in c.definitions:
+                    if kind in ("Input", "State"):
+                        sources[(name, c.type_name)] = sources[(name, node)]
         stream = C.c_void_p()
         L.check(L.load().rscm_gpu_stream_create(self._device, C.byref(stream)))
         ensembles: Dict[str, Ensemble] = {}
@@ -715,7 +767,7 @@ class ModelBuilder:
                 return np.repeat(np.array(values, dtype=np.float64)[:, None], n_members, axis=1)
 
             owner_of: Dict[str, str] = {}  # storage ensemble of a Python component's variable -> the component
-            for comp in self._components:
+            for comp in components:
                 if getattr(comp, "is_python", False):
                     # a host component: its outputs live in one device series each (an aggregate-kind
                     # ensemble used as storage, never launched), so that GPU components can link to them
@@ -837,7 +889,7 @@ class ModelBuilder:
                     ens.set_forcing(table if ens.input_rows else table[0])
 
             model.param_home = {k: v for k, v in model.param_home.items() if v[1] >= 0}
-            for comp in self._components:
+            for comp in components:
                 if getattr(comp, "is_python", False):
                     node = model._host_nodes[comp.type_name]
                     for name in comp.input_names():

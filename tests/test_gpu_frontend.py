@@ -178,6 +178,45 @@ def test_notebook_coupled_model_vs_generic_stepper(api, rm):
     model.close()
 
 
+def test_two_components_of_one_type_the_one_that_runs_last_stands(api, rm):
+    """builder.rs:531-559 accepts a second provider of a variable (the later component becomes its owner, with
+    an edge from the earlier one); each writes index n+1 every step and the write of whichever runs last in the
+    breadth-first order stands (runtime.rs:504-527).  Two TwoLayer components with different parameters in the
+    coupled graph, the extra one registered second and registered last, against the generic stepper over one
+    shared collection."""
+    t = np.arange(1750.0, 1901.0)
+    tl_a = dict(lambda0=0.9, a=0.02, efficacy=1.1, eta=0.6, heat_capacity_surface=7.0, heat_capacity_deep=90.0)
+    finals = []
+    for at in (1, 4):
+        b, (years, vals), tl, cc = _coupled_builder(api, t)
+        b._components.insert(at, api.TwoLayerBuilder.from_parameters(tl_a).build())
+        model = b.build()
+        model.run()
+        got = model.timeseries()
+        comps = [rm.CarbonCycle(cc["tau"], cc["conc_pi"], cc["alpha_temperature"]), rm.CO2ERF(3.7, 278.0),
+                 rm.TwoLayer(*[tl[k] for k in api.core.TL_PARAM_ORDER])]
+        comps.insert(at, rm.TwoLayer(*[tl_a[k] for k in api.core.TL_PARAM_ORDER]))
+        ref = rm.ModelBuilder(
+            axis=rm.TimeAxis.from_values(t), components=comps,
+            aggregates=[("Effective Radiative Forcing", "Sum", ["Effective Radiative Forcing|CO2"])],
+            exogenous={"Emissions|CO2|Anthropogenic":
+                       rm.ExoSeries(list(vals), rm.TimeAxis.from_bounds(list(years) + [2101.0]), "Linear")},
+            initial_values={"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0,
+                            "Atmospheric Concentration|CO2": 278.0, "Surface Temperature": 0.0,
+                            "Deep Ocean Temperature": 0.0}).build()
+        ref.run()
+        for name, want in ref.data.items():
+            g = got.get_timeseries_by_name(name).values()
+            w = np.array(want)
+            assert (np.isnan(g) == np.isnan(w)).all(), (at, name)
+            ok = ~np.isnan(w)
+            assert (np.abs(g[ok] - w[ok]) <= RTOL * np.maximum(1.0, np.abs(w[ok]))).all(), (at, name)
+        finals.append(got.get_timeseries_by_name("Surface Temperature").values()[-1])
+        assert finals[-1] > 0.05
+        model.close()
+    assert finals[0] != finals[1]  # the survivor differs between the two registrations
+
+
 def test_coupled_model_with_two_preindustrial_concentrations(api, rm):
     """CarbonCycle.conc_pi != CO2ERF.conc_pi (builder.rs allows any parameters): the fused coupled kernel
     carries one conc_pi row, so the model is built as the same graph of linked ensembles -- and has to

@@ -178,6 +178,39 @@ def test_graph_order_is_the_reference_bfs():
             assert got == want, (perm, got, want)
 
 
+def test_graph_order_with_two_components_of_one_type():
+    """Several providers of one variable (builder.rs:531-559): every component keeps its node and the edge
+    from the earlier provider to the later one; the order is the oracle's breadth-first walk of that graph."""
+    from rscm_amd.components import CarbonCycleBuilder
+    init = {"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
+            "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}
+    make = {"CarbonCycle": lambda: CarbonCycleBuilder.from_parameters(dict(tau=25.0, conc_pi=278.0, alpha_temperature=0.1)).build(),
+            "CO2ERF": lambda: CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build(),
+            "TwoLayer": lambda: TwoLayerBuilder.from_parameters(P_TL).build()}
+    ref = {"CarbonCycle": lambda: rm.CarbonCycle(25.0, 278.0, 0.1), "CO2ERF": lambda: rm.CO2ERF(3.7, 278.0),
+           "TwoLayer": lambda: rm.TwoLayer(*P_TL.values())}
+    agg = [("Effective Radiative Forcing", "Sum", ["Effective Radiative Forcing|CO2"])]
+    for seq in (["TwoLayer", "CarbonCycle", "CO2ERF", "TwoLayer"], ["CarbonCycle", "CO2ERF", "TwoLayer", "TwoLayer"],
+                ["CO2ERF", "TwoLayer", "CO2ERF", "CarbonCycle"], ["CarbonCycle", "TwoLayer", "CarbonCycle", "CO2ERF", "TwoLayer"]):
+        schema = core.VariableSchema()
+        for n in list(init) + ["Effective Radiative Forcing|CO2", "Emissions|CO2|Anthropogenic"]:
+            schema.add_variable(n, "")
+        schema.add_aggregate(agg[0][0], "", agg[0][1], agg[0][2])
+        b = core.ModelBuilder().with_time_axis(core.TimeAxis.from_values(np.arange(1750.0, 1756.0))).with_schema(schema)
+        for k in seq:
+            b.with_rust_component(make[k]())
+        b.with_initial_values(init)
+        names = b._node_names()
+        assert [n.split("#")[0] for n in names] == seq and len(set(names)) == len(names)
+        assert all(("#" in n) == (k < len(seq) - 1 - seq[::-1].index(t)) for k, (n, t) in enumerate(zip(names, seq)))
+        _, _, _, aggregates = b._resolve()
+        got = [n.split("#")[0] for n in b._graph_order(aggregates)]
+        m = rm.ModelBuilder(axis=rm.TimeAxis.from_values(np.arange(1750.0, 1756.0)), components=[ref[k]() for k in seq],
+                            aggregates=agg, initial_values=init).build()
+        want = [m.order_nodes[i].type_name for i in m._bfs() if m.order_nodes[i] is not None]
+        assert got == want, (seq, got, want)
+
+
 def test_priors_and_lhs():
     ps = cal.ParameterSet().add("x", cal.Uniform(0.0, 2.0)).add("y", cal.Uniform(-1.0, 1.0))
     assert ps.param_names == ["x", "y"]
