@@ -268,7 +268,11 @@ extern "C" {
  * passed), NaN contributors skipped, all-NaN -> NaN.  The input block starts out all-NaN, so only the
  * rows that are linked or set take part.  output 1 the aggregate.
  *   params  operation (0 Sum, 1 Mean, 2 Weighted = sum of value * weight, no renormalisation),
- *           weights[8] */
+ *           weights[8]
+ * More than eight contributors are chained through several such ensembles (a partial enters the next stage
+ * as its row 0: the additions keep compute_aggregate's order).  For a Mean that takes three helper
+ * operations: 3 = number of non-NaN rows, 4 = row 0 (a count carried in) + number of non-NaN rows 1..7,
+ * 5 = row 0 / row 1 (sum / count; NaN when the count is 0). */
 #define RSCM_AG_NINPUTS 8
 #define RSCM_AG_NPARAMS 9
 

@@ -203,7 +203,7 @@ AG_NINPUTS = 8
 AG_INPUTS = tuple(f"contributor_{k}" for k in range(AG_NINPUTS))
 AG_VARS = {"contributors": 0, "aggregate": 1}
 AG_PARAM_NAMES = ("operation",) + tuple(f"weight_{k}" for k in range(AG_NINPUTS))
-AG_OPERATIONS = {"Sum": 0.0, "Mean": 1.0, "Weighted": 2.0}
+AG_OPERATIONS = {"Sum": 0.0, "Mean": 1.0, "Weighted": 2.0, "Count": 3.0, "CountCarry": 4.0, "Quotient": 5.0}
 
 # per kind: (variable ids, parameter names, input rows of variable 0 or None for a single series)
 KIND_TABLE = {

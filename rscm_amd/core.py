@@ -824,37 +824,52 @@ class ModelBuilder:
             # partial-sum stages -- stage k adds up to seven further contributors to the partial of stage
             # k-1 -- which keeps compute_aggregate's order of additions (schema.rs:760-802: one running sum
             # over the contributors in declaration order, NaN skipped, all-NaN -> NaN), so the result
-            # carries the same bits.  Weighted: the partial enters the next stage with weight 1.  Mean would
-            # need the count of non-NaN contributors carried along and is limited to eight.
+            # carries the same bits.  Weighted: the partial enters the next stage with weight 1.  A Mean of
+            # more than eight is that Sum chain, a second chain that counts the non-NaN contributors, and a
+            # last stage that divides the one by the other (sum / n as f64, NaN for n = 0).
             agg_stages: Dict[str, List[Tuple[str, List[str]]]] = {}
-            for agg, (_, op, contributors, weights) in aggregates.items():
-                contributors = list(contributors)
-                wts = list(weights or [])
-                if len(contributors) > L.AG_NINPUTS and op == "Mean":
-                    raise NotImplementedError(f"aggregate {agg!r}: a Mean of more than {L.AG_NINPUTS} contributors")
-                stages, k = [], 0
+
+            def add_stage(agg: str, name: str, op: str, rows: List[str], weights: List[float], out_var: str, final: bool) -> None:
+                ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
+                               window_rows=series_window if windowed else None,
+                               output_stride=output_stride if (final and (want_out is None or agg in want_out)) else 0)
+                ensembles[name] = ens
+                ens.set_stream(stream.value)
+                w = list(weights) + [0.0] * (L.AG_NINPUTS - len(weights))
+                ens.set_params(params_of([L.AG_OPERATIONS[op]] + w))
+                var_home[out_var] = (name, 1)
+                agg_stages[agg].append((name, rows))
+
+            def chain(agg: str, op: str, carry_op: str, contributors: List[str], wts: List[float], tag: str, final: bool) -> str:
+                """Stages over `contributors`; returns the variable the last one writes."""
+                k, n_stage, out_var = 0, 0, ""
                 while True:
-                    first = not stages
+                    first = n_stage == 0
                     take = L.AG_NINPUTS if first else L.AG_NINPUTS - 1
                     last = len(contributors) - k <= take
                     chunk = contributors[k:k + take]
                     wchunk = wts[k:k + take] if wts else []
                     k += len(chunk)
-                    name = f"Aggregator:{agg}" if last else f"Aggregator:{agg}#{len(stages)}"
-                    rows = chunk if first else [f"{agg}#partial{len(stages) - 1}"] + chunk
+                    is_final = final and last
+                    name = f"Aggregator:{agg}" if is_final else f"Aggregator:{agg}#{tag}{n_stage}"
+                    rows = chunk if first else [out_var] + chunk
                     wrow = wchunk if first else [1.0] + wchunk
-                    ens = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
-                                   window_rows=series_window if windowed else None,
-                                   output_stride=output_stride if (last and (want_out is None or agg in want_out)) else 0)
-                    ensembles[name] = ens
-                    ens.set_stream(stream.value)
-                    w = list(wrow) + [0.0] * (L.AG_NINPUTS - len(wrow))
-                    ens.set_params(params_of([L.AG_OPERATIONS[op]] + w))
-                    var_home[agg if last else f"{agg}#partial{len(stages)}"] = (name, 1)
-                    stages.append((name, rows))
+                    out_var = agg if is_final else f"{agg}#partial{tag}{n_stage}"
+                    add_stage(agg, name, op if first else carry_op, rows, wrow, out_var, is_final)
+                    n_stage += 1
                     if last:
-                        break
-                agg_stages[agg] = stages
+                        return out_var
+
+            for agg, (_, op, contributors, weights) in aggregates.items():
+                contributors = list(contributors)
+                agg_stages[agg] = []
+                if op == "Mean" and len(contributors) > L.AG_NINPUTS:
+                    total = chain(agg, "Sum", "Sum", contributors, [], "", False)
+                    count = chain(agg, "Count", "CountCarry", contributors, [], "count", False)
+                    add_stage(agg, f"Aggregator:{agg}", "Quotient", [total, count], [], agg, True)
+                else:
+                    chain(agg, op, op, contributors, list(weights or []), "", True)
+                stages = agg_stages[agg]
                 if len(stages) > 1:  # the partial stages run right before the aggregate itself
                     at = order.index(f"Aggregator:{agg}")
                     order[at:at] = [n for n, _ in stages[:-1]]

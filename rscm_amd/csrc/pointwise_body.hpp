@@ -101,6 +101,19 @@ __device__ __forceinline__ void eval(const double (&p)[2], const double (&in)[1]
 __device__ __forceinline__ void eval(const double (&p)[9], const double (&in)[8], double (&out)[1])
 {
     const int op = (int)p[0];
+    if (__builtin_expect(op >= 3, 0)) {
+        // the helper stages of a Mean over more than eight contributors (rscm_gpu.h): 3 counts the non-NaN
+        // rows, 4 the same with row 0 a count carried in, 5 divides row 0 (their sum) by row 1 (their number)
+        if (op == 5) {
+            out[0] = in[1] > 0.0 ? in[0] / in[1] : __builtin_nan("");
+            return;
+        }
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) n += (j > 0 || op == 3) && in[j] == in[j];
+        out[0] = (op == 4 ? in[0] : 0.0) + (double)n;
+        return;
+    }
     double s = 0.0;
     int n = 0;
 #pragma unroll

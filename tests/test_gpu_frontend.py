@@ -250,11 +250,12 @@ def test_coupled_model_with_two_preindustrial_concentrations(api, rm):
     model.close()
 
 
-@pytest.mark.parametrize("operation", ["Sum", "Weighted"])
+@pytest.mark.parametrize("operation", ["Sum", "Weighted", "Mean"])
 def test_aggregate_of_more_than_eight_contributors(api, operation):
     """compute_aggregate (schema.rs:760-802) folds any number of contributors; an aggregate ensemble takes
     eight, so eleven run as two chained stages whose additions keep the declaration order: the same bits
-    as one running sum.  Some contributors are NaN at some times (skipped), one row is NaN throughout."""
+    as one running sum (a Mean: that sum, a chained count of the non-NaN contributors, and their quotient).
+    Some contributors are NaN at some times (skipped), one row is NaN throughout."""
     c = api.core
     t = np.arange(1850.0, 1881.0)
     axis = c.TimeAxis.from_values(t)
@@ -279,7 +280,7 @@ def test_aggregate_of_more_than_eight_contributors(api, operation):
     assert isinstance(model, c.GraphModel) and "Aggregator:Effective Radiative Forcing#0" in model._order
     model.run()
     got = model.timeseries()
-    assert not any("#partial" in n for n in got.names())
+    assert not any("#" in n for n in got.names())
     erf = got.get_timeseries_by_name("Effective Radiative Forcing").values()
     want = np.full(len(t), np.nan)
     for n in range(len(t) - 1):      # contributors at n + 1, in declaration order, NaN skipped
@@ -289,21 +290,10 @@ def test_aggregate_of_more_than_eight_contributors(api, operation):
             if not np.isnan(v):
                 acc = acc + (v * weights[k] if weights else v)
                 cnt += 1
-        want[n + 1] = acc if cnt else np.nan
+        want[n + 1] = (acc / float(cnt) if operation == "Mean" else acc) if cnt else np.nan
     assert_bit_equal(erf, want, f"{operation} of eleven contributors")
     assert np.isfinite(got.get_timeseries_by_name("Surface Temperature").values()[1:]).all()
     model.close()
-    with pytest.raises(NotImplementedError, match="Mean of more than"):
-        s2 = c.VariableSchema()
-        for n in names + ["Surface Temperature", "Deep Ocean Temperature"]:
-            s2.add_variable(n, "")
-        s2.add_aggregate("Effective Radiative Forcing", "W/m^2", "Mean", names)
-        b2 = (c.ModelBuilder().with_time_axis(axis).with_schema(s2)
-              .with_rust_component(api.TwoLayerBuilder.from_parameters(fixed).build())
-              .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
-        for n in names:
-            b2 = b2.with_exogenous_variable(n, c.Timeseries(series[n], axis, "W/m^2", c.InterpolationStrategy.Previous))
-        b2.build()
 
 
 def _tl_runner(api, t, F, names, outputs=("Surface Temperature",), mode=0):
