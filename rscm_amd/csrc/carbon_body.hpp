@@ -15,6 +15,46 @@ constexpr double kGtcPerPpm = 2.13;  // crates/rscm-components/src/constants.rs:
 // constant over it (get() ignores t).  The arithmetic is that of the fused coupled chain
 // (csrc/coupled.hip, year<false>), so a graph assembled from linked ensembles reproduces the
 // fused kind bit for bit.  in = {Emissions|CO2|Anthropogenic, Surface Temperature}.
+// The RK4 sub-steps of one model step.  SPEC: the forty divisions by the year's lifetime as the
+// three-instruction quotient with the reciprocal hoisted (rk4_device.hpp), the numerators' exponent-window
+// tags folded into `acc` -- the year is replayed with the compiler's divisions if any tag falls outside,
+// as in the fused chain (coupled.hip, year<SPEC>), instead of a branch per division.
+template <bool SPEC>
+__device__ __forceinline__ int32_t carbon_cycle_year(double lifetime, double rlife, double conc_pi, double emis, double e_ppm, int32_t m, double hc,
+                                                     double half_c, double sixth_c, double& conc, double& cum_u, double& cum_e, int32_t acc)
+{
+    auto quot = [&](double n, int32_t& tag) -> double {
+        if constexpr (SPEC) {
+            tag = window_tag(n);
+            return spec_div(n, lifetime, rlife);
+        } else {
+            return n / lifetime;
+        }
+    };
+    for (int32_t s = 0; s < m; ++s) {
+        int32_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        const double up1 = quot(conc - conc_pi, t1);
+        const double k1c = e_ppm - up1, k1u = up1 * kGtcPerPpm;
+        const double up2 = quot((conc + k1c * half_c) - conc_pi, t2);
+        const double k2c = e_ppm - up2, k2u = up2 * kGtcPerPpm;
+        const double up3 = quot((conc + k2c * half_c) - conc_pi, t3);
+        const double k3c = e_ppm - up3, k3u = up3 * kGtcPerPpm;
+        const double up4 = quot((conc + k3c * hc) - conc_pi, t4);
+        const double k4c = e_ppm - up4, k4u = up4 * kGtcPerPpm;
+        if constexpr (SPEC) {
+            acc = max3_i32(max3_i32(acc, t1, t2), t3, t4);
+            // inside the windows 2*k cannot overflow: the doubling fused into the addition rounds the same
+            conc = rk4_combine_fused2(conc, k1c, k2c, k3c, k4c, sixth_c);
+            cum_u = rk4_combine_fused2(cum_u, k1u, k2u, k3u, k4u, sixth_c);
+        } else {
+            conc = rk4_combine(conc, k1c, k2c, k3c, k4c, sixth_c);
+            cum_u = rk4_combine(cum_u, k1u, k2u, k3u, k4u, sixth_c);
+        }
+        cum_e = rk4_combine(cum_e, emis, emis, emis, emis, sixth_c);
+    }
+    return acc;
+}
+
 template <int SRC>
 __device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
 {
@@ -26,27 +66,23 @@ __device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i
     const size_t vs = (size_t)a.rows * N;
     const size_t r0 = (size_t)step_begin * N + i;
     double conc = a.series[r0], cum_u = a.series[vs + r0], cum_e = a.series[2 * vs + r0];
-    const double hc = a.h, half_c = hc / 2.0, sixth_c = hc / 6.0;
+    const double hc = a.h, half_c = a.h_half, sixth_c = a.h_sixth;
     for (int32_t n = step_begin; n < step_end; ++n) {
         const double emis = in.at(0, n), temperature = in.at(1, n);
         const double lifetime = tau * exp(alpha * temperature);
-        // forty divisions by the year's lifetime: the hoisted-reciprocal quotient of rk4_device.hpp
-        // (IEEE-identical inside its exponent windows, the compiler's division outside them)
-        const ConstDiv dl = make_const_div(lifetime);
+        const double rlife = refined_rcp(lifetime);
+        const int32_t acc0 = divisor_in_window(lifetime) ? (int32_t)0x80000000 : 0;  // 0: never "all inside"
         const double e_ppm = emis / kGtcPerPpm;
         const int32_t m = a.nsub[n];
-        for (int32_t s = 0; s < m; ++s) {
-            const double up1 = div_const(conc - conc_pi, dl);
-            const double k1c = e_ppm - up1, k1u = up1 * kGtcPerPpm;
-            const double up2 = div_const((conc + k1c * half_c) - conc_pi, dl);
-            const double k2c = e_ppm - up2, k2u = up2 * kGtcPerPpm;
-            const double up3 = div_const((conc + k2c * half_c) - conc_pi, dl);
-            const double k3c = e_ppm - up3, k3u = up3 * kGtcPerPpm;
-            const double up4 = div_const((conc + k3c * hc) - conc_pi, dl);
-            const double k4c = e_ppm - up4, k4u = up4 * kGtcPerPpm;
-            conc = rk4_combine(conc, k1c, k2c, k3c, k4c, sixth_c);
-            cum_u = rk4_combine(cum_u, k1u, k2u, k3u, k4u, sixth_c);
-            cum_e = rk4_combine(cum_e, emis, emis, emis, emis, sixth_c);
+        const double conc0 = conc, cum_u0 = cum_u, cum_e0 = cum_e;
+        const int32_t acc = carbon_cycle_year<true>(lifetime, rlife, conc_pi, emis, e_ppm, m, hc, half_c, sixth_c, conc, cum_u, cum_e, acc0);
+        // A NaN lifetime makes the concentration and the uptake NaN on either path (cumulative emissions
+        // involve no division); everything else must have stayed inside the windows.
+        if (__builtin_expect(acc >= 0 && lifetime == lifetime, 0)) {
+            conc = conc0;
+            cum_u = cum_u0;
+            cum_e = cum_e0;
+            carbon_cycle_year<false>(lifetime, rlife, conc_pi, emis, e_ppm, m, hc, half_c, sixth_c, conc, cum_u, cum_e, 0);
         }
         const size_t r = (size_t)(n + 1) * N + i;
         a.series[r] = conc;

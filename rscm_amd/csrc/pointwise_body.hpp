@@ -95,68 +95,91 @@ __device__ __forceinline__ void eval(const double (&p)[2], const double (&in)[1]
     out[0] = (p[0] / kLn2) * log(1.0 + (in[0] - p[1]) / p[1]);
 }
 
-// compute_aggregate, schema.rs:760-802; p = {operation (0 Sum, 1 Mean, 2 Weighted), weights[8]};
-// in = up to eight contributors.  NaN contributors are skipped and all-NaN gives NaN, so an unused
-// row is simply a NaN row (the input block of this kind starts out as all NaN).
-__device__ __forceinline__ void eval(const double (&p)[9], const double (&in)[8], double (&out)[1])
+// compute_aggregate, schema.rs:760-802; params = {operation (0 Sum, 1 Mean, 2 Weighted), weights[8]}; up to
+// eight contributors, read at_end() (AggregatorComponent, schema.rs:886-901).  NaN contributors are skipped
+// and all-NaN gives NaN, so an unused row is simply a NaN row (the input block of this kind starts out all
+// NaN); rows beyond the last contributor that was ever linked or set (n_inputs_used, wave-uniform) are NaN by
+// construction and not read at all.  Operations 3-5 are the helper stages of a Mean over more than eight
+// contributors (rscm_gpu.h): 3 counts the non-NaN rows, 4 the same with row 0 a count carried in, 5 divides
+// row 0 (their sum) by row 1 (their number).
+//
+// Written apart from the other pointwise kinds: in a graph this component is pure overhead (one load, one
+// add, one store), so the loops run over the rows in use with scalar branches, the operation -- one value
+// for the whole ensemble in practice, a scalar register then (param_at_scalar) -- is branched on rather than
+// selected on, and the weights are read by the Weighted operation only.
+template <int SRC>
+__device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
 {
-    const int op = (int)p[0];
-    if (__builtin_expect(op >= 3, 0)) {
-        // the helper stages of a Mean over more than eight contributors (rscm_gpu.h): 3 counts the non-NaN
-        // rows, 4 the same with row 0 a count carried in, 5 divides row 0 (their sum) by row 1 (their number)
-        if (op == 5) {
-            out[0] = in[1] > 0.0 ? in[0] / in[1] : __builtin_nan("");
-            return;
-        }
-        int n = 0;
+    const int64_t N = a.n_members;
+    const int op = (int)param_at_scalar(a.params, a.uniform_rows, 0, N, i);
+    const int32_t used = a.n_inputs_used;
+    const MemberInputs<SRC, 8> inputs(a.inputs, a.scen, a.links, a.n_times, N, i);
+    double w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) n += (j > 0 || op == 3) && in[j] == in[j];
-        out[0] = (op == 4 ? in[0] : 0.0) + (double)n;
-        return;
-    }
-    double s = 0.0;
-    int n = 0;
+    for (int k = 0; k < 8; ++k) w[k] = (op == 2 && k < used) ? param_at_scalar(a.params, a.uniform_rows, 1 + k, N, i) : 0.0;
+    a.status[i] = 0;
+    for (int32_t n = step_begin; n < step_end; ++n) {
+        double result;
+        if (__builtin_expect(op >= 3, 0)) {
+            const double in0 = used > 0 ? inputs.at(0, n + 1) : __builtin_nan("");
+            if (op == 5) {
+                const double in1 = used > 1 ? inputs.at(1, n + 1) : __builtin_nan("");
+                result = in1 > 0.0 ? in0 / in1 : __builtin_nan("");
+            } else {
+                int cnt = (op == 3 && in0 == in0) ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (in[j] == in[j]) {
-            s = s + (op == 2 ? in[j] * p[1 + j] : in[j]);
-            ++n;
+                for (int k = 1; k < 8; ++k) {
+                    if (k >= used) break;
+                    const double v = inputs.at(k, n + 1);
+                    cnt += v == v;
+                }
+                result = (op == 4 ? in0 : 0.0) + (double)cnt;
+            }
+        } else {
+            double s = 0.0;
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= used) break;
+                const double v = inputs.at(k, n + 1);
+                if (v == v) {
+                    s = s + (op == 2 ? v * w[k] : v);
+                    ++cnt;
+                }
+            }
+            if (op == 1) s = s / (double)cnt;
+            result = cnt ? s : __builtin_nan("");
         }
+        a.out[(a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i] = result;
     }
-    if (op == 1) s = s / (double)n;
-    out[0] = n ? s : __builtin_nan("");
 }
 
 // Member i of component KIND over the steps [step_begin, step_end).
 template <int KIND, int SRC>
 __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
 {
+    if constexpr (KIND == kKindAggregate) {
+        aggregate_body<SRC>(a, i, step_begin, step_end);
+        return;
+    } else {
     using S = Shape<KIND>;
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     double p[S::P];
 #pragma unroll
-    for (int j = 0; j < S::P; ++j) {
-        // the aggregate's eight weight rows matter to the Weighted operation only
-        if (KIND == kKindAggregate && j > 0 && p[0] != 2.0) p[j] = 0.0;
-        else p[j] = param_at(a.params, a.uniform_rows, j, N, i);
-    }
+    for (int j = 0; j < S::P; ++j) p[j] = param_at_scalar(a.params, a.uniform_rows, j, N, i);
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
     a.status[i] = 0;
     for (int32_t n = step_begin; n < step_end; ++n) {
         double in[S::NI], out[S::NO];
 #pragma unroll
-        for (int k = 0; k < S::NI; ++k) {
-            // AggregatorComponent reads at_end() (schema.rs:886-901).  Rows beyond the last contributor that was
-            // ever linked or set are NaN by construction (the input block starts out all-NaN): not read at all.
-            if (KIND == kKindAggregate) in[k] = k < a.n_inputs_used ? inputs.at(k, n + 1) : __builtin_nan("");
-            else in[k] = inputs.at(k, n);
-        }
+        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, n);
         eval(p, in, out);
         const size_t r = (a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i;
 #pragma unroll
         for (int o = 0; o < S::NO; ++o) a.out[(size_t)o * var_stride + r] = out[o];
+    }
     }
 }
 

@@ -45,6 +45,21 @@ __device__ __forceinline__ double param_at(const double* __restrict__ params, ui
     return params[(size_t)j * N + (u ? (int64_t)0 : i)];
 }
 
+// The same value, with a uniform row read through the constant address space: s_load_dwordx2 into scalar
+// registers -- no vector memory instruction, no address arithmetic per lane, and code that branches on the
+// value (the aggregate's operation) branches uniformly.  For the light bodies only: in the register-bound
+// kernels (ClimateUDEB, OceanCarbon) dozens of parameters in scalar registers spill.  The block is not
+// written while a kernel that reads it runs.
+__device__ __forceinline__ double param_at_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i)
+{
+    const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;  // wave-uniform: a scalar branch
+    if (u) {
+        typedef const __attribute__((address_space(4))) double* scalar_row;
+        return *(scalar_row)(uintptr_t)(params + (size_t)j * N);
+    }
+    return params[(size_t)j * N + i];
+}
+
 // The NI input rows of member i.  SRC 0: one shared table [NI][T]; 1: per-member scenario of a
 // table [S][NI][T]; 2: linked rows (coalesced [T][N] reads) mixed with table rows.  SRC < 2
 // compiles to the plain table indexing the kernels had before links existed.
@@ -105,6 +120,8 @@ struct TwoLayerArgs {
     const int32_t* scen;     // [N] or nullptr
     const int32_t* nsub;     // [T-1] RK4 sub-steps of step n = ceil((b[n+1]-b[n])/h)
     double h;                // RK4 step (reference: 0.1)
+    double h_half, h_sixth;  // h / 2.0 and h / 6.0 as the host's IEEE division rounds them (= the device's): uniform
+                             // values, but a per-lane division per launch -- per model step in a fused graph launch
     double* ts;              // [T][N]
     double* td;              // [T][N]
     uint8_t* status;         // [N]
@@ -245,6 +262,7 @@ struct CarbonArgs {
     const double* bounds;    // [T+1]
     const int32_t* nsub;     // CarbonCycle: [T-1] RK4 sub-steps per model step
     double h;                // CarbonCycle: RK4 step
+    double h_half, h_sixth;  // h / 2.0, h / 6.0 (see TwoLayerArgs)
     int32_t rows;            // stored rows per series (T, or the window length)
     double* series;          // [n_states + n_outputs][rows][N], states first
     uint8_t* status;

@@ -1383,6 +1383,8 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.scen = linked ? nullptr : h->d_scen;
         a.nsub = h->d_nsub_tl;
         a.h = h->h_tl;
+        a.h_half = h->h_tl / 2.0;
+        a.h_sixth = h->h_tl / 6.0;
         a.ts = h->series(RSCM_TL_VAR_TS);
         a.td = h->series(RSCM_TL_VAR_TD);
         a.status = h->d_status;
@@ -1514,6 +1516,8 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
         a.bounds = h->d_bounds;
         a.nsub = h->d_nsub_cc;
         a.h = h->h_cc;
+        a.h_half = h->h_cc / 2.0;
+        a.h_sixth = h->h_cc / 6.0;
         a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
@@ -2178,6 +2182,8 @@ hipError_t launch_loglik(rscm_ens* h)
     a.scen = h->d_scen;
     a.nsub = h->d_nsub_tl;
     a.h = h->h_tl;
+    a.h_half = h->h_tl / 2.0;
+    a.h_sixth = h->h_tl / 6.0;
     a.ts = h->series(RSCM_TL_VAR_TS);
     a.td = h->series(RSCM_TL_VAR_TD);
     a.status = h->d_status;

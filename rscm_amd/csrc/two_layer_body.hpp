@@ -135,8 +135,8 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
     double* out_td = a.td + (size_t)(step_begin + 1) * N + i;
 
     const double h = a.h;
-    const double half_step = h / 2.0;
-    const double sixth = h / 6.0;
+    const double half_step = a.h_half;
+    const double sixth = a.h_sixth;
     const int32_t last = step_end - 1;
 
     LikAcc lik;
