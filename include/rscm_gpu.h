@@ -477,7 +477,11 @@ RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, 
  * forcing formulas, budgets, aggregates, grid transforms, the RK4 box models) instead of one per component:
  * each thread runs the components' per-member bodies in graph order -- every graph edge is per member, so this
  * is the same computation, bit for bit.  ClimateUDEB, OceanCarbon and HalocarbonChemistry keep their own
- * launches.  enabled = 0 switches the fusion off for the process (A/B tests); default on. */
+ * launches.  A graph made of light components only runs ALL its steps in one launch, and between the steps
+ * every component keeps its varying parameters, its state and what its consumers read in thread-private LDS
+ * slots instead of reading them back from HBM (the series are still written every step).
+ * enabled = 0 switches the fusion off for the process, 2 keeps the fusion but not the LDS slots (A/B tests);
+ * default 1. */
 RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
 /* Step launches issued by rscm_ens_run_lockstep (component kernels + fused groups; HalocarbonChemistry counts
  * as one) and the component steps they carried, since the last call; resets both counters. */

@@ -55,20 +55,21 @@ __device__ __forceinline__ int32_t carbon_cycle_year(double lifetime, double rli
     return acc;
 }
 
-template <int SRC>
-__device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
+template <int SRC, class Cache = NoCache>
+__device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i, int32_t step_begin, int32_t step_end, const Cache& cache = Cache())
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    const double tau = param_at(a.params, a.uniform_rows, 0, N, i), conc_pi = param_at(a.params, a.uniform_rows, 1, N, i),
-                 alpha = param_at(a.params, a.uniform_rows, 2, N, i);
+    const double tau = cache.param(a.params, a.uniform_rows, 0, N, i), conc_pi = cache.param(a.params, a.uniform_rows, 1, N, i),
+                 alpha = cache.param(a.params, a.uniform_rows, 2, N, i);
     const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
     const size_t r0 = (size_t)step_begin * N + i;
-    double conc = a.series[r0], cum_u = a.series[vs + r0], cum_e = a.series[2 * vs + r0];
+    double conc = cache.state(0, a.series + r0), cum_u = cache.state(1, a.series + vs + r0), cum_e = cache.state(2, a.series + 2 * vs + r0);
     const double hc = a.h, half_c = a.h_half, sixth_c = a.h_sixth;
     for (int32_t n = step_begin; n < step_end; ++n) {
-        const double emis = in.at(0, n), temperature = in.at(1, n);
+        // (a fused launch calls per model step: n is the step it is at, which is what the cache holds)
+        const double emis = in.at(0, n, cache), temperature = in.at(1, n, cache);
         const double lifetime = tau * exp(alpha * temperature);
         const double rlife = refined_rcp(lifetime);
         const int32_t acc0 = divisor_in_window(lifetime) ? (int32_t)0x80000000 : 0;  // 0: never "all inside"
@@ -88,8 +89,11 @@ __device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i
         a.series[r] = conc;
         a.series[vs + r] = cum_u;
         a.series[2 * vs + r] = cum_e;
+        cache.put(0, conc);
+        cache.put(1, cum_u);
+        cache.put(2, cum_e);
     }
-    a.status[i] = (is_finite(conc) && is_finite(cum_u) && is_finite(cum_e)) ? 0 : 1;
+    if (cache.last_step()) a.status[i] = (is_finite(conc) && is_finite(cum_u) && is_finite(cum_e)) ? 0 : 1;
 }
 
 template <int SRC>

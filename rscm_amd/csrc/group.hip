@@ -32,46 +32,67 @@ namespace {
 
 // FULL = false leaves out the register-hungry bodies (TerrestrialCarbon 134 VGPRs, CH4 110, GhgForcing 102,
 // OzoneForcing 101, AerosolDirect 92, N2O 87): a segment made of box models, CO2ERF, budgets, aggregates and
-// grid transforms only then runs at <= 80 registers, i.e. six wavefronts per SIMD instead of three -- these
+// grid transforms only then runs at <= 96 registers, i.e. five wavefronts per SIMD instead of three -- these
 // launches wait on four dependent memory round trips per step and need the occupancy to hide them.
-template <bool FULL>
+template <bool FULL, class Cache>
+__device__ __forceinline__ void run_op(const GroupOp& op, int64_t i, int32_t b, int32_t e, const Cache& cache)
+{
+    switch (op.kind) {
+        case 0:  // RSCM_KIND_TWO_LAYER (forcing through L2: a linked series or the scenario table)
+            if (op.variant == 0) tl::two_layer_body<0, false, true>(op.u.tl, nullptr, i, b, e, cache);
+            else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, b, e, cache);
+            break;
+        case 3:  // RSCM_KIND_GHG_FORCING, linked concentrations
+            if constexpr (FULL) {
+                if (op.variant == 0) ghg::ghg_body<0, false, true>(op.u.ghg, nullptr, i, b, e);
+                else ghg::ghg_body<1, false, true>(op.u.ghg, nullptr, i, b, e);
+            }
+            break;
+        case kKindOzoneForcing: if constexpr (FULL) pw::pointwise_body<kKindOzoneForcing, 2>(op.u.pw, i, b, e); break;
+        case kKindAerosolDirect: if constexpr (FULL) pw::pointwise_body<kKindAerosolDirect, 2>(op.u.pw, i, b, e); break;
+        case kKindAerosolIndirect: pw::pointwise_body<kKindAerosolIndirect, 2>(op.u.pw, i, b, e, cache); break;
+        case kKindFourBoxOhu: pw::pointwise_body<kKindFourBoxOhu, 2>(op.u.pw, i, b, e, cache); break;
+        case kKindOspp: pw::pointwise_body<kKindOspp, 2>(op.u.pw, i, b, e, cache); break;
+        case kKindCo2Erf: pw::pointwise_body<kKindCo2Erf, 2>(op.u.pw, i, b, e, cache); break;
+        case kKindAggregate: pw::pointwise_body<kKindAggregate, 2>(op.u.pw, i, b, e, cache); break;
+        case kKindCh4Chemistry: if constexpr (FULL) chem::ch4_body<2>(op.u.chem, i, b, e); break;
+        case kKindN2oChemistry: if constexpr (FULL) chem::n2o_body<2>(op.u.chem, i, b, e); break;
+        case kKindCo2Budget: carbon::co2_budget_body<2>(op.u.carbon, i, b, e); break;
+        case kKindTerrestrialCarbon: if constexpr (FULL) carbon::terrestrial_body<2>(op.u.carbon, i, b, e); break;
+        case kKindCarbonCycle: carbon::carbon_cycle_body<2>(op.u.carbon, i, b, e, cache); break;
+        default: break;
+    }
+}
+
+// CACHED (a graph of light components only, stepped many model steps in one launch): between the steps every op
+// keeps its varying parameter rows, the latest row of its series and thereby what its consumers read in
+// thread-private LDS slots (OpCache, assigned by rscm_gpu.cpp) -- in steady state the launch reads nothing back
+// from HBM and only streams the series out, like a kernel written for the graph would.
+template <bool FULL, bool CACHED>
 __global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members, int32_t step_begin,
                                                        int32_t step_end)
 {
+    extern __shared__ double lds_slots[];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_members) return;
     // Several model steps in one launch when the table is the WHOLE graph (no heavy component in between):
     // step after step, component after component, as Model::run does -- the waves never drain between steps.
-    for (int32_t b = step_begin; b < step_end; ++b) {
-    const int32_t e = b + 1;
-    for (int32_t k = 0; k < n_ops; ++k) {
-        const GroupOp& op = ops[k];
-        switch (op.kind) {
-            case 0:  // RSCM_KIND_TWO_LAYER (forcing through L2: a linked series or the scenario table)
-                if (op.variant == 0) tl::two_layer_body<0, false, true>(op.u.tl, nullptr, i, b, e);
-                else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, b, e);
-                break;
-            case 3:  // RSCM_KIND_GHG_FORCING, linked concentrations
-                if constexpr (FULL) {
-                    if (op.variant == 0) ghg::ghg_body<0, false, true>(op.u.ghg, nullptr, i, b, e);
-                    else ghg::ghg_body<1, false, true>(op.u.ghg, nullptr, i, b, e);
-                }
-                break;
-            case kKindOzoneForcing: if constexpr (FULL) pw::pointwise_body<kKindOzoneForcing, 2>(op.u.pw, i, b, e); break;
-            case kKindAerosolDirect: if constexpr (FULL) pw::pointwise_body<kKindAerosolDirect, 2>(op.u.pw, i, b, e); break;
-            case kKindAerosolIndirect: pw::pointwise_body<kKindAerosolIndirect, 2>(op.u.pw, i, b, e); break;
-            case kKindFourBoxOhu: pw::pointwise_body<kKindFourBoxOhu, 2>(op.u.pw, i, b, e); break;
-            case kKindOspp: pw::pointwise_body<kKindOspp, 2>(op.u.pw, i, b, e); break;
-            case kKindCo2Erf: pw::pointwise_body<kKindCo2Erf, 2>(op.u.pw, i, b, e); break;
-            case kKindAggregate: pw::pointwise_body<kKindAggregate, 2>(op.u.pw, i, b, e); break;
-            case kKindCh4Chemistry: if constexpr (FULL) chem::ch4_body<2>(op.u.chem, i, b, e); break;
-            case kKindN2oChemistry: if constexpr (FULL) chem::n2o_body<2>(op.u.chem, i, b, e); break;
-            case kKindCo2Budget: carbon::co2_budget_body<2>(op.u.carbon, i, b, e); break;
-            case kKindTerrestrialCarbon: if constexpr (FULL) carbon::terrestrial_body<2>(op.u.carbon, i, b, e); break;
-            case kKindCarbonCycle: carbon::carbon_cycle_body<2>(op.u.carbon, i, b, e); break;
-            default: break;
+    if constexpr (CACHED) {
+        // the first step fills the slots (cold: parameters and states come from HBM), the others live on them
+        for (int32_t k = 0; k < n_ops; ++k) {
+            const GroupOp& op = ops[k];
+            run_op<FULL>(op, i, step_begin, step_begin + 1, LdsCache<false>{lds_slots + threadIdx.x, op.cache, step_begin + 1 == step_end});
         }
-    }
+        for (int32_t b = step_begin + 1; b < step_end; ++b) {
+            for (int32_t k = 0; k < n_ops; ++k) {
+                const GroupOp& op = ops[k];
+                run_op<FULL>(op, i, b, b + 1, LdsCache<true>{lds_slots + threadIdx.x, op.cache, b + 1 == step_end});
+            }
+        }
+    } else {
+        for (int32_t b = step_begin; b < step_end; ++b) {
+            for (int32_t k = 0; k < n_ops; ++k) run_op<FULL>(ops[k], i, b, b + 1, NoCache());
+        }
     }
 }
 
@@ -88,12 +109,19 @@ bool group_kind_is_small(int32_t kind)
 }
 
 hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, bool all_small,
-                        hipStream_t s)
+                        int32_t cache_slots, hipStream_t s)
 {
     if (n_ops <= 0 || n_members <= 0 || step_end <= step_begin) return hipSuccess;
     const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
-    if (all_small) hipLaunchKernelGGL((group_kernel<false>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
-    else hipLaunchKernelGGL((group_kernel<true>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
+    if (cache_slots > 0) {
+        if (!all_small) return hipErrorInvalidValue;
+        const size_t lds = (size_t)cache_slots * kBlock * sizeof(double);
+        hipLaunchKernelGGL((group_kernel<false, true>), grid, dim3(kBlock), lds, s, d_ops, n_ops, n_members, step_begin, step_end);
+    } else if (all_small) {
+        hipLaunchKernelGGL((group_kernel<false, false>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
+    } else {
+        hipLaunchKernelGGL((group_kernel<true, false>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
+    }
     return hipGetLastError();
 }
 

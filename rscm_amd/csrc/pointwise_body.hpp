@@ -107,30 +107,41 @@ __device__ __forceinline__ void eval(const double (&p)[2], const double (&in)[1]
 // add, one store), so the loops run over the rows in use with scalar branches, the operation -- one value
 // for the whole ensemble in practice, a scalar register then (param_at_scalar) -- is branched on rather than
 // selected on, and the weights are read by the Weighted operation only.
-template <int SRC>
-__device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
+template <int SRC, class Cache = NoCache>
+__device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end, const Cache& cache = Cache())
 {
     const int64_t N = a.n_members;
-    const int op = (int)param_at_scalar(a.params, a.uniform_rows, 0, N, i);
+    const int op = (int)cache.param_scalar(a.params, a.uniform_rows, 0, N, i);
     const int32_t used = a.n_inputs_used;
     const MemberInputs<SRC, 8> inputs(a.inputs, a.scen, a.links, a.n_times, N, i);
+    if (used == 1 && op < 2) {
+        // One contributor, Sum or Mean (the total of a single forcing, say): 0.0 + v, and v / 1 is v.
+        for (int32_t n = step_begin; n < step_end; ++n) {
+            const double v = inputs.at(0, n + 1, cache);
+            const double result = v == v ? 0.0 + v : __builtin_nan("");
+            a.out[(a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i] = result;
+            cache.put(0, result);
+        }
+        if (cache.last_step()) a.status[i] = 0;
+        return;
+    }
     double w[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = (op == 2 && k < used) ? param_at_scalar(a.params, a.uniform_rows, 1 + k, N, i) : 0.0;
-    a.status[i] = 0;
+    for (int k = 0; k < 8; ++k) w[k] = (op == 2 && k < used) ? cache.param_scalar(a.params, a.uniform_rows, 1 + k, N, i) : 0.0;
+    if (cache.last_step()) a.status[i] = 0;
     for (int32_t n = step_begin; n < step_end; ++n) {
         double result;
         if (__builtin_expect(op >= 3, 0)) {
-            const double in0 = used > 0 ? inputs.at(0, n + 1) : __builtin_nan("");
+            const double in0 = used > 0 ? inputs.at(0, n + 1, cache) : __builtin_nan("");
             if (op == 5) {
-                const double in1 = used > 1 ? inputs.at(1, n + 1) : __builtin_nan("");
+                const double in1 = used > 1 ? inputs.at(1, n + 1, cache) : __builtin_nan("");
                 result = in1 > 0.0 ? in0 / in1 : __builtin_nan("");
             } else {
                 int cnt = (op == 3 && in0 == in0) ? 1 : 0;
 #pragma unroll
                 for (int k = 1; k < 8; ++k) {
                     if (k >= used) break;
-                    const double v = inputs.at(k, n + 1);
+                    const double v = inputs.at(k, n + 1, cache);
                     cnt += v == v;
                 }
                 result = (op == 4 ? in0 : 0.0) + (double)cnt;
@@ -141,7 +152,7 @@ __device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (k >= used) break;
-                const double v = inputs.at(k, n + 1);
+                const double v = inputs.at(k, n + 1, cache);
                 if (v == v) {
                     s = s + (op == 2 ? v * w[k] : v);
                     ++cnt;
@@ -151,15 +162,16 @@ __device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i
             result = cnt ? s : __builtin_nan("");
         }
         a.out[(a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i] = result;
+        cache.put(0, result);
     }
 }
 
 // Member i of component KIND over the steps [step_begin, step_end).
-template <int KIND, int SRC>
-__device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
+template <int KIND, int SRC, class Cache = NoCache>
+__device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end, const Cache& cache = Cache())
 {
     if constexpr (KIND == kKindAggregate) {
-        aggregate_body<SRC>(a, i, step_begin, step_end);
+        aggregate_body<SRC>(a, i, step_begin, step_end, cache);
         return;
     } else {
     using S = Shape<KIND>;
@@ -167,18 +179,21 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
     const int32_t T = a.n_times;
     double p[S::P];
 #pragma unroll
-    for (int j = 0; j < S::P; ++j) p[j] = param_at_scalar(a.params, a.uniform_rows, j, N, i);
+    for (int j = 0; j < S::P; ++j) p[j] = cache.param_scalar(a.params, a.uniform_rows, j, N, i);
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
-    a.status[i] = 0;
+    if (cache.last_step()) a.status[i] = 0;
     for (int32_t n = step_begin; n < step_end; ++n) {
         double in[S::NI], out[S::NO];
 #pragma unroll
-        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, n);
+        for (int k = 0; k < S::NI; ++k) in[k] = inputs.at(k, n, cache);
         eval(p, in, out);
         const size_t r = (a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i;
 #pragma unroll
-        for (int o = 0; o < S::NO; ++o) a.out[(size_t)o * var_stride + r] = out[o];
+        for (int o = 0; o < S::NO; ++o) {
+            a.out[(size_t)o * var_stride + r] = out[o];
+            cache.put(o, out[o]);
+        }
     }
     }
 }

@@ -25,6 +25,15 @@ constexpr int kMaxLds = 160 * 1024;          // CDNA4: 160 KiB per CU
 // Linked inputs (rscm_ens_link_input): input row k of a member is read from the stored series of
 // another ensemble of the same shape -- row[k] is that series, [T][N], off[k] the index offset of
 // the reference's VariableSource (0: Exogenous / OwnState -> index n, 1: UpstreamOutput -> n+1).
+// Where a fused multi-step launch (csrc/group.hip) keeps an op's per-member values between model steps: LDS
+// slots (one double per thread each) instead of the round trip through HBM.  -1: not kept.
+struct OpCache {
+    int32_t series_slot;   // first slot of the latest row of the op's own series (its state, and what consumers read)
+    int32_t param_slot;    // first slot of its parameter rows
+    int32_t link_slot[8];  // per input row: the slot of the producer's value this link reads at the current step
+    uint32_t link_warm;    // bit k: link k reads what its producer kept in the PREVIOUS step (feedback): not at a launch's first step
+};
+
 // A null row[k] leaves row k with the scenario table.  Passed by value: the kernels read it from
 // the kernarg segment with scalar loads.
 constexpr int kMaxLinks = 8;
@@ -60,6 +69,73 @@ __device__ __forceinline__ double param_at_scalar(const double* __restrict__ par
     return params[(size_t)j * N + i];
 }
 
+// How a body reads parameters, its own previous state and linked inputs, and where it leaves its results
+// besides the series in HBM.  The stand-alone kernels use NoCache (everything compiles to the plain loads);
+// the fused multi-step launch passes an LdsCache.
+struct NoCache {
+    static constexpr bool kOn = false;
+    __device__ __forceinline__ double param(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
+    {
+        return param_at(params, uniform, j, N, i);
+    }
+    __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
+    {
+        return param_at_scalar(params, uniform, j, N, i);
+    }
+    __device__ __forceinline__ double state(int, const double* p) const { return *p; }
+    __device__ __forceinline__ void put(int, double) const {}
+    __device__ __forceinline__ bool has_link(int) const { return false; }
+    __device__ __forceinline__ double link(int) const { return 0.0; }
+    __device__ __forceinline__ bool last_step() const { return true; }
+};
+
+// Thread-private columns of LDS: slot s of this thread at col[s * kCacheStride].  Every value is written and
+// read by the same thread, in program order: no barrier.  WARM: not the first model step of the launch, so
+// the slots hold what the previous step left (the launch runs its first step with the cold variant).  What comes out of a slot is the double that went in -- the
+// same bits as the row in HBM, which is still written every step.
+constexpr int kCacheStride = kBlock;
+template <bool WARM>
+struct LdsCache {
+    static constexpr bool kOn = true;
+    double* col;
+    OpCache c;
+    bool last;
+    __device__ __forceinline__ double param(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
+    {
+        const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;
+        if (u || c.param_slot < 0) return param_at_scalar(params, uniform, j, N, i);  // a uniform row is one scalar load
+        double* slot = col + (size_t)(c.param_slot + j) * kCacheStride;
+        if constexpr (WARM) {
+            return *slot;
+        } else {
+            const double v = params[(size_t)j * N + i];
+            *slot = v;
+            return v;
+        }
+    }
+    __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
+    {
+        return param(params, uniform, j, N, i);
+    }
+    __device__ __forceinline__ double state(int v, const double* p) const
+    {
+        if constexpr (WARM) {
+            if (c.series_slot >= 0) return col[(size_t)(c.series_slot + v) * kCacheStride];
+        }
+        return *p;
+    }
+    __device__ __forceinline__ void put(int v, double x) const
+    {
+        if (c.series_slot >= 0) col[(size_t)(c.series_slot + v) * kCacheStride] = x;
+    }
+    __device__ __forceinline__ bool has_link(int k) const
+    {
+        return c.link_slot[k] >= 0 && (WARM || ((c.link_warm >> k) & 1u) == 0);
+    }
+    __device__ __forceinline__ double link(int k) const { return col[(size_t)c.link_slot[k] * kCacheStride]; }
+    __device__ __forceinline__ bool last_step() const { return last; }
+};
+
 // The NI input rows of member i.  SRC 0: one shared table [NI][T]; 1: per-member scenario of a
 // table [S][NI][T]; 2: linked rows (coalesced [T][N] reads) mixed with table rows.  SRC < 2
 // compiles to the plain table indexing the kernels had before links existed.
@@ -67,32 +143,34 @@ template <int SRC, int NI>
 struct MemberInputs {
     const double* base;
     int32_t T;
-    const double* p[SRC == 2 ? NI : 1];
-    size_t stride[SRC == 2 ? NI : 1];
-    __device__ __forceinline__ MemberInputs(const double* table, const int32_t* scen, const InputLinks& links,
-                                            int32_t n_times, int64_t N, int64_t i)
-        : T(n_times)
+    int64_t N, i;
+    const InputLinks* links;
+    __device__ __forceinline__ MemberInputs(const double* table, const int32_t* scen, const InputLinks& links_, int32_t n_times, int64_t N_,
+                                            int64_t i_)
+        : T(n_times), N(N_), i(i_), links(&links_)
     {
         static_assert(SRC != 2 || NI <= kMaxLinks, "more input rows than InputLinks holds");
-        const size_t s = SRC == 0 ? (size_t)0 : (scen ? (size_t)scen[i] : (size_t)0);
+        const size_t s = SRC == 0 ? (size_t)0 : (scen ? (size_t)scen[i_] : (size_t)0);
         base = table + s * NI * n_times;
-        if constexpr (SRC == 2) {
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                if (links.row[k]) {
-                    p[k] = links.row[k] + (size_t)links.off[k] * N + i;
-                    stride[k] = (size_t)N;
-                } else {
-                    p[k] = base + (size_t)k * n_times;
-                    stride[k] = 1;
-                }
-            }
-        }
     }
+    // SRC 2: the address is formed where the value is wanted (wave-uniform row choice, a few scalar
+    // instructions) -- in a fused launch most linked values come out of LDS and need none
     __device__ __forceinline__ double at(int k, int32_t n) const
     {
-        if constexpr (SRC == 2) return p[k][(size_t)n * stride[k]];
-        else return base[(size_t)k * T + n];
+        if constexpr (SRC == 2) {
+            const double* row = links->row[k];
+            if (row) return row[(size_t)(links->off[k] + n) * N + i];
+        }
+        return base[(size_t)k * T + n];
+    }
+    // the value of the CURRENT model step (the one the fused launch is at): from the producer's LDS slot if kept there
+    template <class Cache>
+    __device__ __forceinline__ double at(int k, int32_t n, const Cache& cache) const
+    {
+        if constexpr (Cache::kOn && SRC == 2) {
+            if (cache.has_link(k)) return cache.link(k);
+        }
+        return at(k, n);
     }
 };
 
@@ -387,13 +465,15 @@ struct GroupOp {
         CarbonArgs carbon;
         Args() : pw() {}
     } u;
-    GroupOp() : kind(-1), variant(0), u() {}
+    OpCache cache;     // LDS slots of a multi-step launch (all -1 otherwise)
+    GroupOp() : kind(-1), variant(0), u(), cache() {}
 };
 constexpr int kMaxGroupOps = 16;
 // all_small: every op is one of the kinds group_kind_is_small accepts (the low-register variant of the kernel)
 bool group_kind_is_small(int32_t kind);
+// cache_slots > 0 (all_small only): the ops carry LDS slots (OpCache), cache_slots doubles per thread in all
 hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, bool all_small,
-                        hipStream_t s);
+                        int32_t cache_slots, hipStream_t s);
 
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);

@@ -1727,6 +1727,7 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
 }
 
 static bool g_fuse_lockstep = true;
+static bool g_lockstep_cache = true;  // multi-step fused launches keep per-member values in LDS between steps
 static int64_t g_lockstep_launches = 0, g_lockstep_component_steps = 0;  // since the last rscm_gpu_lockstep_stats
 
 int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
@@ -1740,6 +1741,7 @@ int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
     g_fuse_lockstep = enabled != 0;
+    g_lockstep_cache = enabled == 1;
     return RSCM_OK;
 }
 
@@ -1771,11 +1773,76 @@ static void clear_step_fields(rscm::GroupOp& op)
     }
 }
 
+// LDS slots for a multi-step launch of a graph of light components (csrc/group.hip, CACHED): every op that
+// can keep values there gets one slot per series (the latest row: its own state for the next step, and what
+// its consumers read) and, while the budget lasts, one per parameter row if any of its rows varies over the
+// members.  A link is served from the producer's slot when the value it wants is the one the slot holds at
+// that point of the step: a producer earlier in the order read at n+1 (this step's value), or a producer
+// later in the order read at n (what it left in the previous step -- not at a launch's first step).
+static constexpr int32_t kCacheSlotBudget = 20;  // x 2 KiB per workgroup: four workgroups (16 wavefronts) per CU
+static bool keeps_slots(int32_t kind)
+{
+    switch (kind) {
+        case RSCM_KIND_TWO_LAYER: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_AEROSOL_INDIRECT: case RSCM_KIND_FOURBOX_OHU:
+        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE:
+            return true;
+        default: return false;
+    }
+}
+static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t count, std::vector<rscm::OpCache>& out)
+{
+    out.assign((size_t)count, rscm::OpCache{});
+    int32_t next = 0;
+    for (int32_t k = 0; k < count; ++k) {
+        rscm::OpCache& c = out[(size_t)k];
+        c.series_slot = c.param_slot = -1;
+        for (int32_t& s : c.link_slot) s = -1;
+        c.link_warm = 0;
+        const rscm_ens* h = plan->handles[first + k];
+        const int32_t n_series = h->V - 1;
+        if (keeps_slots(h->kind) && n_series > 0 && next + n_series <= kCacheSlotBudget) {
+            c.series_slot = next;
+            next += n_series;
+        }
+    }
+    for (int32_t k = 0; k < count; ++k) {
+        const rscm_ens* h = plan->handles[first + k];
+        const uint64_t all_rows = h->P >= 64 ? ~0ull : ((1ull << h->P) - 1ull);
+        const bool varies = (h->uniform_rows & all_rows) != all_rows;
+        if (keeps_slots(h->kind) && h->kind != RSCM_KIND_AGGREGATE && varies && h->P <= 16 && next + h->P <= kCacheSlotBudget) {
+            out[(size_t)k].param_slot = next;
+            next += h->P;
+        }
+    }
+    for (int32_t k = 0; k < count; ++k) {
+        const rscm_ens* h = plan->handles[first + k];
+        if (!keeps_slots(h->kind)) continue;
+        for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
+            const auto& l = h->links[j];
+            if (!l.src) continue;
+            int32_t at = -1;
+            for (int32_t q = 0; q < count; ++q)
+                if (plan->handles[first + q] == l.src) at = q;
+            if (at < 0 || out[(size_t)at].series_slot < 0 || l.var < 1 || l.var > l.src->V - 1) continue;
+            const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
+            if (at < k ? !reads_end : reads_end) continue;  // the slot holds the other row at that point
+            out[(size_t)k].link_slot[j] = out[(size_t)at].series_slot + (l.var - 1);
+            if (at >= k) out[(size_t)k].link_warm |= 1u << j;
+        }
+    }
+    return next;
+}
+
 // Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
 // the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
 static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
 {
     rscm_ens* lead = plan->handles[first];
+    bool all_small = true;
+    for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
+    std::vector<rscm::OpCache> slots;
+    int32_t cache_slots = 0;
+    if (len > 1 && all_small && g_lockstep_cache) cache_slots = assign_cache_slots(plan, first, count, slots);
     for (int32_t k = first; k < first + count; ++k) {
         rscm_ens* h = plan->handles[k];
         if (int rc = step_check(h, n, n + len)) return rc;
@@ -1791,6 +1858,12 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         if (int rc = step_launch(h, n, n + 1, links, linked, &op)) return rc;
         if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", k, h->kind);
         clear_step_fields(op);
+        if (cache_slots > 0) {
+            op.cache = slots[(size_t)(k - first)];
+        } else {
+            op.cache.series_slot = op.cache.param_slot = -1;
+            for (int32_t& sl : op.cache.link_slot) sl = -1;
+        }
         if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
             if (plan->ring_pos == LockstepPlan::kRing) {  // every slot may still be the source of a queued copy
                 HIPCHK(hipStreamSynchronize(lead->stream));
@@ -1804,9 +1877,7 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         }
         h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
     }
-    bool all_small = true;
-    for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
-    HIPCHK(rscm::launch_group(plan->d_ops + first, count, lead->N, n, n + len, all_small, lead->stream));
+    HIPCHK(rscm::launch_group(plan->d_ops + first, count, lead->N, n, n + len, all_small, cache_slots, lead->stream));
     for (int32_t k = first; k < first + count; ++k)
         if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
     return RSCM_OK;

@@ -105,19 +105,21 @@ __device__ __forceinline__ void lik_consume(const TwoLayerArgs& a, LikAcc& L, in
 
 // Member i over the steps [a.step_begin, a.step_end).  LDS: the forcing slice staged by the caller in
 // lds_forcing ([n_scen][len]); otherwise read through L2 (table or linked series).
-template <int MODE, bool LDS, bool STORE>
+// Cache: NoCache for the stand-alone kernels; the fused multi-step launch (group.hip) keeps parameters, the
+// state and the linked forcing of the current step in LDS between its steps (rscm_device.hpp, LdsCache).
+template <int MODE, bool LDS, bool STORE, class Cache = NoCache>
 __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const double* lds_forcing, int64_t i, int32_t step_begin,
-                                               int32_t step_end)
+                                               int32_t step_end, const Cache& cache = Cache())
 {
     const int32_t len = step_end - step_begin;
     const int64_t N = a.n_members;
 
-    const double lambda0 = param_at(a.params, a.uniform_rows, 0, N, i);
-    const double pa = param_at(a.params, a.uniform_rows, 1, N, i);
-    const double efficacy = param_at(a.params, a.uniform_rows, 2, N, i);
-    const double eta = param_at(a.params, a.uniform_rows, 3, N, i);
-    const double cs = param_at(a.params, a.uniform_rows, 4, N, i);
-    const double cd = param_at(a.params, a.uniform_rows, 5, N, i);
+    const double lambda0 = cache.param(a.params, a.uniform_rows, 0, N, i);
+    const double pa = cache.param(a.params, a.uniform_rows, 1, N, i);
+    const double efficacy = cache.param(a.params, a.uniform_rows, 2, N, i);
+    const double eta = cache.param(a.params, a.uniform_rows, 3, N, i);
+    const double cs = cache.param(a.params, a.uniform_rows, 4, N, i);
+    const double cd = cache.param(a.params, a.uniform_rows, 5, N, i);
     const int32_t scen = a.scen ? a.scen[i] : 0;
     // a linked forcing (rscm_ens_link_input, always the non-LDS variant) is another ensemble's
     // [T][N] series: coalesced, one stride of N per year
@@ -128,9 +130,21 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
         if constexpr (LDS) return lds_forcing[fl0 + n];
         else return fglob[(size_t)n * fstride];
     };
+    // the year a fused launch is at: the linked forcing from the producer's LDS slot if it is kept there
+    auto forcing_first = [&]() -> double {
+        if constexpr (Cache::kOn) {
+            if (a.link && cache.has_link(0)) return cache.link(0);
+        }
+        return forcing_at(step_begin);
+    };
+    // next year's forcing: a fused launch calls per year (n == last), there is no next year to fetch
+    auto forcing_ahead = [&](int32_t n, int32_t np, double current) -> double {
+        if constexpr (Cache::kOn) return n < np ? forcing_at(np) : current;
+        else return forcing_at(np);
+    };
 
-    double ts = a.ts[(size_t)step_begin * N + i];
-    double td = a.td[(size_t)step_begin * N + i];
+    double ts = cache.state(0, a.ts + (size_t)step_begin * N + i);
+    double td = cache.state(1, a.td + (size_t)step_begin * N + i);
     double* out_ts = a.ts + (size_t)(step_begin + 1) * N + i;
     double* out_td = a.td + (size_t)(step_begin + 1) * N + i;
 
@@ -143,7 +157,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
     if constexpr (!STORE) lik_consume(a, lik, step_begin, ts, td);  // observations of the start row
 
     // next year's forcing and sub-step count are fetched a year ahead of their use
-    double erf_next = forcing_at(step_begin);
+    double erf_next = forcing_first();
     int32_t m_next = a.nsub[step_begin];
 
     if constexpr (MODE == 0) {
@@ -163,7 +177,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             const double erf = erf_next;
             const int32_t m = m_next;
             const int32_t np = n < last ? n + 1 : n;
-            erf_next = forcing_at(np);
+            erf_next = forcing_ahead(n, np, erf_next);
             m_next = a.nsub[np];
             const double ts0 = ts, td0 = td;
             int32_t acc = acc0;
@@ -180,6 +194,8 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             if constexpr (STORE) {
                 *out_ts = ts;
                 *out_td = td;
+                cache.put(0, ts);
+                cache.put(1, td);
                 out_ts += N;
                 out_td += N;
             } else {
@@ -198,7 +214,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             const double erf = erf_next * inv_cs;
             const int32_t m = m_next;
             const int32_t np = n < last ? n + 1 : n;
-            erf_next = forcing_at(np);
+            erf_next = forcing_ahead(n, np, erf_next);
             m_next = a.nsub[np];
             for (int32_t s = 0; s < m; ++s) {
                 double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
@@ -215,6 +231,8 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             if constexpr (STORE) {
                 *out_ts = ts;
                 *out_td = td;
+                cache.put(0, ts);
+                cache.put(1, td);
                 out_ts += N;
                 out_td += N;
             } else {
@@ -222,7 +240,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             }
         }
     }
-    a.status[i] = (is_finite(ts) && is_finite(td)) ? 0 : 1;
+    if (cache.last_step()) a.status[i] = (is_finite(ts) && is_finite(td)) ? 0 : 1;
     if constexpr (!STORE) {
         // observations whose row is never reached were never computed -> member failure
         if (lik.oi < a.n_obs) lik.bad = true;
