@@ -125,6 +125,108 @@ def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra):
         L.check(L.load().rscm_gpu_stream_destroy(0, stream))
 
 
+def test_light_graph_with_lds_slots_matches_the_unfused_run(ra):
+    """A graph of light components only runs all its steps in one launch and keeps parameters, states and
+    linked values in LDS slots between the steps (rscm_gpu_set_lockstep_fusion: 1 with the slots, 2 without,
+    0 one launch per component and step).  Seven components with every kind of edge: a producer earlier in the
+    order read at n+1 (served from its slot), a producer later in the order read at n (its slot of the previous
+    step: not at a launch's first step), an earlier producer read at n and a kind that keeps no slots (both read
+    from HBM), more parameter rows than the slot budget holds, varying and uniform rows.  Same bits all ways,
+    also when the run is cut into launches."""
+    from oracle import cbind as orc
+    from rscm_amd import _lib as L
+    from rscm_amd.ensemble import run_lockstep
+    t = axis_values(1750, 1870)
+    b = np.append(t, t[-1] + 1.0)
+    T, n = len(t), 777
+    rng = np.random.default_rng(11)
+    yr = np.arange(T, dtype=float)
+
+    def params(kind, vary):
+        P = np.repeat(orc.pointwise_default_params(kind).reshape(-1, 1), n, axis=1)
+        for k in vary:
+            j = orc.PW_PARAM_NAMES[kind].index(k)
+            P[j] = P[j] * rng.uniform(0.8, 1.25, n)
+        return P
+
+    stream = C.c_void_p()
+    L.check(L.load().rscm_gpu_stream_create(0, C.byref(stream)))
+    ai, ohu, tr, ospp, agg, tl, bud = (ra.Ensemble(k, n, b) for k in (
+        ra.KIND_AEROSOL_INDIRECT, ra.KIND_FOURBOX_OHU, ra.KIND_AGGREGATE, ra.KIND_OSPP, ra.KIND_AGGREGATE, ra.KIND_TWO_LAYER,
+        ra.KIND_CO2_BUDGET))
+    graph = (ai, ohu, tr, ospp, agg, tl, bud)
+    try:
+        for x in graph:
+            x.set_stream(stream.value)
+        ai.set_params(params(orc.PW_AEROSOL_INDIRECT, ("cloud_albedo_coefficient", "reference_burden", "sox_weight")))
+        ai.set_forcing(np.stack([1.0 + 0.3 * yr, 10.0 + 0.1 * yr]))
+        ohu.set_params(params(orc.PW_FOURBOX_OHU, ("northern_ocean_ratio",)))
+        ohu.link_input(0, agg, 1, ra.SRC_EXOGENOUS)          # a later producer, read at n
+        tr.set_params(np.repeat(np.array([2.0, 0.2, 0.3, 0.1, 0.4, 0, 0, 0, 0])[:, None], n, axis=1))
+        for k in range(4):
+            tr.link_input(k, ohu, 1 + k, ra.SRC_UPSTREAM)     # an earlier producer, read at n+1
+        tr.set_initial(1, 0.0)
+        ospp.set_params(params(orc.PW_OSPP, ()))              # every row uniform
+        ospp.set_forcing(np.stack([np.zeros(T), 0.2 * yr]))
+        ospp.link_input(0, tl, 1, ra.SRC_EXOGENOUS)           # feedback: Surface Temperature at n
+        w = np.zeros((9, n))
+        w[0], w[1], w[2], w[3], w[4] = 2.0, 1.0, rng.uniform(0.05, 0.15, n), 1e-3, 0.5
+        agg.set_params(w)
+        F = np.full((8, T), np.nan)
+        F[3] = 4.0 * (1.0 - np.exp(-yr / 60.0))
+        agg.set_forcing(F)
+        agg.link_input(0, ai, 1, ra.SRC_UPSTREAM)
+        agg.link_input(1, tr, 1, ra.SRC_UPSTREAM)
+        agg.link_input(2, ospp, 1, ra.SRC_UPSTREAM)
+        agg.set_initial(1, 0.0)
+        P = coupled_params(n)
+        tl.set_params(P[:6])
+        tl.set_initial(1, 0.0)
+        tl.set_initial(2, 0.0)
+        tl.link_input(0, agg, 1, ra.SRC_UPSTREAM)
+        bud.set_params(np.repeat(np.array([[2.123], [278.0]]), n, axis=1))
+        bud.set_forcing(np.stack([8.0 + 0.02 * yr, 1.0 + 0.0 * yr, 2.0 + 0.0 * yr, 1.5 + 0.0 * yr]))
+        bud.link_input(2, tr, 1, ra.SRC_EXOGENOUS)            # an earlier producer read at n; the budget keeps no slots
+        bud.set_initial(1, 278.0)
+        for x in graph:
+            L.check(L.load().rscm_ens_set_link_order_check(x._h, 0))
+
+        def collect():
+            return [x.get_series(v) for x in graph for v in sorted(v for v in x.var_ids.values() if v > 0)]
+
+        def run(mode, pieces=()):
+            for x in graph:
+                x.rewind()
+                x.clear_series()
+            L.check(L.load().rscm_gpu_set_lockstep_fusion(mode))
+            for stop in pieces:
+                run_lockstep(graph, stop)
+            run_lockstep(graph)
+            return collect()
+
+        plain = run(0)
+        assert np.isfinite(plain[8][1:]).all() and np.isfinite(plain[-3][2:]).all()  # Surface Temperature, the budget's CO2
+        _stats()
+        slots = run(1)
+        assert _stats() == (1, 7 * (T - 1))
+        for k, (a, w_) in enumerate(zip(slots, plain)):
+            assert_bit_equal(a, w_, f"one launch with LDS slots vs one launch per component and step: series {k}")
+        for k, (a, w_) in enumerate(zip(run(2), plain)):
+            assert_bit_equal(a, w_, f"one launch without the slots: series {k}")
+        for k, (a, w_) in enumerate(zip(run(1, pieces=(1, 2, 40)), plain)):
+            assert_bit_equal(a, w_, f"with slots, in four launches: series {k}")
+    finally:
+        for x in graph:
+            for k in range(8):
+                try:
+                    x.unlink_input(k)
+                except Exception:
+                    pass
+        for x in reversed(graph):
+            x.close()
+        L.check(L.load().rscm_gpu_stream_destroy(0, stream))
+
+
 @pytest.mark.parametrize("execution_order", ["reference", "topological"])
 def test_fused_magicc_graph_keeps_the_bits(ra, execution_order):
     mod = _chain()
