@@ -26,6 +26,8 @@ CONC = 278.0 + 0.5 * (t - 1750.0)
 P = coupled_params(N)
 stream = C.c_void_p()
 L.check(L.load().rscm_gpu_stream_create(0, C.byref(stream)))
+# RSCM_GROUP_MODE: rscm_gpu_set_lockstep_fusion's argument (1: one launch with LDS slots, the default; 2: without them)
+L.check(L.load().rscm_gpu_set_lockstep_fusion(int(os.environ.get("RSCM_GROUP_MODE", "1"))))
 
 
 def variant(name):
