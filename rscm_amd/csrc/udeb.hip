@@ -432,11 +432,17 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
         win_sum = s[10 * N];
         win_lo = a.step_begin > 1 ? a.win_kfull[a.step_begin - 1] : 0;
         hist_last = a.hist[(size_t)(a.step_begin - 1) * N + i];
+        // One wavefront per SIMD: nothing hides a load's latency but the loads that are in flight with it.
+        // The southern column first, all 50 loads at once into the registers of col[], from there to its LDS
+        // slots; then the northern one (two round trips to HBM; interleaved with the LDS writes, a layer at a
+        // time, the compiler waited for every pair: 25 round trips per launch, and the graph launches every step).
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            col[l] = T_nh[(size_t)l * N];
-            park[l][lane] = T_sh[(size_t)l * N];
-        }
+        for (int l = 0; l < NL; ++l) col[l] = T_sh[(size_t)l * N];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) park[l][lane] = col[l];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) col[l] = T_nh[(size_t)l * N];
     }
     const int32_t scen = a.scen ? a.scen[i] : 0;
     // a linked forcing (rscm_ens_link_input) is another ensemble's [T][N] series
@@ -619,10 +625,12 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     s[10 * N] = win_sum;
     // the columns go back to HBM once per launch (rscm_ens_run resumes from them)
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        T_nh[(size_t)l * N] = col[l];
-        T_sh[(size_t)l * N] = park[l][lane];
-    }
+    for (int l = 0; l < NL; ++l) T_nh[(size_t)l * N] = col[l];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) col[l] = park[l][lane];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) T_sh[(size_t)l * N] = col[l];
 }
 
 }  // namespace
