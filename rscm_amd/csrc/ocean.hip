@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
 #pragma unroll
     for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
     m.temp_on = P(23) != 0.0;
-    const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
+    const MemberInputsEager<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
     const double* __restrict__ irf = irf_table;  // [H], wave-uniform indices: a read-only kernel argument -> scalar loads
     double* __restrict__ hist = a.hist + i;   // [months][N]
     a.status[i] = 0;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel
 #pragma unroll
     for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
     m.temp_on = P(23) != 0.0;
-    const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
+    const MemberInputsEager<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
     const double* __restrict__ irf = irf_table;
     double* __restrict__ hist = a.hist + i;
     a.status[i] = 0;

@@ -174,6 +174,42 @@ struct MemberInputs {
     }
 };
 
+// The same rows with every address formed once, up front (pointer + stride per row in vector registers):
+// for kernels that read their inputs inside long multi-step loops and are short of SCALAR registers
+// (OceanCarbon's convolution keeps a 47-entry window of the response table there).
+template <int SRC, int NI>
+struct MemberInputsEager {
+    const double* base;
+    int32_t T;
+    const double* p[SRC == 2 ? NI : 1];
+    size_t stride[SRC == 2 ? NI : 1];
+    __device__ __forceinline__ MemberInputsEager(const double* table, const int32_t* scen, const InputLinks& links, int32_t n_times, int64_t N,
+                                                 int64_t i)
+        : T(n_times)
+    {
+        static_assert(SRC != 2 || NI <= kMaxLinks, "more input rows than InputLinks holds");
+        const size_t s = SRC == 0 ? (size_t)0 : (scen ? (size_t)scen[i] : (size_t)0);
+        base = table + s * NI * n_times;
+        if constexpr (SRC == 2) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                if (links.row[k]) {
+                    p[k] = links.row[k] + (size_t)links.off[k] * N + i;
+                    stride[k] = (size_t)N;
+                } else {
+                    p[k] = base + (size_t)k * n_times;
+                    stride[k] = 1;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ double at(int k, int32_t n) const
+    {
+        if constexpr (SRC == 2) return p[k][(size_t)n * stride[k]];
+        else return base[(size_t)k * T + n];
+    }
+};
+
 // kernel<0> / kernel<1> / kernel<2> by where the inputs come from
 #define RSCM_LAUNCH_BY_SOURCE(KERNEL, args, grid, block, stream, ...)                                        \
     do {                                                                                                     \
