@@ -31,6 +31,7 @@ TL_LOW = np.array([0.8, 0.0, 1.0, 0.5, 5.0, 50.0])
 TL_HIGH = np.array([1.5, 0.1, 1.8, 1.0, 15.0, 200.0])
 SEED = 20260327
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+HBM_STORE_STREAM_GBS = 5460.0  # what a store-only streaming kernel reaches on the card (tools/hbm_stream.hip, profiles/r2_hbm_stream.txt)
 FP64_VALU_PEAK_TINSTR = 39.3   # 256 CU x 4 SIMD x 16 f64 lanes x 2.4 GHz (FMA would count 2 flops)
 ALG_BYTES_PER_MEMBER_YEAR = 16.0   # store Ts, Td
 ALG_OPS_PER_MEMBER_YEAR = 700.0    # 620 add/mul + 80 div, exact mode
@@ -56,6 +57,7 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
     traffic, source = measured_traffic(kind, members, mode)
     hbm = {"bound": "hbm", "binding": "fp64_valu", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+           "peak_measured_store_stream": HBM_STORE_STREAM_GBS, "frac_of_measured": gbs / HBM_STORE_STREAM_GBS,
            "traffic_source": (f"{source}: separate rocprofv3 --pmc passes of this launch (FETCH_SIZE x2 + WRITE_SIZE, KiB), "
                               "read from profiles/traffic.json; not re-measured inside bench.py") if source else None,
            "kernel": "coupled_kernel" if kind == "coupled" else "two_layer_kernel", "kernel_ms": kernel_ms,
