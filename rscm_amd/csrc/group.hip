@@ -68,11 +68,9 @@ __device__ __forceinline__ void run_op(const GroupOp& op, int64_t i, int32_t b, 
 // keeps its varying parameter rows, the latest row of its series and thereby what its consumers read in
 // thread-private LDS slots (OpCache, assigned by rscm_gpu.cpp) -- in steady state the launch reads nothing back
 // from HBM and only streams the series out, like a kernel written for the graph would.
-template <bool FULL, bool CACHED>
-__global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members, int32_t step_begin,
-                                                       int32_t step_end)
+template <bool FULL, bool CACHED, class Ops>
+__device__ __forceinline__ void run_graph(const Ops& ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, double* lds_slots)
 {
-    extern __shared__ double lds_slots[];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_members) return;
     // Several model steps in one launch when the table is the WHOLE graph (no heavy component in between):
@@ -96,6 +94,26 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict
     }
 }
 
+// The op table in device memory (any number of ops; rscm_gpu.cpp uploads what changed since the last launch) ...
+template <bool FULL, bool CACHED>
+__global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members, int32_t step_begin,
+                                                       int32_t step_end)
+{
+    extern __shared__ double lds_slots[];
+    run_graph<FULL, CACHED>(ops, n_ops, n_members, step_begin, step_end, lds_slots);
+}
+
+// ... or, up to kGroupTableOps ops, by value in the kernel-argument segment: nothing to upload when a window slide
+// or a new link changes an op's pointers (the windowed MAGICC graph re-sent 2.7 ops per model step), and the
+// fields still arrive through scalar loads.
+template <bool FULL, bool CACHED>
+__global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable table, int32_t n_ops, int64_t n_members, int32_t step_begin,
+                                                            int32_t step_end)
+{
+    extern __shared__ double lds_slots[];
+    run_graph<FULL, CACHED>(table.ops, n_ops, n_members, step_begin, step_end, lds_slots);
+}
+
 }  // namespace
 
 bool group_kind_is_small(int32_t kind)
@@ -108,20 +126,29 @@ bool group_kind_is_small(int32_t kind)
     }
 }
 
-hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, bool all_small,
-                        int32_t cache_slots, hipStream_t s)
+template <class... Args>
+static void launch_variant(bool by_value, bool all_small, int32_t cache_slots, dim3 grid, size_t lds, hipStream_t s, const GroupOp* d_ops,
+                           const GroupTable* table, Args... rest)
+{
+    if (by_value) {  // (never with LDS slots: indexing the by-value table for the slot records sends it to scratch)
+        if (all_small) hipLaunchKernelGGL((group_kernel_args<false, false>), grid, dim3(kBlock), 0, s, *table, rest...);
+        else hipLaunchKernelGGL((group_kernel_args<true, false>), grid, dim3(kBlock), 0, s, *table, rest...);
+    } else {
+        if (cache_slots > 0) hipLaunchKernelGGL((group_kernel<false, true>), grid, dim3(kBlock), lds, s, d_ops, rest...);
+        else if (all_small) hipLaunchKernelGGL((group_kernel<false, false>), grid, dim3(kBlock), 0, s, d_ops, rest...);
+        else hipLaunchKernelGGL((group_kernel<true, false>), grid, dim3(kBlock), 0, s, d_ops, rest...);
+    }
+}
+
+hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
+                        bool all_small, int32_t cache_slots, hipStream_t s)
 {
     if (n_ops <= 0 || n_members <= 0 || step_end <= step_begin) return hipSuccess;
+    if (cache_slots > 0 && !all_small) return hipErrorInvalidValue;
+    if ((table != nullptr) == (d_ops != nullptr) || (table && (n_ops > kGroupTableOps || cache_slots > 0))) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
-    if (cache_slots > 0) {
-        if (!all_small) return hipErrorInvalidValue;
-        const size_t lds = (size_t)cache_slots * kBlock * sizeof(double);
-        hipLaunchKernelGGL((group_kernel<false, true>), grid, dim3(kBlock), lds, s, d_ops, n_ops, n_members, step_begin, step_end);
-    } else if (all_small) {
-        hipLaunchKernelGGL((group_kernel<false, false>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
-    } else {
-        hipLaunchKernelGGL((group_kernel<true, false>), grid, dim3(kBlock), 0, s, d_ops, n_ops, n_members, step_begin, step_end);
-    }
+    const size_t lds = (size_t)cache_slots * kBlock * sizeof(double);
+    launch_variant(table != nullptr, all_small, cache_slots, grid, lds, s, d_ops, table, n_ops, n_members, step_begin, step_end);
     return hipGetLastError();
 }
 

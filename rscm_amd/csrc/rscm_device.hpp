@@ -505,11 +505,18 @@ struct GroupOp {
     GroupOp() : kind(-1), variant(0), u(), cache() {}
 };
 constexpr int kMaxGroupOps = 16;
+// up to this many ops travel by value in the kernel-argument segment (4 KiB in all) instead of a device table
+constexpr int kGroupTableOps = 8;
+struct GroupTable {
+    GroupOp ops[kGroupTableOps];
+};
+static_assert(sizeof(GroupTable) <= 3840, "the by-value op table must fit the kernel-argument segment beside the other arguments");
 // all_small: every op is one of the kinds group_kind_is_small accepts (the low-register variant of the kernel)
 bool group_kind_is_small(int32_t kind);
-// cache_slots > 0 (all_small only): the ops carry LDS slots (OpCache), cache_slots doubles per thread in all
-hipError_t launch_group(const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, bool all_small,
-                        int32_t cache_slots, hipStream_t s);
+// cache_slots > 0 (all_small only): the ops carry LDS slots (OpCache), cache_slots doubles per thread in all.
+// Exactly one of d_ops (device table) and table (host, passed by value, n_ops <= kGroupTableOps) is given.
+hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
+                        bool all_small, int32_t cache_slots, hipStream_t s);
 
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);

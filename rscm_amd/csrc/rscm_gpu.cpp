@@ -1848,6 +1848,12 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         if (int rc = step_check(h, n, n + len)) return rc;
         if (int rc = step_window_pre(h, n, n + len)) return rc;
     }
+    // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
+    // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
+    // only what changed since the last launch is uploaded
+    const bool by_value = count <= rscm::kGroupTableOps && cache_slots == 0;
+    rscm::GroupTable table;
+    if (by_value) memset((void*)&table, 0, sizeof table);
     for (int32_t k = first; k < first + count; ++k) {
         rscm_ens* h = plan->handles[k];
         rscm::InputLinks links{};
@@ -1864,7 +1870,9 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
             op.cache.series_slot = op.cache.param_slot = -1;
             for (int32_t& sl : op.cache.link_slot) sl = -1;
         }
-        if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
+        if (by_value) {
+            memcpy((void*)&table.ops[k - first], &op, sizeof op);
+        } else if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
             if (plan->ring_pos == LockstepPlan::kRing) {  // every slot may still be the source of a queued copy
                 HIPCHK(hipStreamSynchronize(lead->stream));
                 plan->ring_pos = 0;
@@ -1877,7 +1885,8 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         }
         h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
     }
-    HIPCHK(rscm::launch_group(plan->d_ops + first, count, lead->N, n, n + len, all_small, cache_slots, lead->stream));
+    HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
+                              cache_slots, lead->stream));
     for (int32_t k = first; k < first + count; ++k)
         if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
     return RSCM_OK;
