@@ -310,6 +310,8 @@ def linked_graph_extra(members, device, stream, years):
     return {"member_years_per_s": members * years / best, "ms": best * 1e3, "launches": int(nl.value) // 3,
             "component_steps": int(ns.value) // 3,
             "fused_coupled_kernel_ms": fused_best * 1e3, "ratio_to_fused_coupled_kernel": best / fused_best,
+            # the same 7 series written per member-year as the fused kernel (56 B); the LDS slots keep the reads out of HBM
+            "hbm_frac": 56.0 * members * years / best / 1e9 / HBM_PEAK_GBS,
             "note": "CarbonCycle, CO2ERF, Sum, TwoLayer as four linked ensembles in lock-step; all four are light "
                     "components, so the run is one fused group launch (csrc/group.hip) that keeps parameters, states "
                     "and linked values in LDS between the model steps"}
