@@ -128,6 +128,34 @@ def test_two_layer_exact_bitwise_vs_oracle(ra, orc, n_members, source):
     assert (st.astype(bool) == bad).all()
 
 
+@pytest.mark.parametrize("n_points", [2, 3])
+@pytest.mark.parametrize("n_members", [1, 65])
+def test_smallest_shapes(ra, orc, n_points, n_members):
+    """The shortest axis TimeAxis::from_values accepts (two points: ONE step, runtime.rs:524 runs len-1 of them)
+    and three points, one member and one member more than a wavefront: bit-exact against the oracle; a run over
+    an empty range is a no-op; a likelihood over no observations is the empty sum."""
+    t = axis_values(1750, 1750 + n_points - 1)
+    P = two_layer_params(n_members, seed=SEED + 7 * n_points + n_members)
+    F = f_syn(t)
+    b = orc.bounds_from_values(t)
+    for source in (0, 1):
+        want = orc.two_layer_run(b, P, F, 0.25, -0.5, source=source, threads=1)
+        with ra.Ensemble(ra.KIND_TWO_LAYER, n_members, b) as e:
+            e.set_params(P)
+            e.set_forcing(F, None, source)
+            e.set_initial("Surface Temperature", 0.25)
+            e.set_initial("Deep Ocean Temperature", -0.5)
+            e.run(0)                       # [0, 0): nothing to do
+            assert e.time_index == 0
+            e.run()
+            assert e.finished() and e.time_index == n_points - 1
+            assert_bit_equal(e.get_series("Surface Temperature"), want[0], f"Ts, {n_points} points, source {source}")
+            assert_bit_equal(e.get_series("Deep Ocean Temperature"), want[1], f"Td, {n_points} points, source {source}")
+            assert not e.status().any()
+            ll = e.loglik(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), np.zeros(0))
+            assert ll.shape == (n_members,) and (ll == 0.0).all()
+
+
 def test_two_layer_golden_fixture(ra):
     g = np.load(os.path.join(GOLDEN, "two_layer_golden.npz"))
     for source in (0, 1):
