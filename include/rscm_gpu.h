@@ -480,8 +480,8 @@ RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, 
  * launches.  A graph made of light components only runs ALL its steps in one launch, and between the steps
  * every component keeps its varying parameters, its state and what its consumers read in thread-private LDS
  * slots instead of reading them back from HBM (the series are still written every step).
- * enabled = 0 switches the fusion off for the process, 2 keeps the fusion but not the LDS slots (A/B tests);
- * default 1. */
+ * enabled = 0 switches the fusion off for the process, 2 keeps the fusion but not the LDS slots, 3 keeps both
+ * but sends every op table through device memory instead of the kernel arguments (A/B tests); default 1. */
 RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
 /* Step launches issued by rscm_ens_run_lockstep (component kernels + fused groups; HalocarbonChemistry counts
  * as one) and the component steps they carried, since the last call; resets both counters. */

@@ -1728,6 +1728,7 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
 
 static bool g_fuse_lockstep = true;
 static bool g_lockstep_cache = true;  // multi-step fused launches keep per-member values in LDS between steps
+static bool g_group_by_value = true;  // short op lists travel in the kernel arguments
 static int64_t g_lockstep_launches = 0, g_lockstep_component_steps = 0;  // since the last rscm_gpu_lockstep_stats
 
 int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
@@ -1742,6 +1743,7 @@ int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
     g_fuse_lockstep = enabled != 0;
     g_lockstep_cache = enabled == 1;
+    g_group_by_value = enabled != 3;
     return RSCM_OK;
 }
 
@@ -1851,7 +1853,7 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
     // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
     // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
     // only what changed since the last launch is uploaded
-    const bool by_value = count <= rscm::kGroupTableOps && cache_slots == 0;
+    const bool by_value = g_group_by_value && count <= rscm::kGroupTableOps && cache_slots == 0;
     rscm::GroupTable table;
     if (by_value) memset((void*)&table, 0, sizeof table);
     for (int32_t k = first; k < first + count; ++k) {
