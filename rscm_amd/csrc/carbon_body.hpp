@@ -96,26 +96,30 @@ __device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i
     if (cache.last_step()) a.status[i] = (is_finite(conc) && is_finite(cum_u) && is_finite(cum_e)) ? 0 : 1;
 }
 
-template <int SRC>
-__device__ __forceinline__ void co2_budget_body(const CarbonArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
+template <int SRC, class Cache = NoCache>
+__device__ __forceinline__ void co2_budget_body(const CarbonArgs& a, int64_t i, int32_t step_begin, int32_t step_end, const Cache& cache = Cache())
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    const double gtc_per_ppm = param_at(a.params, a.uniform_rows, 0, N, i);
+    const double gtc_per_ppm = cache.param(a.params, a.uniform_rows, 0, N, i);
     const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
-    a.status[i] = 0;
-    double co2 = a.series[(size_t)step_begin * N + i];
+    if (cache.last_step()) a.status[i] = 0;
+    double co2 = cache.state(0, a.series + (size_t)step_begin * N + i);
     for (int32_t n = step_begin; n < step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double total_emissions = in.at(0, n) + in.at(1, n);
-        const double total_uptake = in.at(2, n) + in.at(3, n);
+        const double total_emissions = in.at(0, n, cache) + in.at(1, n, cache);
+        const double total_uptake = in.at(2, n, cache) + in.at(3, n, cache);
         const double net_to_atm = total_emissions - total_uptake;
         co2 = co2 + (net_to_atm * dt) / gtc_per_ppm;
+        const double airborne = total_emissions > 0.0 ? net_to_atm / total_emissions : 0.0;
         const size_t r = (size_t)(n + 1) * N + i;
         a.series[r] = co2;
         a.series[vs + r] = net_to_atm;
-        a.series[2 * vs + r] = total_emissions > 0.0 ? net_to_atm / total_emissions : 0.0;
+        a.series[2 * vs + r] = airborne;
+        cache.put(0, co2);
+        cache.put(1, net_to_atm);
+        cache.put(2, airborne);
     }
 }
 

@@ -1786,8 +1786,8 @@ static bool keeps_slots(int32_t kind)
 {
     switch (kind) {
         case RSCM_KIND_TWO_LAYER: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_AEROSOL_INDIRECT: case RSCM_KIND_FOURBOX_OHU:
-        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE:
-            return true;
+        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE: case RSCM_KIND_CO2_BUDGET:
+            return true;  // every kind the light variant of the group kernel runs
         default: return false;
     }
 }

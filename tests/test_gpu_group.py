@@ -130,8 +130,8 @@ def test_light_graph_with_lds_slots_matches_the_unfused_run(ra):
     linked values in LDS slots between the steps (rscm_gpu_set_lockstep_fusion: 1 with the slots, 2 without,
     0 one launch per component and step).  Seven components with every kind of edge: a producer earlier in the
     order read at n+1 (served from its slot), a producer later in the order read at n (its slot of the previous
-    step: not at a launch's first step), an earlier producer read at n and a kind that keeps no slots (both read
-    from HBM), more parameter rows than the slot budget holds, varying and uniform rows.  Same bits all ways,
+    step: not at a launch's first step), an earlier producer read at n (from HBM: its slot already holds n+1), more
+    series and parameter rows than the slot budget holds, varying and uniform rows.  Same bits all ways,
     also when the run is cut into launches."""
     from oracle import cbind as orc
     from rscm_amd import _lib as L
@@ -186,7 +186,7 @@ def test_light_graph_with_lds_slots_matches_the_unfused_run(ra):
         tl.link_input(0, agg, 1, ra.SRC_UPSTREAM)
         bud.set_params(np.repeat(np.array([[2.123], [278.0]]), n, axis=1))
         bud.set_forcing(np.stack([8.0 + 0.02 * yr, 1.0 + 0.0 * yr, 2.0 + 0.0 * yr, 1.5 + 0.0 * yr]))
-        bud.link_input(2, tr, 1, ra.SRC_EXOGENOUS)            # an earlier producer read at n; the budget keeps no slots
+        bud.link_input(2, tr, 1, ra.SRC_EXOGENOUS)            # an earlier producer read at n: not from its slot
         bud.set_initial(1, 278.0)
         for x in graph:
             L.check(L.load().rscm_ens_set_link_order_check(x._h, 0))
