@@ -494,12 +494,13 @@ def main():
 
         # BASELINE.json configs[3], one GPU's share at full size: 125 000 members x 9000 MONTHLY steps of the MAGICC
         # graph, windowed series + annual outputs (scripts/run_configs3_share.py)
-        def configs3_share():
+        def configs3_share(*flags):
             import contextlib
             import io
             from scripts import run_configs3_share as prog
-            argv, sys.argv = sys.argv, ["run_configs3_share.py"]
+            argv, sys.argv = sys.argv, ["run_configs3_share.py", *flags]
             buf = io.StringIO()
+            code = 0
             try:
                 with contextlib.redirect_stdout(buf):
                     try:
@@ -510,9 +511,13 @@ def main():
                 sys.argv = argv
             out = json.loads(buf.getvalue().strip().splitlines()[-1])
             out["exit_code"] = code
+            if code not in (0, None):  # the parity anchor (first 64 members == a 64-member run) or a member failed
+                raise RuntimeError(f"run_configs3_share exited with {code}: {json.dumps(out)[:400]}")
             return out
 
         side("configs3_share_125000x9000_fast", configs3_share)
+        # the same in RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) history convolution in the reference's summation order
+        side("configs3_share_125000x9000_exact", lambda: configs3_share("--exact"))
 
         # SURVEY 8d asks for the end-to-end figure beside the resident one: host parameters in,
         # run, full Ts and Td series out into page-locked buffers (never reported as `value`)

@@ -480,12 +480,7 @@ RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, 
  * launches.  A graph made of light components only runs ALL its steps in one launch, and between the steps
  * every component keeps its varying parameters, its state and what its consumers read in thread-private LDS
  * slots instead of reading them back from HBM (the series are still written every step).
- * enabled = 0 switches the fusion off for the process, 2 keeps the fusion but not the LDS slots, 3 keeps both
- * but sends every op table through device memory instead of the kernel arguments (A/B tests); default 1. */
-RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
-/* Step launches issued by rscm_ens_run_lockstep (component kernels + fused groups; HalocarbonChemistry counts
- * as one) and the component steps they carried, since the last call; resets both counters. */
-RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps);
+ * (A/B switches and launch counters for tests: include/rscm_gpu_internal.h.) */
 RSCM_API int rscm_ens_sync(rscm_ens* h);
 RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
 /* Rewind to time index 0 keeping parameters, forcing and initial values (outputs are
@@ -512,6 +507,11 @@ RSCM_API int rscm_ens_get_series(rscm_ens* h, int32_t var_id, int32_t t_begin, i
                         int32_t t_stride, int64_t m_begin, int64_t m_end, double* out);
 /* Device pointer of series[var] ([T][N] contiguous) for zero-copy consumers. */
 RSCM_API int rscm_ens_series_devptr(rscm_ens* h, int32_t var_id, void** out);
+/* Device pointer of the parameter block ([P][N]) for callers that fill it on the device (the device sampler's
+ * proposal kernel, a torch view).  The pointer stays valid until rscm_ens_destroy and may be written at any
+ * time between launches: from this call on the handle never again treats a parameter row as uniform over the
+ * members (the kernels' shortcut for rows rscm_ens_set_params found to hold one value), whatever later
+ * rscm_ens_set_params calls upload. */
 RSCM_API int rscm_ens_params_devptr(rscm_ens* h, void** out);
 /* Per-member status after the last run: bit0 = a state variable is non-finite at the current
  * time index (the reference's failed-member case: NaN/Inf -> Err -> -inf log-posterior). */
@@ -660,24 +660,8 @@ RSCM_API int rscm_gpu_copy_to_device(int32_t device_id, void* device_ptr, const 
 RSCM_API int rscm_gpu_host_free(void* p);
 
 /* ---- diagnostics --------------------------------------------------------------------------- */
-/* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an
- * O(T) recurrence: lags below `near_lags` months explicitly, the rest through decaying modes fitted to the
- * scaled impulse response (parameters/ocean_carbon.rs:85-216) by the host.  This runs that fit alone (no
- * GPU): the largest deviation of the fitted response from the tabulated one over the window (negative: the
- * parameters do not allow the recurrence and FAST keeps the tiled convolution), the number of modes, of
- * modes that still weigh when a pulse leaves the window, and the largest amplitude. */
-RSCM_API int rscm_gpu_ocean_fit_selftest(int32_t model, double irf_scale, double irf_switch_time,
-                                         int64_t max_history_months, double* max_error, int32_t* n_modes,
-                                         int32_t* near_lags, int32_t* n_exit, double* max_abs_coefficient);
 /* Whether this OceanCarbon ensemble's RSCM_MODE_FAST runs the recurrence, and the fit's deviation. */
 RSCM_API int rscm_ens_ocean_fast_info(rscm_ens* h, int32_t* uses_recurrence, double* fit_error);
-/* Element-wise num[i]/den[i] on the device through (a) the compiler's IEEE f64 division and
- * (b) the three-instruction hoisted-reciprocal quotient of rk4_device.hpp with no fallback;
- * used_fast[i] = 1 where both operands are inside the windows in which the kernels trust (b).
- * The parity tests require out_ref == out_fast bit for bit wherever used_fast is 1. */
-RSCM_API int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const double* den,
-                          double* out_ref, double* out_fast, uint8_t* used_fast);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,53 @@
+/*
+ * rscm_gpu_internal.h -- test and A/B hooks of librscm_gpu.so.  NOT part of the drop-in boundary
+ * (include/rscm_gpu.h): nothing here replaces a reference interface, a host integration binds none of it.
+ * The library exports these symbols for tests/, scripts/ and bench.py only.
+ *
+ * Threading: the lock-step switches and counters are per calling thread (thread_local in
+ * csrc/lockstep.cpp) -- the boundary's model is one handle per device per thread, so a thread that
+ * flips an A/B switch changes its own rscm_ens_run_lockstep calls and nobody else's.
+ */
+#ifndef RSCM_GPU_INTERNAL_H
+#define RSCM_GPU_INTERNAL_H
+
+#include "rscm_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* How the calling thread's rscm_ens_run_lockstep calls are cut into launches:
+ *   0  one launch per component and step (no fusion);
+ *   1  default: light components fused per step, a graph of light components only in one launch for all
+ *      steps with thread-private LDS slots, and -- RSCM_MODE_FAST graphs whose only heavy components are
+ *      ClimateUDEB and OceanCarbon -- the whole graph in ONE persistent launch per window chunk;
+ *   2  as 1 without the LDS slots;
+ *   3  as 1 with every op table sent through device memory instead of the kernel arguments;
+ *   4  as 1 without the persistent whole-graph launch (heavy components keep their one-step launches). */
+RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
+/* Step launches issued by the calling thread's rscm_ens_run_lockstep calls (component kernels + fused
+ * groups; HalocarbonChemistry counts as one) and the component steps they carried, since the thread's
+ * last call of this function; resets both counters. */
+RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps);
+
+/* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an
+ * O(T) recurrence: lags below `near_lags` months explicitly, the rest through decaying modes fitted to the
+ * scaled impulse response (parameters/ocean_carbon.rs:85-216) by the host.  This runs that fit alone (no
+ * GPU): the largest deviation of the fitted response from the tabulated one over the window (negative: the
+ * parameters do not allow the recurrence and FAST keeps the tiled convolution), the number of modes, of
+ * modes that still weigh when a pulse leaves the window, and the largest amplitude. */
+RSCM_API int rscm_gpu_ocean_fit_selftest(int32_t model, double irf_scale, double irf_switch_time,
+                                         int64_t max_history_months, double* max_error, int32_t* n_modes,
+                                         int32_t* near_lags, int32_t* n_exit, double* max_abs_coefficient);
+
+/* Element-wise num[i]/den[i] on the device through (a) the compiler's IEEE f64 division and
+ * (b) the three-instruction hoisted-reciprocal quotient of rk4_device.hpp with no fallback;
+ * used_fast[i] = 1 where both operands are inside the windows in which the kernels trust (b).
+ * The parity tests require out_ref == out_fast bit for bit wherever used_fast is 1. */
+RSCM_API int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const double* den,
+                                   double* out_ref, double* out_fast, uint8_t* used_fast);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSCM_GPU_INTERNAL_H */

@@ -1,0 +1,262 @@
+// The lock-step scheduler of component graphs: Model::step for a list of linked ensembles
+// (crates/rscm-core/src/model/runtime.rs:504-527 walks the graph once per step; here the walk is cut into
+// launches -- fused groups of light components, the heavy components' own kernels, or one launch for
+// many steps of the whole graph).
+#include "ens.hpp"
+
+extern "C" {
+
+// A/B switches and launch counters (include/rscm_gpu_internal.h).  Per calling thread: the boundary's model is
+// one handle per device per thread, so two threads stepping two graphs neither race on the counters nor see
+// each other's switches.
+namespace {
+struct LockstepSettings {
+    bool fuse = true;        // consecutive light components of a step in one launch
+    bool cache = true;       // multi-step fused launches keep per-member values in LDS between steps
+    bool by_value = true;    // short op lists travel in the kernel arguments
+    bool persistent = true;  // whole graphs with heavy components in one launch per window chunk
+    int64_t launches = 0, component_steps = 0;  // since the thread's last rscm_gpu_lockstep_stats
+};
+thread_local LockstepSettings t_ls;
+}  // namespace
+
+int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
+{
+    if (launches) *launches = t_ls.launches;
+    if (component_steps) *component_steps = t_ls.component_steps;
+    t_ls.launches = t_ls.component_steps = 0;
+    return RSCM_OK;
+}
+
+int rscm_gpu_set_lockstep_fusion(int32_t enabled)
+{
+    if (enabled < 0 || enabled > 4) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..4)", enabled);
+    t_ls.fuse = enabled != 0;
+    t_ls.cache = enabled == 1 || enabled == 3 || enabled == 4;
+    t_ls.by_value = enabled != 3;
+    t_ls.persistent = enabled == 1 || enabled == 3;
+    return RSCM_OK;
+}
+
+// Kinds whose one-step launch the group kernel can absorb (csrc/group.hip): the light per-member
+// components.  ClimateUDEB, OceanCarbon, HalocarbonChemistry and the fused coupled chain keep their own
+// launches; GhgForcing joins only with linked concentrations (its table path uses host-built rows).
+static bool fusable(const rscm_ens* h)
+{
+    switch (h->kind) {
+        case RSCM_KIND_TWO_LAYER: case RSCM_KIND_OZONE_FORCING: case RSCM_KIND_AEROSOL_DIRECT: case RSCM_KIND_AEROSOL_INDIRECT:
+        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON:
+        case RSCM_KIND_FOURBOX_OHU: case RSCM_KIND_OSPP: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE:
+            return true;
+        case RSCM_KIND_GHG_FORCING: return h->n_linked > 0;
+        default: return false;
+    }
+}
+
+// the step range is an argument of the fused launch, not part of the table
+static void clear_step_fields(rscm::GroupOp& op)
+{
+    switch (op.kind) {
+        case RSCM_KIND_TWO_LAYER: op.u.tl.step_begin = op.u.tl.step_end = 0; break;
+        case RSCM_KIND_GHG_FORCING: op.u.ghg.step_begin = op.u.ghg.step_end = 0; break;
+        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: op.u.chem.step_begin = op.u.chem.step_end = 0; break;
+        case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON: case RSCM_KIND_CARBON_CYCLE:
+            op.u.carbon.step_begin = op.u.carbon.step_end = 0; break;
+        default: op.u.pw.step_begin = op.u.pw.step_end = 0; break;
+    }
+}
+
+// LDS slots for a multi-step launch of a graph of light components (csrc/group.hip, CACHED): every op that
+// can keep values there gets one slot per series (the latest row: its own state for the next step, and what
+// its consumers read) and, while the budget lasts, one per parameter row if any of its rows varies over the
+// members.  A link is served from the producer's slot when the value it wants is the one the slot holds at
+// that point of the step: a producer earlier in the order read at n+1 (this step's value), or a producer
+// later in the order read at n (what it left in the previous step -- not at a launch's first step).
+static constexpr int32_t kCacheSlotBudget = 20;  // x 2 KiB per workgroup: four workgroups (16 wavefronts) per CU
+static bool keeps_slots(int32_t kind)
+{
+    switch (kind) {
+        case RSCM_KIND_TWO_LAYER: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_AEROSOL_INDIRECT: case RSCM_KIND_FOURBOX_OHU:
+        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE: case RSCM_KIND_CO2_BUDGET:
+            return true;  // every kind the light variant of the group kernel runs
+        default: return false;
+    }
+}
+static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t count, std::vector<rscm::OpCache>& out)
+{
+    out.assign((size_t)count, rscm::OpCache{});
+    int32_t next = 0;
+    for (int32_t k = 0; k < count; ++k) {
+        rscm::OpCache& c = out[(size_t)k];
+        c.series_slot = c.param_slot = -1;
+        for (int32_t& s : c.link_slot) s = -1;
+        c.link_warm = 0;
+        const rscm_ens* h = plan->handles[first + k];
+        const int32_t n_series = h->V - 1;
+        if (keeps_slots(h->kind) && n_series > 0 && next + n_series <= kCacheSlotBudget) {
+            c.series_slot = next;
+            next += n_series;
+        }
+    }
+    for (int32_t k = 0; k < count; ++k) {
+        const rscm_ens* h = plan->handles[first + k];
+        const uint64_t all_rows = h->P >= 64 ? ~0ull : ((1ull << h->P) - 1ull);
+        const bool varies = (h->uniform_rows & all_rows) != all_rows;
+        if (keeps_slots(h->kind) && h->kind != RSCM_KIND_AGGREGATE && varies && h->P <= 16 && next + h->P <= kCacheSlotBudget) {
+            out[(size_t)k].param_slot = next;
+            next += h->P;
+        }
+    }
+    for (int32_t k = 0; k < count; ++k) {
+        const rscm_ens* h = plan->handles[first + k];
+        if (!keeps_slots(h->kind)) continue;
+        for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
+            const auto& l = h->links[j];
+            if (!l.src) continue;
+            int32_t at = -1;
+            for (int32_t q = 0; q < count; ++q)
+                if (plan->handles[first + q] == l.src) at = q;
+            if (at < 0 || out[(size_t)at].series_slot < 0 || l.var < 1 || l.var > l.src->V - 1) continue;
+            const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
+            if (at < k ? !reads_end : reads_end) continue;  // the slot holds the other row at that point
+            out[(size_t)k].link_slot[j] = out[(size_t)at].series_slot + (l.var - 1);
+            if (at >= k) out[(size_t)k].link_warm |= 1u << j;
+        }
+    }
+    return next;
+}
+
+// Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
+// the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
+static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
+{
+    rscm_ens* lead = plan->handles[first];
+    bool all_small = true;
+    for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
+    std::vector<rscm::OpCache> slots;
+    int32_t cache_slots = 0;
+    if (len > 1 && all_small && t_ls.cache) cache_slots = assign_cache_slots(plan, first, count, slots);
+    for (int32_t k = first; k < first + count; ++k) {
+        rscm_ens* h = plan->handles[k];
+        if (int rc = step_check(h, n, n + len)) return rc;
+        if (int rc = step_window_pre(h, n, n + len)) return rc;
+    }
+    // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
+    // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
+    // only what changed since the last launch is uploaded
+    const bool by_value = t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0;
+    rscm::GroupTable table;
+    if (by_value) memset((void*)&table, 0, sizeof table);
+    for (int32_t k = first; k < first + count; ++k) {
+        rscm_ens* h = plan->handles[k];
+        rscm::InputLinks links{};
+        int32_t linked = 0;
+        if (int rc = step_links(h, n, n + 1, links, linked)) return rc;
+        rscm::GroupOp op;
+        memset((void*)&op, 0, sizeof op);
+        if (int rc = step_launch(h, n, n + 1, links, linked, &op)) return rc;
+        if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", k, h->kind);
+        clear_step_fields(op);
+        if (cache_slots > 0) {
+            op.cache = slots[(size_t)(k - first)];
+        } else {
+            op.cache.series_slot = op.cache.param_slot = -1;
+            for (int32_t& sl : op.cache.link_slot) sl = -1;
+        }
+        if (by_value) {
+            memcpy((void*)&table.ops[k - first], &op, sizeof op);
+        } else if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
+            if (plan->ring_pos == LockstepPlan::kRing) {  // every slot may still be the source of a queued copy
+                HIPCHK(hipStreamSynchronize(lead->stream));
+                plan->ring_pos = 0;
+            }
+            rscm::GroupOp* slot = plan->staging + plan->ring_pos++;
+            memcpy((void*)slot, &op, sizeof op);
+            HIPCHK(hipMemcpyAsync(plan->d_ops + k, slot, sizeof op, hipMemcpyHostToDevice, lead->stream));
+            memcpy((void*)&plan->cached[k], &op, sizeof op);
+            plan->valid[k] = 1;
+        }
+        h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
+    }
+    HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
+                              cache_slots, lead->stream));
+    for (int32_t k = first; k < first + count; ++k)
+        if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
+    return RSCM_OK;
+}
+
+int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end)
+{
+    GUARD_BEGIN
+    if (!handles || n_handles < 1) return fail(RSCM_ERR_INVALID, "need at least one handle");
+    for (int32_t k = 0; k < n_handles; ++k) {
+        if (!handles[k]) return fail(RSCM_ERR_INVALID, "handle %d is NULL", k);
+        if (handles[k]->stream != handles[0]->stream)
+            return fail(RSCM_ERR_STATE, "handle %d runs on another stream than handle 0", k);
+        if (handles[k]->time_index != step_begin)
+            return fail(RSCM_ERR_STATE, "handle %d is at time index %d, not at step_begin %d", k, handles[k]->time_index, step_begin);
+    }
+    // Consecutive fusable components become one launch per step (csrc/group.hip); the others, and
+    // fusable ones on their own, keep their kernels.
+    std::vector<std::pair<int32_t, int32_t>> segments;  // (first, count)
+    for (int32_t k = 0; k < n_handles;) {
+        int32_t c = 1;
+        if (t_ls.fuse && fusable(handles[k]))
+            while (k + c < n_handles && c < rscm::kMaxGroupOps && fusable(handles[k + c]) && handles[k + c]->N == handles[k]->N &&
+                   handles[k + c]->device == handles[k]->device)
+                ++c;
+        segments.emplace_back(k, c);
+        k += c;
+    }
+    bool any_fused = false;
+    for (const auto& sgm : segments) any_fused = any_fused || sgm.second > 1;
+    LockstepPlan* plan = nullptr;
+    if (any_fused) {
+        rscm_ens* lead = handles[0];
+        if (int rc = set_device(lead)) return rc;
+        plan = lead->plan;
+        const std::vector<rscm_ens*> list(handles, handles + n_handles);
+        if (!plan || plan->handles != list) {
+            if (!plan) plan = lead->plan = new LockstepPlan();
+            HIPCHK(hipStreamSynchronize(lead->stream));
+            HIPCHK(hipFree(plan->d_ops));
+            plan->d_ops = nullptr;
+            plan->handles = list;
+            plan->cached.assign((size_t)n_handles, rscm::GroupOp());
+            plan->valid.assign((size_t)n_handles, 0);
+            plan->ring_pos = 0;
+            HIPCHK(hipMalloc(&plan->d_ops, (size_t)n_handles * sizeof(rscm::GroupOp)));
+            if (!plan->staging) HIPCHK(hipHostMalloc((void**)&plan->staging, LockstepPlan::kRing * sizeof(rscm::GroupOp), hipHostMallocDefault));
+        }
+    }
+    if (segments.size() == 1 && segments[0].second > 1) {
+        // The whole graph is one fused segment: many model steps per launch.  A chunk ends where a windowed
+        // handle runs out of rows (its window slides between launches).
+        for (int32_t n = step_begin; n < step_end;) {
+            int32_t len = step_end - n;
+            for (int32_t k = 0; k < n_handles; ++k) {
+                const rscm_ens* h = handles[k];
+                if (h->windowed) len = std::min(len, std::max(1, h->rows - h->keep_rows()));
+            }
+            t_ls.launches += 1;
+            t_ls.component_steps += (int64_t)n_handles * len;
+            if (int rc = fused_segment(plan, 0, n_handles, n, len)) return rc;
+            n += len;
+        }
+        return RSCM_OK;
+    }
+    for (int32_t n = step_begin; n < step_end; ++n)
+        for (const auto& sgm : segments) {
+            t_ls.launches += 1;
+            t_ls.component_steps += sgm.second;
+            if (sgm.second > 1) {
+                if (int rc = fused_segment(plan, sgm.first, sgm.second, n, 1)) return rc;
+            } else if (int rc = run_range(handles[sgm.first], n, n + 1, false)) {
+                return rc;
+            }
+        }
+    return RSCM_OK;
+    GUARD_END
+}
+
+}  // extern "C"

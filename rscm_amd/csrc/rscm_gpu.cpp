@@ -6,26 +6,12 @@
 // tolerance-parity kinds for that reason among others (tests/test_gpu_ghg.py, tests/test_gpu_ocean.py
 // state the bounds; GhgForcing's linked-input path evaluates the same factors with the device
 // library and is compared with the table path in tests/test_gpu_links.py).
-#include "../../include/rscm_gpu.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <limits>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "rscm_device.hpp"
+#include "ens.hpp"
 #include "udeb_tables.hpp"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
 int fail(int code, const char* fmt, ...)
 {
@@ -38,19 +24,7 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
-#define HIPCHK(expr)                                                                       \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(e_ == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,      \
-                        "%s failed: %s", #expr, hipGetErrorString(e_));                    \
-    } while (0)
-
-#define GUARD_BEGIN try {
-#define GUARD_END                                                                          \
-    }                                                                                      \
-    catch (const std::bad_alloc&) { return fail(RSCM_ERR_NOMEM, "host allocation failed"); } \
-    catch (...) { return fail(RSCM_ERR_INVALID, "unexpected C++ exception"); }
+namespace {
 
 constexpr double kTThreshold = 5e-3;  // crates/rscm-core/src/ivp/mod.rs:73
 
@@ -258,158 +232,8 @@ static_assert(rscm::kKindOzoneForcing == RSCM_KIND_OZONE_FORCING && rscm::kKindA
                   rscm::kKindCo2Erf == RSCM_KIND_CO2_ERF && rscm::kKindAggregate == RSCM_KIND_AGGREGATE,
               "rscm_device.hpp and include/rscm_gpu.h disagree on a kind value");
 
-// Cached state of rscm_ens_run_lockstep for one list of handles (kept by the first of them): the device
-// table of fused-launch operations (csrc/group.hip) and what it currently holds.
-struct LockstepPlan {
-    std::vector<rscm_ens*> handles;
-    rscm::GroupOp* d_ops = nullptr;          // [handles.size()]
-    std::vector<rscm::GroupOp> cached;       // the table's contents (step fields zeroed)
-    std::vector<uint8_t> valid;
-    rscm::GroupOp* staging = nullptr;        // page-locked ring the uploads are sourced from
-    int32_t ring_pos = 0;
-    static constexpr int32_t kRing = 128;
-};
-
-struct rscm_ens {
-    int32_t kind = 0;
-    int64_t N = 0;
-    int32_t T = 0;
-    int32_t rows = 0;  // stored rows per series: T, or 1 with RSCM_FLAG_NO_SERIES
-    int32_t device = 0;
-    int32_t P = 0, V = 0;
-    int32_t mode = RSCM_MODE_EXACT;
-    std::vector<double> bounds;
-    double h_tl = 0.1, h_cc = 0.1;
-    bool schedule_dirty = true;
-    std::vector<int32_t> nsub_tl, nsub_cc;
-    int32_t* d_nsub_tl = nullptr;
-    int32_t* d_nsub_cc = nullptr;
-
-    double* d_params = nullptr;  // [P][N]
-    int32_t ag_rows_set = 0;     // aggregate kind: 1 + the highest contributor row rscm_ens_set_forcing has ever been given data for
-    uint64_t uniform_rows = 0;   // bit j: parameter row j (< 64) holds one value for every member (the kernels then read element 0: param_at)
-    double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
-    double* d_forcing = nullptr; // [S][n_inputs][T]
-    int32_t n_inputs = 1;        // rows per scenario of the shared input block
-    double* d_ghg_tables = nullptr;  // GhgForcing: [S][kGhgRows][T] derived scenario rows
-    int32_t ghg_method = 1;
-    // OceanCarbon: flux history (internal state) and the tabulated impulse response
-    double* d_ocean_hist = nullptr;  // [ocean_hist_rows][N]: a ring, pulse j in row j mod ocean_hist_rows
-    int64_t ocean_hist_rows = 0;     // min((T-1)*12, max_hist + slack): the convolution never looks further back
-    double* d_ocean_irf = nullptr;   // [max(max_hist, 1)]
-    double* d_ocean_partial = nullptr;  // [(tile years - 1) * steps][N] split-tile running sums (one-step launches)
-    int32_t ocean_tile_base = -1;       // first step of the split tile d_ocean_partial belongs to, -1: none
-    int32_t ocean_tile_years = 0;       // its length (depends on the arithmetic mode it was started in)
-    int32_t ocean_steps = 0;
-    int64_t ocean_max_hist = 0;
-    bool ocean_ready = false;
-    // RSCM_MODE_FAST: the far response as decaying modes (ocean_fit_modes) and their running sums
-    rscm::OceanModes ocean_modes{};
-    bool ocean_recur_ok = false;
-    int32_t ocean_near = 0;
-    double ocean_fit_error = 0.0;
-    double* d_ocean_mode_state = nullptr;  // [kOceanModes][N]
-    double* d_ocean_mode_table = nullptr;  // [3][kOceanModes]: d_q, c_q, e_q
-    int32_t ocean_modes_at = -1;           // time index the running sums stand at (-1: re-form them from the history)
-    int32_t* d_scen = nullptr;   // [N] or null
-    int32_t n_scen = 0;
-    int32_t source = RSCM_SRC_EXOGENOUS;
-    uint8_t* d_status = nullptr;
-
-    // ClimateUDEB internal state
-    double* d_ocean = nullptr;    // [2][NL][N]
-    double* d_scal = nullptr;     // [kUdebScalars][N]
-    double* d_hist = nullptr;     // [T][N]
-    double* d_tables = nullptr;   // geometry tables
-    double* d_bounds = nullptr;   // [T+1]
-    int32_t* d_win_kfull = nullptr;  // [T]
-    double* d_win_partw = nullptr;   // [T]
-    int32_t udeb_n_layers = 0, udeb_steps = 0, udeb_land_hc = 0, udeb_efficacy = 0;
-    bool udeb_ready = false;
-    std::vector<double> udeb_tables;
-
-    double* d_partial = nullptr;  // summary scratch
-    double* d_out4 = nullptr;
-    double* d_loglik = nullptr;   // [N]
-    // observations prepared for the fused run+likelihood kernel (prepare_obs)
-    void* d_obs = nullptr;
-    size_t obs_capacity = 0;
-    int32_t obs_n = 0, obs_normalize = 0, obs_first_is_deep = 0;
-    int32_t obs_last_tidx = 0;        // the latest time index any prepared observation refers to
-    bool loglik_stop_at_last_obs = false;  // fused run+likelihood launches end there (the device sampler: only ln L is used)
-
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-
-    // linked inputs (rscm_ens_link_input)
-    struct Link { rscm_ens* src = nullptr; int32_t var = 0; int32_t off = 0; };
-    Link links[rscm::kMaxLinks];
-    int32_t n_linked = 0;
-    bool link_order_check = true;
-    int32_t link_refs = 0;  // links of other ensembles into this one's series
-
-    LockstepPlan* plan = nullptr;  // rscm_ens_run_lockstep with this handle first
-
-    int32_t time_index = 0;
-    bool params_set = false, forcing_set = false;
-    std::vector<uint8_t> initial_set;  // per variable id
-
-    // Windowed storage (RSCM_FLAG_WINDOWED): d_series holds rows [win0, win0 + rows) of every series.
-    bool windowed = false;
-    int32_t win0 = 0;            // absolute time index of the first stored row
-    int32_t lookback = 0;        // own rows before the current one that a step reads (chemistry kinds)
-    bool read_ahead = false;     // a linked consumer may read index n+1 before this producer wrote it: rows after a slide must be NaN
-    double* d_row0 = nullptr;    // [V-1][N] the initial rows, saved when step 0 starts (rewind restores them)
-    bool row0_saved = false;
-    int32_t out_stride = 0;      // > 0: every out_stride-th row of the output variables is kept in d_out
-    int32_t n_out = 0, out_rows = 0;
-    std::vector<int32_t> out_vars;      // variable ids kept
-    std::vector<int32_t> out_slot;      // per variable id: slot in d_out or -1
-    int32_t* d_out_vars = nullptr;
-    double* d_out = nullptr;     // [n_out][out_rows][N]
-    int32_t keep_rows() const { return std::max(lookback + 1, 2); }
-
-    // Base of series[var] such that row t lives at base + t * N (for a windowed handle the address of
-    // the virtual row 0: only rows [win0, win0 + rows) exist).
-    double* series(int32_t var) const
-    {
-        return d_series + ((int64_t)(var - 1) * (int64_t)rows - (int64_t)win0) * N;
-    }
-    // Device address of row t of a stored variable where it is resident: the output store (every
-    // out_stride-th row of the output variables, up to the current index), else the window; nullptr
-    // if the row is not held any more.
-    const double* row_ptr(int32_t var, int32_t t) const
-    {
-        if (!windowed) return (rows == T || t == 0) ? series(var) + (size_t)t * N : nullptr;
-        if (t >= win0 && t < win0 + rows) return series(var) + (size_t)t * N;  // the window is the live copy
-        if (out_stride > 0 && out_slot[var] >= 0 && t % out_stride == 0 && t <= time_index)
-            return d_out + ((size_t)out_slot[var] * out_rows + (size_t)(t / out_stride)) * N;
-        return nullptr;
-    }
-    bool is_state(int32_t var) const
-    {
-        if (kind == RSCM_KIND_TWO_LAYER) return var == RSCM_TL_VAR_TS || var == RSCM_TL_VAR_TD;
-        if (kind == RSCM_KIND_UDEB) return var >= RSCM_UD_VAR_ST_NH_OCEAN && var <= RSCM_UD_VAR_ST_SH_LAND;
-        if (kind == RSCM_KIND_CH4_CHEMISTRY || kind == RSCM_KIND_N2O_CHEMISTRY) return var == RSCM_CHEM_VAR_CONC;
-        if (kind == RSCM_KIND_CO2_BUDGET) return var == 1;
-        if (kind == RSCM_KIND_TERRESTRIAL_CARBON) return var >= 1 && var <= 4;
-        if (kind == RSCM_KIND_OCEAN_CARBON) return var == 1 || var == 2;
-        if (kind == RSCM_KIND_HALOCARBON) return var >= 1 && var <= RSCM_HC_NSPECIES;
-        if (kind == RSCM_KIND_CARBON_CYCLE) return var >= 1 && var <= 3;
-        if (kind >= RSCM_KIND_GHG_FORCING) return false;  // stateless components
-        return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
-    }
-};
 
 namespace {
-
-int set_device(const rscm_ens* h)
-{
-    HIPCHK(hipSetDevice(h->device));
-    return RSCM_OK;
-}
 
 int refresh_schedule(rscm_ens* h)
 {
@@ -472,12 +296,19 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
     const int64_t ring = (((int64_t)max_hist + 60 + 11) / 12) * 12;
     const int64_t rows = std::min(all_pulses, ring);
     if (!h->d_ocean_hist || rows != h->ocean_hist_rows) {
+        // the ring holds the pulses of the steps taken so far (internal state): a new length mid-run would
+        // throw them away and leave the next convolution reading whatever the new allocation contains
+        if (h->d_ocean_hist && h->time_index > 0)
+            return fail(RSCM_ERR_STATE, "max_history_months changes the flux-history ring from %lld to %lld rows at time index %d: "
+                        "rewind (rscm_ens_rewind / rscm_ens_set_time_index(0)) before changing it", (long long)h->ocean_hist_rows,
+                        (long long)rows, h->time_index);
         HIPCHK(hipFree(h->d_ocean_hist));
         h->d_ocean_hist = nullptr;
         const hipError_t e = hipMalloc(&h->d_ocean_hist, (size_t)rows * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,
                         "flux history of %lld members x %lld months: %s", (long long)h->N, (long long)rows, hipGetErrorString(e));
+        HIPCHK(hipMemset(h->d_ocean_hist, 0, (size_t)rows * h->N * sizeof(double)));
         h->ocean_hist_rows = rows;
     }
     if (!h->d_ocean_partial) {
@@ -860,8 +691,6 @@ int rscm_ens_destroy(rscm_ens* h)
     return RSCM_OK;
 }
 
-#define NEED(h) \
-    if (!(h)) return fail(RSCM_ERR_INVALID, "handle is NULL")
 
 int rscm_ens_n_params(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->P; return RSCM_OK; }
 int rscm_ens_n_vars(const rscm_ens* h, int32_t* out) { NEED(h); *out = h->V; return RSCM_OK; }
@@ -960,7 +789,14 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
     if (h->kind == RSCM_KIND_N2O_CHEMISTRY) {  // rows the stratospheric delay looks back (n2o.rs:203-218)
         double d = 1.0;
         for (int64_t i = 0; i < h->N; ++i) d = std::max(d, soa[(size_t)4 * h->N + i]);
-        h->lookback = (int32_t)std::min(d, 1e6) + 1;
+        const int32_t lookback = (int32_t)std::min(d, 1e6) + 1;
+        // a window that has already slid kept only keep_rows() of the OLD look-back: the rows a longer delay
+        // reads are gone (the body would read before the window's first row)
+        if (h->windowed && h->win0 > 0 && std::max(0, h->time_index - lookback) < h->win0 && lookback > h->lookback)
+            return fail(RSCM_ERR_STATE, "a stratospheric delay that looks %d rows back needs row %d, but the window already starts at row %d: "
+                        "rewind (rscm_ens_rewind) or restore a checkpoint before raising the delay", lookback,
+                        std::max(0, h->time_index - lookback), h->win0);
+        h->lookback = lookback;
     }
     HIPCHK(hipMemcpyAsync(h->d_params, soa, (size_t)h->P * h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     {   // rows that hold the same bits for every member
@@ -971,7 +807,7 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
             for (int64_t i = 1; i < h->N && same; ++i) same = memcmp(&row[i], &row[0], sizeof(double)) == 0;
             if (same) uni |= 1ull << j;
         }
-        h->uniform_rows = uni;
+        h->uniform_rows = h->params_exposed ? 0 : uni;  // a caller holding the device pointer may rewrite any row
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -1273,7 +1109,7 @@ int rscm_ens_rewind(rscm_ens* h)
 
 // ---- one launch range of one handle, in pieces (rscm_ens_run_lockstep fuses the launches of several handles) ----
 // (1) what must hold before anything is enqueued
-static int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
+int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     NEED(h);
     if (step_begin < 0 || step_end > h->T - 1 || step_begin > step_end)
@@ -1291,6 +1127,11 @@ static int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
         if (step_end - step_begin + keep > h->rows)
             return fail(RSCM_ERR_STATE, "steps [%d, %d) do not fit a window of %d rows (%d are kept for look-back): step in shorter ranges",
                         step_begin, step_end, h->rows, keep);
+        // the rows the first step looks back at must be resident (they are after any slide made with this
+        // look-back; not after the look-back was raised on a window that had already moved)
+        if (std::max(0, step_begin - h->lookback) < h->win0)
+            return fail(RSCM_ERR_STATE, "step %d reads row %d of its own series, the window starts at row %d", step_begin,
+                        std::max(0, step_begin - h->lookback), h->win0);
     }
     if (!h->params_set) return fail(RSCM_ERR_STATE, "parameters not set");
     if (!h->forcing_set && h->n_linked < h->n_inputs) return fail(RSCM_ERR_STATE, "shared input series not set");
@@ -1301,7 +1142,7 @@ static int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
 }
 
 // (2) schedule tables and the handle's own window: room for the rows this range writes
-static int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end)
+int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     const int32_t keep = h->keep_rows();
     if (int rc = set_device(h)) return rc;
@@ -1325,7 +1166,7 @@ static int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end)
 }
 
 // (3) the producing ensembles' series as they stand now (after every window of the graph has been moved)
-static int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out)
+int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out)
 {
     // linked inputs: the producing ensembles' series, in launch order on one stream
     links = rscm::InputLinks{};
@@ -1357,7 +1198,7 @@ static int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::I
 
 // (4) the launch itself -- or, with op_out, its arguments for the group kernel (csrc/group.hip) if the kind can
 // be fused with its neighbours (op_out->kind = -1 otherwise; nothing is launched either way)
-static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
+int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
                        rscm::GroupOp* op_out)
 {
     const int32_t len = step_end - step_begin;
@@ -1646,7 +1487,7 @@ static int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const 
 }
 
 // (5) bookkeeping after the launch: time index, strided outputs, room for the next step
-static int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end)
+int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     const int32_t keep = h->keep_rows();
     h->time_index = step_end;
@@ -1664,7 +1505,7 @@ static int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end)
 
 // One launch of the kind's kernel over [step_begin, step_end).  `timed` brackets it with the events
 // rscm_ens_last_run_ms reads; the lock-step loop of rscm_ens_run_lockstep leaves them out.
-static int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
+int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
 {
     NEED(h);
     if (int rc = step_check(h, step_begin, step_end)) return rc;
@@ -1723,248 +1564,6 @@ int rscm_ens_run_async(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     GUARD_BEGIN
     return run_range(h, step_begin, step_end, true);
-    GUARD_END
-}
-
-static bool g_fuse_lockstep = true;
-static bool g_lockstep_cache = true;  // multi-step fused launches keep per-member values in LDS between steps
-static bool g_group_by_value = true;  // short op lists travel in the kernel arguments
-static int64_t g_lockstep_launches = 0, g_lockstep_component_steps = 0;  // since the last rscm_gpu_lockstep_stats
-
-int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
-{
-    if (launches) *launches = g_lockstep_launches;
-    if (component_steps) *component_steps = g_lockstep_component_steps;
-    g_lockstep_launches = g_lockstep_component_steps = 0;
-    return RSCM_OK;
-}
-
-int rscm_gpu_set_lockstep_fusion(int32_t enabled)
-{
-    g_fuse_lockstep = enabled != 0;
-    g_lockstep_cache = enabled == 1;
-    g_group_by_value = enabled != 3;
-    return RSCM_OK;
-}
-
-// Kinds whose one-step launch the group kernel can absorb (csrc/group.hip): the light per-member
-// components.  ClimateUDEB, OceanCarbon, HalocarbonChemistry and the fused coupled chain keep their own
-// launches; GhgForcing joins only with linked concentrations (its table path uses host-built rows).
-static bool fusable(const rscm_ens* h)
-{
-    switch (h->kind) {
-        case RSCM_KIND_TWO_LAYER: case RSCM_KIND_OZONE_FORCING: case RSCM_KIND_AEROSOL_DIRECT: case RSCM_KIND_AEROSOL_INDIRECT:
-        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON:
-        case RSCM_KIND_FOURBOX_OHU: case RSCM_KIND_OSPP: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE:
-            return true;
-        case RSCM_KIND_GHG_FORCING: return h->n_linked > 0;
-        default: return false;
-    }
-}
-
-// the step range is an argument of the fused launch, not part of the table
-static void clear_step_fields(rscm::GroupOp& op)
-{
-    switch (op.kind) {
-        case RSCM_KIND_TWO_LAYER: op.u.tl.step_begin = op.u.tl.step_end = 0; break;
-        case RSCM_KIND_GHG_FORCING: op.u.ghg.step_begin = op.u.ghg.step_end = 0; break;
-        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: op.u.chem.step_begin = op.u.chem.step_end = 0; break;
-        case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON: case RSCM_KIND_CARBON_CYCLE:
-            op.u.carbon.step_begin = op.u.carbon.step_end = 0; break;
-        default: op.u.pw.step_begin = op.u.pw.step_end = 0; break;
-    }
-}
-
-// LDS slots for a multi-step launch of a graph of light components (csrc/group.hip, CACHED): every op that
-// can keep values there gets one slot per series (the latest row: its own state for the next step, and what
-// its consumers read) and, while the budget lasts, one per parameter row if any of its rows varies over the
-// members.  A link is served from the producer's slot when the value it wants is the one the slot holds at
-// that point of the step: a producer earlier in the order read at n+1 (this step's value), or a producer
-// later in the order read at n (what it left in the previous step -- not at a launch's first step).
-static constexpr int32_t kCacheSlotBudget = 20;  // x 2 KiB per workgroup: four workgroups (16 wavefronts) per CU
-static bool keeps_slots(int32_t kind)
-{
-    switch (kind) {
-        case RSCM_KIND_TWO_LAYER: case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_AEROSOL_INDIRECT: case RSCM_KIND_FOURBOX_OHU:
-        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: case RSCM_KIND_AGGREGATE: case RSCM_KIND_CO2_BUDGET:
-            return true;  // every kind the light variant of the group kernel runs
-        default: return false;
-    }
-}
-static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t count, std::vector<rscm::OpCache>& out)
-{
-    out.assign((size_t)count, rscm::OpCache{});
-    int32_t next = 0;
-    for (int32_t k = 0; k < count; ++k) {
-        rscm::OpCache& c = out[(size_t)k];
-        c.series_slot = c.param_slot = -1;
-        for (int32_t& s : c.link_slot) s = -1;
-        c.link_warm = 0;
-        const rscm_ens* h = plan->handles[first + k];
-        const int32_t n_series = h->V - 1;
-        if (keeps_slots(h->kind) && n_series > 0 && next + n_series <= kCacheSlotBudget) {
-            c.series_slot = next;
-            next += n_series;
-        }
-    }
-    for (int32_t k = 0; k < count; ++k) {
-        const rscm_ens* h = plan->handles[first + k];
-        const uint64_t all_rows = h->P >= 64 ? ~0ull : ((1ull << h->P) - 1ull);
-        const bool varies = (h->uniform_rows & all_rows) != all_rows;
-        if (keeps_slots(h->kind) && h->kind != RSCM_KIND_AGGREGATE && varies && h->P <= 16 && next + h->P <= kCacheSlotBudget) {
-            out[(size_t)k].param_slot = next;
-            next += h->P;
-        }
-    }
-    for (int32_t k = 0; k < count; ++k) {
-        const rscm_ens* h = plan->handles[first + k];
-        if (!keeps_slots(h->kind)) continue;
-        for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
-            const auto& l = h->links[j];
-            if (!l.src) continue;
-            int32_t at = -1;
-            for (int32_t q = 0; q < count; ++q)
-                if (plan->handles[first + q] == l.src) at = q;
-            if (at < 0 || out[(size_t)at].series_slot < 0 || l.var < 1 || l.var > l.src->V - 1) continue;
-            const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
-            if (at < k ? !reads_end : reads_end) continue;  // the slot holds the other row at that point
-            out[(size_t)k].link_slot[j] = out[(size_t)at].series_slot + (l.var - 1);
-            if (at >= k) out[(size_t)k].link_warm |= 1u << j;
-        }
-    }
-    return next;
-}
-
-// Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
-// the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
-static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
-{
-    rscm_ens* lead = plan->handles[first];
-    bool all_small = true;
-    for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
-    std::vector<rscm::OpCache> slots;
-    int32_t cache_slots = 0;
-    if (len > 1 && all_small && g_lockstep_cache) cache_slots = assign_cache_slots(plan, first, count, slots);
-    for (int32_t k = first; k < first + count; ++k) {
-        rscm_ens* h = plan->handles[k];
-        if (int rc = step_check(h, n, n + len)) return rc;
-        if (int rc = step_window_pre(h, n, n + len)) return rc;
-    }
-    // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
-    // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
-    // only what changed since the last launch is uploaded
-    const bool by_value = g_group_by_value && count <= rscm::kGroupTableOps && cache_slots == 0;
-    rscm::GroupTable table;
-    if (by_value) memset((void*)&table, 0, sizeof table);
-    for (int32_t k = first; k < first + count; ++k) {
-        rscm_ens* h = plan->handles[k];
-        rscm::InputLinks links{};
-        int32_t linked = 0;
-        if (int rc = step_links(h, n, n + 1, links, linked)) return rc;
-        rscm::GroupOp op;
-        memset((void*)&op, 0, sizeof op);
-        if (int rc = step_launch(h, n, n + 1, links, linked, &op)) return rc;
-        if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", k, h->kind);
-        clear_step_fields(op);
-        if (cache_slots > 0) {
-            op.cache = slots[(size_t)(k - first)];
-        } else {
-            op.cache.series_slot = op.cache.param_slot = -1;
-            for (int32_t& sl : op.cache.link_slot) sl = -1;
-        }
-        if (by_value) {
-            memcpy((void*)&table.ops[k - first], &op, sizeof op);
-        } else if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
-            if (plan->ring_pos == LockstepPlan::kRing) {  // every slot may still be the source of a queued copy
-                HIPCHK(hipStreamSynchronize(lead->stream));
-                plan->ring_pos = 0;
-            }
-            rscm::GroupOp* slot = plan->staging + plan->ring_pos++;
-            memcpy((void*)slot, &op, sizeof op);
-            HIPCHK(hipMemcpyAsync(plan->d_ops + k, slot, sizeof op, hipMemcpyHostToDevice, lead->stream));
-            memcpy((void*)&plan->cached[k], &op, sizeof op);
-            plan->valid[k] = 1;
-        }
-        h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
-    }
-    HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
-                              cache_slots, lead->stream));
-    for (int32_t k = first; k < first + count; ++k)
-        if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
-    return RSCM_OK;
-}
-
-int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t step_begin, int32_t step_end)
-{
-    GUARD_BEGIN
-    if (!handles || n_handles < 1) return fail(RSCM_ERR_INVALID, "need at least one handle");
-    for (int32_t k = 0; k < n_handles; ++k) {
-        if (!handles[k]) return fail(RSCM_ERR_INVALID, "handle %d is NULL", k);
-        if (handles[k]->stream != handles[0]->stream)
-            return fail(RSCM_ERR_STATE, "handle %d runs on another stream than handle 0", k);
-        if (handles[k]->time_index != step_begin)
-            return fail(RSCM_ERR_STATE, "handle %d is at time index %d, not at step_begin %d", k, handles[k]->time_index, step_begin);
-    }
-    // Consecutive fusable components become one launch per step (csrc/group.hip); the others, and
-    // fusable ones on their own, keep their kernels.
-    std::vector<std::pair<int32_t, int32_t>> segments;  // (first, count)
-    for (int32_t k = 0; k < n_handles;) {
-        int32_t c = 1;
-        if (g_fuse_lockstep && fusable(handles[k]))
-            while (k + c < n_handles && c < rscm::kMaxGroupOps && fusable(handles[k + c]) && handles[k + c]->N == handles[k]->N &&
-                   handles[k + c]->device == handles[k]->device)
-                ++c;
-        segments.emplace_back(k, c);
-        k += c;
-    }
-    bool any_fused = false;
-    for (const auto& sgm : segments) any_fused = any_fused || sgm.second > 1;
-    LockstepPlan* plan = nullptr;
-    if (any_fused) {
-        rscm_ens* lead = handles[0];
-        if (int rc = set_device(lead)) return rc;
-        plan = lead->plan;
-        const std::vector<rscm_ens*> list(handles, handles + n_handles);
-        if (!plan || plan->handles != list) {
-            if (!plan) plan = lead->plan = new LockstepPlan();
-            HIPCHK(hipStreamSynchronize(lead->stream));
-            HIPCHK(hipFree(plan->d_ops));
-            plan->d_ops = nullptr;
-            plan->handles = list;
-            plan->cached.assign((size_t)n_handles, rscm::GroupOp());
-            plan->valid.assign((size_t)n_handles, 0);
-            plan->ring_pos = 0;
-            HIPCHK(hipMalloc(&plan->d_ops, (size_t)n_handles * sizeof(rscm::GroupOp)));
-            if (!plan->staging) HIPCHK(hipHostMalloc((void**)&plan->staging, LockstepPlan::kRing * sizeof(rscm::GroupOp), hipHostMallocDefault));
-        }
-    }
-    if (segments.size() == 1 && segments[0].second > 1) {
-        // The whole graph is one fused segment: many model steps per launch.  A chunk ends where a windowed
-        // handle runs out of rows (its window slides between launches).
-        for (int32_t n = step_begin; n < step_end;) {
-            int32_t len = step_end - n;
-            for (int32_t k = 0; k < n_handles; ++k) {
-                const rscm_ens* h = handles[k];
-                if (h->windowed) len = std::min(len, std::max(1, h->rows - h->keep_rows()));
-            }
-            g_lockstep_launches += 1;
-            g_lockstep_component_steps += (int64_t)n_handles * len;
-            if (int rc = fused_segment(plan, 0, n_handles, n, len)) return rc;
-            n += len;
-        }
-        return RSCM_OK;
-    }
-    for (int32_t n = step_begin; n < step_end; ++n)
-        for (const auto& sgm : segments) {
-            g_lockstep_launches += 1;
-            g_lockstep_component_steps += sgm.second;
-            if (sgm.second > 1) {
-                if (int rc = fused_segment(plan, sgm.first, sgm.second, n, 1)) return rc;
-            } else if (int rc = run_range(handles[sgm.first], n, n + 1, false)) {
-                return rc;
-            }
-        }
-    return RSCM_OK;
     GUARD_END
 }
 
@@ -2061,7 +1660,10 @@ int rscm_ens_params_devptr(rscm_ens* h, void** out)
     NEED(h);
     if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
     *out = h->d_params;
-    h->uniform_rows = 0;   // whatever the caller writes there
+    // Whatever the caller writes there, now or later through a pointer it kept: from here on no row of this
+    // handle is ever treated as uniform again (rscm_ens_set_params keeps the flag clear as well).
+    h->params_exposed = true;
+    h->uniform_rows = 0;
     h->params_set = true;  // the caller fills it on the device
     return RSCM_OK;
 }

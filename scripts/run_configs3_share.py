@@ -49,21 +49,16 @@ def run(members, years, exact):
                 component_steps=int(ns.value), warm=warm, co2=co2, failed=status), rows
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--members", type=int, default=125_000)
-    ap.add_argument("--years", type=int, default=750)
-    ap.add_argument("--exact", action="store_true", help="RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) convolution")
-    args = ap.parse_args()
-    big, rows = run(args.members, args.years, args.exact)
-    # Parity anchor at this size: a 64-member ensemble that is GIVEN the first 64 members' parameters
-    # (build_chain draws whole vectors from one seeded generator: replayed here for the big ensemble's draws)
+def first_64(members, years, exact):
+    """Parity anchor at this size: a 64-member ensemble that is GIVEN the first 64 members' parameters of the
+    `members`-member one (build_chain draws whole vectors from one seeded generator: replayed here for the big
+    ensemble's draws).  Returns the kept (annual) rows of NAMES."""
     import scripts.bench_magicc_chain as mod
-    small = build_chain(64, args.years, "topological", steps_per_year=12, series_window=16, output_stride=12)
+    small = build_chain(64, years, "topological", steps_per_year=12, series_window=16, output_stride=12)
     rng = np.random.default_rng(20260327)
-    ecs = rng.uniform(2.0, 4.5, args.members)
-    kappa = rng.uniform(0.5, 1.2, args.members)
-    beta_f = rng.uniform(0.7, 1.3, args.members)
+    ecs = rng.uniform(2.0, 4.5, members)
+    kappa = rng.uniform(0.5, 1.2, members)
+    beta_f = rng.uniform(0.7, 1.3, members)
     ud = small.ensembles["ClimateUDEB"]
     P = ud.get_params()
     P[L.UD_PARAM_NAMES.index("ecs")] = ecs[:64]
@@ -74,14 +69,26 @@ def main():
     base_beta = mod.chain_components()[7].param_vector()[L.TC_PARAM_NAMES.index("beta")]
     Q[L.TC_PARAM_NAMES.index("beta")] = base_beta * beta_f[:64]
     tc.set_params(Q)
-    if not args.exact:
+    if not exact:
         small.set_mode(L.MODE_FAST)
     small.run()
+    rows = {n: small.get_series(n, t_stride=12) for n in NAMES}
+    small.close()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--members", type=int, default=125_000)
+    ap.add_argument("--years", type=int, default=750)
+    ap.add_argument("--exact", action="store_true", help="RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) convolution")
+    args = ap.parse_args()
+    big, rows = run(args.members, args.years, args.exact)
+    small_rows = first_64(args.members, args.years, args.exact)
     same = {}
     for n in NAMES:
-        a, b = rows[n][:, :64], small.get_series(n, t_stride=12)
+        a, b = rows[n][:, :64], small_rows[n]
         same[n] = bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)) or np.array_equal(a, b, equal_nan=True))
-    small.close()
     steps = args.years * 12
     out = {"workload": f"BASELINE configs[3], one GPU's share: MAGICC graph, {args.members} members x {steps} monthly steps "
                        f"({args.years} years), window 16 rows + annual outputs of all 36 series, mode {'EXACT' if args.exact else 'FAST'}",

@@ -8,10 +8,22 @@ from rscm_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "rscm_gpu.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"RSCM_API\s+[\w\s\*]+?\b(rscm_\w+)\s*\(", text))
+def _declared(headers=("rscm_gpu.h", "rscm_gpu_internal.h")):
+    """The boundary (rscm_gpu.h) and the test / A-B hooks the library also exports (rscm_gpu_internal.h)."""
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"RSCM_API\s+[\w\s\*]+?\b(rscm_\w+)\s*\(", text))
+    return names
+
+
+def test_test_hooks_are_not_in_the_public_header():
+    public = _declared(("rscm_gpu.h",))
+    hooks = _declared(("rscm_gpu_internal.h",))
+    assert hooks and not (public & hooks)
+    for name in ("rscm_gpu_set_lockstep_fusion", "rscm_gpu_lockstep_stats", "rscm_gpu_selftest_div", "rscm_gpu_ocean_fit_selftest"):
+        assert name in hooks
 
 
 def test_header_and_binding_table_agree():

@@ -351,3 +351,79 @@ def test_long_chains_split_into_several_fused_launches(ra):
         for x in [ud, tl] + aggs[::-1]:
             x.close()
         L.check(L.load().rscm_gpu_stream_destroy(0, stream))
+
+
+def test_two_threads_step_two_graphs_with_their_own_fusion_settings(ra):
+    """The A/B switches and launch counters of rscm_ens_run_lockstep are per calling thread
+    (include/rscm_gpu_internal.h): two threads step two linked coupled chains at the same time, one fused with
+    LDS slots, one unfused, each sees its own launch count, and both get the bits of a single-thread run."""
+    import threading
+    from rscm_amd import _lib as L
+    from rscm_amd.ensemble import run_lockstep
+    t = axis_values(1750, 1900)
+    b = np.append(t, t[-1] + 1.0)
+    T = len(t)
+    E = emissions_syn(t)
+
+    def chain(n, seed, mode, out):
+        L.check(L.load().rscm_gpu_set_lockstep_fusion(mode))
+        P = coupled_params(n, seed=seed)
+        stream = C.c_void_p()
+        L.check(L.load().rscm_gpu_stream_create(0, C.byref(stream)))
+        cc, ce, ag, tl = (ra.Ensemble(k, n, b) for k in (ra.KIND_CARBON_CYCLE, ra.KIND_CO2_ERF, ra.KIND_AGGREGATE, ra.KIND_TWO_LAYER))
+        try:
+            for x in (cc, ce, ag, tl):
+                x.set_stream(stream.value)
+            cc.set_params(P[[6, 7, 8]])
+            ce.set_params(P[[9, 7]])
+            ag.set_params(np.zeros((9, n)))
+            tl.set_params(P[:6])
+            cc.set_forcing(np.stack([E, np.full(T, np.nan)]))
+            for v, x in ((1, 278.0), (2, 0.0), (3, 0.0)):
+                cc.set_initial(v, x)
+            tl.set_initial(1, 0.0)
+            tl.set_initial(2, 0.0)
+            cc.link_input(1, tl, 1, ra.SRC_EXOGENOUS)
+            ce.link_input(0, cc, 1, ra.SRC_UPSTREAM)
+            ag.link_input(0, ce, 1, ra.SRC_UPSTREAM)
+            tl.link_input(0, ag, 1, ra.SRC_UPSTREAM)
+            a, bb = C.c_int64(), C.c_int64()
+            L.check(L.load().rscm_gpu_lockstep_stats(None, None))
+            for _ in range(3):
+                for x in (cc, ce, ag, tl):
+                    x.clear_series()
+                run_lockstep((cc, ce, ag, tl))
+            L.check(L.load().rscm_gpu_lockstep_stats(C.byref(a), C.byref(bb)))
+            out["launches"] = a.value
+            out["series"] = [tl.get_series(1), tl.get_series(2), cc.get_series(1), ag.get_series(1)]
+        except Exception as exc:  # pragma: no cover
+            out["error"] = repr(exc)
+        finally:
+            cc.unlink_input(1)
+            for x in (tl, ag, ce, cc):
+                x.close()
+            L.check(L.load().rscm_gpu_stream_destroy(0, stream))
+
+    jobs = [(3000, 11, 1), (2000, 12, 0)]
+    want = [dict() for _ in jobs]
+    for (n, seed, mode), w in zip(jobs, want):   # single thread first
+        chain(n, seed, mode, w)
+        assert "error" not in w, w.get("error")
+    got = [dict() for _ in jobs]
+    th = [threading.Thread(target=chain, args=(n, seed, mode, g)) for (n, seed, mode), g in zip(jobs, got)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for g, w, (n, seed, mode) in zip(got, want, jobs):
+        assert "error" not in g, g.get("error")
+        assert g["launches"] == w["launches"] == (3 if mode == 1 else 3 * 4 * (T - 1))
+        for k, (x, y) in enumerate(zip(g["series"], w["series"])):
+            assert_bit_equal(x, y, f"two threads vs one, fusion mode {mode}: series {k}")
+    # the switches of the worker threads never touched this thread's: still the default (fused)
+    w2 = dict()
+    L.check(L.load().rscm_gpu_lockstep_stats(None, None))
+    L.check(L.load().rscm_gpu_set_lockstep_fusion(1))
+    chain(2000, 12, 1, w2)
+    for k, (x, y) in enumerate(zip(w2["series"], want[1]["series"])):
+        assert_bit_equal(x, y, f"fused vs unfused: series {k}")

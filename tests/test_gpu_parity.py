@@ -980,3 +980,35 @@ def test_quantile_series_is_numpy_nanquantile(ra, orc):
         assert np.isfinite(g["quantiles"][1][1:-1]).all()
         with pytest.raises(Exception, match="Quantiles must be in the range"):
             e.quantile_series(1, [1.5])
+
+
+def test_params_devptr_disarms_the_uniform_row_shortcut_for_good(ra):
+    """rscm_ens_params_devptr hands out the [P][N] block for device-side writers.  A caller may keep the pointer,
+    upload uniform rows with rscm_ens_set_params later and then write varied values through the pointer: the
+    kernels must read every member's own value (no row is treated as uniform again on such a handle)."""
+    import ctypes as C
+    from rscm_amd import _lib as L
+    t = axis_values(1750, 1800)
+    b = np.append(t, t[-1] + 1.0)
+    F = f_syn(t)
+    n = 300
+    P = two_layer_params(n, seed=77)
+    U = np.repeat(P[:, :1], n, axis=1).copy()   # every row uniform
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as ref:
+        ref.set_params(P)
+        ref.set_forcing(F)
+        ref.set_initial(1, 0.0)
+        ref.set_initial(2, 0.0)
+        ref.run()
+        want = ref.get_series(1)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
+        ptr = C.c_void_p()
+        L.check(e._lib.rscm_ens_params_devptr(e._h, C.byref(ptr)))
+        e.set_params(U)                          # host upload of uniform rows AFTER the pointer went out
+        e.set_forcing(F)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        Pc = np.ascontiguousarray(P)
+        L.check(e._lib.rscm_gpu_copy_to_device(0, ptr, Pc.ctypes.data_as(C.c_void_p), Pc.nbytes))
+        e.run()
+        assert_bit_equal(e.get_series(1), want, "varied parameters written through a cached device pointer")

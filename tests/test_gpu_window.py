@@ -135,6 +135,31 @@ def test_windowed_n2o_looks_back_through_its_window(ra):
         e.set_initial(1, 270.0)
         with pytest.raises(RscmGpuError, match="too short"):
             e.step()
+    # a longer delay on a window that has already slid: the rows it looks back at were not kept
+    Q = P.copy()
+    Q[names.index("strat_delay")] = 1.0
+    with ra.Ensemble(ra.KIND_N2O_CHEMISTRY, n, b, window_rows=16) as e:
+        e.set_params(Q)
+        e.set_forcing(inputs)
+        e.set_initial(1, 270.0)
+        for _ in range(40):
+            e.step()
+        R = Q.copy()
+        R[names.index("strat_delay")] = 5.0
+        with pytest.raises(RscmGpuError, match="window already starts"):
+            e.set_params(R)
+        e.step()                # still consistent with the old delay
+        e.rewind()
+        e.set_params(R)         # from the start of the axis the longer look-back is fine
+        for _ in range(40):
+            e.step()
+        got = e.get_series(1, 30, 41, 1)
+    with ra.Ensemble(ra.KIND_N2O_CHEMISTRY, n, b) as full:
+        full.set_params(R)
+        full.set_forcing(inputs)
+        full.set_initial(1, 270.0)
+        full.run(40)
+        assert_bit_equal(got, full.get_series(1)[30:41], "N2O with the longer delay after a rewind")
 
 
 def test_windowed_linked_coupled_chain_equals_the_fused_kernel(ra):
@@ -307,6 +332,38 @@ def test_configs3_share_runs_at_full_size(ra):
     assert all(out["first_64_members_equal_a_64_member_run"].values())
     assert out["warming_end_K"]["count"] == 125_000 and 1.0 < out["warming_end_K"]["mean"] < 12.0
     assert out["co2_end_ppm"]["min"] > 278.0
+
+
+def test_configs3_share_exact_mode_and_fast_against_it(ra):
+    """BASELINE.json configs[3], one GPU's share in RSCM_MODE_EXACT (OceanCarbon's literal history convolution, the
+    reference's summation order): 125 000 members x 600 MONTHLY steps -- 42 slides of the 16-row windows, 600 x 12
+    pulses into OceanCarbon's flux-history ring, 50 annual output rows.  The first 64 members equal a 64-member EXACT run
+    given their parameters, bit for bit; and the RSCM_MODE_FAST run of the same ensemble (OceanCarbon's O(T)
+    recurrence over fitted modes -- an approximation of the algorithm, not only of the rounding) stays within 1e-9
+    relative of EXACT on every kept row of five variables (measured: printed)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from scripts import run_configs3_share as prog
+    N, years = 125_000, 50
+    big, rows = prog.run(N, years, True)
+    assert big["failed"] == 0
+    print(f"configs[3] share, EXACT, {years * 12} monthly steps: {big['run_s']:.2f} s, {big['launches'] / (years * 12):.1f} launches per step")
+    small = prog.first_64(N, years, True)
+    for name in prog.NAMES:
+        assert rows[name].shape == (years + 1, N)
+        assert_bit_equal(rows[name][:, :64], small[name], f"EXACT, first 64 of {N} members vs a 64-member run: {name}")
+    fast_info, fast = prog.run(N, years, False)
+    assert fast_info["failed"] == 0
+    worst = 0.0
+    for name in prog.NAMES:
+        ok = ~np.isnan(rows[name])
+        assert (np.isnan(fast[name]) == np.isnan(rows[name])).all()
+        err = np.abs(fast[name][ok] - rows[name][ok]) / np.maximum(1.0, np.abs(rows[name][ok]))
+        worst = max(worst, float(err.max()))
+        assert err.max() <= 1e-9, (name, err.max())
+    print(f"FAST vs EXACT over {years * 12} monthly steps, {N} members: max relative deviation {worst:.2e}")
 
 
 def test_windowed_graph_in_fast_mode(ra):
