@@ -34,232 +34,15 @@
 // their inputs, so a member sitting within rounding of one of those thresholds may take the
 // other branch than the reference for that year (an O(1e-3) relative change of lambda for one
 // year); no such member occurs in the test ensembles.
-#include "rk4_device.hpp"
-#include "rscm_device.hpp"
+#include <cstdlib>
+
+#include "udeb_body.hpp"
 
 namespace rscm {
 
 namespace {
 
-constexpr double kDiffCm2sToM2yr = 3155.76;  // parameters/climate_udeb.rs
-constexpr double kRhoSeawater = 1026.0;
-constexpr double kCpSeawater = 3985.0;
-constexpr double kSecondsPerYear = 31557600.0;
-
-struct UdebP {
-    double dz_mix, dz, kappa, kappa_min, kappa_dkdt, w0, f_var, t_thresh_nh, t_thresh_sh;
-    double ecs, rf_2x, rlo, fb_q, fb_cumt, fb_period, k_lo, k_ns, amplify, nh_land, sh_land;
-    double alpha, gamma, pi_ratio, k_lg, land_hc_thick, rf0, rf1, rf2, rf3, prescribed_eff, max_temp;
-    double fgno, fgnl, fgso, fgsl, q0, q1, q2, q3;  // box fractions, co2_qfrac
-};
-
-struct LamResult {
-    double lam_o, lam_l, eff;
-    bool ok;
-};
-
-__device__ __forceinline__ double heat_capacity_per_unit_area(double depth_m)
-{
-    return kRhoSeawater * kCpSeawater * depth_m / kSecondsPerYear;
-}
-
-// rscm-core/src/utils/linear_algebra.rs invert_4x4 (Gauss-Jordan, partial pivoting), rows kept in
-// registers: every index is static, row swaps are per-lane selects.
-__device__ __forceinline__ bool invert_4x4(const double m[4][4], double inv[4][4])
-{
-    double aug[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) aug[i][j] = j < 4 ? m[i][j] : (j - 4 == i ? 1.0 : 0.0);
-    }
-    bool ok = true;
-#pragma unroll
-    for (int col = 0; col < 4; ++col) {
-        int max_row = col;
-        double max_val = fabs(aug[col][col]);
-#pragma unroll
-        for (int row = col + 1; row < 4; ++row) {
-            const double val = fabs(aug[row][col]);
-            if (val > max_val) {
-                max_val = val;
-                max_row = row;
-            }
-        }
-        if (max_val < 1e-15) ok = false;
-#pragma unroll
-        for (int row = col + 1; row < 4; ++row) {
-            const bool sw = max_row == row;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const double x = aug[col][j], y = aug[row][j];
-                aug[col][j] = sw ? y : x;
-                aug[row][j] = sw ? x : y;
-            }
-        }
-        // aug[col][j] /= pivot for j = 0..7: one refined reciprocal, then the 3-instruction
-        // quotient (identical to IEEE division for these O(1) operands; rk4_device.hpp)
-        const double pivot = aug[col][col];
-        const double rp = refined_rcp(pivot);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) aug[col][j] = spec_div(aug[col][j], pivot, rp);
-#pragma unroll
-        for (int row = 0; row < 4; ++row) {
-            if (row == col) continue;
-            const double factor = aug[row][col];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) aug[row][j] -= factor * aug[col][j];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) inv[i][j] = aug[i][j + 4];
-    return ok;
-}
-
-// Equilibrium box temperatures per unit forcing for one (lambda_ocean, lambda_land) pair the way
-// the reference forms them (lamcalc.rs: build the 4x4 exchange matrix, invert_4x4, multiply by
-// area*qfrac).  Used only for the lanes whose matrix is too close to singular for the direct
-// elimination below -- it keeps the reference's partial pivoting and its singularity verdict.
-__device__ __noinline__ bool lam_box_temps_general(const UdebP& p, double lam_o, double lam_l, double x[4])
-{
-    const double k_lo = p.k_lo, k_ns = p.k_ns, alpha = p.amplify;
-    const double area[4] = {p.fgno, p.fgnl, p.fgso, p.fgsl};
-    const double qfrac[4] = {p.q0, p.q1, p.q2, p.q3};
-    const double m[4][4] = {{p.fgno * lam_o + k_lo * alpha + k_ns, -k_lo, -k_ns, 0.0},
-                            {-k_lo * alpha, p.fgnl * lam_l + k_lo, 0.0, 0.0},
-                            {-k_ns, 0.0, p.fgso * lam_o + k_lo * alpha + k_ns, -k_lo},
-                            {0.0, 0.0, -k_lo * alpha, p.fgsl * lam_l + k_lo}};
-    double inv[4][4];
-    if (!invert_4x4(m, inv)) return false;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        double sum = 0.0;
-#pragma unroll
-        for (int col = 0; col < 4; ++col) sum += inv[row][col] * area[col] * qfrac[col];
-        x[row] = sum;
-    }
-    return true;
-}
-
-// climate/lamcalc.rs lamcalc(): secant-style iteration on lambda_ocean until the land/ocean
-// warming ratio matches RLO within 1e-3; only the last three iterates are ever read.
-//
-// The exchange matrix couples each land box to its own ocean box only,
-//     [ A0   -k   -n    0 ]        A0 = fgno*lam_o + k*a + n     k = k_lo, n = k_ns, a = amplify
-//     [-k*a   B1   0    0 ]        B1 = fgnl*lam_l + k
-//     [ -n    0    A2  -k ]        A2 = fgso*lam_o + k*a + n
-//     [  0    0  -k*a   B3]        B3 = fgsl*lam_l + k
-// so M x = v is solved by eliminating the two land rows and applying Cramer's rule to the 2x2
-// ocean system: ~40 flops and three reciprocals per iterate where the general inverse costs ~600
-// instructions.  Tolerance parity like the rest of this kernel; an ill-conditioned elimination
-// (small B1, B3 or determinant) takes the reference's pivoted inverse instead.
-__device__ __forceinline__ LamResult lamcalc(const UdebP& p, double ecs)
-{
-    const double q = p.rf_2x, k_lo = p.k_lo, k_ns = p.k_ns;
-    const double ka = k_lo * p.amplify, kka = k_lo * ka, nn = k_ns * k_ns, kan = ka + k_ns;
-    const double lam = q / ecs;
-    const double fgosum = p.fgno + p.fgso, fglsum = p.fgnl + p.fgsl, fratio = fgosum / fglsum;
-    const double fr_rlo = fratio / p.rlo;
-    const double r_fo = 1.0 / fgosum, r_fl = 1.0 / fglsum;
-    const double v0 = p.fgno * p.q0, v1 = p.fgnl * p.q1, v2 = p.fgso * p.q2, v3 = p.fgsl * p.q3;
-    const double kv1 = k_lo * v1, kv3 = k_lo * v3;
-    // lamo[i-2], lamo[i-1], lamo[i]; diff likewise (arrays start zero-filled in the reference)
-    double lamo_m2 = 0.0, lamo_m1 = lam, lamo_i = lam + 0.7;
-    double diff_m2 = 0.0, diff_m1 = 0.0;
-    double dlamo = 0.7;
-    int iflag = 0;
-    LamResult out = {0.0, 0.0, 1.0, false};
-    for (int i = 2; i <= 40; ++i) {
-        const double lam_l = __builtin_fma(fr_rlo, lam - lamo_i, lam);
-        const double lam_o = lamo_i;
-        const double A0 = __builtin_fma(p.fgno, lam_o, kan), A2 = __builtin_fma(p.fgso, lam_o, kan);
-        const double B1 = __builtin_fma(p.fgnl, lam_l, k_lo), B3 = __builtin_fma(p.fgsl, lam_l, k_lo);
-        const double r1 = refined_rcp(B1), r3 = refined_rcp(B3);
-        const double P = __builtin_fma(-kka, r1, A0), Q = __builtin_fma(-kka, r3, A2);
-        const double e0 = __builtin_fma(kv1, r1, v0), e2 = __builtin_fma(kv3, r3, v2);
-        const double pq = P * Q;
-        const double det = pq - nn;
-        double x[4];
-        const bool direct = fabs(B1) > 0.05 * k_lo && fabs(B3) > 0.05 * k_lo && fabs(det) > 0.01 * (fabs(pq) + nn);
-        if (__builtin_expect(direct, 1)) {
-            const double rd = refined_rcp(det);
-            x[0] = __builtin_fma(e0, Q, k_ns * e2) * rd;
-            x[2] = __builtin_fma(P, e2, k_ns * e0) * rd;
-            x[1] = __builtin_fma(ka, x[0], v1) * r1;
-            x[3] = __builtin_fma(ka, x[2], v3) * r3;
-        } else if (!lam_box_temps_general(p, lam_o, lam_l, x)) {
-            return out;
-        }
-        const double t0 = q * x[0], t1 = q * x[1], t2 = q * x[2], t3 = q * x[3];
-        const double ocean_mean = __builtin_fma(p.fgno, t0, p.fgso * t2) * r_fo;
-        const double land_mean = __builtin_fma(p.fgnl, t1, p.fgsl * t3) * r_fl;
-        const double diff_i = p.rlo - land_mean / ocean_mean;
-        if (fabs(diff_i) < 0.001) {
-            out.lam_o = lam_o;
-            out.lam_l = lam_l;
-            out.ok = true;
-            const double rf_sum = p.rf0 * p.fgno + p.rf1 * p.fgnl + p.rf2 * p.fgso + p.rf3 * p.fgsl;
-            if (fabs(rf_sum) <= 1e-15) {
-                out.eff = 1.0;
-            } else {
-                const double t_global = p.fgno * t0 + p.fgnl * t1 + p.fgso * t2 + p.fgsl * t3;
-                out.eff = t_global / ecs;
-            }
-            return out;
-        }
-        if (diff_i * diff_m1 < 0.0) iflag = 1;
-        double next;
-        if (iflag == 0) {
-            if (fabs(diff_i) > fabs(diff_m1)) dlamo = -dlamo;
-            next = lamo_i + dlamo;
-        } else if (diff_i * diff_m1 < 0.0) {
-            const double denom = diff_i - diff_m1;
-            next = fabs(denom) < 1e-30 ? lamo_i + dlamo : lamo_i - diff_i * (lamo_i - lamo_m1) / denom;
-        } else {
-            const double denom = diff_i - diff_m2;
-            next = fabs(denom) < 1e-30 ? lamo_i + dlamo : lamo_i - diff_i * (lamo_i - lamo_m2) / denom;
-        }
-        lamo_m2 = lamo_m1;
-        lamo_m1 = lamo_i;
-        lamo_i = next;
-        diff_m2 = diff_m1;
-        diff_m1 = diff_i;
-    }
-    return out;
-}
-
-__device__ __forceinline__ double sst_to_air(const UdebP& p, double sst)
-{
-    const double t_star = fabs(p.gamma) > 1e-15 ? -(p.alpha - 1.0) / (2.0 * p.gamma) : __builtin_inf();
-    if (sst < t_star) return p.alpha * sst + p.gamma * sst * sst;
-    const double delta_max = p.alpha * t_star + p.gamma * t_star * t_star - t_star;
-    return sst + delta_max;
-}
-
-__device__ __forceinline__ double land_temperature(const UdebP& p, double ocean_temp, double land_forcing,
-                                                   double land_fraction, double lambda_land)
-{
-    const double numerator = land_forcing * land_fraction + p.k_lo * p.amplify * ocean_temp;
-    const double denominator = lambda_land * land_fraction + p.k_lo;
-    return fmin(numerator / denominator, p.max_temp);
-}
-
-// Per-member geometry folded with this year's sub-step length, and everything else of a column
-// solve that only changes once a year (the lambdas come out of LAMCALC per year): the sub-step
-// loop is left with multiplies.  ClimateUDEB is a tolerance-parity kind (tests/test_gpu_udeb.py
-// states 1e-9 against the CPU oracle), so quotients by these denominators are products with a
-// refined reciprocal and sums of products are fused; the bit-exact two-layer kernel does neither.
-struct YearGeom {
-    double dt_dz, dt_dzmix, dt_cmix;        // dt/dz, dt/dz_mix, dt/c_mix
-    double dt_dz2, dt_dzdz1, dt_dzmixdz1;   // dt/(dz*dz), dt/(dz*dz/2), dt/(dz_mix*dz/2)
-    double kC, kdC, kminC;                  // kappa, dkappa/dT, kappa_min in m^2/yr
-    double kC2, kdC2, kminC2;               // the same times dt/(dz*dz): the interior rows want kappa_l * dt/dz^2
-    double fb[2];                           // (lambda_o + lambda_l*k_lo*amp*f_l/den) * dt/c_mix
-    double famp[2];                         // 1 + k_lo*f_l/den
-    double lhc[2];                          // k_lg * dt / (c_mix * f_o), land heat capacity only
-};
+using namespace udeb;
 
 // One implicit sub-step of one hemisphere's column (ocean_column.rs step_hemisphere).
 // dp[] holds this member's column on entry (registers) and the new column on return; slot i
@@ -633,14 +416,45 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     for (int l = 0; l < NL; ++l) T_sh[(size_t)l * N] = col[l];
 }
 
+
+// Two wavefronts per 64 members, one hemisphere each (udeb_body.hpp).  WAVES: wavefronts per SIMD the register
+// budget is cut for (1: all of c' in registers; 2: KC of its entries in LDS).
+template <int NL, int KC, int WAVES>
+__global__ __launch_bounds__(kUdeb2Block, WAVES) void udeb2_kernel(UdebArgs a)
+{
+    __shared__ Udeb2Lds<KC> lds;
+    Udeb2<NL, KC> m(lds);
+    m.begin(a);
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) m.step(a, n);
+    m.end(a);
+}
+
 }  // namespace
+
+template <int NL>
+static void launch_udeb2(const UdebArgs& a, int variant, hipStream_t s)
+{
+    const dim3 grid((unsigned)((a.n_members + 63) / 64));
+    if (variant == 2) hipLaunchKernelGGL((udeb2_kernel<NL, 0, 1>), grid, dim3(kUdeb2Block), 0, s, a);
+    else if (variant == 3) hipLaunchKernelGGL((udeb2_kernel<NL, (NL >= 40 ? 24 : NL / 2), 2>), grid, dim3(kUdeb2Block), 0, s, a);
+    else hipLaunchKernelGGL((udeb2_kernel<NL, (NL >= 32 ? 16 : NL / 2), 2>), grid, dim3(kUdeb2Block), 0, s, a);
+}
 
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
-    if (a.n_layers != 50) return hipErrorInvalidValue;  // the column is unrolled for NL = 50
-    const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
-    hipLaunchKernelGGL(udeb_kernel<50>, grid, dim3(kUdebBlock), 0, s, a);
+    // development switch: 0 the one-thread-per-member kernel, 1..3 the two-wavefront variants
+    static const int variant = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 0) {
+        if (a.n_layers != 50) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
+        hipLaunchKernelGGL(udeb_kernel<50>, grid, dim3(kUdebBlock), 0, s, a);
+        return hipGetLastError();
+    }
+    switch (a.n_layers) {   // the column loops are unrolled: one instance per supported layer count
+        case 50: launch_udeb2<50>(a, variant, s); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -1,0 +1,641 @@
+// ClimateUDEB per-member arithmetic shared by the kernels that run it (csrc/udeb.hip: the stand-alone launch;
+// csrc/graph.hip: inside the persistent whole-graph launch): rscm-magicc's 4-box upwelling-diffusion
+// energy-balance model.
+//
+// What it replaces, per model step n (reference file:line):
+//   ClimateUDEB::solve_impl            crates/rscm-magicc/src/climate/udeb/mod.rs:399-656
+//   adjusted_ecs / LAMCALC re-solve    mod.rs:302-350, climate/lamcalc.rs
+//   step_hemisphere (implicit column, Thomas solve), update_upwelling, diagnostics
+//                                      crates/rscm-magicc/src/climate/udeb/ocean_column.rs
+//   thomas_solve, invert_4x4           crates/rscm-core/src/utils/linear_algebra.rs
+// around the stepper conventions of crates/rscm-core/src/model/runtime.rs (ERF exogenous:
+// at_start = F[n], at_end = F[n+1]; outputs written at n+1).
+#pragma once
+
+#include "rk4_device.hpp"
+#include "rscm_device.hpp"
+
+namespace rscm {
+namespace udeb {
+
+constexpr double kDiffCm2sToM2yr = 3155.76;  // parameters/climate_udeb.rs
+constexpr double kRhoSeawater = 1026.0;
+constexpr double kCpSeawater = 3985.0;
+constexpr double kSecondsPerYear = 31557600.0;
+
+struct UdebP {
+    double dz_mix, dz, kappa, kappa_min, kappa_dkdt, w0, f_var, t_thresh_nh, t_thresh_sh;
+    double ecs, rf_2x, rlo, fb_q, fb_cumt, fb_period, k_lo, k_ns, amplify, nh_land, sh_land;
+    double alpha, gamma, pi_ratio, k_lg, land_hc_thick, rf0, rf1, rf2, rf3, prescribed_eff, max_temp;
+    double fgno, fgnl, fgso, fgsl, q0, q1, q2, q3;  // box fractions, co2_qfrac
+};
+
+struct LamResult {
+    double lam_o, lam_l, eff;
+    bool ok;
+};
+
+__device__ __forceinline__ double heat_capacity_per_unit_area(double depth_m)
+{
+    return kRhoSeawater * kCpSeawater * depth_m / kSecondsPerYear;
+}
+
+// rscm-core/src/utils/linear_algebra.rs invert_4x4 (Gauss-Jordan, partial pivoting), rows kept in
+// registers: every index is static, row swaps are per-lane selects.
+__device__ __forceinline__ bool invert_4x4(const double m[4][4], double inv[4][4])
+{
+    double aug[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aug[i][j] = j < 4 ? m[i][j] : (j - 4 == i ? 1.0 : 0.0);
+    }
+    bool ok = true;
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+        int max_row = col;
+        double max_val = fabs(aug[col][col]);
+#pragma unroll
+        for (int row = col + 1; row < 4; ++row) {
+            const double val = fabs(aug[row][col]);
+            if (val > max_val) {
+                max_val = val;
+                max_row = row;
+            }
+        }
+        if (max_val < 1e-15) ok = false;
+#pragma unroll
+        for (int row = col + 1; row < 4; ++row) {
+            const bool sw = max_row == row;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double x = aug[col][j], y = aug[row][j];
+                aug[col][j] = sw ? y : x;
+                aug[row][j] = sw ? x : y;
+            }
+        }
+        // aug[col][j] /= pivot for j = 0..7: one refined reciprocal, then the 3-instruction
+        // quotient (identical to IEEE division for these O(1) operands; rk4_device.hpp)
+        const double pivot = aug[col][col];
+        const double rp = refined_rcp(pivot);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aug[col][j] = spec_div(aug[col][j], pivot, rp);
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            if (row == col) continue;
+            const double factor = aug[row][col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) aug[row][j] -= factor * aug[col][j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inv[i][j] = aug[i][j + 4];
+    return ok;
+}
+
+// Equilibrium box temperatures per unit forcing for one (lambda_ocean, lambda_land) pair the way
+// the reference forms them (lamcalc.rs: build the 4x4 exchange matrix, invert_4x4, multiply by
+// area*qfrac).  Used only for the lanes whose matrix is too close to singular for the direct
+// elimination below -- it keeps the reference's partial pivoting and its singularity verdict.
+// (Out of line and by value: a reference to the parameter block here would pin all of it in scratch memory for
+// the whole kernel -- the column solves would reload their parameters from there.)
+struct LamBoxes { double x0, x1, x2, x3; bool ok; };
+__device__ __noinline__ LamBoxes lam_box_temps_general(double k_lo, double k_ns, double alpha, double fgno, double fgnl, double fgso, double fgsl,
+                                                       double q0, double q1, double q2, double q3, double lam_o, double lam_l)
+{
+    const double area[4] = {fgno, fgnl, fgso, fgsl};
+    const double qfrac[4] = {q0, q1, q2, q3};
+    const double m[4][4] = {{fgno * lam_o + k_lo * alpha + k_ns, -k_lo, -k_ns, 0.0},
+                            {-k_lo * alpha, fgnl * lam_l + k_lo, 0.0, 0.0},
+                            {-k_ns, 0.0, fgso * lam_o + k_lo * alpha + k_ns, -k_lo},
+                            {0.0, 0.0, -k_lo * alpha, fgsl * lam_l + k_lo}};
+    double inv[4][4];
+    LamBoxes out = {0.0, 0.0, 0.0, 0.0, false};
+    if (!invert_4x4(m, inv)) return out;
+    double x[4];
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        double sum = 0.0;
+#pragma unroll
+        for (int col = 0; col < 4; ++col) sum += inv[row][col] * area[col] * qfrac[col];
+        x[row] = sum;
+    }
+    out.x0 = x[0]; out.x1 = x[1]; out.x2 = x[2]; out.x3 = x[3];
+    out.ok = true;
+    return out;
+}
+
+// climate/lamcalc.rs lamcalc(): secant-style iteration on lambda_ocean until the land/ocean
+// warming ratio matches RLO within 1e-3; only the last three iterates are ever read.
+//
+// The exchange matrix couples each land box to its own ocean box only,
+//     [ A0   -k   -n    0 ]        A0 = fgno*lam_o + k*a + n     k = k_lo, n = k_ns, a = amplify
+//     [-k*a   B1   0    0 ]        B1 = fgnl*lam_l + k
+//     [ -n    0    A2  -k ]        A2 = fgso*lam_o + k*a + n
+//     [  0    0  -k*a   B3]        B3 = fgsl*lam_l + k
+// so M x = v is solved by eliminating the two land rows and applying Cramer's rule to the 2x2
+// ocean system: ~40 flops and three reciprocals per iterate where the general inverse costs ~600
+// instructions.  Tolerance parity like the rest of this kernel; an ill-conditioned elimination
+// (small B1, B3 or determinant) takes the reference's pivoted inverse instead.
+__device__ __forceinline__ LamResult lamcalc(const UdebP& p, double ecs)
+{
+    const double q = p.rf_2x, k_lo = p.k_lo, k_ns = p.k_ns;
+    const double ka = k_lo * p.amplify, kka = k_lo * ka, nn = k_ns * k_ns, kan = ka + k_ns;
+    const double lam = q / ecs;
+    const double fgosum = p.fgno + p.fgso, fglsum = p.fgnl + p.fgsl, fratio = fgosum / fglsum;
+    const double fr_rlo = fratio / p.rlo;
+    const double r_fo = 1.0 / fgosum, r_fl = 1.0 / fglsum;
+    const double v0 = p.fgno * p.q0, v1 = p.fgnl * p.q1, v2 = p.fgso * p.q2, v3 = p.fgsl * p.q3;
+    const double kv1 = k_lo * v1, kv3 = k_lo * v3;
+    // lamo[i-2], lamo[i-1], lamo[i]; diff likewise (arrays start zero-filled in the reference)
+    double lamo_m2 = 0.0, lamo_m1 = lam, lamo_i = lam + 0.7;
+    double diff_m2 = 0.0, diff_m1 = 0.0;
+    double dlamo = 0.7;
+    int iflag = 0;
+    LamResult out = {0.0, 0.0, 1.0, false};
+    for (int i = 2; i <= 40; ++i) {
+        const double lam_l = __builtin_fma(fr_rlo, lam - lamo_i, lam);
+        const double lam_o = lamo_i;
+        const double A0 = __builtin_fma(p.fgno, lam_o, kan), A2 = __builtin_fma(p.fgso, lam_o, kan);
+        const double B1 = __builtin_fma(p.fgnl, lam_l, k_lo), B3 = __builtin_fma(p.fgsl, lam_l, k_lo);
+        const double r1 = refined_rcp(B1), r3 = refined_rcp(B3);
+        const double P = __builtin_fma(-kka, r1, A0), Q = __builtin_fma(-kka, r3, A2);
+        const double e0 = __builtin_fma(kv1, r1, v0), e2 = __builtin_fma(kv3, r3, v2);
+        const double pq = P * Q;
+        const double det = pq - nn;
+        double x[4];
+        const bool direct = fabs(B1) > 0.05 * k_lo && fabs(B3) > 0.05 * k_lo && fabs(det) > 0.01 * (fabs(pq) + nn);
+        if (__builtin_expect(direct, 1)) {
+            const double rd = refined_rcp(det);
+            x[0] = __builtin_fma(e0, Q, k_ns * e2) * rd;
+            x[2] = __builtin_fma(P, e2, k_ns * e0) * rd;
+            x[1] = __builtin_fma(ka, x[0], v1) * r1;
+            x[3] = __builtin_fma(ka, x[2], v3) * r3;
+        } else {
+            const LamBoxes g = lam_box_temps_general(k_lo, k_ns, p.amplify, p.fgno, p.fgnl, p.fgso, p.fgsl, p.q0, p.q1, p.q2, p.q3, lam_o, lam_l);
+            if (!g.ok) return out;
+            x[0] = g.x0; x[1] = g.x1; x[2] = g.x2; x[3] = g.x3;
+        }
+        const double t0 = q * x[0], t1 = q * x[1], t2 = q * x[2], t3 = q * x[3];
+        const double ocean_mean = __builtin_fma(p.fgno, t0, p.fgso * t2) * r_fo;
+        const double land_mean = __builtin_fma(p.fgnl, t1, p.fgsl * t3) * r_fl;
+        const double diff_i = p.rlo - land_mean / ocean_mean;
+        if (fabs(diff_i) < 0.001) {
+            out.lam_o = lam_o;
+            out.lam_l = lam_l;
+            out.ok = true;
+            const double rf_sum = p.rf0 * p.fgno + p.rf1 * p.fgnl + p.rf2 * p.fgso + p.rf3 * p.fgsl;
+            if (fabs(rf_sum) <= 1e-15) {
+                out.eff = 1.0;
+            } else {
+                const double t_global = p.fgno * t0 + p.fgnl * t1 + p.fgso * t2 + p.fgsl * t3;
+                out.eff = t_global / ecs;
+            }
+            return out;
+        }
+        if (diff_i * diff_m1 < 0.0) iflag = 1;
+        double next;
+        if (iflag == 0) {
+            if (fabs(diff_i) > fabs(diff_m1)) dlamo = -dlamo;
+            next = lamo_i + dlamo;
+        } else if (diff_i * diff_m1 < 0.0) {
+            const double denom = diff_i - diff_m1;
+            next = fabs(denom) < 1e-30 ? lamo_i + dlamo : lamo_i - diff_i * (lamo_i - lamo_m1) / denom;
+        } else {
+            const double denom = diff_i - diff_m2;
+            next = fabs(denom) < 1e-30 ? lamo_i + dlamo : lamo_i - diff_i * (lamo_i - lamo_m2) / denom;
+        }
+        lamo_m2 = lamo_m1;
+        lamo_m1 = lamo_i;
+        lamo_i = next;
+        diff_m2 = diff_m1;
+        diff_m1 = diff_i;
+    }
+    return out;
+}
+
+__device__ __forceinline__ double sst_to_air(const UdebP& p, double sst)
+{
+    const double t_star = fabs(p.gamma) > 1e-15 ? -(p.alpha - 1.0) / (2.0 * p.gamma) : __builtin_inf();
+    if (sst < t_star) return p.alpha * sst + p.gamma * sst * sst;
+    const double delta_max = p.alpha * t_star + p.gamma * t_star * t_star - t_star;
+    return sst + delta_max;
+}
+
+__device__ __forceinline__ double land_temperature(const UdebP& p, double ocean_temp, double land_forcing,
+                                                   double land_fraction, double lambda_land)
+{
+    const double numerator = land_forcing * land_fraction + p.k_lo * p.amplify * ocean_temp;
+    const double denominator = lambda_land * land_fraction + p.k_lo;
+    return fmin(numerator / denominator, p.max_temp);
+}
+
+// Per-member geometry folded with this year's sub-step length, and everything else of a column
+// solve that only changes once a year (the lambdas come out of LAMCALC per year): the sub-step
+// loop is left with multiplies.  ClimateUDEB is a tolerance-parity kind (tests/test_gpu_udeb.py
+// states 1e-9 against the CPU oracle), so quotients by these denominators are products with a
+// refined reciprocal and sums of products are fused; the bit-exact two-layer kernel does neither.
+struct YearGeom {
+    double dt_dz, dt_dzmix, dt_cmix;        // dt/dz, dt/dz_mix, dt/c_mix
+    double dt_dz2, dt_dzdz1, dt_dzmixdz1;   // dt/(dz*dz), dt/(dz*dz/2), dt/(dz_mix*dz/2)
+    double kC, kdC, kminC;                  // kappa, dkappa/dT, kappa_min in m^2/yr
+    double kC2, kdC2, kminC2;               // the same times dt/(dz*dz): the interior rows want kappa_l * dt/dz^2
+    double fb[2];                           // (lambda_o + lambda_l*k_lo*amp*f_l/den) * dt/c_mix
+    double famp[2];                         // 1 + k_lo*f_l/den
+    double lhc[2];                          // k_lg * dt / (c_mix * f_o), land heat capacity only
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Two wavefronts per 64 members: wavefront 0 of a 128-thread workgroup carries the northern column of
+// members [64 b, 64 b + 64), wavefront 1 the southern one.  Why: one thread per member holds ~245 doubles
+// during a column solve (two columns, the Thomas c' array, ~45 parameters, the year's folded geometry) --
+// 256 VGPRs + 256 AGPRs + a column parked in LDS and swapped after every solve; a third of the kernel's
+// vector instructions were VGPR <-> AGPR moves, spills and that swap (profiles/r2_udeb_resource_usage.txt).
+// A hemisphere per lane holds one column + c' + the parameters of its own boxes: ~135 doubles, no swap.
+// The two solves of a sub-step are independent (mod.rs:487-560: both read the previous sub-step's land
+// temperatures, inter-hemispheric exchange and upwelling); what couples them afterwards -- air and land
+// temperatures for the exchange term, the global mean for the upwelling -- goes through 2 x 8 bytes per
+// member of LDS and one s_barrier per sub-step.  The scalar work between the solves (LAMCALC, efficacies,
+// land temperatures) is done by both wavefronts: a few per cent of the column arithmetic.
+// ---------------------------------------------------------------------------------------------
+constexpr int kUdeb2Block = 128;
+
+// KC: how many entries of the c' array live in LDS instead of registers (the first KC rows: written first,
+// read back last).  KC = 0 keeps all of c' in registers (one wavefront per SIMD); KC >= 16 brings a lane under
+// 256 registers, i.e. two wavefronts per SIMD.
+template <int KC>
+struct Udeb2Lds {
+    double cp[KC > 0 ? KC : 1][kUdeb2Block];
+    double xs[2][2][2][64];   // sub-step exchange [parity][hemisphere][air, land][lane]
+    double xy[2][2][3][64];   // end-of-year exchange [parity][hemisphere][sst, air, heat-content partial][lane]
+};
+
+// The same implicit sub-step as step_hemisphere of the one-thread kernel (same row algebra, same order of
+// operations: the two kernels agree bit for bit), for ONE hemisphere per lane.
+template <int NL, int KC>
+__device__ __forceinline__ double step_column(const UdebP& p, const YearGeom& y, const double* tables, int32_t land_hc,
+                                              double (&dp)[NL], int hemi, double (*cp)[kUdeb2Block], int tid,
+                                              double forcing, double hemi_hx, double ground_temp,
+                                              double land_temp, double alpha_eff, double w)
+{
+    // The 5 x NL table values of a solve are wave-uniform and read with scalar loads where they are used.  Nothing
+    // in the solve changes from one sub-step to the next as far as their addresses go, so left to itself the
+    // compiler hoists all of them out of the sub-step and year loops (500 scalar registers, spilled into vector
+    // lanes: one v_readlane pair per use): an opaque zero offset per solve keeps the loads inside.
+    int32_t opaque = 0;
+    asm volatile("" : "+s"(opaque));
+    tables += opaque;
+    const double* af_top = tables;            // [NL]
+    const double* af_bot = tables + NL;       // [NL]
+    const double* af_diff = tables + 2 * NL;  // [NL]
+    const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
+    const double* G = tables + 4 * NL + (size_t)hemi * NL;  // profile-advection weights
+    const bool sh = hemi != 0;
+    const double t_top = dp[0];
+    const double kslope = y.kdC * (t_top - dp[NL - 1]);
+    auto kappa_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope, y.kC), y.kminC); };
+    const double kslope2 = y.kdC2 * (t_top - dp[NL - 1]);
+    auto tdd_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope2, y.kC2), y.kminC2); };
+    const double delta_w = w - p.w0;
+    const double dwv = fabs(delta_w) > 1e-15 ? delta_w : 0.0;
+
+    constexpr int NR = NL - KC > 0 ? NL - KC : 1;
+    double ncr[NR];  // -c' of rows KC .. NL-1 (registers); rows 0 .. KC-1 are in cp[row][tid]
+    double nc_prev;  // -c' of the row just eliminated
+    const double kap0 = kappa_at(0);
+    {   // ---- row 0 (mixed layer)
+        const double term_diff = kap0 * y.dt_dzmixdz1;
+        const double term_upwell = w * y.dt_dzmix;
+        const double tf = alpha_eff * (sh ? y.fb[1] : y.fb[0]);
+        const double b0 = __builtin_fma(tf, af_top[0],
+                                        __builtin_fma(__builtin_fma(term_upwell, p.pi_ratio, term_diff), af_bot[0], 1.0));
+        const double nc0 = (term_diff + term_upwell) * af_bot[0];
+        const double q = __builtin_fma(forcing, sh ? y.famp[1] : y.famp[0], hemi_hx) * y.dt_cmix;
+        double d0 = __builtin_fma(q, af_top[0], t_top);
+        if (land_hc) d0 = __builtin_fma(-(land_temp - ground_temp) * (sh ? y.lhc[1] : y.lhc[0]), af_top[0], d0);
+        d0 = __builtin_fma(y.dt_dzmix * dwv, G[0], d0);
+        const double r = refined_rcp(b0);
+        nc_prev = nc0 * r;
+        if (0 < KC) cp[0][tid] = nc_prev; else ncr[0] = nc_prev;
+        dp[0] = d0 * r;
+    }
+    const double tul = w * y.dt_dz;
+    const double s_afd = p.pi_ratio * tul * t_top;
+    const double dwq = y.dt_dz * dwv;
+    double tdu = kap0 * y.dt_dzdz1;  // row 1: dz_up = dz/2
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+        const double t_i = dp[i];
+        const double tdu_aft = tdu * af_top[i];
+        double bi, di;
+        if (i < NL - 1) {
+            const double tdd = tdd_at(i);
+            bi = __builtin_fma(tdu + tul, af_top[i], __builtin_fma(tdd, af_bot[i], 1.0));
+            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_diff[i], t_i));
+            const double denom = __builtin_fma(-tdu_aft, nc_prev, bi);
+            const double r0 = __builtin_amdgcn_rcp(denom);
+            const double e = __builtin_fma(-denom, r0, 1.0);
+            const double u = __builtin_fma(e, e, e);
+            const double t = (tdd + tul) * af_bot[i] * r0;
+            nc_prev = __builtin_fma(t, u, t);
+            if (i < KC) cp[i][tid] = nc_prev; else ncr[i - KC] = nc_prev;
+            const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
+            dp[i] = __builtin_fma(sdp, u, sdp);
+            tdu = tdd;
+        } else {
+            bi = __builtin_fma(tdu + tul, af_top[i], 1.0);
+            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_top[i], t_i));
+            const double denom = __builtin_fma(-tdu_aft, nc_prev, bi);
+            dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
+        }
+    }
+    double x = dp[NL - 1];
+    dp[NL - 1] = fmin(x, p.max_temp);
+#pragma unroll
+    for (int i = NL - 2; i >= 0; --i) {
+        const double nc = i < KC ? cp[i][tid] : ncr[i - KC];
+        x = __builtin_fma(nc, x, dp[i]);
+        dp[i] = fmin(x, p.max_temp);
+    }
+    return dp[0];
+}
+
+// One member-hemisphere of a ClimateUDEB ensemble across the model steps of a launch: begin() (construction
+// or resume), step(n) for consecutive n, end() (internal state back to HBM).  Every thread of the workgroup
+// must make the same calls: step() and begin() hold workgroup barriers.  Lanes past the end of the ensemble
+// compute on a copy of the last member and store nothing.
+template <int NL, int KC>
+struct Udeb2 {
+    Udeb2Lds<KC>& lds;
+    int tid, lane;
+    int hemi;        // 0: northern column, 1: southern (wave-uniform)
+    int64_t N, i;
+    bool live;       // this lane stands for a member of the ensemble
+    UdebP p;
+    int32_t status;
+    LamResult base;
+    double col[NL];
+    double up, land, gr, ae, hx;   // this hemisphere's upwelling, land and ground temperature, alpha_eff, exchange term
+    double land_o;                 // the other hemisphere's land temperature as of the last sub-step
+    double top_o;                  // the other hemisphere's mixed-layer temperature as of the last year end
+    double win_sum, hist_last;
+    int32_t win_lo;
+    double c_ground, c_mix, steps;
+    const double* F;
+    size_t f_stride;
+    uint32_t n_sub;                // sub-steps taken in this launch (parity of the exchange slots)
+
+    __device__ __forceinline__ explicit Udeb2(Udeb2Lds<KC>& l) : lds(l) {}
+
+    // (the launch arguments are handed to every call instead of being kept: a reference held in this object makes
+    // the compiler copy the by-value kernel argument -- 2.6 KB with the geometry tables -- into scratch)
+    static __device__ __forceinline__ double* box(const UdebArgs& a, int k) { return k == 0 ? a.st0 : k == 1 ? a.st1 : k == 2 ? a.st2 : a.st3; }
+
+    __device__ __forceinline__ void begin(const UdebArgs& a)
+    {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        hemi = __builtin_amdgcn_readfirstlane(tid >> 6);
+        N = a.n_members;
+        const int64_t i_raw = (int64_t)blockIdx.x * 64 + lane;
+        live = i_raw < N;
+        i = live ? i_raw : N - 1;
+        auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
+        p.dz_mix = P(1); p.dz = P(2); p.kappa = P(3); p.kappa_min = P(4); p.kappa_dkdt = P(5);
+        p.w0 = P(6); p.f_var = P(7); p.t_thresh_nh = P(8); p.t_thresh_sh = P(9);
+        p.ecs = P(10); p.rf_2x = P(11); p.rlo = P(12); p.fb_q = P(13); p.fb_cumt = P(14); p.fb_period = P(15);
+        p.k_lo = P(16); p.k_ns = P(17); p.amplify = P(18); p.nh_land = P(19); p.sh_land = P(20);
+        p.alpha = P(22); p.gamma = P(23); p.pi_ratio = P(24); p.k_lg = P(26); p.land_hc_thick = P(27);
+        p.rf0 = P(28); p.rf1 = P(29); p.rf2 = P(30); p.rf3 = P(31); p.prescribed_eff = P(33); p.max_temp = P(36);
+        p.fgnl = p.nh_land / 2.0; p.fgno = 0.5 - p.fgnl; p.fgsl = p.sh_land / 2.0; p.fgso = 0.5 - p.fgsl;
+        {   // compute_qfrac
+            const double rf_sum = p.rf0 * p.fgno + p.rf1 * p.fgnl + p.rf2 * p.fgso + p.rf3 * p.fgsl;
+            if (fabs(rf_sum) <= 1e-15) { p.q0 = p.q1 = p.q2 = p.q3 = 1.0; }
+            else { p.q0 = p.rf0 / rf_sum; p.q1 = p.rf1 / rf_sum; p.q2 = p.rf2 / rf_sum; p.q3 = p.rf3 / rf_sum; }
+        }
+        // ---- construction: from_parameters (mod.rs:161-227)
+        status = 0;
+        if (!is_finite(p.prescribed_eff) || p.prescribed_eff <= 0.0) status = 2;
+        base = LamResult{0.0, 0.0, 1.0, false};
+        if (status == 0) {
+            base = lamcalc(p, p.ecs);
+            if (!base.ok) status = 4;
+        }
+        if (live && hemi == 0) a.status[i] = (uint8_t)status;
+        // ---- internal state (ClimateUDEBState::new) or resume
+        win_sum = 0.0;
+        hist_last = 0.0;
+        win_lo = 0;
+        n_sub = 0;
+        double* T_own = a.ocean + (size_t)hemi * NL * N + i;
+        if (a.step_begin == 0) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) col[l] = 0.0;
+            up = p.w0;
+            land = gr = hx = land_o = top_o = 0.0;
+            ae = p.alpha;
+        } else {
+            const double* s = a.scal + (size_t)hemi * N + i;   // rows 2k + hemisphere
+            up = s[0 * N]; land = s[2 * N]; gr = s[4 * N]; ae = s[6 * N]; hx = s[8 * N];
+            land_o = a.scal[(size_t)(2 + (1 - hemi)) * N + i];
+            win_sum = a.scal[(size_t)10 * N + i];
+            win_lo = a.step_begin > 1 ? a.win_kfull[a.step_begin - 1] : 0;
+            hist_last = a.hist[(size_t)(a.step_begin - 1) * N + i];
+            top_o = a.ocean[(size_t)(1 - hemi) * NL * N + i];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) col[l] = T_own[(size_t)l * N];
+        }
+        const int32_t scen = a.scen ? a.scen[i] : 0;
+        F = a.link ? a.link + i : a.erf + (size_t)scen * a.n_times;   // a linked forcing is another ensemble's [T][N] series
+        f_stride = a.link ? (size_t)N : (size_t)1;
+        steps = (double)a.steps_per_year;
+        c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
+        c_mix = heat_capacity_per_unit_area(p.dz_mix);
+    }
+
+    // model step n -> n + 1 (one launch may take many)
+    __device__ __forceinline__ void step(const UdebArgs& a, int32_t n)
+    {
+        const bool sh = hemi != 0;
+        const double* tables = a.tables;  // kernarg segment
+        const double nan = __builtin_nan("");
+        const bool dead = status != 0;    // the reference refuses to build this component: every output NaN
+        const double erf_start = F[(size_t)n * f_stride], erf_end = F[(size_t)(n + 1) * f_stride];
+        const size_t r0 = (size_t)n * N + i, r1 = r0 + (size_t)N;
+        // warm start (mod.rs:436-446)
+        {
+            const double prev0 = a.st0[r0];
+            const double top_nh = sh ? top_o : col[0];
+            if (top_nh == 0.0 && prev0 != 0.0) {
+                col[0] = box(a, 2 * hemi)[r0];
+                top_o = box(a, 2 * (1 - hemi))[r0];
+                land = box(a, 2 * hemi + 1)[r0];
+                land_o = box(a, 2 * (1 - hemi) + 1)[r0];
+                gr = land;
+            }
+        }
+        const double dt_year = a.bounds[n + 1] - a.bounds[n];
+        const double dt_sub = dt_year / steps;
+        // ---- time-varying ECS (adjusted_ecs) and the LAMCALC re-solve: both wavefronts, same values
+        const double erf_mid = (erf_start + erf_end) / 2.0;
+        double cum_t = 0.0;
+        if (n > 0) {
+            const int32_t k_full = a.win_kfull[n];
+            const double part_w = a.win_partw[n];
+            const double* hcol = a.hist + i;
+            win_sum += hist_last;
+            for (; win_lo < k_full; ++win_lo) win_sum -= hcol[(size_t)win_lo * N];
+            if (p.fb_cumt != 0.0) {
+                cum_t = win_sum;
+                if (part_w > 0.0) cum_t += hcol[(size_t)(k_full - 1) * N] * part_w;
+            }
+        }
+        const double cumt_2x = p.ecs * p.fb_period;
+        const double cumt_factor = fabs(cumt_2x) > 1e-15 ? 1.0 + p.fb_cumt * (cum_t - cumt_2x) / cumt_2x : 1.0;
+        const double q_factor = 1.0 + p.fb_q * (fmax(erf_mid, 0.0) - p.rf_2x);
+        const double adj_ecs = p.ecs * cumt_factor * q_factor;
+        double lam_o = base.lam_o, lam_l = base.lam_l, co2_eff = base.eff;
+        if (fabs(adj_ecs - p.ecs) > 1e-10) {
+            const LamResult rr = lamcalc(p, adj_ecs);
+            if (rr.ok) {
+                lam_o = rr.lam_o;
+                lam_l = rr.lam_l;
+                co2_eff = rr.eff;
+            }
+        }
+        int eff_mode = 0;  // apply_efficacy_and_qfrac
+        if (a.efficacy_apply == 1) { eff_mode = 1; }
+        else if (a.efficacy_apply == 2 && is_finite(co2_eff) && co2_eff > 0.0) { eff_mode = 2; }
+        const double ae_y = ae;  // alpha_eff is fixed for the year
+        // this hemisphere's boxes
+        const double fg_o = sh ? p.fgso : p.fgno, fg_l = sh ? p.fgsl : p.fgnl;
+        const double q_o = sh ? p.q2 : p.q0, q_l = sh ? p.q3 : p.q1;
+        const double t_thresh = sh ? p.t_thresh_sh : p.t_thresh_nh;
+        YearGeom y;
+        {
+            const double dz1 = p.dz / 2.0;
+            y.dt_dz = dt_sub / p.dz;
+            y.dt_dzmix = dt_sub / p.dz_mix;
+            y.dt_cmix = dt_sub / c_mix;
+            y.dt_dz2 = dt_sub / (p.dz * p.dz);
+            y.dt_dzdz1 = dt_sub / (p.dz * dz1);
+            y.dt_dzmixdz1 = dt_sub / (p.dz_mix * dz1);
+            y.kC = p.kappa * kDiffCm2sToM2yr;
+            y.kdC = p.kappa_dkdt * kDiffCm2sToM2yr;
+            y.kminC = p.kappa_min * kDiffCm2sToM2yr;
+            y.kC2 = y.kC * y.dt_dz2;
+            y.kdC2 = y.kdC * y.dt_dz2;
+            y.kminC2 = y.kminC * y.dt_dz2;
+            const double f_l = (sh ? p.sh_land : p.nh_land) / 2.0;
+            const double f_o = 0.5 - f_l;
+            const double den = f_o * (p.k_lo + f_l * lam_l);
+            y.fb[0] = y.fb[1] = (lam_o + lam_l * p.k_lo * p.amplify * f_l / den) * y.dt_cmix;
+            y.famp[0] = y.famp[1] = 1.0 + p.k_lo * f_l / den;
+            y.lhc[0] = y.lhc[1] = a.land_hc ? p.k_lg * dt_sub / (c_mix * f_o) : 0.0;
+        }
+        double t_air = 0.0, t_air_o = 0.0;
+        for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
+            const double frac = (double)step_idx / steps;
+            const double erf = erf_start + frac * (erf_end - erf_start);
+            double adj = erf;
+            if (eff_mode == 1) adj = erf * p.prescribed_eff;
+            else if (eff_mode == 2) adj = erf * p.prescribed_eff / co2_eff;
+            const double f_ocean = adj * q_o, f_land = adj * q_l;
+            if (a.land_hc) {
+                if (!(fg_l < 1e-15)) gr += p.k_lg * (land - gr) / (fg_l * c_ground) * dt_sub;
+            }
+            const double sst = step_column<NL, KC>(p, y, tables, a.land_hc, col, hemi, lds.cp, tid, f_ocean, hx, gr, land, ae_y, up);
+            t_air = sst_to_air(p, sst);
+            land = land_temperature(p, t_air, f_land, fg_l, lam_l);
+            // what the other hemisphere needs of this one: air and land temperature
+            const uint32_t par = n_sub & 1u;
+            lds.xs[par][hemi][0][lane] = t_air;
+            lds.xs[par][hemi][1][lane] = land;
+            __syncthreads();
+            t_air_o = lds.xs[par][1 - hemi][0][lane];
+            land_o = lds.xs[par][1 - hemi][1][lane];
+            ++n_sub;
+            if (fg_o > 1e-15) hx = p.k_ns / fg_o * (t_air_o - t_air);
+            const double a_nh = sh ? t_air_o : t_air, l_nh = sh ? land_o : land;
+            const double a_sh = sh ? t_air : t_air_o, l_sh = sh ? land : land_o;
+            const double global_temp = a_nh * p.fgno + l_nh * p.fgnl + a_sh * p.fgso + l_sh * p.fgsl;
+            {   // update_upwelling
+                const double w_min = p.w0 * (1.0 - p.f_var);
+                up = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp / t_thresh, 1.0)), w_min);
+            }
+        }
+        // ---- end of year
+        const double sst = col[0];
+        const double air = sst_to_air(p, sst);
+        ae = fabs(sst) < 1e-15 ? p.alpha : air / sst;
+        const double rho_c = kRhoSeawater * kCpSeawater;
+        const uint32_t ypar = (uint32_t)n & 1u;
+        if (!sh) {   // calculate_ocean_heat_content adds hemisphere by hemisphere, layer by layer: the northern part first
+            double total = 0.0;
+            total += rho_c * p.dz_mix * sst;
+#pragma unroll
+            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
+            lds.xy[ypar][0][2][lane] = total;
+        }
+        lds.xy[ypar][hemi][0][lane] = sst;
+        lds.xy[ypar][hemi][1][lane] = air;
+        __syncthreads();
+        const double sst_o = lds.xy[ypar][1 - hemi][0][lane];
+        const double air_o = lds.xy[ypar][1 - hemi][1][lane];
+        top_o = sst_o;
+        const double air_nh = sh ? air_o : air, land_nh = sh ? land_o : land;
+        const double air_sh = sh ? air : air_o, land_sh = sh ? land : land_o;
+        const double global_temp = air_nh * p.fgno + land_nh * p.fgnl + air_sh * p.fgso + land_sh * p.fgsl;
+        hist_last = global_temp * dt_year;
+        if (!sh) {
+            if (live) a.hist[r0] = hist_last;
+            double adj_end = erf_end;
+            if (eff_mode == 1) adj_end = erf_end * p.prescribed_eff;
+            else if (eff_mode == 2) adj_end = erf_end * p.prescribed_eff / co2_eff;
+            const double w[4] = {p.fgno, p.fgnl, p.fgso, p.fgsl};
+            const double lambdas[4] = {lam_o, lam_l, lam_o, lam_l};
+            const double fe[4] = {adj_end * p.q0, adj_end * p.q1, adj_end * p.q2, adj_end * p.q3};
+            const double tt[4] = {air_nh, land_nh, air_sh, land_sh};
+            double q_global = 0.0, feedback_global = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q_global += w[k] * fe[k];
+                feedback_global += w[k] * lambdas[k] * tt[k];
+            }
+            if (live) {
+                a.heat_uptake[r1] = dead ? nan : q_global - feedback_global;
+                a.st0[r1] = dead ? nan : air;
+                a.st1[r1] = dead ? nan : land;
+                a.sst[r1] = dead ? nan : (sst + sst_o) / 2.0;
+            }
+        } else {
+            double total = lds.xy[ypar][0][2][lane];
+            total += rho_c * p.dz_mix * sst;
+#pragma unroll
+            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
+            if (live) {
+                a.ohc[r1] = dead ? nan : total / 2.0;
+                a.st2[r1] = dead ? nan : air;
+                a.st3[r1] = dead ? nan : land;
+            }
+        }
+    }
+
+    // the internal state goes back to HBM once per launch (rscm_ens_run resumes from it)
+    __device__ __forceinline__ void end(const UdebArgs& a)
+    {
+        if (!live || status != 0) return;
+        double* s = a.scal + (size_t)hemi * N + i;
+        s[0 * N] = up; s[2 * N] = land; s[4 * N] = gr; s[6 * N] = ae; s[8 * N] = hx;
+        if (hemi == 0) a.scal[(size_t)10 * N + i] = win_sum;
+        double* T_own = a.ocean + (size_t)hemi * NL * N + i;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) T_own[(size_t)l * N] = col[l];
+    }
+};
+
+}  // namespace udeb
+}  // namespace rscm

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, session a: the two-wavefront ClimateUDEB kernel against the one-thread kernel (parity tests + timing per variant)
+set -o pipefail
+mkdir -p gpurun_out
+for v in 0 1 2 3; do
+  echo "=== RSCM_UDEB_VARIANT=$v" | tee -a gpurun_out/r3a_udeb.log
+  RSCM_UDEB_VARIANT=$v timeout -k 10 300 python -m pytest tests/test_gpu_udeb.py -x -q 2>&1 | tail -3 | tee -a gpurun_out/r3a_udeb.log || exit 1
+  RSCM_UDEB_VARIANT=$v timeout -k 10 300 python scripts/bench_udeb.py 65536 100000 125000 2>&1 | tee -a gpurun_out/r3a_udeb.log || exit 1
+  RSCM_UDEB_VARIANT=$v timeout -k 10 300 python scripts/bench_udeb_steps.py 65536 125000 2>&1 | tee -a gpurun_out/r3a_udeb.log || exit 1
+done

@@ -224,7 +224,7 @@ def test_internal_state_kinds_refuse_time_jumps(ra, orc):
 
 
 # measured over the three presets, temperature feedback on and off, 600 years: 5e-12 / 1.6e-11 / 5e-13 (printed below)
-FAST_TOL = 1e-9
+FAST_TOL = 2e-10
 
 
 def _fast_info(e):
@@ -241,7 +241,7 @@ def test_ocean_fast_mode_tolerance(ra, orc, model):
     explicitly, the older ones through 21 decaying modes fitted to the scaled impulse response (host fit,
     deviation from the table <= 5e-10, here ~1e-12) with one running sum each.  Against the EXACT mode
     (which equals the CPU oracle bit for bit) over 600 years -- the 500-year window fills and pulses leave
-    it -- the outputs agree to FAST_TOL = 1e-9 relative (measured <= 2e-11: printed).  Launch boundaries and
+    it -- the outputs agree to FAST_TOL = 2e-10 relative (measured <= 2e-11: printed).  Launch boundaries and
     one-step launches do not change a bit of the FAST result; joining a run that EXACT began re-forms the
     running sums from the flux history."""
     rng = np.random.default_rng(12)
