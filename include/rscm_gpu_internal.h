@@ -18,17 +18,25 @@ extern "C" {
 
 /* How the calling thread's rscm_ens_run_lockstep calls are cut into launches:
  *   0  one launch per component and step (no fusion);
- *   1  default: light components fused per step, a graph of light components only in one launch for all
- *      steps with thread-private LDS slots, and -- RSCM_MODE_FAST graphs whose only heavy components are
- *      ClimateUDEB and OceanCarbon -- the whole graph in ONE persistent launch per window chunk;
+ *   1  default: consecutive light components fused per step; a graph of light components only in one launch for
+ *      all steps, with thread-private LDS slots between the steps;
  *   2  as 1 without the LDS slots;
  *   3  as 1 with every op table sent through device memory instead of the kernel arguments;
- *   4  as 1 without the persistent whole-graph launch (heavy components keep their one-step launches). */
+ *   4  as 1, and a graph whose heavy components are at most one ClimateUDEB and one OceanCarbon (RSCM_MODE_FAST
+ *      recurrence) runs as ONE launch per window chunk (csrc/graph.hip: the ocean columns stay on chip across the
+ *      steps).  Bit-identical to mode 1 and measured slower than it on an MI355X: opt-in. */
 RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
 /* Step launches issued by the calling thread's rscm_ens_run_lockstep calls (component kernels + fused
  * groups; HalocarbonChemistry counts as one) and the component steps they carried, since the thread's
  * last call of this function; resets both counters. */
 RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps);
+
+/* Where a whole-graph launch (csrc/graph.hip) spends its time: with enable != 0 the calling thread's following
+ * whole-graph launches add, per component kind, the shader cycles their wavefronts spent in that kind's steps to 32
+ * device counters (index = RSCM_KIND_*, 31 = ClimateUDEB's begin / end).  Each call returns the counters collected
+ * since the previous one in out32 (may be NULL) and resets them; enable = 0 stops collecting.  Diagnostic only: the
+ * stamps cost a few per cent (profiles/r3_graph_stamps.txt). */
+RSCM_API int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32);
 
 /* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an
  * O(T) recurrence: lags below `near_lags` months explicitly, the rest through decaying modes fitted to the

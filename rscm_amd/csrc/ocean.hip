@@ -27,39 +27,13 @@
 // roofline).  exp() of the temperature factor comes from the device
 // math library: results agree with the CPU oracle to its last-place error, and bit for bit when
 // the temperature feedback is off (tests/test_gpu_ocean.py).
-#include "rscm_device.hpp"
+#include "ocean_body.hpp"
 
 namespace rscm {
 
 namespace {
 
-constexpr double kPpmToGtc = 2.124;                 // carbon/ocean.rs:26
-constexpr double kMicromolPerPpmM3PerKg = 1.72e17;  // parameters/ocean_carbon.rs:4
-
-struct OceanMember {
-    double pco2_pi, k_gas, temp_sens, dic_conv, coef[5];
-    bool temp_on;
-};
-
-// delta_pco2_from_dic + ocean_pco2 (parameters/ocean_carbon.rs:218-245); powi(k) as LLVM expands it
-__device__ __forceinline__ double pco2_from_dic(const OceanMember& m, double d, double temp_factor)
-{
-    const double d2 = d * d, d3 = d * d2, d4 = d2 * d2, d5 = d * d4;
-    const double g[5] = {d, d2 * 1e-3, -d3 * 1e-5, d4 * 1e-7, -d5 * 1e-10};
-    double s = 0.0;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) s += m.coef[q] * g[q];
-    return (m.pco2_pi + s) * temp_factor;
-}
-
-// The flux history is a ring of a.hist_rows pulses (>= max_history_months + the pulses of one tile; the
-// whole run's pulses when that is shorter): pulse j lives in row j mod hist_rows.  All pulse indices are
-// wave-uniform, so the ring arithmetic stays on the scalar unit: one modulo per tile, then increments.
-__device__ __forceinline__ int32_t ring_add(int32_t r, int32_t k, int32_t R)
-{
-    const int32_t x = r + k;
-    return x >= R ? x - R : x;
-}
+using namespace ocean;
 
 // acc + f*r: one rounded multiply and one rounded add like the reference (EXACT), or fused
 // (RSCM_MODE_FAST: half the instructions, results differ by rounding only)
@@ -244,122 +218,16 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
 // differ from the EXACT mode by that fit and by the summation order: tests/test_gpu_ocean.py states
 // the tolerance.  Per member-year: 12 x (NEAR + 2 x 21 + exits + ~25) f64 operations and 216 B of HBM
 // traffic (12 pulses written, 12 leaving pulses read, 3 output rows) against 144 k operations and 24 KB.
+// One wavefront per SIMD: the 72 pulses, 21 mode sums, 12 partial convolutions and 12 leaving pulses of a step are
+// ~250 registers; cut to 256 for two wavefronts per SIMD the compiler spills 122 of them (17.3 ms against 16.2 ms at
+// 262 144 members x 750 years), and the twelve independent sums of a step hide their own latencies.
 template <int NEAR, int SRC>
-__global__ __launch_bounds__(kBlock, NEAR <= 60 ? 2 : 1) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table,
+__global__ __launch_bounds__(kBlock, 1) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table,
                                                              const double* __restrict__ mode_table)
 {
-    constexpr int STEPS = 12, M = kOceanModes;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    const int64_t N = a.n_members;
-    const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
-    OceanMember m;
-    m.pco2_pi = P(2);
-    m.k_gas = P(3) / (P(4) * 12.0);
-    m.temp_sens = P(5);
-    m.dic_conv = kMicromolPerPpmM3PerKg / (P(7) * P(8));
-    const double sst_pi = P(9);
-#pragma unroll
-    for (int q = 0; q < 5; ++q) m.coef[q] = P(13 + q) + P(18 + q) * sst_pi;
-    m.temp_on = P(23) != 0.0;
-    const MemberInputsEager<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
-    const double* __restrict__ irf = irf_table;
-    double* __restrict__ hist = a.hist + i;
-    a.status[i] = 0;
-    const int64_t H = a.max_hist;
-    const size_t vs = (size_t)a.rows * N;
-    // ---- state at the start of the launch
-    int64_t m0 = (int64_t)a.step_begin * STEPS;
-    double S[M];
-    if (a.rebuild) {
-        // S_q(m0 - 1) = sum over the pulses j with lag m0 - 1 - j in [NEAR, H): Horner in d_q, oldest pulse first
-#pragma unroll
-        for (int q = 0; q < M; ++q) S[q] = 0.0;
-        const int64_t j_lo = m0 - H > 0 ? m0 - H : 0;
-        int32_t jr = (int32_t)(j_lo % a.hist_rows);
-        for (int64_t j = j_lo; j <= m0 - 1 - NEAR; ++j, jr = ring_add(jr, 1, a.hist_rows)) {
-            const double f = hist[(size_t)jr * N];
-#pragma unroll
-            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], mode_table[q], f);
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < M; ++q) S[q] = a.mode_state[(size_t)q * N + i];
-    }
-    double w[NEAR + STEPS];  // w[x] = f(m0 - NEAR + x): the last NEAR pulses, then this step's
-#pragma unroll
-    for (int x = 0; x < NEAR; ++x) {
-        const int64_t j = m0 - NEAR + x;
-        w[x] = j >= 0 ? hist[(size_t)(j % a.hist_rows) * N] : 0.0;
-    }
-    const size_t r0 = (size_t)a.step_begin * N + i;
-    double pco2 = a.series[r0], cumulative = a.series[vs + r0];
-    const int32_t R = a.hist_rows;
-    int32_t mr = (int32_t)(m0 % R);                                  // ring row of this sub-step's pulse
-    int32_t mr_out = m0 >= H ? (int32_t)((m0 - H) % R) : 0;          // ... of the pulse that leaves the window (used once m >= H)
-    double* __restrict__ out = a.series + r0;
-    const bool few_exits = a.modes.n_exit <= 10;                     // the modes whose weight at lag H is not negligible come first
-    for (int32_t n = a.step_begin; n < a.step_end; ++n, m0 += STEPS) {
-        const double co2 = in.at(0, n), delta_sst = in.at(1, n);
-        const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double dt_month = dt / (double)STEPS;
-        const double temp_factor = m.temp_on ? exp(m.temp_sens * delta_sst) : 1.0;
-        const bool leaving = m0 >= H;   // sub-steps of a step that straddles m = H take the general path below
-        const bool straddle = !leaving && m0 + STEPS > H;
-        double total = 0.0;
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const double flux_ppm = m.k_gas * (co2 - pco2);
-            w[NEAR + s] = flux_ppm;
-            hist[(size_t)mr * N] = flux_ppm;
-            const double flux_gtc_yr = flux_ppm * 12.0 * kPpmToGtc;
-            total += flux_gtc_yr / (double)STEPS;
-            cumulative += flux_gtc_yr * dt_month;
-            // The 60-120 response values and 3 x 21 mode constants of a sub-step are wave-uniform and read with
-            // scalar loads.  They do not fit the 102 SGPRs of a wave at once: an opaque zero offset per sub-step
-            // keeps the compiler from hoisting all of them out of the loops (and then spilling them into VGPR
-            // lanes, one v_readlane pair per use) -- they are re-read from the scalar cache where they are used.
-            int32_t opaque = 0;
-            asm volatile("" : "+s"(opaque));
-            const double* __restrict__ rt = irf + opaque;
-            const double* __restrict__ md = mode_table + opaque;           // d_q
-            const double* __restrict__ mc = mode_table + M + opaque;       // c_q
-            const double* __restrict__ me = mode_table + 2 * M + opaque;   // e_q
-            // the far lags: the pulse that is NEAR months old enters, the one H months old leaves
-            const double f_in = w[s];
-#pragma unroll
-            for (int q = 0; q < M; ++q) S[q] = __builtin_fma(S[q], md[q], f_in);
-            if (leaving || (straddle && m0 + s >= H)) {  // wave-uniform
-                const double f_out = hist[(size_t)mr_out * N];
-                mr_out = ring_add(mr_out, 1, R);
-                if (few_exits) {
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) S[q] = __builtin_fma(-me[q], f_out, S[q]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < M; ++q) S[q] = __builtin_fma(-me[q], f_out, S[q]);   // e_q = 0 beyond n_exit
-                }
-            }
-            mr = ring_add(mr, 1, R);
-            double integral = 0.0;
-#pragma unroll
-            for (int q = M - 1; q >= 0; --q) integral = __builtin_fma(mc[q], S[q], integral);  // fastest-decaying (smallest) first
-            // the near lags, oldest first
-#pragma unroll
-            for (int lag = NEAR - 1; lag >= 0; --lag) integral = __builtin_fma(w[NEAR + s - lag], rt[lag], integral);
-            const double delta_dic = integral * m.dic_conv;
-            pco2 = pco2_from_dic(m, delta_dic, temp_factor);
-        }
-#pragma unroll
-        for (int x = 0; x < NEAR; ++x) w[x] = w[x + STEPS];
-        out += N;
-        out[0] = pco2;
-        out[vs] = cumulative;
-        out[2 * vs] = total;
-    }
-#pragma unroll
-    for (int q = 0; q < M; ++q) a.mode_state[(size_t)q * N + i] = S[q];
+    ocean_recur_run<NEAR, SRC>(a, irf_table, mode_table, i, a.step_begin, a.step_end, a.rebuild != 0);
 }
 
 template <int NEAR>

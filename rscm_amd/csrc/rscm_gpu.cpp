@@ -1199,7 +1199,7 @@ int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLin
 // (4) the launch itself -- or, with op_out, its arguments for the group kernel (csrc/group.hip) if the kind can
 // be fused with its neighbours (op_out->kind = -1 otherwise; nothing is launched either way)
 int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
-                       rscm::GroupOp* op_out)
+                rscm::GroupOp* op_out, rscm::GraphHeavy* heavy_out)
 {
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
@@ -1339,7 +1339,16 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.rows = h->rows;
         a.series = h->series(1);
         a.status = h->d_status;
-        if (op_out) { op_out->kind = -1; return RSCM_OK; }
+        if (op_out) {
+            // the whole-graph launch (csrc/graph.hip) runs the O(T) recurrence with 60 explicit lags step by step
+            op_out->kind = -1;
+            if (heavy_out && a.recur && a.near == 60) {
+                heavy_out->ocean = a;
+                heavy_out->has_ocean = 1;
+                op_out->kind = h->kind;
+            }
+            return RSCM_OK;
+        }
         HIPCHK(rscm::launch_ocean(a, h->stream));
     } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON || h->kind == RSCM_KIND_CARBON_CYCLE) {
         rscm::CarbonArgs a{};
@@ -1454,7 +1463,15 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.ohc = h->series(RSCM_UD_VAR_OHC);
         a.sst = h->series(RSCM_UD_VAR_SST);
         a.status = h->d_status;
-        if (op_out) { op_out->kind = -1; return RSCM_OK; }
+        if (op_out) {
+            op_out->kind = -1;
+            if (heavy_out && a.n_layers == 50) {  // the whole-graph launch keeps the columns on chip across its steps
+                heavy_out->udeb = a;
+                heavy_out->has_udeb = 1;
+                op_out->kind = h->kind;
+            }
+            return RSCM_OK;
+        }
         HIPCHK(rscm::launch_udeb(a, h->stream));
     } else {
         rscm::CoupledArgs a{};
@@ -1514,7 +1531,7 @@ int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
     int32_t linked = 0;
     if (int rc = step_links(h, step_begin, step_end, links, linked)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (int rc = step_launch(h, step_begin, step_end, links, linked, nullptr)) return rc;
+    if (int rc = step_launch(h, step_begin, step_end, links, linked, nullptr, nullptr)) return rc;
     if (int rc = step_finish(h, step_begin, step_end)) return rc;
     if (timed) {
         HIPCHK(hipEventRecord(h->ev1, h->stream));

@@ -82,7 +82,9 @@ def main():
     ap.add_argument("--members", type=int, default=125_000)
     ap.add_argument("--years", type=int, default=750)
     ap.add_argument("--exact", action="store_true", help="RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) convolution")
+    ap.add_argument("--fusion", type=int, default=1, help="rscm_gpu_set_lockstep_fusion mode (4: the whole-graph launch; include/rscm_gpu_internal.h)")
     args = ap.parse_args()
+    L.check(L.load().rscm_gpu_set_lockstep_fusion(args.fusion))
     big, rows = run(args.members, args.years, args.exact)
     small_rows = first_64(args.members, args.years, args.exact)
     same = {}
