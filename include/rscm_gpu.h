@@ -602,6 +602,22 @@ RSCM_API int rscm_sampler_half_step(rscm_sampler* s, int32_t half, int32_t ident
 RSCM_API int rscm_sampler_exchange_buffers(rscm_sampler* s, void** send, void** recv, int64_t* doubles_per_rank);
 RSCM_API int rscm_sampler_apply_exchange(rscm_sampler* s, int32_t half);
 RSCM_API int rscm_sampler_sync(rscm_sampler* s);
+/* The same sampler over a GRAPH of linked ensembles as the evaluator -- EnsembleSampler<R: ModelRunner, L> is generic over the
+ * runner (sampler/ensemble.rs:86-106,143-177); here the runner is any component graph stepped by rscm_ens_run_lockstep.
+ * handles[0 .. n_handles) in graph order, n_walkers / 2 / n_ranks members each, whole series stored, one stream.  Sampled
+ * dimension d is parameter row param_rows[d] of handles[param_owner[d]] (every other parameter keeps what rscm_ens_set_params
+ * gave it); observation j is variable obs_var[j] of handles[obs_owner[j]] at time index obs_tidx[j].  Every half-step: the
+ * handles are rewound (clear_between_runs != 0: their stored rows NaN again, for graphs in which a consumer runs ahead of its
+ * producer, rscm_ens_set_link_order_check), the proposal kernel writes each proposed value into its owner's parameter block,
+ * the graph is stepped to the last observed index -- later steps cannot change ln L -- and the likelihood kernel sums over the
+ * observation rows where their owners store them: no host round trip per sweep.  Everything else (priors, groups, sharding,
+ * driving calls, reproducibility) as for rscm_sampler_create_sharded. */
+RSCM_API int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32_t clear_between_runs, int32_t n_walkers,
+                              int32_t n_dims, const int32_t* param_owner, const int32_t* param_rows, const int32_t* prior_kind,
+                              const double* prior_a, const double* prior_b, const double* prior_low, const double* prior_high,
+                              int32_t n_obs, const int32_t* obs_owner, const int32_t* obs_var, const int32_t* obs_tidx,
+                              const double* obs_value, const double* obs_sigma, int32_t normalize, double stretch_a, uint64_t seed,
+                              int32_t rank, int32_t n_ranks, rscm_sampler** out);
 RSCM_API int rscm_sampler_destroy(rscm_sampler* s);
 /* Split the walkers into n_groups independent ensembles of n_walkers / n_groups walkers each
  * (consecutive blocks of the walker index): every group is a sampler of its own -- its own two

@@ -288,6 +288,9 @@ SIGNATURES = {
                                       _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.POINTER(_h)]),
     "rscm_sampler_create_sharded": (C.c_int, [_h, C.c_int32, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp, _dp, C.c_int32, _ip, _ip,
                                               _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(_h)]),
+    "rscm_sampler_create_graph": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, _dp, _dp, _dp, _dp,
+                                            C.c_int32, _ip, _ip, _ip, _dp, _dp, C.c_int32, C.c_double, C.c_uint64, C.c_int32, C.c_int32,
+                                            C.POINTER(_h)]),
     "rscm_sampler_begin_iteration": (C.c_int, [_h]),
     "rscm_sampler_half_step": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "rscm_sampler_exchange_buffers": (C.c_int, [_h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

@@ -897,7 +897,11 @@ class DeviceEnsembleSampler:
     the accept step never leave the device, the host only fetches the walker positions it wants
     to keep.  Same interface as ``EnsembleSampler``; priors must be ``Uniform`` or ``Normal``.  A
     two-layer model is scored by the fused run+likelihood kernel, any other kind (the coupled
-    chain, ClimateUDEB, ...) is run and scored from its stored series, still on the device.
+    chain, ClimateUDEB, ...) is run and scored from its stored series, still on the device; a graph
+    of linked ensembles (``ModelRunner`` over a ``GraphModel``) is the evaluator as a whole
+    (``rscm_sampler_create_graph``): every half-step the proposal kernel writes each proposed value into
+    the parameter block of the component that owns it, the graph is stepped in lock-step to the last
+    observed index and the likelihood kernel reads the observations where their owners store them.
     Random numbers are counter-based from ``seed``."""
 
     def __init__(self, params: ParameterSet, runner: ModelRunner, likelihood: GaussianLikelihood,
@@ -906,9 +910,6 @@ class DeviceEnsembleSampler:
             raise ValueError(f"Stretch move scale parameter must be > 1.0, got {stretch_a}")
         if list(params.param_names) != runner.param_names:
             raise ValueError("the parameter set must name the runner's parameters, in its order")
-        if getattr(runner, "_graph", False):
-            raise NotImplementedError("the device sampler drives one evaluating ensemble; a graph of linked "
-                                      "ensembles is calibrated with EnsembleSampler (batched evaluations on the GPU)")
         self.params, self.runner, self.likelihood, self.target = params, runner, likelihood, target
         self.a = float(stretch_a)
         self.default_n_walkers = max(2 * len(params), 32)
@@ -971,19 +972,50 @@ class DeviceEnsembleSampler:
             if n_groups != 1:
                 raise ValueError("a sharded sampler runs one ensemble (n_groups = 1)")
         n_eval = n_walkers // 2 // world
-        two_layer = self.runner._model(1).ensemble.kind == L.KIND_TWO_LAYER
-        model = self.runner._lik_model(n_eval) if two_layer else self.runner._model(n_eval)
-        ens, lib = model.ensemble, model.ensemble._lib
-        ens.rewind()
-        ov, ot, val, sig = self._observations(model)
-        rows = np.array(self.runner._rows, dtype=np.int32)
         kinds, pa, pb, plo, phi = self._prior
-        base = L.f64(model.base_params)
         h = C.c_void_p()
-        L.check(lib.rscm_sampler_create_sharded(ens._h, n_walkers, len(rows), L.iptr(rows), L.dptr(base), L.iptr(kinds),
-                                                L.dptr(pa), L.dptr(pb), L.dptr(plo), L.dptr(phi), len(ov), L.iptr(ov), L.iptr(ot),
-                                                L.dptr(val), L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
-                                                C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), rank, world, C.byref(h)))
+        if getattr(self.runner, "_graph", False):
+            model = self.runner._model(n_eval)
+            if model._host_nodes:
+                raise NotImplementedError("a graph with Python components steps through the host: calibrate it with EnsembleSampler")
+            model.rewind()
+            order = list(model._order)
+            handles = [model.ensembles[name] for name in order]
+            ens, lib = handles[0], handles[0]._lib
+            # the non-sampled parameters: the builder's values for every member (the proposal kernel overwrites the sampled rows)
+            for owner in {model.param_home[p][0] for p in self.runner.param_names}:
+                model.ensembles[owner].set_params(np.repeat(model.base_params[owner][:, None], n_eval, axis=1))
+            p_owner = np.array([order.index(model.param_home[p][0]) for p in self.runner.param_names], dtype=np.int32)
+            p_rows = np.array([model.param_home[p][1] for p in self.runner.param_names], dtype=np.int32)
+            oo, ov, ot, val, sig = [], [], [], [], []
+            for name, vt in self.target.variables():
+                owner_ens, vid = model.variable_home(name)
+                k = next(j for j, e in enumerate(handles) if e is owner_ens)
+                for obs in vt.observations:
+                    idx = model._axis.index_of(obs.time)
+                    if idx is None:
+                        raise KeyError(f"Model output missing time: {obs.time}")
+                    oo.append(k), ov.append(vid), ot.append(idx), val.append(obs.value), sig.append(obs.uncertainty)
+            oo, ov, ot = (np.array(x, dtype=np.int32) for x in (oo, ov, ot))
+            val, sig = L.f64(val), L.f64(sig)
+            arr = (C.c_void_p * len(handles))(*[e._h.value for e in handles])
+            L.check(lib.rscm_sampler_create_graph(arr, len(handles), 1 if model._reads_unwritten else 0, n_walkers, len(p_rows),
+                                                  L.iptr(p_owner), L.iptr(p_rows), L.iptr(kinds), L.dptr(pa), L.dptr(pb), L.dptr(plo),
+                                                  L.dptr(phi), len(ov), L.iptr(oo), L.iptr(ov), L.iptr(ot), L.dptr(val), L.dptr(sig),
+                                                  1 if self.likelihood.normalize else 0, self.a,
+                                                  C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), rank, world, C.byref(h)))
+        else:
+            two_layer = self.runner._model(1).ensemble.kind == L.KIND_TWO_LAYER
+            model = self.runner._lik_model(n_eval) if two_layer else self.runner._model(n_eval)
+            ens, lib = model.ensemble, model.ensemble._lib
+            ens.rewind()
+            ov, ot, val, sig = self._observations(model)
+            rows = np.array(self.runner._rows, dtype=np.int32)
+            base = L.f64(model.base_params)
+            L.check(lib.rscm_sampler_create_sharded(ens._h, n_walkers, len(rows), L.iptr(rows), L.dptr(base), L.iptr(kinds),
+                                                    L.dptr(pa), L.dptr(pb), L.dptr(plo), L.dptr(phi), len(ov), L.iptr(ov), L.iptr(ot),
+                                                    L.dptr(val), L.dptr(sig), 1 if self.likelihood.normalize else 0, self.a,
+                                                    C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), rank, world, C.byref(h)))
         try:
             if world > 1 or (is_distributed() and shard is not False):
                 return self._run_sharded(lib, h, ens, pos, n_iterations, thin, n_walkers, world)

@@ -471,6 +471,7 @@ struct SamplerArgs {
     double* lp;          // [n_local] log prior of the proposals
     const double* loglik;  // [n_local] written by the evaluator's fused run+likelihood launch
     double* eval_params;   // [P][n_local] the evaluator's parameter block
+    double* const* param_ptr;  // graph evaluator: [D] parameter row of each sampled dimension in its owning ensemble's block ([n_local] each); else null
     double* exchange;      // pack: [D + 1][n_local] out; unpack: [n_ranks][D + 1][n_local] in (positions, then log prob)
     int32_t n_ranks;
     int64_t* n_accepted;   // [W]

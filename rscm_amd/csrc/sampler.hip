@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kBlock) void propose_kernel(SamplerArgs a)
     }
     const int64_t W = a.n_walkers;
     double lp = 0.0;
-    for (int32_t r = 0; r < a.n_params; ++r) a.eval_params[(size_t)r * H + kl] = a.base_params[r];
+    if (!a.param_ptr)
+        for (int32_t r = 0; r < a.n_params; ++r) a.eval_params[(size_t)r * H + kl] = a.base_params[r];
     for (int32_t d = 0; d < a.n_dims; ++d) {
         const double x = a.pos[(size_t)d * W + active];
         const double cval = a.pos[(size_t)d * W + comp];
@@ -86,9 +87,11 @@ __global__ __launch_bounds__(kBlock) void propose_kernel(SamplerArgs a)
     // valid position instead and the result is discarded.  Garbage parameters (negative heat
     // capacities ...) would push whole wavefronts onto the kernel's slow replay path.
     const bool in_support = lp > -__builtin_inf();
-    for (int32_t d = 0; d < a.n_dims; ++d)
-        a.eval_params[(size_t)a.param_rows[d] * H + kl] =
-            (in_support || a.identity) ? a.proposal[(size_t)d * H + kl] : a.pos[(size_t)d * W + active];
+    for (int32_t d = 0; d < a.n_dims; ++d) {
+        // one evaluating ensemble: row param_rows[d] of its block; a graph: the row of the ensemble that owns the parameter
+        double* dst = a.param_ptr ? a.param_ptr[d] + kl : a.eval_params + (size_t)a.param_rows[d] * H + kl;
+        *dst = (in_support || a.identity) ? a.proposal[(size_t)d * H + kl] : a.pos[(size_t)d * W + active];
+    }
     a.z[kl] = z;
     a.lp[kl] = lp;
 }

@@ -1,7 +1,10 @@
 """End to end (run on the GPU box): calibrate the climate sensitivity of the emissions-driven MAGICC
 graph against MAGICC7's own SSP245 temperatures (tests/golden/magicc7_emissions_driven.json, generated
 with core_climatesensitivity = 3.0), with rscm-calibrate's affine-invariant sampler driving batches
-of members through the ten linked components on the GPU."""
+of members through the ten linked components on the GPU.
+    python scripts/calibrate_magicc_chain.py [--fast] [--device-sampler [--walkers 4096] [--iterations 120]]
+--device-sampler: the whole stretch-move loop on the device with the GRAPH as the evaluator (rscm_sampler_create_graph): no host
+round trip per sweep; the host sampler's run (64 walkers) is printed beside it for the posterior comparison."""
 import json
 import os
 import sys
@@ -63,14 +66,36 @@ for year in range(1900, 2100, 10):          # MAGICC7's year n is our index n + 
     target.add_observation("Surface Temperature", float(year + 1), float(V["Surface Temperature"][year - 1750]), 0.05)
 params = cal.ParameterSet().add("ClimateUDEB.ecs", cal.Uniform(1.5, 6.0)).add("ClimateUDEB.kappa", cal.Uniform(0.3, 2.0))
 sampler = cal.EnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+
+
+def arg(name, default):
+    return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+
+
 t0 = time.perf_counter()
 n_iter, walkers = 120, 64
 chain = sampler.run(n_iter, cal.WalkerInit.from_prior(), n_walkers=walkers, rng=np.random.default_rng(7))
 dt = time.perf_counter() - t0
 flat = chain.flat_samples(discard=60)
 lo, med, hi = np.percentile(flat[:, 0], [5, 50, 95])
-print(f"{n_iter} stretch-move iterations x {walkers} walkers = {n_iter * walkers} runs of the ten-component graph over 350 years in {dt:.1f} s "
+print(f"host sampler: {n_iter} stretch-move iterations x {walkers} walkers = {n_iter * walkers} runs of the ten-component graph over 350 years in {dt:.1f} s "
       f"({n_iter * walkers / dt:.0f} model runs/s)")
 print(f"ECS | MAGICC7 SSP245 temperatures (generated with ECS 3.0): median {med:.2f} K [5-95 %: {lo:.2f}, {hi:.2f}]; "
       f"kappa median {np.median(flat[:, 1]):.2f} cm^2/s; acceptance {sampler.acceptance_rate():.2f}")
+if "--device-sampler" in sys.argv:
+    dev = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    d_iter, d_walkers = arg("--iterations", 120), arg("--walkers", 4096)
+    t0 = time.perf_counter()
+    dchain = dev.run(d_iter, cal.WalkerInit.from_prior(), n_walkers=d_walkers, seed=7)
+    ddt = time.perf_counter() - t0
+    dflat = dchain.flat_samples(discard=d_iter // 2)
+    dlo, dmed, dhi = np.percentile(dflat[:, 0], [5, 50, 95])
+    print(f"device sampler over the graph: {d_iter} iterations x {d_walkers} walkers = {d_iter * d_walkers} runs in {ddt:.1f} s "
+          f"({d_iter * d_walkers / ddt:.0f} model runs/s, {dev.device_ms / d_iter:.1f} ms of device time per sweep)")
+    print(f"ECS median {dmed:.2f} K [5-95 %: {dlo:.2f}, {dhi:.2f}]; kappa median {np.median(dflat[:, 1]):.2f} cm^2/s; "
+          f"acceptance {dev.acceptance_rate():.2f}; host posterior ECS {med:.2f} [{lo:.2f}, {hi:.2f}]")
+    print(json.dumps({"host": {"runs": n_iter * walkers, "seconds": dt, "ecs_median": med, "ecs_5_95": [lo, hi], "kappa_median": float(np.median(flat[:, 1]))},
+                      "device": {"runs": d_iter * d_walkers, "seconds": ddt, "walkers": d_walkers, "iterations": d_iter, "ms_per_sweep": dev.device_ms / d_iter,
+                                 "ecs_median": dmed, "ecs_5_95": [dlo, dhi], "kappa_median": float(np.median(dflat[:, 1])),
+                                 "acceptance": dev.acceptance_rate()}}))
 runner.close()

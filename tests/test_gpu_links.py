@@ -859,8 +859,31 @@ def test_calibrating_a_linked_graph(ra):
     flat = chain.flat_samples(discard=300)
     med = np.median(flat, axis=0)
     assert abs(med[0] - truth[0]) < 0.02 and abs(med[1] - truth[1]) < 1.0, med
-    with pytest.raises(NotImplementedError, match="EnsembleSampler"):
-        cal.DeviceEnsembleSampler(params, runner, lik, target)
+    # the device sampler over the graph as the evaluator (rscm_sampler_create_graph): the proposal kernel writes lambda0 into
+    # TwoLayer's parameter block and tau into CarbonCycle's, the graph is stepped to the last observed index, the likelihood
+    # kernel reads Ts and CO2 where their owners store them -- no host round trip per sweep
+    dev = cal.DeviceEnsembleSampler(params, runner, lik, target)
+    rng = np.random.default_rng(0)
+    pos = params.sample_random(128, rng)
+    pos[7, 1] = 50.0   # outside Uniform(15, 45)
+    want = sampler.log_posterior_batch(pos)
+    one = dev.run(1, cal.WalkerInit.explicit(pos), n_walkers=128, seed=5)
+    got_pos, got_lp = one.flat_samples(), one.flat_log_probs()
+    same = (got_pos == pos).all(axis=1)
+    assert same.any() and (~same).any() and want[7] == -np.inf
+    # walkers that did not move keep their initial score; accepted proposals carry their own: both are the host's
+    # numbers (the per-owner partial sums are added in the target's order on both sides)
+    assert np.allclose(got_lp[same], want[same], rtol=1e-12, atol=1e-9) and got_lp[7] == -np.inf
+    moved = sampler.log_posterior_batch(got_pos[~same])
+    assert np.allclose(got_lp[~same], moved, rtol=1e-12, atol=1e-9) and np.isfinite(got_lp[~same]).all()
+    big = dev.run(150, cal.WalkerInit.from_prior(), n_walkers=4096, seed=11)
+    x = big.flat_samples(discard=120)
+    dmed = np.median(x, axis=0)
+    assert abs(dmed[0] - truth[0]) < 0.02 and abs(dmed[1] - truth[1]) < 1.0, dmed
+    hstd, dstd = flat.std(axis=0), x.std(axis=0)
+    assert np.all(np.abs(dmed - med) < 3.0 * hstd), (dmed, med)          # the host sampler's posterior ...
+    assert np.all(dstd < 3.0 * hstd) and np.all(dstd > hstd / 3.0), (dstd, hstd)   # ... location and spread
+    assert 0.15 < dev.acceptance_rate() < 0.9 and (dev.n_proposed == 150).all()
     runner.close()
 
 
