@@ -290,7 +290,7 @@ struct UdebArgs {
     const double* bounds;   // [T+1] (device)
     const int32_t* win_kfull;  // [T] first history entry that enters the cumulative-T window whole
     const double* win_partw;   // [T] weight of entry win_kfull-1 (0: not in the window)
-    // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] init_nh[NL] init_sh[NL], NL = 50: passed BY
+    // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] G_nh[NL] G_sh[NL], NL = n_layers <= 50, packed: passed BY
     // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
     double tables[6 * 50];
     double* ocean;          // [2][NL][N] layer temperatures
@@ -537,6 +537,7 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
+bool udeb_layers_supported(int32_t n_layers);  // the layer counts the column kernels are instantiated for
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);

@@ -356,7 +356,10 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             if (row(j, i) != row(j, 0))
                 return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d must be the same for every member", j);
     const double nl = row(RSCM_UD_P_N_LAYERS, 0), steps = row(RSCM_UD_P_STEPS_PER_YEAR, 0);
-    if (nl != 50.0) return fail(RSCM_ERR_INVALID, "ClimateUDEB on the device supports n_layers = 50, got %g", nl);
+    if (nl != std::floor(nl) || !rscm::udeb_layers_supported((int32_t)nl))
+        return fail(RSCM_ERR_INVALID, "ClimateUDEB on the device supports n_layers = 20, 30, 40 or 50 (the column solve is unrolled per layer count), got %g", nl);
+    if (h->udeb_ready && (int32_t)nl != h->udeb_n_layers && h->time_index > 0)
+        return fail(RSCM_ERR_STATE, "n_layers changes the ocean columns (internal state) at time index %d: rewind first", h->time_index);
     if (row(RSCM_UD_P_OCEAN_TEMP_PROFILE, 0) != 2.0)
         return fail(RSCM_ERR_INVALID, "ClimateUDEB on the device supports ocean_temp_profile = 2 (CMIP5)");
     if (!(steps >= 1.0) || steps > 1000.0 || steps != std::floor(steps))
@@ -398,7 +401,7 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
         HIPCHK(hipMemcpyAsync(h->d_win_partw, partw.data(), partw.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    if (!h->d_ocean) HIPCHK(hipMalloc(&h->d_ocean, (size_t)2 * h->udeb_n_layers * h->N * sizeof(double)));
+    if (!h->d_ocean) HIPCHK(hipMalloc(&h->d_ocean, (size_t)2 * 50 * h->N * sizeof(double)));  // room for the largest supported column
     h->udeb_ready = true;
     return RSCM_OK;
 }
@@ -1450,8 +1453,9 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.bounds = h->d_bounds;
         a.win_kfull = h->d_win_kfull;
         a.win_partw = h->d_win_partw;
-        if (h->udeb_tables.size() != sizeof(a.tables) / sizeof(double)) return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
-        memcpy(a.tables, h->udeb_tables.data(), sizeof(a.tables));
+        if (h->udeb_tables.size() != (size_t)6 * h->udeb_n_layers || h->udeb_tables.size() > sizeof(a.tables) / sizeof(double))
+            return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
+        memcpy(a.tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double));
         a.ocean = h->d_ocean;
         a.scal = h->d_scal;
         a.hist = h->d_hist;

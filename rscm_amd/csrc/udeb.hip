@@ -71,22 +71,38 @@ __global__ __launch_bounds__(kUdeb2Block, WAVES) void udeb2_kernel(UdebArgs a)
 
 }  // namespace
 
+template <int NL>
+static void launch_udeb_nl(const UdebArgs& a, bool two_waves, hipStream_t s)
+{
+    if (two_waves) {
+        const dim3 grid((unsigned)((a.n_members + 63) / 64));
+        hipLaunchKernelGGL((udeb2_kernel<NL, 0, 1>), grid, dim3(kUdeb2Block), 0, s, a);
+    } else {
+        const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
+        hipLaunchKernelGGL(udeb_kernel<NL>, grid, dim3(kUdebBlock), 0, s, a);
+    }
+}
+
+bool udeb_layers_supported(int32_t n_layers)
+{
+    return n_layers == 20 || n_layers == 30 || n_layers == 40 || n_layers == 50;
+}
+
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
-    if (a.n_layers != 50) return hipErrorInvalidValue;  // the column loops are unrolled: one instance per supported layer count
     // Up to 32 768 members there are fewer wavefronts than SIMDs either way: the two-wavefront kernel solves a member's
     // two hemispheres at the same time on two SIMDs (half the latency per model step); beyond that the two kernels
     // take the same time per member (profiles/r3_udeb_two_wave_experiment.txt) and the one-thread kernel is kept.
     // RSCM_UDEB_VARIANT = 0 / 2 forces one of them (A/B runs).
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
     const bool two_waves = forced == 2 || (forced != 0 && a.n_members <= 32768);
-    if (two_waves) {
-        const dim3 grid((unsigned)((a.n_members + 63) / 64));
-        hipLaunchKernelGGL((udeb2_kernel<50, 0, 1>), grid, dim3(kUdeb2Block), 0, s, a);
-    } else {
-        const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
-        hipLaunchKernelGGL(udeb_kernel<50>, grid, dim3(kUdebBlock), 0, s, a);
+    switch (a.n_layers) {   // the column loops are unrolled, the column lives in registers: one instance per supported layer count
+        case 20: launch_udeb_nl<20>(a, two_waves, s); break;
+        case 30: launch_udeb_nl<30>(a, two_waves, s); break;
+        case 40: launch_udeb_nl<40>(a, two_waves, s); break;
+        case 50: launch_udeb_nl<50>(a, two_waves, s); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -90,6 +90,29 @@ def _ensemble_params(orc, n, seed=0, **fixed):
     return P
 
 
+@pytest.mark.parametrize("n_members", [96, 40000])   # the two-wavefront kernel (<= 32 768 members) and the one-thread kernel
+@pytest.mark.parametrize("n_layers", [20, 30, 40])
+def test_udeb_gpu_other_layer_counts(ra, orc, n_layers, n_members):
+    """n_layers is a parameter of the reference (parameters/climate_udeb.rs:41, validated >= 2 at climate/udeb/mod.rs:164);
+    the device unrolls the column solve per layer count and is instantiated for 20, 30, 40 and 50 layers.  Same bar against
+    the oracle as at 50 layers (the oracle takes any count); other counts are refused with the list."""
+    years = np.arange(1850.0, 1931.0)
+    b = np.append(years, 1931.0)
+    P = _ensemble_params(orc, n_members, seed=n_layers, n_layers=float(n_layers))
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0), 3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0)])
+    scen = (np.arange(n_members) % 2).astype(np.int32)
+    pick = np.arange(n_members) if n_members <= 512 else np.random.default_rng(1).choice(n_members, 256, replace=False)
+    want, wst = orc.udeb_run(b, P[:, pick].copy(), F, scen=scen[pick].copy(), threads=8)
+    got, st = _gpu(ra, b, P, F, scen=scen, chunks=(1, 29))
+    assert not st.any() and not wst.any()
+    _assert_close({k: v[:, pick] for k, v in got.items()}, want, f"{n_layers} layers")
+    if n_members <= 512:
+        with pytest.raises(ra.RscmGpuError, match="20, 30, 40 or 50"):
+            Q = P.copy()
+            Q[orc.UDEB_PARAM_NAMES.index("n_layers")] = 25.0
+            _gpu(ra, b, Q, F, scen=scen)
+
+
 def test_udeb_gpu_ensemble_vs_oracle(ra, orc):
     years = np.arange(1850.0, 1951.0)
     b = np.append(years, 1951.0)
@@ -136,8 +159,8 @@ def test_udeb_structural_parameters_must_be_uniform(ra, orc):
         with pytest.raises(RscmGpuError, match="same for every member"):
             e.set_params(bad)
         bad = P.copy()
-        bad[0] = 40.0
-        with pytest.raises(RscmGpuError, match="n_layers = 50"):
+        bad[0] = 45.0
+        with pytest.raises(RscmGpuError, match="n_layers = 20, 30, 40 or 50"):
             e.set_params(bad)
         e.set_params(P)
         e.set_forcing(np.zeros(len(years)))
