@@ -20,6 +20,8 @@
 // scalar cache.  Heavy components -- ClimateUDEB (two 50-layer columns in registers and LDS),
 // OceanCarbon (history convolution), HalocarbonChemistry (species-parallel grid) -- keep their own
 // launches; rscm_gpu.cpp cuts the step's component list into segments accordingly.
+#include <utility>
+
 #include "group_body.hpp"
 
 namespace rscm {
@@ -76,6 +78,72 @@ __global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable tab
     run_graph<FULL, CACHED>(table.ops, n_ops, n_members, step_begin, step_end, lds_slots);
 }
 
+
+// ---- a kernel per graph: the op KINDS fixed at compile time -------------------------------------------------
+// The interpreter above pays, per op and model step, for what it cannot know: the switch on the kind, the op's
+// fields re-read through the scalar cache (a dynamic index into the table), the slot records of its LDS cache --
+// 444 scalar and ~150 extra vector instructions per wavefront-step on the coupled chain against the fused
+// coupled kernel's 52 scalar ones (profiles/r2_group_ops_counters.txt).  For the graphs the front end emits
+// most often the sequence of kinds is a template argument: the bodies are called directly, the table travels by
+// value in the kernel arguments and every field, pointer and slot number is a kernel-argument load the compiler
+// hoists out of the step loop.  Same bodies, same template arguments, same LDS slots: the same bits.
+template <int KIND, class Cache>
+__device__ __forceinline__ void run_kind(const GroupOp& op, int64_t i, int32_t b, const Cache& cache)
+{
+    if constexpr (KIND == 0) {
+        if (op.variant == 0) tl::two_layer_body<0, false, true>(op.u.tl, nullptr, i, b, b + 1, cache);
+        else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, b, b + 1, cache);
+    } else if constexpr (KIND == kKindCarbonCycle) carbon::carbon_cycle_body<2>(op.u.carbon, i, b, b + 1, cache);
+    else if constexpr (KIND == kKindCo2Budget) carbon::co2_budget_body<2>(op.u.carbon, i, b, b + 1, cache);
+    else pw::pointwise_body<KIND, 2>(op.u.pw, i, b, b + 1, cache);   // CO2ERF, aggregate, AerosolIndirect, FourBoxOHU, OSPP
+}
+
+template <int... KINDS>
+struct KindSeq {
+    static constexpr int n = sizeof...(KINDS);
+    static constexpr int kinds[sizeof...(KINDS)] = {KINDS...};
+};
+
+template <class Seq, int... IDX>
+__device__ __forceinline__ void run_seq_step(const GroupTable& table, int64_t i, int32_t b, bool warm, bool last, double* slots,
+                                             std::integer_sequence<int, IDX...>)
+{
+    if (warm) (run_kind<Seq::kinds[IDX]>(table.ops[IDX], i, b, LdsCache<true>{slots, table.ops[IDX].cache, last}), ...);
+    else (run_kind<Seq::kinds[IDX]>(table.ops[IDX], i, b, LdsCache<false>{slots, table.ops[IDX].cache, last}), ...);
+}
+
+template <class Seq>
+__global__ __launch_bounds__(kBlock) void group_seq_kernel(const GroupTable table, int64_t n_members, int32_t step_begin, int32_t step_end)
+{
+    extern __shared__ double lds_slots[];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_members) return;
+    double* slots = lds_slots + threadIdx.x;
+    const auto idx = std::make_integer_sequence<int, Seq::n>();
+    run_seq_step<Seq>(table, i, step_begin, false, step_begin + 1 == step_end, slots, idx);   // cold: fills the slots
+    for (int32_t b = step_begin + 1; b < step_end; ++b) {
+        // the fields of four ops do not fit the scalar registers at once: an opaque zero offset per step keeps their
+        // loads inside the step (a few s_load_dwordx16 from the kernel-argument segment) instead of hoisted and spilled
+        int32_t opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        run_seq_step<Seq>((&table)[opaque], i, b, true, b + 1 == step_end, slots, idx);
+    }
+}
+
+// the graphs with a kernel of their own: the coupled chain of BASELINE configs[2] / the reference's notebook as four
+// linked components (CarbonCycle -> CO2ERF -> Sum -> TwoLayer), and the same with the two-layer model alone behind a Sum
+using SeqCoupled = KindSeq<kKindCarbonCycle, kKindCo2Erf, kKindAggregate, 0>;
+using SeqForced = KindSeq<kKindAggregate, 0>;
+
+template <class Seq>
+static bool seq_matches(const int32_t* kinds, int32_t n)
+{
+    if (n != Seq::n) return false;
+    for (int k = 0; k < n; ++k)
+        if (kinds[k] != Seq::kinds[k]) return false;
+    return true;
+}
+
 }  // namespace
 
 bool group_kind_is_small(int32_t kind)
@@ -100,6 +168,26 @@ static void launch_variant(bool by_value, bool all_small, int32_t cache_slots, d
         else if (all_small) hipLaunchKernelGGL((group_kernel<false, false>), grid, dim3(kBlock), 0, s, d_ops, rest...);
         else hipLaunchKernelGGL((group_kernel<true, false>), grid, dim3(kBlock), 0, s, d_ops, rest...);
     }
+}
+
+bool group_seq_available(const int32_t* kinds, int32_t n_ops)
+{
+    return seq_matches<SeqCoupled>(kinds, n_ops) || seq_matches<SeqForced>(kinds, n_ops);
+}
+
+bool launch_group_seq(const GroupTable& table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, int32_t cache_slots,
+                      hipStream_t s, hipError_t* status)
+{
+    if (n_ops <= 0 || n_ops > kGroupTableOps || cache_slots <= 0 || n_members <= 0 || step_end <= step_begin) return false;
+    int32_t kinds[kGroupTableOps];
+    for (int32_t k = 0; k < n_ops; ++k) kinds[k] = table.ops[k].kind;
+    const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
+    const size_t lds = (size_t)cache_slots * kBlock * sizeof(double);
+    if (seq_matches<SeqCoupled>(kinds, n_ops)) hipLaunchKernelGGL(group_seq_kernel<SeqCoupled>, grid, dim3(kBlock), lds, s, table, n_members, step_begin, step_end);
+    else if (seq_matches<SeqForced>(kinds, n_ops)) hipLaunchKernelGGL(group_seq_kernel<SeqForced>, grid, dim3(kBlock), lds, s, table, n_members, step_begin, step_end);
+    else return false;
+    *status = hipGetLastError();
+    return true;
 }
 
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,

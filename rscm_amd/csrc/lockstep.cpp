@@ -190,7 +190,14 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
     // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
     // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
     // only what changed since the last launch is uploaded
-    const bool by_value = t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0 && !with_heavy;
+    // a multi-step launch of a graph whose sequence of kinds has a kernel of its own (csrc/group.hip, group_seq_kernel)
+    bool own_kernel = false;
+    if (cache_slots > 0 && !with_heavy && t_ls.by_value && count <= rscm::kGroupTableOps) {
+        int32_t kinds[rscm::kGroupTableOps];
+        for (int32_t k = 0; k < count; ++k) kinds[k] = plan->handles[first + k]->kind;
+        own_kernel = rscm::group_seq_available(kinds, count);
+    }
+    const bool by_value = (t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0 && !with_heavy) || own_kernel;
     rscm::GroupTable table;
     if (by_value) memset((void*)&table, 0, sizeof table);
     for (int32_t k = first; k < first + count; ++k) {
@@ -226,7 +233,12 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         }
         h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
     }
-    if (with_heavy)
+    hipError_t seq_status = hipSuccess;
+    if (own_kernel) {
+        if (!rscm::launch_group_seq(table, count, lead->N, n, n + len, cache_slots, lead->stream, &seq_status))
+            return fail(RSCM_ERR_STATE, "no kernel for this sequence of kinds after all");
+        HIPCHK(seq_status);
+    } else if (with_heavy)
         HIPCHK(rscm::launch_graph(heavy, plan->d_ops + first, count, lead->N, n, n + len, cache_slots, t_ls.stamps, lead->stream));
     else
         HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,

@@ -64,7 +64,12 @@ __device__ __forceinline__ double param_at_scalar(const double* __restrict__ par
     const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;  // wave-uniform: a scalar branch
     if (u) {
         typedef const __attribute__((address_space(4))) double* scalar_row;
-        return *(scalar_row)(uintptr_t)(params + (size_t)j * N);
+        // (the row address is wave-uniform; saying so keeps the scalar load legal where register pressure has moved the
+        // pointer into vector registers -- without it hipcc 7.2 emits an s_load with a VGPR address there and stops with
+        // "Illegal instruction detected: Operand has incorrect register class"; a no-op when the address is scalar already)
+        const uintptr_t p = (uintptr_t)(params + (size_t)j * N);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        return *(scalar_row)(((uintptr_t)hi << 32) | lo);
     }
     return params[(size_t)j * N + i];
 }
@@ -532,6 +537,12 @@ bool group_kind_is_small(int32_t kind);
 // Exactly one of d_ops (device table) and table (host, passed by value, n_ops <= kGroupTableOps) is given.
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
                         bool all_small, int32_t cache_slots, hipStream_t s);
+
+// A multi-step launch of a light graph whose sequence of kinds has a kernel of its own (csrc/group.hip: the op table
+// by value, the kinds compile-time): true if one was launched (*status: its launch status), false if the sequence has none.
+bool group_seq_available(const int32_t* kinds, int32_t n_ops);
+bool launch_group_seq(const GroupTable& table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end, int32_t cache_slots,
+                      hipStream_t s, hipError_t* status);
 
 hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);

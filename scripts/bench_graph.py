@@ -4,7 +4,9 @@ lock-step, beside RSCM_KIND_COUPLED (one launch for the whole run).  The four co
 so rscm_ens_run_lockstep fuses them into one group launch (csrc/group.hip) that covers every step;
 `--unfused` issues four launches per model step instead.
 
-    python scripts/bench_graph.py [members ...] [--unfused]"""
+    python scripts/bench_graph.py [members ...] [--unfused | --interpreter]
+--interpreter: the group kernel's op interpreter with the table in device memory (rscm_gpu_set_lockstep_fusion(3)) instead of
+the kernel compiled for this sequence of kinds (group_seq_kernel)."""
 import ctypes as C
 import os
 import sys
@@ -26,6 +28,8 @@ INIT = (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0
 ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
 if "--unfused" in sys.argv:
     L.check(L.load().rscm_gpu_set_lockstep_fusion(0))
+if "--interpreter" in sys.argv:
+    L.check(L.load().rscm_gpu_set_lockstep_fusion(3))
 for N in ([int(a) for a in ARGS] or [100_000, 1_000_000]):
     P = coupled_params(N)
     with ra.Ensemble(ra.KIND_COUPLED, N, b) as f:
