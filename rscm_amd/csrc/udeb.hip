@@ -53,7 +53,11 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     if (i >= a.n_members) return;
     Udeb1<NL> m(park);
     m.begin(a, i);
-    for (int32_t n = a.step_begin; n < a.step_end; ++n) m.step(a, n);
+    if (m.status != 0) {  // the reference refuses to build this component: every output NaN
+        for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<true>(a, n);
+        return;
+    }
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<false>(a, n);
     m.end(a);
 }
 
