@@ -287,6 +287,7 @@ struct UdebArgs {
     int32_t step_begin, step_end;
     int32_t n_scen;
     int32_t n_layers, steps_per_year, land_hc, efficacy_apply;  // uniform over the ensemble
+    int32_t fast;           // RSCM_MODE_FAST: one refinement term of the row reciprocals instead of two
     const double* params;   // [37][N], ClimateUDEBParameters order (include/rscm_gpu.h)
     uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
     const double* erf;      // [S][T]

@@ -1445,6 +1445,7 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.steps_per_year = h->udeb_steps;
         a.land_hc = h->udeb_land_hc;
         a.efficacy_apply = h->udeb_efficacy;
+        a.fast = h->mode == RSCM_MODE_FAST ? 1 : 0;
         a.params = h->d_params;
         a.uniform_rows = h->uniform_rows;
         a.erf = h->d_forcing;

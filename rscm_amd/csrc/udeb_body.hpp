@@ -216,20 +216,40 @@ __device__ __forceinline__ LamResult lamcalc(const UdebP& p, double ecs)
     return out;
 }
 
-__device__ __forceinline__ double sst_to_air(const UdebP& p, double sst)
+// The scalar model code between the column solves (mod.rs:487-560), shared by the two kernels (so that they carry the same
+// bits).  ClimateUDEB is a tolerance-parity kind: a quotient by a value that is fixed for the launch or for the year is a
+// product with its reciprocal, formed once -- six IEEE divisions (58 cycles each) less per sub-step.
+struct AirMap {       // sst_to_air (ocean_column.rs): alpha sst + gamma sst^2 up to the vertex of the parabola, parallel to sst beyond it
+    double alpha, gamma, t_star, delta_max;
+};
+__device__ __forceinline__ AirMap make_air_map(const UdebP& p)
 {
-    const double t_star = fabs(p.gamma) > 1e-15 ? -(p.alpha - 1.0) / (2.0 * p.gamma) : __builtin_inf();
-    if (sst < t_star) return p.alpha * sst + p.gamma * sst * sst;
-    const double delta_max = p.alpha * t_star + p.gamma * t_star * t_star - t_star;
-    return sst + delta_max;
+    AirMap m;
+    m.alpha = p.alpha;
+    m.gamma = p.gamma;
+    m.t_star = fabs(p.gamma) > 1e-15 ? -(p.alpha - 1.0) / (2.0 * p.gamma) : __builtin_inf();
+    m.delta_max = p.alpha * m.t_star + p.gamma * m.t_star * m.t_star - m.t_star;   // (not used when t_star is infinite)
+    return m;
+}
+__device__ __forceinline__ double sst_to_air(const AirMap& m, double sst)
+{
+    if (sst < m.t_star) return m.alpha * sst + m.gamma * sst * sst;
+    return sst + m.delta_max;
 }
 
-__device__ __forceinline__ double land_temperature(const UdebP& p, double ocean_temp, double land_forcing,
-                                                   double land_fraction, double lambda_land)
+// land_temperature: (f_land fg_l + k_lo amplify t_air) / (lambda_land fg_l + k_lo), capped; the denominator is the year's
+__device__ __forceinline__ double land_temperature(double ka, double max_temp, double ocean_temp, double land_forcing, double land_fraction,
+                                                   double r_den)
 {
-    const double numerator = land_forcing * land_fraction + p.k_lo * p.amplify * ocean_temp;
-    const double denominator = lambda_land * land_fraction + p.k_lo;
-    return fmin(numerator / denominator, p.max_temp);
+    const double numerator = land_forcing * land_fraction + ka * ocean_temp;
+    return fmin(numerator * r_den, max_temp);
+}
+
+// the effective forcing at sub-step step_idx of the year: linear between the year's ends, times the efficacy factor
+__device__ __forceinline__ double substep_forcing(double erf_start, double erf_end, int32_t step_idx, double inv_steps, double eff_scale)
+{
+    const double frac = (double)step_idx * inv_steps;
+    return (erf_start + frac * (erf_end - erf_start)) * eff_scale;
 }
 
 // Per-member geometry folded with this year's sub-step length, and everything else of a column
@@ -259,7 +279,8 @@ struct YearGeom {
 //   d_i        = T_i + (pi*tul*T0)*af_diff[i] + (dt/dz*dw)*G[i]
 //   G[i]       = init[i+1]*af_bot[i] - init[i]*af_top[i] + T_polar*af_diff[i]   (host table)
 // and the Thomas recurrences with one refined reciprocal per row; c' is kept negated.
-template <int NL>
+// FAST (RSCM_MODE_FAST): one refinement term of the row reciprocals instead of two (relative error 2^-46 instead of 2^-69 per row).
+template <int NL, bool FAST>
 __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom& y,
                                                   const double* tables, int32_t land_hc,
                                                   double (&dp)[NL], int hemi,
@@ -327,7 +348,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
             // feeds the next row's denominator is five dependent operations instead of seven
             const double r0 = __builtin_amdgcn_rcp(denom);
             const double e = __builtin_fma(-denom, r0, 1.0);
-            const double u = __builtin_fma(e, e, e);
+            const double u = FAST ? e : __builtin_fma(e, e, e);
             const double t = (tdd + tul) * af_bot[i] * r0;
             ncp[i] = __builtin_fma(t, u, t);
             const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
@@ -373,7 +394,9 @@ struct Udeb1 {
     double up_nh, up_sh, land_nh, land_sh, gr_nh, gr_sh, ae_nh, ae_sh, hx_nh, hx_sh;
     double win_sum, hist_last;   // running window sum of the temperature history: entries [win_lo, n-1) after year n-1
     int32_t win_lo;
-    double c_ground, c_mix, steps;
+    double c_ground, c_mix, steps, inv_steps;
+    AirMap airmap;
+    double hxf_nh, hxf_sh, inv_thresh_nh, inv_thresh_sh, ka, w_min;   // k_ns / f_ocean, 1 / t_thresh, k_lo amplify, w0 (1 - f_var)
     const double* F;
     size_t f_stride;
 
@@ -445,13 +468,21 @@ struct Udeb1 {
         F = a.link ? a.link + i : a.erf + (size_t)scen * a.n_times;   // a linked forcing is another ensemble's [T][N] series
         f_stride = a.link ? (size_t)N : (size_t)1;
         steps = (double)a.steps_per_year;
+        inv_steps = 1.0 / steps;
         c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
         c_mix = heat_capacity_per_unit_area(p.dz_mix);
+        airmap = make_air_map(p);
+        hxf_nh = p.fgno > 1e-15 ? p.k_ns / p.fgno : 0.0;
+        hxf_sh = p.fgso > 1e-15 ? p.k_ns / p.fgso : 0.0;
+        inv_thresh_nh = 1.0 / p.t_thresh_nh;
+        inv_thresh_sh = 1.0 / p.t_thresh_sh;
+        ka = p.k_lo * p.amplify;
+        w_min = p.w0 * (1.0 - p.f_var);
     }
 
     // model step n -> n + 1.  CHECK_DEAD = false: the caller has dealt with members the reference refuses to build
     // (nan_rows) and calls step() only for the others.
-    template <bool CHECK_DEAD = true>
+    template <bool CHECK_DEAD = true, bool FAST = false>
     __device__ __forceinline__ void step(const UdebArgs& a, int32_t n)
     {
         const size_t r0 = (size_t)n * N + i, r1 = r0 + (size_t)N;
@@ -541,16 +572,17 @@ struct Udeb1 {
                 y.lhc[h] = a.land_hc ? p.k_lg * dt_sub / (c_mix * f_o) : 0.0;
             }
         }
+        // the year's constants of the scalar model code
+        const double eff_scale = eff_mode == 1 ? p.prescribed_eff : eff_mode == 2 ? p.prescribed_eff / co2_eff : 1.0;
+        const double r_land_nh = 1.0 / (lam_l * p.fgnl + p.k_lo), r_land_sh = 1.0 / (lam_l * p.fgsl + p.k_lo);
+        const double gfac_nh = (a.land_hc && !(p.fgnl < 1e-15)) ? p.k_lg / (p.fgnl * c_ground) * dt_sub : 0.0;
+        const double gfac_sh = (a.land_hc && !(p.fgsl < 1e-15)) ? p.k_lg / (p.fgsl * c_ground) * dt_sub : 0.0;
         for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
-            const double frac = (double)step_idx / steps;
-            const double erf = erf_start + frac * (erf_end - erf_start);
-            double adj = erf;
-            if (eff_mode == 1) adj = erf * p.prescribed_eff;
-            else if (eff_mode == 2) adj = erf * p.prescribed_eff / co2_eff;
+            const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f0 = adj * p.q0, f1 = adj * p.q1, f2 = adj * p.q2, f3 = adj * p.q3;
             if (a.land_hc) {
-                if (!(p.fgnl < 1e-15)) gr_nh += p.k_lg * (land_nh - gr_nh) / (p.fgnl * c_ground) * dt_sub;
-                if (!(p.fgsl < 1e-15)) gr_sh += p.k_lg * (land_sh - gr_sh) / (p.fgsl * c_ground) * dt_sub;
+                gr_nh = __builtin_fma(land_nh - gr_nh, gfac_nh, gr_nh);
+                gr_sh = __builtin_fma(land_sh - gr_sh, gfac_sh, gr_sh);
             }
             // NH then SH, the solver instantiated for each (a loop around one copy ties the register allocation of the
             // solve to its back edge: 360 instead of 92 accumulator moves per sub-step)
@@ -558,10 +590,10 @@ struct Udeb1 {
 #pragma unroll
             for (int hemi = 0; hemi < 2; ++hemi) {
                 const bool sh = hemi != 0;
-                sst_pair[hemi] = step_hemisphere<NL>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
-                                                     sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
-                                                     sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
-                                                     sh ? up_sh : up_nh);
+                sst_pair[hemi] = step_hemisphere<NL, FAST>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
+                                                           sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
+                                                           sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
+                                                           sh ? up_sh : up_nh);
                 // exchange the solved column with the parked hemisphere
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
@@ -571,21 +603,19 @@ struct Udeb1 {
                 }
             }
             const double sst_nh = sst_pair[0], sst_sh = sst_pair[1];
-            const double t_air_nho = sst_to_air(p, sst_nh), t_air_sho = sst_to_air(p, sst_sh);
-            land_nh = land_temperature(p, t_air_nho, f1, p.fgnl, lam_l);
-            land_sh = land_temperature(p, t_air_sho, f3, p.fgsl, lam_l);
-            if (p.fgno > 1e-15) hx_nh = p.k_ns / p.fgno * (t_air_sho - t_air_nho);
-            if (p.fgso > 1e-15) hx_sh = p.k_ns / p.fgso * (t_air_nho - t_air_sho);
+            const double t_air_nho = sst_to_air(airmap, sst_nh), t_air_sho = sst_to_air(airmap, sst_sh);
+            land_nh = land_temperature(ka, p.max_temp, t_air_nho, f1, p.fgnl, r_land_nh);
+            land_sh = land_temperature(ka, p.max_temp, t_air_sho, f3, p.fgsl, r_land_sh);
+            if (p.fgno > 1e-15) hx_nh = hxf_nh * (t_air_sho - t_air_nho);
+            if (p.fgso > 1e-15) hx_sh = hxf_sh * (t_air_nho - t_air_sho);
             const double global_temp = t_air_nho * p.fgno + land_nh * p.fgnl + t_air_sho * p.fgso + land_sh * p.fgsl;
-            {   // update_upwelling
-                const double w_min = p.w0 * (1.0 - p.f_var);
-                up_nh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp / p.t_thresh_nh, 1.0)), w_min);
-                up_sh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp / p.t_thresh_sh, 1.0)), w_min);
-            }
+            // update_upwelling
+            up_nh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh_nh, 1.0)), w_min);
+            up_sh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh_sh, 1.0)), w_min);
         }
         // ---- end of year
         const double sst_nh = col[0], sst_sh = park[0][lane];
-        const double air_nh = sst_to_air(p, sst_nh), air_sh = sst_to_air(p, sst_sh);
+        const double air_nh = sst_to_air(airmap, sst_nh), air_sh = sst_to_air(airmap, sst_sh);
         ae_nh = fabs(sst_nh) < 1e-15 ? p.alpha : air_nh / sst_nh;
         ae_sh = fabs(sst_sh) < 1e-15 ? p.alpha : air_sh / sst_sh;
         const double global_temp = air_nh * p.fgno + land_nh * p.fgnl + air_sh * p.fgso + land_sh * p.fgsl;
@@ -673,7 +703,7 @@ struct Udeb2Lds {
 
 // The same implicit sub-step as step_hemisphere of the one-thread kernel (same row algebra, same order of
 // operations: the two kernels agree bit for bit), for ONE hemisphere per lane.
-template <int NL, int KC>
+template <int NL, int KC, bool FAST>
 __device__ __forceinline__ double step_column(const UdebP& p, const YearGeom& y, const double* tables, int32_t land_hc,
                                               double (&dp)[NL], int hemi, double (*cp)[kUdeb2Block], int tid,
                                               double forcing, double hemi_hx, double ground_temp,
@@ -736,7 +766,7 @@ __device__ __forceinline__ double step_column(const UdebP& p, const YearGeom& y,
             const double denom = __builtin_fma(-tdu_aft, nc_prev, bi);
             const double r0 = __builtin_amdgcn_rcp(denom);
             const double e = __builtin_fma(-denom, r0, 1.0);
-            const double u = __builtin_fma(e, e, e);
+            const double u = FAST ? e : __builtin_fma(e, e, e);
             const double t = (tdd + tul) * af_bot[i] * r0;
             nc_prev = __builtin_fma(t, u, t);
             if (i < KC) cp[i][tid] = nc_prev; else ncr[i - KC] = nc_prev;
@@ -781,7 +811,9 @@ struct Udeb2 {
     double top_o;                  // the other hemisphere's mixed-layer temperature as of the last year end
     double win_sum, hist_last;
     int32_t win_lo;
-    double c_ground, c_mix, steps;
+    double c_ground, c_mix, steps, inv_steps;
+    AirMap airmap;
+    double hxf, inv_thresh, ka, w_min;   // this hemisphere's k_ns / f_ocean and 1 / t_thresh; k_lo amplify, w0 (1 - f_var)
     const double* F;
     size_t f_stride;
     uint32_t n_sub;                // sub-steps taken in this launch (parity of the exchange slots)
@@ -850,11 +882,21 @@ struct Udeb2 {
         F = a.link ? a.link + i : a.erf + (size_t)scen * a.n_times;   // a linked forcing is another ensemble's [T][N] series
         f_stride = a.link ? (size_t)N : (size_t)1;
         steps = (double)a.steps_per_year;
+        inv_steps = 1.0 / steps;
         c_ground = a.land_hc ? heat_capacity_per_unit_area(p.land_hc_thick) : 0.0;
         c_mix = heat_capacity_per_unit_area(p.dz_mix);
+        airmap = make_air_map(p);
+        {
+            const double fg_ocean = hemi ? p.fgso : p.fgno;
+            hxf = fg_ocean > 1e-15 ? p.k_ns / fg_ocean : 0.0;
+            inv_thresh = 1.0 / (hemi ? p.t_thresh_sh : p.t_thresh_nh);
+        }
+        ka = p.k_lo * p.amplify;
+        w_min = p.w0 * (1.0 - p.f_var);
     }
 
     // model step n -> n + 1 (one launch may take many)
+    template <bool FAST = false>
     __device__ __forceinline__ void step(const UdebArgs& a, int32_t n)
     {
         const bool sh = hemi != 0;
@@ -911,7 +953,6 @@ struct Udeb2 {
         // this hemisphere's boxes
         const double fg_o = sh ? p.fgso : p.fgno, fg_l = sh ? p.fgsl : p.fgnl;
         const double q_o = sh ? p.q2 : p.q0, q_l = sh ? p.q3 : p.q1;
-        const double t_thresh = sh ? p.t_thresh_sh : p.t_thresh_nh;
         YearGeom y;
         {
             const double dz1 = p.dz / 2.0;
@@ -934,20 +975,18 @@ struct Udeb2 {
             y.famp[0] = y.famp[1] = 1.0 + p.k_lo * f_l / den;
             y.lhc[0] = y.lhc[1] = a.land_hc ? p.k_lg * dt_sub / (c_mix * f_o) : 0.0;
         }
+        // the year's constants of the scalar model code (the same expressions as in Udeb1::step)
+        const double eff_scale = eff_mode == 1 ? p.prescribed_eff : eff_mode == 2 ? p.prescribed_eff / co2_eff : 1.0;
+        const double r_land = 1.0 / (lam_l * fg_l + p.k_lo);
+        const double gfac = (a.land_hc && !(fg_l < 1e-15)) ? p.k_lg / (fg_l * c_ground) * dt_sub : 0.0;
         double t_air = 0.0, t_air_o = 0.0;
         for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
-            const double frac = (double)step_idx / steps;
-            const double erf = erf_start + frac * (erf_end - erf_start);
-            double adj = erf;
-            if (eff_mode == 1) adj = erf * p.prescribed_eff;
-            else if (eff_mode == 2) adj = erf * p.prescribed_eff / co2_eff;
+            const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f_ocean = adj * q_o, f_land = adj * q_l;
-            if (a.land_hc) {
-                if (!(fg_l < 1e-15)) gr += p.k_lg * (land - gr) / (fg_l * c_ground) * dt_sub;
-            }
-            const double sst = step_column<NL, KC>(p, y, tables, a.land_hc, col, hemi, lds.cp, tid, f_ocean, hx, gr, land, ae_y, up);
-            t_air = sst_to_air(p, sst);
-            land = land_temperature(p, t_air, f_land, fg_l, lam_l);
+            if (a.land_hc) gr = __builtin_fma(land - gr, gfac, gr);
+            const double sst = step_column<NL, KC, FAST>(p, y, tables, a.land_hc, col, hemi, lds.cp, tid, f_ocean, hx, gr, land, ae_y, up);
+            t_air = sst_to_air(airmap, sst);
+            land = land_temperature(ka, p.max_temp, t_air, f_land, fg_l, r_land);
             // what the other hemisphere needs of this one: air and land temperature
             const uint32_t par = n_sub & 1u;
             lds.xs[par][hemi][0][lane] = t_air;
@@ -956,18 +995,15 @@ struct Udeb2 {
             t_air_o = lds.xs[par][1 - hemi][0][lane];
             land_o = lds.xs[par][1 - hemi][1][lane];
             ++n_sub;
-            if (fg_o > 1e-15) hx = p.k_ns / fg_o * (t_air_o - t_air);
+            if (fg_o > 1e-15) hx = hxf * (t_air_o - t_air);
             const double a_nh = sh ? t_air_o : t_air, l_nh = sh ? land_o : land;
             const double a_sh = sh ? t_air : t_air_o, l_sh = sh ? land : land_o;
             const double global_temp = a_nh * p.fgno + l_nh * p.fgnl + a_sh * p.fgso + l_sh * p.fgsl;
-            {   // update_upwelling
-                const double w_min = p.w0 * (1.0 - p.f_var);
-                up = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp / t_thresh, 1.0)), w_min);
-            }
+            up = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh, 1.0)), w_min);   // update_upwelling
         }
         // ---- end of year
         const double sst = col[0];
-        const double air = sst_to_air(p, sst);
+        const double air = sst_to_air(airmap, sst);
         ae = fabs(sst) < 1e-15 ? p.alpha : air / sst;
         const double rho_c = kRhoSeawater * kCpSeawater;
         const uint32_t ypar = (uint32_t)n & 1u;

@@ -11,6 +11,7 @@ import test_gpu_udeb as T  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nyears = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 1: RSCM_MODE_FAST
 years = np.arange(1750.0, 1750.0 + nyears)
 b = np.append(years, years[-1] + 1.0)
 P = T._ensemble_params(orc, n, seed=3)
@@ -19,7 +20,8 @@ F = np.stack([np.where(years >= 1751, 3.71, 0.0),
               -1.5 * np.ones(len(years))])
 scen = (np.arange(n) % 3).astype(np.int32)
 want, wst = orc.udeb_run(b, P, F, scen=scen, threads=16)
-got, st = T._gpu(ra, b, P, F, scen=scen)
+got, st = T._gpu(ra, b, P, F, scen=scen, mode=mode)
+print(f"mode {mode}, {n} members x {nyears} years")
 assert (st == wst).all()
 for k in T.NAMES:
     g, w = got[k], want[k]

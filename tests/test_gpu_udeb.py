@@ -36,8 +36,10 @@ def orc():
     return cbind
 
 
-def _gpu(ra, bounds, P, erf, scen=None, chunks=()):
+def _gpu(ra, bounds, P, erf, scen=None, chunks=(), mode=None):
     with ra.Ensemble(ra.KIND_UDEB, P.shape[1], bounds) as e:
+        if mode is not None:
+            e.set_mode(mode)
         e.set_params(P)
         e.set_forcing(erf, scen)
         for k in range(1, 5):
@@ -111,6 +113,34 @@ def test_udeb_gpu_other_layer_counts(ra, orc, n_layers, n_members):
             Q = P.copy()
             Q[orc.UDEB_PARAM_NAMES.index("n_layers")] = 25.0
             _gpu(ra, b, Q, F, scen=scen)
+
+
+@pytest.mark.parametrize("n_members", [257, 40000])   # the two-wavefront kernel and the one-thread kernel
+def test_udeb_gpu_fast_mode(ra, orc, n_members):
+    """RSCM_MODE_FAST: one refinement term of the row reciprocals instead of two (relative error 2^-46 instead of 2^-69
+    per row of the column solve).  The same 1e-9 bar against the oracle as the default mode (measured: 1e-13, printed);
+    the two kernels carry the same bits in this mode too; launch boundaries change nothing."""
+    years = np.arange(1850.0, 1981.0)
+    b = np.append(years, 1981.0)
+    P = _ensemble_params(orc, n_members, seed=9)
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0), 3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0)])
+    scen = (np.arange(n_members) % 2).astype(np.int32)
+    pick = np.arange(n_members) if n_members <= 512 else np.arange(256)
+    want, wst = orc.udeb_run(b, P[:, pick].copy(), F, scen=scen[pick].copy(), threads=8)
+    got, st = _gpu(ra, b, P, F, scen=scen, mode=ra.MODE_FAST)
+    exact, _ = _gpu(ra, b, P, F, scen=scen)
+    assert not st.any() and not wst.any()
+    _assert_close({k: v[:, pick] for k, v in got.items()}, want, "FAST")
+    worst = max(float(np.nanmax(np.abs(got[k] - exact[k]) / np.maximum(1.0, np.abs(exact[k])))) for k in NAMES)
+    print(f"ClimateUDEB FAST vs default mode, {n_members} members x {len(years) - 1} years: max relative deviation {worst:.2e}")
+    assert 0.0 < worst < 1e-11
+    again, _ = _gpu(ra, b, P, F, scen=scen, chunks=(1, 50), mode=ra.MODE_FAST)
+    for k in NAMES:
+        assert np.array_equal(again[k], got[k], equal_nan=True), k
+    if n_members > 32768:   # the first members through the other kernel: the same bits
+        small, _ = _gpu(ra, b, P[:, :256].copy(), F, scen=scen[:256].copy(), mode=ra.MODE_FAST)
+        for k in NAMES:
+            assert np.array_equal(small[k], got[k][:, :256], equal_nan=True), k
 
 
 def test_udeb_gpu_ensemble_vs_oracle(ra, orc):
