@@ -457,20 +457,23 @@ def main():
                                       ("coupled_1e6", 1_000_000, 0, True)):
             side(label, lambda members=members, m=m, cp=cp: two_layer_case(members, m, cp))
 
-        def udeb_case():
-            # next row: rscm-magicc ClimateUDEB, 1e5 members, 12 sub-steps per year
-            e3 = make_udeb_ensemble(100_000, local_rank, stream)
+        def udeb_case(members):
+            # next row: rscm-magicc ClimateUDEB, 12 sub-steps per year (65 536 members: one wavefront per
+            # SIMD, exactly one round; 1e5: 1563 wavefronts on 1024 SIMDs, two rounds; 32 768: the two-wavefront kernel)
+            e3 = make_udeb_ensemble(members, local_rank, stream)
             w3, k3 = timed_passes(e3, 2, 1, torch, dist, 1, tstream)
             e3.close()
-            return {"member_years_per_s": 100_000 * years * 2 / w3, "kernel_ms": k3,
+            return {"member_years_per_s": members * years * 2 / w3, "kernel_ms": k3,
                     # 7 output rows + the history row written, ~1 history entry read back;
                     # the ocean columns stay in registers/LDS for the whole launch
-                    "hbm_frac": 72.0 * 100_000 * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    # ~26.4e3 f64 VALU instructions per member-year (24 column solves of
-                    # ~1055 + LAMCALC + bookkeeping) against 39.3 T f64 lane-ops/s
-                    "fp64_valu_frac": 26.4e3 * 100_000 * years / (k3 * 1e-3) / 39.3e12}
+                    "hbm_frac": 72.0 * members * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    # ~25.6e3 f64 VALU instructions per member-year (24 column solves of ~1020 + LAMCALC +
+                    # bookkeeping; scripts/isa_blocks.py) against 39.3 T f64 lane-ops/s
+                    "fp64_valu_frac": 25.6e3 * members * years / (k3 * 1e-3) / 39.3e12}
 
-        side("udeb_1e5", udeb_case)
+        side("udeb_1e5", lambda: udeb_case(100_000))
+        side("udeb_65536", lambda: udeb_case(65_536))
+        side("udeb_32768", lambda: udeb_case(32_768))
 
         def ghg_case(method):
             # rscm-magicc GhgForcing: a pointwise component, 24 B of ERF written per member-year
