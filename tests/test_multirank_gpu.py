@@ -50,3 +50,13 @@ def test_sharded_sampler_reproduces_the_single_rank_chain(tmp_path, ranks):
         assert res["world"] == ranks and res["ok"], res
         for case in res["cases"]:
             assert case["positions_bit_equal"] and case["log_probs_bit_equal"] and case["counters_equal"]
+
+
+@pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
+def test_sharded_graph_sampler_reproduces_the_single_rank_chain(tmp_path):
+    """rscm_sampler_create_graph with n_ranks = 2: a graph of four linked ensembles as the evaluator, the walkers split over the
+    ranks -- the single-rank chain, bit for bit."""
+    for res in _launch("rehearse_sharded_sampler.py", 2, 29551, tmp_path, ["--graph", "--walkers", "2048", "--sweeps", "3"]):
+        assert res["world"] == 2 and res["ok"] and res["evaluator"] == "graph", res
+        for case in res["cases"]:
+            assert case["positions_bit_equal"] and case["log_probs_bit_equal"] and case["counters_equal"]
