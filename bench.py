@@ -183,6 +183,50 @@ def calibration_extra(device, walkers=100_000, iterations=20):
             "walkers": walkers, "acceptance_rate": sampler.acceptance_rate()}
 
 
+def graph_calibration_extra(device, walkers=100_000, iterations=10):
+    """The calibration loop with a GRAPH as the evaluator (rscm_sampler_create_graph): CarbonCycle -> CO2ERF -> Sum -> TwoLayer as
+    four linked ensembles, TwoLayer.lambda0 and CarbonCycle.tau sampled (two owners), Ts and CO2 observed 1800..1940 (two owners);
+    per half-step the graph runs 190 steps in one launch and is scored on the device."""
+    from rscm_amd import calibrate as cal
+    from rscm_amd import core
+    from rscm_amd.components import CarbonCycleBuilder, CO2ERFBuilder
+    from rscm_amd.two_layer import TwoLayerBuilder
+    t = np.arange(1750.0, 1951.0)
+    axis = core.TimeAxis.from_values(t)
+    schema = core.VariableSchema()
+    for n in ["Emissions|CO2|Anthropogenic", "Surface Temperature", "Deep Ocean Temperature", "Atmospheric Concentration|CO2",
+              "Cumulative Land Uptake", "Cumulative Emissions|CO2", "Effective Radiative Forcing|CO2", "Effective Radiative Forcing|Other"]:
+        schema.add_variable(n, "")
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum", ["Effective Radiative Forcing|CO2", "Effective Radiative Forcing|Other"])
+    tl = dict(lambda0=1.1, a=0.0, efficacy=1.2, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    b = (core.ModelBuilder().with_device(device).with_time_axis(axis).with_schema(schema)
+         .with_rust_component(CarbonCycleBuilder.from_parameters(dict(tau=25.0, conc_pi=278.0, alpha_temperature=0.05)).build())
+         .with_rust_component(CO2ERFBuilder.from_parameters(dict(erf_2xco2=3.7, conc_pi=278.0)).build())
+         .with_rust_component(TwoLayerBuilder.from_parameters(tl).build())
+         .with_exogenous_variable("Emissions|CO2|Anthropogenic",
+                                  core.Timeseries(np.interp(t, [1750.0, 1850.0, 1950.0], [1.0, 1.5, 4.0]), axis, "", core.InterpolationStrategy.Linear))
+         .with_exogenous_variable("Effective Radiative Forcing|Other", core.Timeseries(0.2 * np.sin(t / 9.0), axis, "", core.InterpolationStrategy.Linear))
+         .with_initial_values({"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
+                               "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    runner = cal.ModelRunner(b, ["TwoLayer.lambda0", "tau"], ["Surface Temperature", "Atmospheric Concentration|CO2"])
+    truth = runner.run([1.25, 30.0])
+    target = cal.Target()
+    for yr in range(1800, 1941, 10):
+        target.add_observation("Surface Temperature", float(yr), truth["Surface Temperature"][float(yr)], 0.005)
+        target.add_observation("Atmospheric Concentration|CO2", float(yr), truth["Atmospheric Concentration|CO2"][float(yr)], 0.1)
+    params = cal.ParameterSet().add("TwoLayer.lambda0", cal.Uniform(0.8, 1.6)).add("tau", cal.Uniform(15.0, 45.0))
+    sampler = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    sampler.run(2, cal.WalkerInit.from_prior(), n_walkers=walkers, seed=1)  # warm-up
+    t0 = time.perf_counter()
+    sampler.run(iterations, cal.WalkerInit.from_prior(), thin=iterations, n_walkers=walkers, seed=2)
+    dt = time.perf_counter() - t0
+    runner.close()
+    return {"model_evaluations_per_s": walkers * iterations / (sampler.device_ms * 1e-3),
+            "device_ms_per_iteration": sampler.device_ms / iterations, "wall_s_per_iteration": dt / iterations,
+            "walkers": walkers, "steps_per_evaluation": 190, "acceptance_rate": sampler.acceptance_rate(),
+            "note": "four linked ensembles as the sampler's evaluator; proposals, lock-step run, likelihood and accept step on the device"}
+
+
 def one_pass(ens):
     ens.rewind()
     ens.run(sync=False)
@@ -529,6 +573,8 @@ def main():
         # BASELINE.json configs[4]: the calibration loop, 1e5 walkers per iteration, stretch move
         # and likelihood on the device (rscm_sampler_*)
         side("calibrate_device_1e5", lambda: calibration_extra(local_rank))
+        # ... and with a graph of linked ensembles as the evaluator (rscm_sampler_create_graph)
+        side("calibrate_graph_device_1e5", lambda: graph_calibration_extra(local_rank))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
