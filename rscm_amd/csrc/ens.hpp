@@ -205,3 +205,11 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
 int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed);
 }
+
+// the fused run+likelihood pieces the sampler (sampler_host.cpp) shares with rscm_ens_run_loglik (rscm_gpu.cpp)
+extern "C" {
+int prepare_obs(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_t* obs_tidx, const double* obs_value, const double* obs_sigma,
+                int32_t normalize);
+int check_loglik_ready(rscm_ens* h);
+hipError_t launch_loglik(rscm_ens* h);   // asynchronous, with the prepared observations; fills h->d_loglik
+}

@@ -30,7 +30,8 @@ namespace {
 
 constexpr int kKindUdeb = 2, kKindOceanCarbon = 11;   // RSCM_KIND_UDEB, RSCM_KIND_OCEAN_CARBON (rscm_gpu.cpp asserts)
 
-template <int NL>
+// UFAST: ClimateUDEB's arithmetic mode (one kernel per mode: both inlined into one function cost the column solve 6 % more)
+template <int NL, bool UFAST>
 __global__ __launch_bounds__(kUdebBlock) void graph_kernel(const GraphHeavy hv, const GroupOp* __restrict__ ops, int32_t n_ops, int64_t n_members,
                                                            int32_t step_begin, int32_t step_end, unsigned long long* __restrict__ stamps)
 {
@@ -64,8 +65,7 @@ __global__ __launch_bounds__(kUdebBlock) void graph_kernel(const GraphHeavy hv, 
         for (int32_t k = 0; k < n_ops; ++k, stamp(ops[k - 1].kind & 31)) {
             const GroupOp& op = ops[k];
             if (op.kind == kKindUdeb) {
-                if (hv.udeb.fast) ud.template step<true, true>(hv.udeb, b);
-                else ud.template step<true, false>(hv.udeb, b);
+                ud.template step<true, UFAST>(hv.udeb, b);
             } else if (op.kind == kKindOceanCarbon) {
                 ocean::ocean_recur_run<60, 2>(hv.ocean, hv.ocean.irf, hv.ocean.mode_table, ib, b, b + 1, hv.ocean.rebuild != 0 && b == step_begin);
             } else if (b > step_begin) {   // the slots hold what the previous step left
@@ -89,7 +89,8 @@ hipError_t launch_graph(const GraphHeavy& hv, const GroupOp* d_ops, int32_t n_op
     if (hv.has_ocean && (!hv.ocean.recur || hv.ocean.near != 60 || hv.ocean.steps != 12)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_members + kUdebBlock - 1) / kUdebBlock));
     const size_t lds = (size_t)cache_slots * kUdebBlock * sizeof(double);
-    hipLaunchKernelGGL(graph_kernel<50>, grid, dim3(kUdebBlock), lds, s, hv, d_ops, n_ops, n_members, step_begin, step_end, stamps);
+    if (hv.has_udeb && hv.udeb.fast) hipLaunchKernelGGL((graph_kernel<50, true>), grid, dim3(kUdebBlock), lds, s, hv, d_ops, n_ops, n_members, step_begin, step_end, stamps);
+    else hipLaunchKernelGGL((graph_kernel<50, false>), grid, dim3(kUdebBlock), lds, s, hv, d_ops, n_ops, n_members, step_begin, step_end, stamps);
     return hipGetLastError();
 }
 
