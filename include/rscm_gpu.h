@@ -338,8 +338,13 @@ extern "C" {
                              bit-identical to the CPU oracle for the two-layer kind            */
 #define RSCM_MODE_FAST 1  /* FMA + reciprocal heat capacities; |rel diff| <= 1e-11 on bounded
                              trajectories (tests/test_gpu_parity.py states the tolerance).
-                             RSCM_KIND_OCEAN_CARBON: fused multiply-add in the history convolution
-                             (tests/test_gpu_ocean.py).  The other kinds have one arithmetic.  */
+                             RSCM_KIND_OCEAN_CARBON: the history convolution in O(T) -- the last 60 (2D-BERN:
+                             120) monthly lags explicitly, the older ones through 21 decaying modes fitted to the
+                             impulse response; within 2e-10 of EXACT (tests/test_gpu_ocean.py; the tiled
+                             convolution with fused multiply-adds where the fit does not apply).
+                             RSCM_KIND_UDEB: one refinement term of the column solve's row reciprocals instead
+                             of two (1.4e-13 from the oracle instead of 5e-14; the same 1e-9 bar,
+                             tests/test_gpu_udeb.py).  The other kinds have one arithmetic.  */
 
 typedef struct rscm_ens rscm_ens;
 
