@@ -279,7 +279,7 @@ extern "C" {
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
  * Rows marked [u] are structural and must be equal for every member; the device supports
- * n_layers = 50 and ocean_temp_profile = 2 (CMIP5). */
+ * n_layers = 20, 30, 40 or 50 (the column solve is unrolled per layer count) and ocean_temp_profile = 2 (CMIP5). */
 #define RSCM_UD_NPARAMS 37
 #define RSCM_UD_P_N_LAYERS 0              /* [u] */
 #define RSCM_UD_P_MIXED_LAYER_DEPTH 1     /* [u] */
