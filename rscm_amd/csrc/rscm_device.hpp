@@ -296,7 +296,7 @@ struct UdebArgs {
     const double* bounds;   // [T+1] (device)
     const int32_t* win_kfull;  // [T] first history entry that enters the cumulative-T window whole
     const double* win_partw;   // [T] weight of entry win_kfull-1 (0: not in the window)
-    // af_top[NL] af_bot[NL] af_diff[NL] (1-rel_depth)[NL] G_nh[NL] G_sh[NL], NL = n_layers <= 50, packed: passed BY
+    // rows [NL][6] = {af_top, af_bot, af_diff, 1 - rel_depth, G_nh, G_sh}, NL = n_layers <= 50 (udeb_tables.hpp): passed BY
     // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
     double tables[6 * 50];
     double* ocean;          // [2][NL][N] layer temperatures

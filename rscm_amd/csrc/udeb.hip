@@ -61,13 +61,12 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
     m.end(a);
 }
 
-// Two wavefronts per 64 members, one hemisphere each (udeb_body.hpp).  WAVES: wavefronts per SIMD the register
-// budget is cut for (1: all of c' in registers; 2: KC of its entries in LDS).
-template <int NL, int KC, int WAVES, bool FAST>
-__global__ __launch_bounds__(kUdeb2Block, WAVES) void udeb2_kernel(UdebArgs a)
+// Two wavefronts per 64 members, one hemisphere each (udeb_body.hpp), one wavefront per SIMD.
+template <int NL, bool FAST>
+__global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
 {
-    __shared__ Udeb2Lds<KC> lds;
-    Udeb2<NL, KC> m(lds);
+    __shared__ Udeb2Lds lds;
+    Udeb2<NL> m(lds);
     m.begin(a);
     for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<FAST>(a, n);
     m.end(a);
@@ -80,8 +79,8 @@ static void launch_udeb_nl(const UdebArgs& a, bool two_waves, hipStream_t s)
 {
     if (two_waves) {
         const dim3 grid((unsigned)((a.n_members + 63) / 64));
-        if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, 0, 1, true>), grid, dim3(kUdeb2Block), 0, s, a);
-        else hipLaunchKernelGGL((udeb2_kernel<NL, 0, 1, false>), grid, dim3(kUdeb2Block), 0, s, a);
+        if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true>), grid, dim3(kUdeb2Block), 0, s, a);
+        else hipLaunchKernelGGL((udeb2_kernel<NL, false>), grid, dim3(kUdeb2Block), 0, s, a);
     } else {
         const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
         if (a.fast) hipLaunchKernelGGL((udeb_kernel<NL, true>), grid, dim3(kUdebBlock), 0, s, a);

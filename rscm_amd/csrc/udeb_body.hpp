@@ -280,6 +280,18 @@ struct YearGeom {
 //   G[i]       = init[i+1]*af_bot[i] - init[i]*af_top[i] + T_polar*af_diff[i]   (host table)
 // and the Thomas recurrences with one refined reciprocal per row; c' is kept negated.
 // FAST (RSCM_MODE_FAST): one refinement term of the row reciprocals instead of two (relative error 2^-46 instead of 2^-69 per row).
+//
+// The geometry tables are rows of six values per layer, [NL][6] = {af_top, af_bot, af_diff, 1 - relative depth, G_nh, G_sh}
+// (udeb_tables.hpp), wave-uniform and read with scalar loads.  Scalar loads return out of order, so a wavefront can only wait for
+// ALL of its outstanding ones (s_waitcnt lgkmcnt(0)); with one wavefront per SIMD every batch of table values that is loaded where
+// it is needed exposes its full latency -- 49 waits per sub-step, a fifth of the solve's time.  The sweep therefore walks the
+// column in chunks of kRowsAhead rows: at the top of a chunk the values of the chunk (requested a whole chunk earlier) are
+// awaited, then the next chunk's rows are requested, then the chunk's arithmetic runs under those loads.  An opaque zero offset
+// per solve keeps the loads from being hoisted out of the sub-step and year loops (hundreds of scalar registers, spilled into
+// vector lanes), and a scheduling barrier per chunk keeps each request where it is written.
+constexpr int kRowsAhead = 3;
+constexpr int kTabCols = 6;
+
 template <int NL, bool FAST>
 __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom& y,
                                                   const double* tables, int32_t land_hc,
@@ -287,79 +299,103 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
                                                   double forcing, double hemi_hx, double ground_temp,
                                                   double land_temp, double alpha_eff, double w)
 {
-    // The 5 x NL table values of a solve are wave-uniform and read with scalar loads where they are used; an opaque
-    // zero offset per solve keeps the compiler from hoisting them out of the sub-step and year loops (hundreds of
-    // scalar registers spilled into vector lanes, one v_readlane pair per use).
+    constexpr int R = kRowsAhead;
+    constexpr int NCH = (NL + R - 1) / R;
     int32_t opaque = 0;
     asm volatile("" : "+s"(opaque));
-    tables += opaque;
-    const double* af_top = tables;            // [NL]
-    const double* af_bot = tables + NL;       // [NL]
-    const double* af_diff = tables + 2 * NL;  // [NL]
-    const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
-    const double* G = tables + 4 * NL + (size_t)hemi * NL;  // profile-advection weights
+    const double* __restrict__ tab = tables + opaque;
     const bool sh = hemi != 0;
+    double cur[R][kTabCols], nxt[R][kTabCols];
+    auto request = [&](double (&dst)[R][kTabCols], const double* __restrict__ from, int first) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < kTabCols; ++k) dst[r][k] = (first + r < NL) ? from[(size_t)(first + r) * kTabCols + k] : 0.0;
+    };
+    // The values of a chunk must have arrived before the next chunk is requested (one counter for all scalar loads): naming them
+    // as inputs of an empty asm puts the wait here, a whole chunk after the request.
+    auto await = [&](const double (&v)[R][kTabCols]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" ::"s"(v[r][0]), "s"(v[r][1]), "s"(v[r][2]), "s"(v[r][3]), "s"(v[r][4]), "s"(v[r][5]));
+    };
+    request(cur, tab, 0);
+
     const double t_top = dp[0];
     const double kslope = y.kdC * (t_top - dp[NL - 1]);
-    auto kappa_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope, y.kC), y.kminC); };
     // kappa_l * dt/dz^2 with the (positive) factor folded into the three constants: one multiply
     // less per interior row, the same value to rounding
     const double kslope2 = y.kdC2 * (t_top - dp[NL - 1]);
-    auto tdd_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope2, y.kC2), y.kminC2); };
     const double delta_w = w - p.w0;
     // |delta_w| <= 1e-15: the reference skips the profile-advection terms; adding exact zeros is
     // the same thing without a branch per row
     const double dwv = fabs(delta_w) > 1e-15 ? delta_w : 0.0;
-
-    double ncp[NL];  // -c'
-    const double kap0 = kappa_at(0);
-    {   // ---- row 0 (mixed layer)
-        const double term_diff = kap0 * y.dt_dzmixdz1;
-        const double term_upwell = w * y.dt_dzmix;
-        const double tf = alpha_eff * (sh ? y.fb[1] : y.fb[0]);
-        const double b0 = __builtin_fma(tf, af_top[0],
-                                        __builtin_fma(__builtin_fma(term_upwell, p.pi_ratio, term_diff), af_bot[0], 1.0));
-        const double nc0 = (term_diff + term_upwell) * af_bot[0];
-        const double q = __builtin_fma(forcing, sh ? y.famp[1] : y.famp[0], hemi_hx) * y.dt_cmix;
-        double d0 = __builtin_fma(q, af_top[0], t_top);
-        if (land_hc) d0 = __builtin_fma(-(land_temp - ground_temp) * (sh ? y.lhc[1] : y.lhc[0]), af_top[0], d0);
-        d0 = __builtin_fma(y.dt_dzmix * dwv, G[0], d0);
-        const double r = refined_rcp(b0);
-        ncp[0] = nc0 * r;
-        dp[0] = d0 * r;
-    }
-    // ---- interior rows and the bottom row: forward sweep
     const double tul = w * y.dt_dz;
     const double s_afd = p.pi_ratio * tul * t_top;
     const double dwq = y.dt_dz * dwv;
-    double tdu = kap0 * y.dt_dzdz1;  // row 1: dz_up = dz/2
+
+    double ncp[NL];  // -c'
+    double tdu = 0.0;
 #pragma unroll
-    for (int i = 1; i < NL; ++i) {
-        const double t_i = dp[i];
-        const double tdu_aft = tdu * af_top[i];
-        double bi, di;
-        if (i < NL - 1) {
-            const double tdd = tdd_at(i);
-            bi = __builtin_fma(tdu + tul, af_top[i], __builtin_fma(tdd, af_bot[i], 1.0));
-            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_diff[i], t_i));
-            const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
-            // 1/denom = r0 (1 + e + e^2 + ...), e = 1 - denom*r0: the hardware estimate is good
-            // to ~2^-23, so the series cut after e^2 is exact to rounding, and the c' chain that
-            // feeds the next row's denominator is five dependent operations instead of seven
-            const double r0 = __builtin_amdgcn_rcp(denom);
-            const double e = __builtin_fma(-denom, r0, 1.0);
-            const double u = FAST ? e : __builtin_fma(e, e, e);
-            const double t = (tdd + tul) * af_bot[i] * r0;
-            ncp[i] = __builtin_fma(t, u, t);
-            const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
-            dp[i] = __builtin_fma(sdp, u, sdp);
-            tdu = tdd;
-        } else {
-            bi = __builtin_fma(tdu + tul, af_top[i], 1.0);
-            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_top[i], t_i));
-            const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
-            dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
+    for (int c = 0; c < NCH; ++c) {
+        await(cur);
+        if (c + 1 < NCH) request(nxt, tab, (c + 1) * R);
+        // Nothing crosses: the request stays above the chunk it runs under (left alone the scheduler sinks it to where its values are
+        // used), and no arithmetic of the NEXT chunk is pulled up to wait on it.  Tried instead: ordering through data dependences
+        // only (the next request's address and the chunk's vector operands made to depend on the asm above) -- the requests sink
+        // again, 59.7 ms against 54.5 ms at 65 536 members x 750 years.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = c * R + r;
+            if (i >= NL) break;
+            const double af_top = cur[r][0], af_bot = cur[r][1], af_diff = cur[r][2], omr = cur[r][3], G = sh ? cur[r][5] : cur[r][4];
+            if (i == 0) {   // ---- row 0 (mixed layer)
+                const double kap0 = fmax(__builtin_fma(omr, kslope, y.kC), y.kminC);
+                const double term_diff = kap0 * y.dt_dzmixdz1;
+                const double term_upwell = w * y.dt_dzmix;
+                const double tf = alpha_eff * (sh ? y.fb[1] : y.fb[0]);
+                const double b0 = __builtin_fma(tf, af_top, __builtin_fma(__builtin_fma(term_upwell, p.pi_ratio, term_diff), af_bot, 1.0));
+                const double nc0 = (term_diff + term_upwell) * af_bot;
+                const double q = __builtin_fma(forcing, sh ? y.famp[1] : y.famp[0], hemi_hx) * y.dt_cmix;
+                double d0 = __builtin_fma(q, af_top, t_top);
+                if (land_hc) d0 = __builtin_fma(-(land_temp - ground_temp) * (sh ? y.lhc[1] : y.lhc[0]), af_top, d0);
+                d0 = __builtin_fma(y.dt_dzmix * dwv, G, d0);
+                const double rr = refined_rcp(b0);
+                ncp[0] = nc0 * rr;
+                dp[0] = d0 * rr;
+                tdu = kap0 * y.dt_dzdz1;  // row 1: dz_up = dz/2
+                continue;
+            }
+            // ---- interior rows and the bottom row: forward sweep
+            const double t_i = dp[i];
+            const double tdu_aft = tdu * af_top;
+            if (i < NL - 1) {
+                const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
+                const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
+                const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
+                const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
+                // 1/denom = r0 (1 + e + e^2 + ...), e = 1 - denom*r0: the hardware estimate is good
+                // to ~2^-23, so the series cut after e^2 is exact to rounding, and the c' chain that
+                // feeds the next row's denominator is five dependent operations instead of seven
+                const double r0 = __builtin_amdgcn_rcp(denom);
+                const double e = __builtin_fma(-denom, r0, 1.0);
+                const double u = FAST ? e : __builtin_fma(e, e, e);
+                const double t = (tdd + tul) * af_bot * r0;
+                ncp[i] = __builtin_fma(t, u, t);
+                const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
+                dp[i] = __builtin_fma(sdp, u, sdp);
+                tdu = tdd;
+            } else {
+                const double bi = __builtin_fma(tdu + tul, af_top, 1.0);
+                const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_top, t_i));
+                const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
+                dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < kTabCols; ++k) cur[r][k] = nxt[r][k];
     }
     // ---- back substitution, clamp.  thomas_solve returns the unclamped vector; the state keeps
     // min(x, max_temp)
@@ -691,113 +727,18 @@ struct Udeb1 {
 // ---------------------------------------------------------------------------------------------
 constexpr int kUdeb2Block = 128;
 
-// KC: how many entries of the c' array live in LDS instead of registers (the first KC rows: written first,
-// read back last).  KC = 0 keeps all of c' in registers (one wavefront per SIMD); KC >= 16 brings a lane under
-// 256 registers, i.e. two wavefronts per SIMD.
-template <int KC>
 struct Udeb2Lds {
-    double cp[KC > 0 ? KC : 1][kUdeb2Block];
     double xs[2][2][2][64];   // sub-step exchange [parity][hemisphere][air, land][lane]
     double xy[2][2][3][64];   // end-of-year exchange [parity][hemisphere][sst, air, heat-content partial][lane]
 };
-
-// The same implicit sub-step as step_hemisphere of the one-thread kernel (same row algebra, same order of
-// operations: the two kernels agree bit for bit), for ONE hemisphere per lane.
-template <int NL, int KC, bool FAST>
-__device__ __forceinline__ double step_column(const UdebP& p, const YearGeom& y, const double* tables, int32_t land_hc,
-                                              double (&dp)[NL], int hemi, double (*cp)[kUdeb2Block], int tid,
-                                              double forcing, double hemi_hx, double ground_temp,
-                                              double land_temp, double alpha_eff, double w)
-{
-    // The 5 x NL table values of a solve are wave-uniform and read with scalar loads where they are used.  Nothing
-    // in the solve changes from one sub-step to the next as far as their addresses go, so left to itself the
-    // compiler hoists all of them out of the sub-step and year loops (500 scalar registers, spilled into vector
-    // lanes: one v_readlane pair per use): an opaque zero offset per solve keeps the loads inside.
-    int32_t opaque = 0;
-    asm volatile("" : "+s"(opaque));
-    tables += opaque;
-    const double* af_top = tables;            // [NL]
-    const double* af_bot = tables + NL;       // [NL]
-    const double* af_diff = tables + 2 * NL;  // [NL]
-    const double* omr = tables + 3 * NL;      // 1 - relative depth, [NL-1]
-    const double* G = tables + 4 * NL + (size_t)hemi * NL;  // profile-advection weights
-    const bool sh = hemi != 0;
-    const double t_top = dp[0];
-    const double kslope = y.kdC * (t_top - dp[NL - 1]);
-    auto kappa_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope, y.kC), y.kminC); };
-    const double kslope2 = y.kdC2 * (t_top - dp[NL - 1]);
-    auto tdd_at = [&](int l) -> double { return fmax(__builtin_fma(omr[l], kslope2, y.kC2), y.kminC2); };
-    const double delta_w = w - p.w0;
-    const double dwv = fabs(delta_w) > 1e-15 ? delta_w : 0.0;
-
-    constexpr int NR = NL - KC > 0 ? NL - KC : 1;
-    double ncr[NR];  // -c' of rows KC .. NL-1 (registers); rows 0 .. KC-1 are in cp[row][tid]
-    double nc_prev;  // -c' of the row just eliminated
-    const double kap0 = kappa_at(0);
-    {   // ---- row 0 (mixed layer)
-        const double term_diff = kap0 * y.dt_dzmixdz1;
-        const double term_upwell = w * y.dt_dzmix;
-        const double tf = alpha_eff * (sh ? y.fb[1] : y.fb[0]);
-        const double b0 = __builtin_fma(tf, af_top[0],
-                                        __builtin_fma(__builtin_fma(term_upwell, p.pi_ratio, term_diff), af_bot[0], 1.0));
-        const double nc0 = (term_diff + term_upwell) * af_bot[0];
-        const double q = __builtin_fma(forcing, sh ? y.famp[1] : y.famp[0], hemi_hx) * y.dt_cmix;
-        double d0 = __builtin_fma(q, af_top[0], t_top);
-        if (land_hc) d0 = __builtin_fma(-(land_temp - ground_temp) * (sh ? y.lhc[1] : y.lhc[0]), af_top[0], d0);
-        d0 = __builtin_fma(y.dt_dzmix * dwv, G[0], d0);
-        const double r = refined_rcp(b0);
-        nc_prev = nc0 * r;
-        if (0 < KC) cp[0][tid] = nc_prev; else ncr[0] = nc_prev;
-        dp[0] = d0 * r;
-    }
-    const double tul = w * y.dt_dz;
-    const double s_afd = p.pi_ratio * tul * t_top;
-    const double dwq = y.dt_dz * dwv;
-    double tdu = kap0 * y.dt_dzdz1;  // row 1: dz_up = dz/2
-#pragma unroll
-    for (int i = 1; i < NL; ++i) {
-        const double t_i = dp[i];
-        const double tdu_aft = tdu * af_top[i];
-        double bi, di;
-        if (i < NL - 1) {
-            const double tdd = tdd_at(i);
-            bi = __builtin_fma(tdu + tul, af_top[i], __builtin_fma(tdd, af_bot[i], 1.0));
-            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_diff[i], t_i));
-            const double denom = __builtin_fma(-tdu_aft, nc_prev, bi);
-            const double r0 = __builtin_amdgcn_rcp(denom);
-            const double e = __builtin_fma(-denom, r0, 1.0);
-            const double u = FAST ? e : __builtin_fma(e, e, e);
-            const double t = (tdd + tul) * af_bot[i] * r0;
-            nc_prev = __builtin_fma(t, u, t);
-            if (i < KC) cp[i][tid] = nc_prev; else ncr[i - KC] = nc_prev;
-            const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
-            dp[i] = __builtin_fma(sdp, u, sdp);
-            tdu = tdd;
-        } else {
-            bi = __builtin_fma(tdu + tul, af_top[i], 1.0);
-            di = __builtin_fma(dwq, G[i], __builtin_fma(s_afd, af_top[i], t_i));
-            const double denom = __builtin_fma(-tdu_aft, nc_prev, bi);
-            dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
-        }
-    }
-    double x = dp[NL - 1];
-    dp[NL - 1] = fmin(x, p.max_temp);
-#pragma unroll
-    for (int i = NL - 2; i >= 0; --i) {
-        const double nc = i < KC ? cp[i][tid] : ncr[i - KC];
-        x = __builtin_fma(nc, x, dp[i]);
-        dp[i] = fmin(x, p.max_temp);
-    }
-    return dp[0];
-}
 
 // One member-hemisphere of a ClimateUDEB ensemble across the model steps of a launch: begin() (construction
 // or resume), step(n) for consecutive n, end() (internal state back to HBM).  Every thread of the workgroup
 // must make the same calls: step() and begin() hold workgroup barriers.  Lanes past the end of the ensemble
 // compute on a copy of the last member and store nothing.
-template <int NL, int KC>
+template <int NL>
 struct Udeb2 {
-    Udeb2Lds<KC>& lds;
+    Udeb2Lds& lds;
     int tid, lane;
     int hemi;        // 0: northern column, 1: southern (wave-uniform)
     int64_t N, i;
@@ -818,7 +759,7 @@ struct Udeb2 {
     size_t f_stride;
     uint32_t n_sub;                // sub-steps taken in this launch (parity of the exchange slots)
 
-    __device__ __forceinline__ explicit Udeb2(Udeb2Lds<KC>& l) : lds(l) {}
+    __device__ __forceinline__ explicit Udeb2(Udeb2Lds& l) : lds(l) {}
 
     // (the launch arguments are handed to every call instead of being kept: a reference held in this object makes
     // the compiler copy the by-value kernel argument -- 2.6 KB with the geometry tables -- into scratch)
@@ -984,7 +925,7 @@ struct Udeb2 {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f_ocean = adj * q_o, f_land = adj * q_l;
             if (a.land_hc) gr = __builtin_fma(land - gr, gfac, gr);
-            const double sst = step_column<NL, KC, FAST>(p, y, tables, a.land_hc, col, hemi, lds.cp, tid, f_ocean, hx, gr, land, ae_y, up);
+            const double sst = step_hemisphere<NL, FAST>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up);   // the same function as the one-thread kernel: the same bits
             t_air = sst_to_air(airmap, sst);
             land = land_temperature(ka, p.max_temp, t_air, f_land, fg_l, r_land);
             // what the other hemisphere needs of this one: air and land temperature

@@ -52,15 +52,17 @@ inline double ocean_area_at_depth(double depth_m, double depth_dependent_area)
     return 1.0 + depth_dependent_area * (hydro - 1.0);
 }
 
-// af_top[n] af_bot[n] af_diff[n] one_minus_rel[n] G_nh[n] G_sh[n], where G folds the initial
+// One row of six values per layer, [n][6] = {af_top, af_bot, af_diff, 1 - relative depth, G_nh, G_sh} (a solve reads its
+// tables row by row: the values of a few rows are one contiguous scalar load), where G folds the initial
 // profile and the polar sinking temperature (ClimateUDEBState::new: 1.0) into the weight the
 // profile-advection term of row l carries (ocean_column.rs step_hemisphere):
 //   G[0]     = (init[1] - T_polar) * af_bot[0]
 //   G[l]     = init[l+1]*af_bot[l] - init[l]*af_top[l] + T_polar*af_diff[l]      0 < l < n-1
 //   G[n-1]   = (T_polar - init[n-1]) * af_top[n-1]
+constexpr int kUdebTableCols = 6;
 inline std::vector<double> udeb_tables(int n, double dz_mix, double dz, double depth_dependent_area)
 {
-    std::vector<double> t(6 * (size_t)n, 0.0);
+    std::vector<double> aft((size_t)n), afb((size_t)n), afd((size_t)n), omr((size_t)n, 0.0);
     for (int l = 0; l < n; ++l) {
         double z_top, z_bottom;
         if (l == 0) { z_top = 0.0; z_bottom = dz_mix; }
@@ -68,23 +70,29 @@ inline std::vector<double> udeb_tables(int n, double dz_mix, double dz, double d
         const double a_top = ocean_area_at_depth(z_top, depth_dependent_area);
         const double a_bottom = ocean_area_at_depth(z_bottom, depth_dependent_area);
         const double a_avg = (a_top + a_bottom) / 2.0;
-        t[l] = a_top / a_avg;
-        t[n + l] = a_bottom / a_avg;
-        t[2 * n + l] = (a_top - a_bottom) / a_avg;
+        aft[l] = a_top / a_avg;
+        afb[l] = a_bottom / a_avg;
+        afd[l] = (a_top - a_bottom) / a_avg;
     }
     const double total_depth = dz_mix + ((double)n - 1.0) * dz;
     for (int l = 0; l < n - 1; ++l) {
         const double depth = dz_mix + (double)l * dz;
-        t[3 * n + l] = 1.0 - depth / total_depth;
+        omr[l] = 1.0 - depth / total_depth;
     }
+    std::vector<double> t((size_t)kUdebTableCols * n, 0.0);
     const double t_polar = 1.0;
+    for (int l = 0; l < n; ++l) {
+        t[(size_t)l * kUdebTableCols + 0] = aft[l];
+        t[(size_t)l * kUdebTableCols + 1] = afb[l];
+        t[(size_t)l * kUdebTableCols + 2] = afd[l];
+        t[(size_t)l * kUdebTableCols + 3] = omr[l];
+    }
     for (int hemi = 0; hemi < 2; ++hemi) {
         auto init = [&](int l) { return l < 50 ? cmip5_profile(hemi)[l] : cmip5_profile(hemi)[49]; };
-        double* G = &t[(4 + (size_t)hemi) * n];
-        const double *aft = &t[0], *afb = &t[n], *afd = &t[2 * (size_t)n];
-        G[0] = (init(1) - t_polar) * afb[0];
-        for (int l = 1; l < n - 1; ++l) G[l] = init(l + 1) * afb[l] - init(l) * aft[l] + t_polar * afd[l];
-        G[n - 1] = (t_polar - init(n - 1)) * aft[n - 1];
+        auto G = [&](int l) -> double& { return t[(size_t)l * kUdebTableCols + 4 + hemi]; };
+        G(0) = (init(1) - t_polar) * afb[0];
+        for (int l = 1; l < n - 1; ++l) G(l) = init(l + 1) * afb[l] - init(l) * aft[l] + t_polar * afd[l];
+        G(n - 1) = (t_polar - init(n - 1)) * aft[n - 1];
     }
     return t;
 }
