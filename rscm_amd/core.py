@@ -860,8 +860,7 @@ class ModelBuilder:
                     if last:
                         return out_var
 
-            for agg, (_, op, contributors, weights) in aggregates.items():
-                contributors = list(contributors)
+            def scalar_aggregate(agg: str, op: str, contributors: List[str], weights) -> None:
                 agg_stages[agg] = []
                 if op == "Mean" and len(contributors) > L.AG_NINPUTS:
                     total = chain(agg, "Sum", "Sum", contributors, [], "", False)
@@ -869,6 +868,49 @@ class ModelBuilder:
                     add_stage(agg, f"Aggregator:{agg}", "Quotient", [total, count], [], agg, True)
                 else:
                     chain(agg, op, op, contributors, list(weights or []), "", True)
+
+            for agg, (_, op, contributors, weights) in aggregates.items():
+                contributors = list(contributors)
+                grid = aggregates[agg].grid_type
+                if grid == GridType.Hemispheric:
+                    raise NotImplementedError(f"aggregate {agg!r}: no component of this package produces a Hemispheric variable")
+                if grid == GridType.FourBox:
+                    # AggregatorComponent::solve for a FourBox aggregate (schema.rs:902-923): compute_aggregate per region over the
+                    # contributors' values of that region.  A FourBox variable is four scalar series here, so the aggregate is four
+                    # scalar aggregates "<name>|box<k>" (k = 0..3: the reference's region order) over box k of every contributor,
+                    # plus the scalar view of the result -- sum(value * weight) over the boxes, what a component that declares the
+                    # variable as a scalar input reads (read transform, state/aggregating.rs:162-176) -- under the aggregate's name.
+                    stages: List[Tuple[str, List[str]]] = []
+                    homes = []
+                    for b in range(4):
+                        rows_b = []
+                        for c in contributors:
+                            cb = f"{c}|box{b}"
+                            if cb not in var_home:
+                                if c not in model._fourbox:
+                                    raise ValueError(f"Grid type mismatch: contributor {c!r} of the FourBox aggregate {agg!r} is not a FourBox variable")
+                                owner_c, first_c, _ = model._fourbox[c]
+                                var_home[cb] = (owner_c, first_c + b)
+                            rows_b.append(cb)
+                        scalar_aggregate(f"{agg}|box{b}", op, rows_b, weights)
+                        stages += agg_stages.pop(f"{agg}|box{b}")
+                        homes.append(var_home[f"{agg}|box{b}"])
+                    tname = f"Transform:{agg}"
+                    tr = Ensemble(L.KIND_AGGREGATE, n_members, bounds, device=self._device,
+                                  window_rows=series_window if windowed else None,
+                                  output_stride=output_stride if (want_out is None or agg in want_out) else 0)
+                    ensembles[tname] = tr
+                    tr.set_stream(stream.value)
+                    w = self._grid_weights.get(GridType.FourBox, [0.25, 0.25, 0.25, 0.25])
+                    tr.set_params(params_of([L.AG_OPERATIONS["Weighted"]] + list(w) + [0.0] * 4))
+                    var_home[agg] = (tname, 1)
+                    stages.append((tname, [f"{agg}|box{b}" for b in range(4)]))
+                    agg_stages[agg] = stages
+                    model._fourbox_aggregates[agg] = homes
+                    at = order.index(f"Aggregator:{agg}")
+                    order[at:at + 1] = [n for n, _ in stages]
+                    continue
+                scalar_aggregate(agg, op, contributors, weights)
                 stages = agg_stages[agg]
                 if len(stages) > 1:  # the partial stages run right before the aggregate itself
                     at = order.index(f"Aggregator:{agg}")
@@ -931,6 +973,16 @@ class ModelBuilder:
             for name, (owner, vid) in var_home.items():
                 if name in self._initial:
                     ensembles[owner].set_initial(vid, self._initial[name])
+            for agg, homes in model._fourbox_aggregates.items():
+                if agg in self._initial:  # one scalar for the four regions (builder.rs:797-804); the scalar view was set above
+                    w = self._grid_weights.get(GridType.FourBox, [0.25, 0.25, 0.25, 0.25])
+                    x0 = self._initial[agg]
+                    for owner_b, vid_b in homes:
+                        ensembles[owner_b].set_initial(vid_b, x0)
+                    s0 = 0.0
+                    for wk in w:
+                        s0 = s0 + x0 * wk
+                    ensembles[f"Transform:{agg}"].set_initial(1, s0)
             for owner, ens in list(ensembles.items()):
                 fb = L.FOURBOX_VARS.get(ens.kind)
                 if fb and fb[0] in self._initial:  # a FourBox state initialised with one scalar (builder.rs:797-804)
@@ -1160,6 +1212,7 @@ class GraphModel:
         self._host_nodes: Dict[str, "_HostNode"] = {}  # Python components, stepped on the host
         self._reads_unwritten = False  # some component reads index n+1 of a producer that runs after it
         self._fourbox: Dict[str, Tuple[str, int, bool]] = {}  # FourBox variable -> (producer, first id, stored as scalar)
+        self._fourbox_aggregates: Dict[str, List[Tuple[str, int]]] = {}  # FourBox aggregate -> (ensemble, id) of each region
         self._windowed = False      # ensembles keep a sliding window of rows + strided outputs (build(series_window=...))
         self._output_stride = 1
         self.time_index = 0
@@ -1331,8 +1384,12 @@ class GraphModel:
             boxes = np.stack([ens.get_series(v, m_begin=member, m_end=member + 1)[:, 0] for v in range(first, first + 4)], axis=1)
             coll.add_fourbox_timeseries(name, FourBoxTimeseries(boxes, self._axis, "K" if ens.kind == L.KIND_UDEB else "W/m^2"))
             skip.add(name)
+        for name, homes in self._fourbox_aggregates.items():
+            boxes = np.stack([self.ensembles[o].get_series(v, m_begin=member, m_end=member + 1)[:, 0] for o, v in homes], axis=1)
+            coll.add_fourbox_timeseries(name, FourBoxTimeseries(boxes, self._axis, ""))
+            skip.add(name)
         for name, (owner, vid) in self._var_home.items():
-            if name in skip or "#partial" in name:  # partial sums of aggregates with more than eight contributors are internal
+            if name in skip or "#partial" in name or "|box" in name:  # partial sums and the per-region series of FourBox variables are internal
                 continue
             vals = self.ensembles[owner].get_series(vid, m_begin=member, m_end=member + 1)[:, 0]
             coll.add_timeseries(name, Timeseries(vals, self._axis, "", InterpolationStrategy.Linear), VariableType.Endogenous)

@@ -296,6 +296,84 @@ def test_aggregate_of_more_than_eight_contributors(api, operation):
     model.close()
 
 
+@pytest.mark.parametrize("operation", ["Sum", "Mean", "Weighted"])
+def test_fourbox_aggregate_per_region_and_its_scalar_view(api, operation):
+    """A FourBox-typed aggregate (AggregatorComponent::solve, schema.rs:902-923): compute_aggregate per region over the contributors'
+    values of that region at n + 1.  Two FourBox producers (AerosolDirect's regional forcing, FourBoxOceanHeatUptake's regional heat
+    uptake) are aggregated region by region; TwoLayer declares its forcing as a scalar and reads the aggregate through the read
+    transform (sum over the regions of value x weight, state/aggregating.rs:162-176).  Checked: every region of the aggregate is the
+    running combination of the contributors' regions in declaration order, bit for bit; the scalar view is the weighted sum of the
+    regions; the TwoLayer run equals a stand-alone ensemble forced with that scalar series as an upstream output; the collection
+    holds the aggregate as a FourBox timeseries."""
+    import rscm_amd as ra
+    from rscm_amd import magicc as B
+    from rscm_amd.components import FourBoxOceanHeatUptakeBuilder
+    c = api.core
+    t = np.arange(1850.0, 1891.0)
+    axis = c.TimeAxis.from_values(t)
+    yr = t - 1850.0
+    direct, uptake, agg = "Effective Radiative Forcing|Aerosol|Direct", "Heat Uptake|Ocean", "Effective Radiative Forcing"
+    exo = {"Emissions|SOx": 2.0 + 1.5 * yr, "Emissions|BC": 2.5 + 0.1 * yr, "Emissions|OC": 10.0 + 0.3 * yr, "Emissions|NOx": 10.0 + 0.5 * yr,
+           "Effective Radiative Forcing|Aggregated": 0.5 + 0.04 * yr + 0.2 * np.sin(yr / 3.0)}
+    schema = c.VariableSchema()
+    for n in list(exo) + ["Surface Temperature", "Deep Ocean Temperature"]:
+        schema.add_variable(n, "")
+    schema.add_variable(direct, "", c.GridType.FourBox)
+    schema.add_variable(uptake, "", c.GridType.FourBox)
+    weights = [1.0, -0.5] if operation == "Weighted" else None
+    schema.add_aggregate(agg, "", operation, [direct, uptake], weights, grid_type=c.GridType.FourBox)
+    fixed = dict(lambda0=1.1, a=0.05, efficacy=1.3, eta=0.7, heat_capacity_surface=8.0, heat_capacity_deep=100.0)
+    ratios = dict(northern_ocean_ratio=1.1, northern_land_ratio=0.8, southern_ocean_ratio=1.2, southern_land_ratio=0.9)
+    b = (c.ModelBuilder().with_time_axis(axis).with_schema(schema)
+         .with_rust_component(B.AerosolDirectBuilder.from_parameters({}).build())
+         .with_rust_component(FourBoxOceanHeatUptakeBuilder.from_parameters(ratios).build())
+         .with_rust_component(api.TwoLayerBuilder.from_parameters(fixed).build())
+         .with_initial_values({"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
+    for n, v in exo.items():
+        b = b.with_exogenous_variable(n, c.Timeseries(v, axis, "", c.InterpolationStrategy.Linear))
+    model = b.build(execution_order="topological")
+    assert isinstance(model, c.GraphModel)
+    mine = [n for n in model._order if n == f"Transform:{agg}" or n.startswith(f"Aggregator:{agg}|box")]
+    assert mine == [f"Aggregator:{agg}|box{k}" for k in range(4)] + [f"Transform:{agg}"]
+    model.run()
+    ad, ohu = model.ensembles["AerosolDirect"], model.ensembles["FourBoxOceanHeatUptake"]
+    view = np.zeros(len(t))
+    for k in range(4):
+        a_k, u_k = ad.get_series(1 + k)[:, 0], ohu.get_series(1 + k)[:, 0]
+        got = model.get_series(f"{agg}|box{k}")[:, 0]
+        want = np.full(len(t), np.nan)
+        if operation == "Sum":
+            want[1:] = (0.0 + a_k[1:]) + u_k[1:]
+        elif operation == "Mean":
+            want[1:] = ((0.0 + a_k[1:]) + u_k[1:]) / 2.0
+        else:
+            want[1:] = (0.0 + a_k[1:] * 1.0) + u_k[1:] * -0.5
+        assert_bit_equal(got, want, f"{operation}, region {k}")
+        view = view + np.nan_to_num(got) * 0.25 if k else 0.0 + np.nan_to_num(got) * 0.25
+    scalar = model.get_series(agg)[:, 0]
+    assert_bit_equal(scalar[1:], view[1:], "the scalar view: sum over the regions of value x 0.25")
+    # TwoLayer read that scalar at n + 1 (an upstream output)
+    bounds = np.append(t, t[-1] + 1.0)
+    with ra.Ensemble(ra.KIND_TWO_LAYER, 1, bounds) as e:
+        e.set_params(np.array([[fixed[k]] for k in fixed]))
+        e.set_forcing(np.nan_to_num(scalar), None, ra.SRC_UPSTREAM)
+        e.set_initial(1, 0.0)
+        e.set_initial(2, 0.0)
+        e.run()
+        assert_bit_equal(model.get_series("Surface Temperature")[:, 0], e.get_series(1)[:, 0], "TwoLayer forced by the FourBox aggregate's scalar view")
+    coll = model.timeseries()
+    fb = coll.get_fourbox_timeseries_by_name(agg)
+    assert fb is not None and not any("|box" in n for n in coll.names())
+    model.close()
+    # a contributor that is not a FourBox variable is refused like the reference refuses a grid-type mismatch
+    bad = c.VariableSchema()
+    bad.add_variable("Emissions|SOx", "")
+    bad.add_variable(direct, "", c.GridType.FourBox)
+    bad.add_aggregate("X", "", "Sum", [direct, "Emissions|SOx"], None, grid_type=c.GridType.FourBox)
+    with pytest.raises(ValueError, match="Grid type mismatch"):
+        bad.validate()
+
+
 def _tl_runner(api, t, F, names, outputs=("Surface Temperature",), mode=0):
     c = api.core
     erf = c.Timeseries(F, c.TimeAxis.from_values(t), "W/m^2", c.InterpolationStrategy.Linear)
