@@ -40,6 +40,14 @@ int fail(int code, const char* fmt, ...);
 #define NEED(h) \
     if (!(h)) return fail(RSCM_ERR_INVALID, "handle is NULL")
 
+// Window upkeep of the handles of a lock-step run, collected while a model step (or a chunk of steps) is enqueued and issued as
+// one or two launches at its end (rscm_device.hpp, WindowBatch).  first: moves and output-row copies; second: fills; then the
+// windows' new first rows take effect on the host side.
+struct WindowDeferral {
+    std::vector<rscm::WindowOp> first, second;
+    std::vector<std::pair<rscm_ens*, int32_t>> new_win0;
+};
+
 // Cached state of rscm_ens_run_lockstep for one list of handles (kept by the first of them): the device
 // table of fused-launch operations (csrc/group.hip) and what it currently holds.
 struct LockstepPlan {
@@ -134,6 +142,7 @@ struct rscm_ens {
     int32_t link_refs = 0;  // links of other ensembles into this one's series
 
     LockstepPlan* plan = nullptr;  // rscm_ens_run_lockstep with this handle first
+    WindowDeferral* defer = nullptr;  // set while rscm_ens_run_lockstep collects this handle's window upkeep (lockstep.cpp)
 
     int32_t time_index = 0;
     bool params_set = false, forcing_set = false;
@@ -205,6 +214,8 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
 int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed);
 }
+// issue what a WindowDeferral holds on `stream` and make the new windows current (rscm_gpu.cpp)
+int window_flush(WindowDeferral* d, hipStream_t stream);
 
 // the fused run+likelihood pieces the sampler (sampler_host.cpp) shares with rscm_ens_run_loglik (rscm_gpu.cpp)
 extern "C" {

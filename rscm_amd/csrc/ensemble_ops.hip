@@ -83,6 +83,37 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(double* src, int64
     }
 }
 
+// many of the three above in one launch (rscm_device.hpp, WindowBatch): blockIdx.y picks the descriptor
+__global__ __launch_bounds__(kBlock) void window_batch_kernel(const WindowBatch batch)
+{
+    const WindowOp& op = batch.ops[blockIdx.y];
+    const int64_t N = op.N;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t x0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (op.kind == 0) {
+        const int64_t per_var = (int64_t)op.keep * N, total = per_var * op.n_vars;
+        for (int64_t x = x0; x < total; x += stride) {
+            const int64_t v = x / per_var, o = x - v * per_var;
+            double* var = op.buf + (size_t)v * op.R * N;
+            var[o] = var[(size_t)op.shift * N + o];
+        }
+    } else if (op.kind == 1) {
+        const int64_t total = (int64_t)op.n_out * N;
+        for (int64_t x = x0; x < total; x += stride) {
+            const int64_t k = x / N, i = x - k * N;
+            const int64_t v = op.vars ? op.vars[k] - 1 : k;
+            op.dst[((size_t)k * op.dst_rows + op.dst_row) * N + i] = op.buf[((size_t)v * op.R + op.src_row) * N + i];
+        }
+    } else {
+        const int64_t per_var = (int64_t)(op.R - op.fill_from) * N, total = per_var * op.n_vars;
+        const double nan = __builtin_nan("");
+        for (int64_t x = x0; x < total; x += stride) {
+            const int64_t v = x / per_var, o = x - v * per_var;
+            op.buf[(size_t)v * op.R * N + (size_t)op.fill_from * N + o] = nan;
+        }
+    }
+}
+
 // ---- Gaussian log-likelihood ----------------------------------------------------------------
 // per observation: residual = obs - model; chi = (residual*residual)/(sigma*sigma); l = -0.5*chi;
 // normalised: l -= 0.5*ln(2*pi); l -= ln(sigma).  Per-variable partial sums, then their total
@@ -331,6 +362,22 @@ hipError_t launch_scatter_rows(double* src, int64_t N, int32_t src_rows, int32_t
     if (n_out <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(stream_grid((int64_t)n_out * N)), dim3(kBlock), 0, s, src, N, src_rows, src_row, vars, n_out,
                        dst, dst_rows, dst_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_batch(const WindowBatch& batch, int32_t n_ops, hipStream_t s)
+{
+    if (n_ops <= 0) return hipSuccess;
+    if (n_ops > kMaxWindowOps) return hipErrorInvalidValue;
+    int64_t most = 1;
+    for (int32_t k = 0; k < n_ops; ++k) {
+        const WindowOp& op = batch.ops[k];
+        const int64_t total = op.kind == 0 ? (int64_t)op.keep * op.N * op.n_vars
+                            : op.kind == 1 ? (int64_t)op.n_out * op.N : (int64_t)(op.R - op.fill_from) * op.N * op.n_vars;
+        most = std::max(most, total);
+    }
+    const unsigned gx = (unsigned)std::min<int64_t>((most + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(window_batch_kernel, dim3(gx, (unsigned)n_ops), dim3(kBlock), 0, s, batch);
     return hipGetLastError();
 }
 

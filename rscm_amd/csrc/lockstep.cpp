@@ -293,6 +293,14 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
             if (!plan->staging) HIPCHK(hipHostMalloc((void**)&plan->staging, LockstepPlan::kRing * sizeof(rscm::GroupOp), hipHostMallocDefault));
         }
     }
+    // The window upkeep of the graph's handles (slides at the end of the step that fills a window, output rows) is collected while
+    // a step -- or a chunk of steps in one launch -- is enqueued and issued in one or two launches at its end.
+    WindowDeferral deferral;
+    struct DeferGuard {
+        rscm_ens* const* hs; int32_t n;
+        DeferGuard(rscm_ens* const* h, int32_t k, WindowDeferral* d) : hs(h), n(k) { for (int32_t i = 0; i < n; ++i) hs[i]->defer = d; }
+        ~DeferGuard() { for (int32_t i = 0; i < n; ++i) hs[i]->defer = nullptr; }
+    } guard(handles, n_handles, t_ls.fuse ? &deferral : nullptr);
     if (whole || (segments.size() == 1 && segments[0].second > 1)) {
         // The whole graph is one fused segment: many model steps per launch.  A chunk ends where a windowed
         // handle runs out of rows (its window slides between launches).
@@ -305,11 +313,12 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
             t_ls.launches += 1;
             t_ls.component_steps += (int64_t)n_handles * len;
             if (int rc = fused_segment(plan, 0, n_handles, n, len, whole)) return rc;
+            if (int rc = window_flush(&deferral, handles[0]->stream)) return rc;
             n += len;
         }
         return RSCM_OK;
     }
-    for (int32_t n = step_begin; n < step_end; ++n)
+    for (int32_t n = step_begin; n < step_end; ++n) {
         for (const auto& sgm : segments) {
             t_ls.launches += 1;
             t_ls.component_steps += sgm.second;
@@ -319,6 +328,8 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
                 return rc;
             }
         }
+        if (int rc = window_flush(&deferral, handles[0]->stream)) return rc;
+    }
     return RSCM_OK;
     GUARD_END
 }

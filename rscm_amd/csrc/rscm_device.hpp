@@ -573,6 +573,27 @@ hipError_t launch_gather_rows(const double* src, int64_t N, int32_t src_rows, in
                               double* dst, int32_t dst_rows, int32_t dst_row, hipStream_t s);
 hipError_t launch_scatter_rows(double* src, int64_t N, int32_t src_rows, int32_t src_row, const int32_t* vars, int32_t n_out,
                                const double* dst, int32_t dst_rows, int32_t dst_row, hipStream_t s);
+// The window upkeep of a lock-step graph (slides, NaN fills, output rows) batched: one launch over a table of up to
+// kMaxWindowOps descriptors instead of one small launch per ensemble and event.  A descriptor is a row move (rows [shift, shift +
+// keep) of every variable to the front; shift >= keep: source and destination rows are disjoint), a row copy into the output store,
+// or a fill of rows [fill_from, R).  Moves and copies only read what neither of them writes and go in one launch; fills (which
+// overwrite the rows the moves read) in a second one.
+constexpr int kMaxWindowOps = 40;
+struct WindowOp {
+    double* buf;          // [n_vars][R][N]
+    const int32_t* vars;  // copy: variable ids kept in the output store (null: every variable, in order)
+    double* dst;          // copy: [n_out][dst_rows][N]
+    int64_t N;
+    int32_t R, n_vars;
+    int32_t kind;         // 0: move, 1: copy, 2: fill
+    int32_t shift, keep;  // move
+    int32_t src_row, n_out, dst_rows, dst_row;  // copy
+    int32_t fill_from;    // fill (with NaN)
+};
+struct WindowBatch {
+    WindowOp ops[kMaxWindowOps];
+};
+hipError_t launch_window_batch(const WindowBatch& batch, int32_t n_ops, hipStream_t s);
 // partial[4*n_blocks] then reduced into out[4] = {count_finite, sum, min, max}
 hipError_t launch_summary(const double* row, int64_t n, double* partial, int32_t n_blocks,
                           double* out, hipStream_t s);

@@ -426,6 +426,24 @@ int window_slide(rscm_ens* h, int32_t new_win0)
     const int32_t shift = new_win0 - h->win0;
     if (!h->windowed || shift <= 0) return RSCM_OK;
     const int32_t cnt = std::max(0, h->rows - shift);  // rows still inside the new window
+    if (h->defer && shift >= cnt) {
+        // a lock-step run: the move is issued with every other handle's at the end of the model step; until then this handle's
+        // base address and win0 stay what they are (consumers later in the step read the rows where they still lie)
+        for (const auto& pending : h->defer->new_win0)
+            if (pending.first == h) return fail(RSCM_ERR_STATE, "two window slides of one handle in one lock-step flush");
+        if (cnt > 0) {
+            rscm::WindowOp op{};
+            op.buf = h->d_series; op.N = h->N; op.R = h->rows; op.n_vars = h->V - 1; op.kind = 0; op.shift = shift; op.keep = cnt;
+            h->defer->first.push_back(op);
+        }
+        if (h->read_ahead || cnt == 0) {
+            rscm::WindowOp op{};
+            op.buf = h->d_series; op.N = h->N; op.R = h->rows; op.n_vars = h->V - 1; op.kind = 2; op.fill_from = cnt;
+            h->defer->second.push_back(op);
+        }
+        h->defer->new_win0.emplace_back(h, new_win0);
+        return RSCM_OK;
+    }
     HIPCHK(rscm::launch_slide_rows(h->d_series, h->N, h->rows, h->V - 1, shift, cnt, h->stream));
     if (h->read_ahead || cnt == 0)
         HIPCHK(rscm::launch_fill_rows(h->d_series, h->N, h->rows, h->V - 1, cnt, std::numeric_limits<double>::quiet_NaN(), h->stream));
@@ -450,12 +468,37 @@ int window_seek(rscm_ens* h, int32_t k)
 int window_store_row(rscm_ens* h, int32_t t)
 {
     if (!h->windowed || h->n_out == 0 || t % h->out_stride != 0) return RSCM_OK;
+    if (h->defer) {
+        rscm::WindowOp op{};
+        op.buf = h->d_series; op.N = h->N; op.R = h->rows; op.n_vars = h->V - 1; op.kind = 1;
+        op.vars = h->d_out_vars; op.dst = h->d_out; op.src_row = t - h->win0; op.n_out = h->n_out; op.dst_rows = h->out_rows;
+        op.dst_row = t / h->out_stride;
+        h->defer->first.push_back(op);
+        return RSCM_OK;
+    }
     HIPCHK(rscm::launch_gather_rows(h->d_series, h->N, h->rows, t - h->win0, h->d_out_vars, h->n_out, h->d_out, h->out_rows,
                                     t / h->out_stride, h->stream));
     return RSCM_OK;
 }
 
 }  // namespace
+
+int window_flush(WindowDeferral* d, hipStream_t stream)
+{
+    for (std::vector<rscm::WindowOp>* list : {&d->first, &d->second}) {
+        for (size_t at = 0; at < list->size(); at += rscm::kMaxWindowOps) {
+            const size_t n = std::min(list->size() - at, (size_t)rscm::kMaxWindowOps);
+            rscm::WindowBatch batch;
+            memset((void*)&batch, 0, sizeof batch);
+            memcpy((void*)batch.ops, list->data() + at, n * sizeof(rscm::WindowOp));
+            HIPCHK(rscm::launch_window_batch(batch, (int32_t)n, stream));
+        }
+        list->clear();
+    }
+    for (const auto& w : d->new_win0) w.first->win0 = w.second;
+    d->new_win0.clear();
+    return RSCM_OK;
+}
 
 extern "C" {
 
@@ -1151,6 +1194,12 @@ int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end)
     if (int rc = set_device(h)) return rc;
     if (int rc = refresh_schedule(h)) return rc;
     if (h->windowed && step_end > step_begin) {
+        // room for the rows this range writes must exist before its launch is enqueued: nothing here is left to a later flush
+        struct Immediate {
+            rscm_ens* h; WindowDeferral* d;
+            explicit Immediate(rscm_ens* x) : h(x), d(x->defer) { h->defer = nullptr; }
+            ~Immediate() { h->defer = d; }
+        } now(h);
         if (step_begin == 0) {
             if (h->win0 != 0)
                 if (int rc = window_reset(h, false)) return rc;
