@@ -386,7 +386,7 @@ def magicc_chain_extra(members, years, fast=False):
     return {"member_years_per_s": members * years / dt, "ms": dt * 1e3, "launches": int(nl.value), "ensembles": n,
             "finite_members": warm["count"], "mean_warming_K": warm["mean"],
             "note": "10 components + aggregate + 2 grid transforms, lock-step in topological order; runs of light "
-                    "components share a launch (5 launches per model step)"}
+                    "components share a launch (4 launches per model step)"}
 
 
 def end_to_end_extra(members, device, mode, stream, years):

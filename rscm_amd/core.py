@@ -608,9 +608,13 @@ class ModelBuilder:
         aggregates), edges as ModelBuilder::build adds them, petgraph Bfs from the root (neighbours
         come out most-recently-added edge first).  builder.rs:448-701, runtime.rs:504-527.
 
-        ``topological`` (an extension) orders the same nodes so that every edge points forwards,
-        ties broken by the breadth-first position: the order in which no component reads a
-        value of the current step before it has been produced."""
+        ``topological`` (an extension) orders the same nodes so that every edge points forwards:
+        the order in which no component reads a value of the current step before it has been
+        produced.  Every such order gives the same values; among the nodes that are ready the next
+        one is of the class of the previous one if possible -- components that share a fused
+        launch (csrc/lockstep.cpp) against those with a kernel of their own (ClimateUDEB,
+        OceanCarbon, HalocarbonChemistry, host components) -- so that a step takes as few launches
+        as the edges allow; within a class the breadth-first position decides."""
         names = ["<root>"]
         edges: Dict[int, List[int]] = {}
         endogenous: Dict[str, int] = {}
@@ -673,16 +677,21 @@ class ModelBuilder:
             for b in set(targets):
                 if a:
                     indeg[b] += 1
+        own_kernel = {0: False}
+        for k, comp in enumerate(self._components, start=1):
+            own_kernel[k] = comp.type_name in OWN_KERNEL_TYPES or bool(getattr(comp, "is_python", False))
         ready = sorted((n for n, d in indeg.items() if d == 0), key=lambda n: rank[names[n]])
         topo: List[str] = []
+        last = False
         while ready:
+            ready.sort(key=lambda k: (own_kernel.get(k, False) != last, rank[names[k]]))
             n = ready.pop(0)
+            last = own_kernel.get(n, False)
             topo.append(names[n])
             for m in set(edges.get(n, [])):
                 indeg[m] -= 1
                 if indeg[m] == 0:
                     ready.append(m)
-            ready.sort(key=lambda k: rank[names[k]])
         if len(topo) != len(names) - 1:
             raise ValueError("the component graph has a cycle")
         return topo
@@ -814,7 +823,14 @@ class ModelBuilder:
                             for k in range(4):
                                 tr.link_input(k, ens, fb[1] + k, L.SRC_UPSTREAM)
                                 links.append((tname, k))
-                            order.insert(order.index(comp.type_name) + 1, tname)
+                            at = order.index(comp.type_name) + 1
+                            if execution_order == "topological":
+                                # ... or, in the extension's order, after the own-kernel components that follow the
+                                # producer and do not read the variable: the transform then shares their successors' launch
+                                while (at < len(order) and order[at] in OWN_KERNEL_TYPES and order[at] in by_node and not any(
+                                        v == name and kind in ("Input", "State") for v, _, kind in by_node[order[at]].definitions)):
+                                    at += 1
+                            order.insert(at, tname)
                             var_home[name] = (tname, 1)
                             stored_scalar = self._schema is not None and self._schema.grid_types.get(name) == GridType.Scalar
                             model._fourbox[name] = (comp.type_name, fb[1], stored_scalar)
@@ -1144,6 +1160,9 @@ def load_checkpoint(path) -> Dict[str, object]:
                 node[parts[-1]] = v.item() if v.ndim == 0 else v
     return out
 
+
+# components whose step is a kernel of their own (csrc/lockstep.cpp, fusable()); the others share fused launches
+OWN_KERNEL_TYPES = ("ClimateUDEB", "OceanCarbon", "HalocarbonChemistry")
 
 # type name -> ensemble kind, for graphs assembled from linked ensembles
 COMPONENT_KINDS = {"TwoLayer": L.KIND_TWO_LAYER, "ClimateUDEB": L.KIND_UDEB, "CarbonCycle": L.KIND_CARBON_CYCLE,

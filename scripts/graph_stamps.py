@@ -1,6 +1,6 @@
 """Where the whole-graph launch (csrc/graph.hip) spends its time: configs[3]'s MAGICC graph for a number of monthly
 steps with the in-kernel cycle stamps on (rscm_gpu_graph_stamps), then the same run timed with the stamps off and with
-the whole-graph launch off (fusion mode 1, the default: five launches per step).
+the whole-graph launch off (fusion mode 1, the default: four launches per step).
     python scripts/graph_stamps.py [members] [years]"""
 import ctypes as C
 import json
@@ -20,7 +20,7 @@ members = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
 years = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 lib = L.load()
 out = {"members": members, "monthly_steps": years * 12}
-for label, fusion, stamps in (("whole_graph_stamped", 4, 1), ("whole_graph", 4, 0), ("five_launches_per_step", 1, 0)):
+for label, fusion, stamps in (("whole_graph_stamped", 4, 1), ("whole_graph", 4, 0), ("four_launches_per_step", 1, 0)):
     L.check(lib.rscm_gpu_set_lockstep_fusion(fusion))
     model = build_chain(members, years, "topological", steps_per_year=12, series_window=16, output_stride=12)
     model.set_mode(L.MODE_FAST)

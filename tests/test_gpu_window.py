@@ -303,7 +303,7 @@ def test_configs3_shape_fits_one_gpu(ra):
 def test_configs3_share_runs_at_full_size(ra):
     """BASELINE.json configs[3], one GPU's share AT FULL SIZE: 125 000 members x 9000 monthly steps (1750-2500)
     of the ten-component MAGICC graph (RSCM_MODE_FAST: OceanCarbon's O(T) recurrence; 16-row window, annual
-    outputs).  Checked: no member fails, five launches per model step, the ensemble ends warm with CO2 above
+    outputs).  Checked: no member fails, four launches per model step, the ensemble ends warm with CO2 above
     pre-industrial -- and the first 64 members equal a 64-member run given their parameters, bit for bit, on
     every kept row of five variables (nothing depends on the ensemble size, the position in a wavefront or the
     fused launches).  scripts/run_configs3_share.py is the same thing as a program (profiles/r2_configs3_share_*)."""
@@ -328,7 +328,7 @@ def test_configs3_share_runs_at_full_size(ra):
     out = json.loads(buf.getvalue().strip().splitlines()[-1])
     print(f"configs[3] share: {out['run_s']:.2f} s, {out['hbm_allocated_gib']:.0f} GiB, {out['launches_per_step']:.0f} launches per step, "
           f"{out['member_years_per_s']:.3g} member-years/s")
-    assert out["failed_members"] == 0 and out["launches_per_step"] == 5.0 and out["hbm_allocated_gib"] < 250e9 / 2**30
+    assert out["failed_members"] == 0 and out["launches_per_step"] == 4.0 and out["hbm_allocated_gib"] < 250e9 / 2**30
     assert all(out["first_64_members_equal_a_64_member_run"].values())
     assert out["warming_end_K"]["count"] == 125_000 and 1.0 < out["warming_end_K"]["mean"] < 12.0
     assert out["co2_end_ppm"]["min"] > 278.0
@@ -403,7 +403,7 @@ def test_windowed_graph_in_fast_mode(ra):
 def test_whole_graph_launch_equals_the_per_step_launches(ra):
     """rscm_gpu_set_lockstep_fusion(4): the MAGICC graph in RSCM_MODE_FAST -- eleven light components, ClimateUDEB and
     OceanCarbon -- as ONE launch per window chunk (csrc/graph.hip: thread i runs Model::run's loop for member i, the
-    ocean columns stay on chip across the steps) against the default five launches per step: every kept row of every
+    ocean columns stay on chip across the steps) against the default four launches per step: every kept row of every
     series bit for bit, with windowed and with full storage, over launch boundaries that fall inside a chunk, and a
     handful of launches instead of five per step."""
     import ctypes as C
@@ -437,11 +437,11 @@ def test_whole_graph_launch_equals_the_per_step_launches(ra):
         for kw in (dict(), dict(series_window=12, output_stride=4)):
             want, launches1, steps1, st1 = run(1, **kw)
             got, launches4, steps4, st4 = run(4, **kw)
-            assert steps1 == steps4 == 13 * years and launches1 == 5 * years
+            assert steps1 == steps4 == 13 * years and launches1 == 4 * years
             assert launches4 == 4 if not kw else launches4 < launches1 // 10, launches4   # one per call, or one per window chunk
             assert np.array_equal(st1, st4) and not st1.any()
             assert set(want) == set(got) and len(want) >= 25
             for v in want:
-                assert_bit_equal(got[v], want[v], f"whole-graph launch vs five launches per step ({'windowed' if kw else 'full storage'}): {v}")
+                assert_bit_equal(got[v], want[v], f"whole-graph launch vs four launches per step ({'windowed' if kw else 'full storage'}): {v}")
     finally:
         L.check(lib.rscm_gpu_set_lockstep_fusion(1))
