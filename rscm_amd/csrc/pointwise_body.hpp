@@ -104,21 +104,31 @@ __device__ __forceinline__ void eval(const double (&p)[2], const double (&in)[1]
 // row 0 (their sum) by row 1 (their number).
 //
 // Written apart from the other pointwise kinds: in a graph this component is pure overhead (one load, one
-// add, one store), so the loops run over the rows in use with scalar branches, the operation -- one value
-// for the whole ensemble in practice, a scalar register then (param_at_scalar) -- is branched on rather than
-// selected on, and the weights are read by the Weighted operation only.
+// add, one store) and what it costs is memory latency, so the rows in use are requested first, all together,
+// then the nine parameters (scalar loads issued together when the block is uniform, as it is in practice: the
+// operation is a scalar register then and branched on rather than selected on) -- two waits per step.
 template <int SRC, class Cache = NoCache>
 __device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i, int32_t step_begin, int32_t step_end, const Cache& cache = Cache())
 {
     const int64_t N = a.n_members;
-    const int op = (int)cache.param_scalar(a.params, a.uniform_rows, 0, N, i);
     const int32_t used = a.n_inputs_used;
     const MemberInputs<SRC, 8> inputs(a.inputs, a.scen, a.links, a.n_times, N, i);
+    // The contributors of the first step are asked for BEFORE the operation is known (the operation is a scalar load the
+    // branches below wait for; the rows then are on their way already), and all of a step's rows together: one wait.
+    double v[8];
+    auto fetch = [&](int32_t n) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = k < used ? inputs.at(k, n + 1, cache) : __builtin_nan("");
+    };
+    if (step_begin < step_end) fetch(step_begin);
+    double prm[9];   // the operation and the eight weights, together
+    cache.params(a.params, a.uniform_rows, N, i, prm);
+    const int op = (int)prm[0];
     if (used == 1 && op < 2) {
         // One contributor, Sum or Mean (the total of a single forcing, say): 0.0 + v, and v / 1 is v.
         for (int32_t n = step_begin; n < step_end; ++n) {
-            const double v = inputs.at(0, n + 1, cache);
-            const double result = v == v ? 0.0 + v : __builtin_nan("");
+            if (n > step_begin) fetch(n);
+            const double result = v[0] == v[0] ? 0.0 + v[0] : __builtin_nan("");
             a.out[(a.rows > 1 ? (size_t)(n + 1) : (size_t)0) * N + i] = result;
             cache.put(0, result);
         }
@@ -127,34 +137,30 @@ __device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i
     }
     double w[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = (op == 2 && k < used) ? cache.param_scalar(a.params, a.uniform_rows, 1 + k, N, i) : 0.0;
+    for (int k = 0; k < 8; ++k) w[k] = (op == 2 && k < used) ? prm[1 + k] : 0.0;
     if (cache.last_step()) a.status[i] = 0;
     for (int32_t n = step_begin; n < step_end; ++n) {
+        if (n > step_begin) fetch(n);
         double result;
         if (__builtin_expect(op >= 3, 0)) {
-            const double in0 = used > 0 ? inputs.at(0, n + 1, cache) : __builtin_nan("");
+            const double in0 = v[0];   // (NaN beyond the rows in use)
             if (op == 5) {
-                const double in1 = used > 1 ? inputs.at(1, n + 1, cache) : __builtin_nan("");
+                const double in1 = v[1];
                 result = in1 > 0.0 ? in0 / in1 : __builtin_nan("");
             } else {
                 int cnt = (op == 3 && in0 == in0) ? 1 : 0;
 #pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    if (k >= used) break;
-                    const double v = inputs.at(k, n + 1, cache);
-                    cnt += v == v;
-                }
+                for (int k = 1; k < 8; ++k) cnt += v[k] == v[k];
                 result = (op == 4 ? in0 : 0.0) + (double)cnt;
             }
         } else {
+            // (rows beyond the ones in use are NaN here and skipped like any NaN contributor: the same sum)
             double s = 0.0;
             int cnt = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (k >= used) break;
-                const double v = inputs.at(k, n + 1, cache);
-                if (v == v) {
-                    s = s + (op == 2 ? v * w[k] : v);
+                if (v[k] == v[k]) {
+                    s = s + (op == 2 ? v[k] * w[k] : v[k]);
                     ++cnt;
                 }
             }
@@ -178,8 +184,7 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     double p[S::P];
-#pragma unroll
-    for (int j = 0; j < S::P; ++j) p[j] = cache.param_scalar(a.params, a.uniform_rows, j, N, i);
+    cache.params(a.params, a.uniform_rows, N, i, p);
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
     if (cache.last_step()) a.status[i] = 0;

@@ -74,6 +74,29 @@ __device__ __forceinline__ double param_at_scalar(const double* __restrict__ par
     return params[(size_t)j * N + i];
 }
 
+// All P parameter rows of a component at once.  Where every row is uniform (the usual case in a graph of linked ensembles:
+// a calibration varies a handful of rows of a few components) these are P scalar loads issued back to back and awaited
+// ONCE; asked for one by one through param_at_scalar each sits behind its own uniform-bit branch and is awaited before
+// the next is issued -- 27 dependent trips through the scalar cache per model step for AerosolDirect, and the fused
+// launches of the light components spend two thirds of their time in s_waitcnt (gpurun_out/r3e).
+// Mixed blocks take the vector loads of param_at: no branches either, one wait.
+template <int P>
+__device__ __forceinline__ void params_block(const double* __restrict__ params, uint64_t uniform, int64_t N, int64_t i, double (&p)[P])
+{
+    constexpr uint64_t mask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+    if ((uniform & mask) == mask) {
+        typedef const __attribute__((address_space(4))) double* scalar_row;
+        const uintptr_t q = (uintptr_t)params;   // (wave-uniform; said so for the reason given in param_at_scalar)
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+        const scalar_row row0 = (scalar_row)(((uintptr_t)hi << 32) | lo);
+#pragma unroll
+        for (int j = 0; j < P; ++j) p[j] = row0[(size_t)j * N];
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) p[j] = param_at(params, uniform, j, N, i);
+    }
+}
+
 // How a body reads parameters, its own previous state and linked inputs, and where it leaves its results
 // besides the series in HBM.  The stand-alone kernels use NoCache (everything compiles to the plain loads);
 // the fused multi-step launch passes an LdsCache.
@@ -86,6 +109,11 @@ struct NoCache {
     __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
     {
         return param_at_scalar(params, uniform, j, N, i);
+    }
+    template <int P>
+    __device__ __forceinline__ void params(const double* __restrict__ block, uint64_t uniform, int64_t N, int64_t i, double (&p)[P]) const
+    {
+        params_block<P>(block, uniform, N, i, p);
     }
     __device__ __forceinline__ double state(int, const double* p) const { return *p; }
     __device__ __forceinline__ void put(int, double) const {}
@@ -122,6 +150,17 @@ struct LdsCache {
     __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
     {
         return param(params, uniform, j, N, i);
+    }
+    template <int P>
+    __device__ __forceinline__ void params(const double* __restrict__ block, uint64_t uniform, int64_t N, int64_t i, double (&p)[P]) const
+    {
+        constexpr uint64_t mask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
+        if ((uniform & mask) == mask) {   // nothing of this block lives in a slot
+            params_block<P>(block, uniform, N, i, p);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) p[j] = param(block, uniform, j, N, i);
     }
     __device__ __forceinline__ double state(int v, const double* p) const
     {
