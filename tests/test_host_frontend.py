@@ -211,6 +211,53 @@ def test_graph_order_with_two_components_of_one_type():
         assert got == want, (seq, got, want)
 
 
+def test_topological_order_keeps_launch_classes_together():
+    """execution_order="topological" (an extension: every edge forwards) on the emissions-driven MAGICC graph: any
+    such order gives the same values, so ties go to the component of the previous one's launch class -- the
+    own-kernel components (ClimateUDEB, OceanCarbon) end up adjacent and a step is two fused launches plus those
+    two, where the breadth-first position alone cut the light components into three runs."""
+    import scripts.bench_magicc_chain as chain
+    t, exo, init, contributors = chain.chain_inputs(3, 12)
+    schema = core.VariableSchema()
+    for n in list(exo) + [k for k in init if k not in ("Surface Temperature", "Effective Radiative Forcing")] + contributors + [
+            "Heat Uptake", "Ocean Heat Content", "Sea Surface Temperature", "Carbon Flux|Terrestrial", "Carbon Flux|Ocean",
+            "Emissions|CO2|Net", "Airborne Fraction|CO2", "Lifetime|CH4", "Lifetime|N2O"]:
+        schema.add_variable(n, "")
+    schema.add_variable("Surface Temperature", "K", core.GridType.FourBox)
+    schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum", contributors)
+    axis = core.TimeAxis.from_values(t)
+    b = core.ModelBuilder().with_time_axis(axis).with_schema(schema).with_initial_values(init)
+    comps = chain.chain_components()
+    for c in comps:
+        b.with_rust_component(c)
+    for name, vals in exo.items():
+        b.with_exogenous_variable(name, core.Timeseries(vals, axis, "", core.InterpolationStrategy.Linear))
+    _, _, _, aggregates = b._resolve()
+    bfs = b._graph_order(aggregates)
+    topo = b._graph_order(aggregates, topological=True)
+    assert sorted(bfs) == sorted(topo) and len(topo) == len(comps) + 1
+    # every producer before its consumers
+    produced_by = {}
+    for c in comps:
+        for name, _, kind in c.definitions:
+            if kind in ("Output", "State"):
+                produced_by[name] = c.type_name
+    produced_by["Effective Radiative Forcing"] = "Aggregator:Effective Radiative Forcing"
+    at = {n: k for k, n in enumerate(topo)}
+    for c in comps:
+        for name, _, kind in c.definitions:
+            if kind == "Input" and name in produced_by and produced_by[name] != c.type_name:
+                # (a feedback that closes a cycle is a State of its owner or comes in through the initial values: not an edge)
+                assert at[produced_by[name]] < at[c.type_name] or name in init, (name, produced_by[name], c.type_name)
+    for name in contributors:
+        if name in produced_by:
+            assert at[produced_by[name]] < at["Aggregator:Effective Radiative Forcing"]
+    own = [n in core.OWN_KERNEL_TYPES for n in topo]
+    runs = 1 + sum(own[k] != own[k - 1] for k in range(1, len(own)))
+    assert runs == 3 and own.index(True) + 2 == len(own) - own[::-1].index(True), topo   # light ..., UDEB, ocean, light ...
+    assert abs(at["ClimateUDEB"] - at["OceanCarbon"]) == 1
+
+
 def test_priors_and_lhs():
     ps = cal.ParameterSet().add("x", cal.Uniform(0.0, 2.0)).add("y", cal.Uniform(-1.0, 1.0))
     assert ps.param_names == ["x", "y"]
