@@ -104,7 +104,6 @@ __device__ __forceinline__ void co2_budget_body(const CarbonArgs& a, int64_t i, 
     const double gtc_per_ppm = cache.param(a.params, a.uniform_rows, 0, N, i);
     const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
-    if (cache.last_step()) a.status[i] = 0;
     double co2 = cache.state(0, a.series + (size_t)step_begin * N + i);
     for (int32_t n = step_begin; n < step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
@@ -121,6 +120,7 @@ __device__ __forceinline__ void co2_budget_body(const CarbonArgs& a, int64_t i, 
         cache.put(1, net_to_atm);
         cache.put(2, airborne);
     }
+    if (cache.last_step()) a.status[i] = 0;   // (last: the byte's store may alias anything, no load moves across it)
 }
 
 // carbon/terrestrial.rs:82-100
@@ -143,6 +143,12 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
+    // state and the first step's rows first: in flight together with the parameters (rscm_device.hpp, StepRows)
+    const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
+    const size_t vs = (size_t)a.rows * N;
+    const size_t r0 = (size_t)step_begin * N + i;
+    double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];
+    StepRows<3> ahead = rows_at(in, step_begin);
     const double npp_pi = P(0), co2_pi = P(1), beta = P(2), npp_ts = P(3), resp_ts = P(4), det_ts = P(5), soil_ts = P(6),
                  hum_ts = P(7), plant_pi = P(8), det_pi = P(9), soil_pi = P(10), hum_pi = P(11), resp_pi = P(12),
                  f_npp_plant = P(13), f_npp_det = P(14), f_plant_det = P(15), f_det_soil = P(16), f_soil_hum = P(17);
@@ -159,14 +165,11 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
     const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
     const double r_tau_plant = guarded_rcp(tau_plant), r_tau_det = guarded_rcp(tau_det), r_tau_soil = guarded_rcp(tau_soil),
                  r_tau_hum = guarded_rcp(tau_hum);
-    const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
-    const size_t vs = (size_t)a.rows * N;
-    a.status[i] = 0;
-    const size_t r0 = (size_t)step_begin * N + i;
-    double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];
     for (int32_t n = step_begin; n < step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
-        const double co2 = in.at(0, n), temperature = in.at(1, n), landuse = in.at(2, n);
+        const StepRows<3> now = ahead;
+        if (n + 1 < step_end) ahead = rows_at(in, n + 1);
+        const double co2 = now.v[0], temperature = now.v[1], landuse = now.v[2];
         const double fert = (!fert_on || co2 <= 0.0) ? 1.0 : fmax(1.0 + beta * log(co2 / co2_pi), 0.1);
         auto tf = [&](double sens) -> double { return temp_on ? exp(sens * temperature) : 1.0; };
         const double npp = npp_pi * fert * tf(npp_ts);
@@ -190,6 +193,7 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
         a.series[3 * vs + r] = hum = n_hum;
         a.series[4 * vs + r] = npp - total_resp - landuse;
     }
+    a.status[i] = 0;
 }
 
 

@@ -21,6 +21,11 @@ __device__ __forceinline__ void ch4_body(const ChemArgs& a, int64_t i, int32_t s
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
+    // state and the first step's rows first: in flight together with the parameters (rscm_device.hpp, StepRows)
+    const MemberInputs<SRC, 5> in(a.inputs, a.scen, a.links, T, N, i);
+    double cur = a.conc[(size_t)step_begin * N + i];
+    double prev = step_begin > 0 ? a.conc[(size_t)(step_begin - 1) * N + i] : cur;  // previous().unwrap_or(current)
+    StepRows<5> ahead = rows_at(in, step_begin);
     const double ch4_pi = P(0), natural = P(1), tau_oh0 = P(2);
     const double tau_other = 1.0 / (1.0 / P(3) + 1.0 / P(4) + 1.0 / P(5));  // parameters/ch4_chemistry.rs tau_other
     const double self_fb = P(6), gamma = P(7), s_nox = P(8), s_co = P(9), s_nmvoc = P(10), temp_sens = P(11);
@@ -30,14 +35,12 @@ __device__ __forceinline__ void ch4_body(const ChemArgs& a, int64_t i, int32_t s
     const double x = -gamma * self_fb;
     const double r_ref = guarded_rcp(burden_reference), r_other = guarded_rcp(tau_other), r_ppb = guarded_rcp(ppb_to_tg);
     const double r_tau0 = guarded_rcp(tau_oh0);
-    const MemberInputs<SRC, 5> in(a.inputs, a.scen, a.links, T, N, i);
-    a.status[i] = 0;
-    double cur = a.conc[(size_t)step_begin * N + i];
-    double prev = step_begin > 0 ? a.conc[(size_t)(step_begin - 1) * N + i] : cur;  // previous().unwrap_or(current)
     for (int32_t n = step_begin; n < step_end; ++n) {
-        const double emissions = in.at(0, n), temperature = in.at(1, n);
-        const double delta_nox = in.at(2, n) - nox_ref, delta_co = in.at(3, n) - co_ref;
-        const double delta_nmvoc = in.at(4, n) - nmvoc_ref;
+        const StepRows<5> now = ahead;
+        if (n + 1 < step_end) ahead = rows_at(in, n + 1);
+        const double emissions = now.v[0], temperature = now.v[1];
+        const double delta_nox = now.v[2] - nox_ref, delta_co = now.v[3] - co_ref;
+        const double delta_nmvoc = now.v[4] - nmvoc_ref;
         const double total_emissions = emissions + natural;
         const double burden_prev = prev * ppb_to_tg;
         double base = tau_oh0;
@@ -70,6 +73,7 @@ __device__ __forceinline__ void ch4_body(const ChemArgs& a, int64_t i, int32_t s
         prev = cur;
         cur = next;
     }
+    a.status[i] = 0;
 }
 
 template <int SRC>
@@ -78,25 +82,29 @@ __device__ __forceinline__ void n2o_body(const ChemArgs& a, int64_t i, int32_t s
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
+    // state and the first step's row first: in flight together with the parameters (the delayed rows cannot be: their
+    // address is a parameter)
+    const MemberInputs<SRC, 1> in(a.inputs, a.scen, a.links, T, N, i);
+    auto C = [&](int64_t k) -> double { return a.conc[(size_t)k * N + i]; };
+    double cur = C(step_begin);
+    double prev = step_begin > 0 ? C(step_begin - 1) : cur;
+    StepRows<1> ahead = rows_at(in, step_begin);
     const double n2o_pi = P(0), natural = P(1), tau0 = P(2), lifetime_fb = P(3), ppb_to_tg = P(5);
     int64_t delay = (int64_t)P(4);
     if (delay < 1) delay = 1;  // strat_delay.max(1)
     const double burden_reference = n2o_pi * ppb_to_tg;
     const double r_ref = guarded_rcp(burden_reference), r_ppb = guarded_rcp(ppb_to_tg);
-    const MemberInputs<SRC, 1> in(a.inputs, a.scen, a.links, T, N, i);
-    auto C = [&](int64_t k) -> double { return a.conc[(size_t)k * N + i]; };
-    a.status[i] = 0;
-    double cur = C(step_begin);
-    double prev = step_begin > 0 ? C(step_begin - 1) : cur;
     for (int32_t n = step_begin; n < step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
+        const StepRows<1> now = ahead;
+        if (n + 1 < step_end) ahead = rows_at(in, n + 1);
         // n2o.rs:203-218: at_offset(-delay) else previous; at_offset(-(delay+1)) else the former
         double t_delay = prev;  // delay == 1: C(n-1) is `prev` already (and the fall-back for n == 0)
         if (delay > 1 && (int64_t)n - delay >= 0) t_delay = C((int64_t)n - delay);
         double t_delay_m1 = t_delay;
         if ((int64_t)n - delay - 1 >= 0) t_delay_m1 = C((int64_t)n - delay - 1);
         const double lagged = (t_delay + t_delay_m1) / 2.0;
-        const double total_emissions = in.at(0, n) + natural;
+        const double total_emissions = now.v[0] + natural;
         const double burden_prev = prev * ppb_to_tg, burden_lagged = lagged * ppb_to_tg;
         double burden = cur * ppb_to_tg, tau_eff = tau0;
 #pragma unroll
@@ -114,6 +122,7 @@ __device__ __forceinline__ void n2o_body(const ChemArgs& a, int64_t i, int32_t s
         prev = cur;
         cur = next;
     }
+    a.status[i] = 0;
 }
 
 

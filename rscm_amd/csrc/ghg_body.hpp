@@ -24,6 +24,10 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
+    // LINKED: the first step's concentrations first, in flight together with the parameters (rscm_device.hpp, StepRows)
+    const MemberInputs<LINKED ? 2 : 0, 3> conc(a.conc, a.scen, a.links, T, N, i);
+    StepRows<3> ahead = {};
+    if constexpr (LINKED) ahead = rows_at(conc, step_begin);
     const double co2_pi = P(1), ch4_pi = P(2), n2o_pi = P(3);
     const double adj_co2 = P(18), adj_ch4 = P(19), adj_n2o = P(20);
     const double ln_c0 = log(co2_pi), sq_m0 = sqrt(ch4_pi), sq_n0 = sqrt(n2o_pi);
@@ -31,7 +35,6 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
     // read-only __restrict__ kernel argument: without a scenario map the row addresses are
     // wave-uniform and become scalar loads
     const double* __restrict__ tab = tables + (HAS_SCEN ? (size_t)a.scen[i] : (size_t)0) * kGhgRows * T;
-    const MemberInputs<LINKED ? 2 : 0, 3> conc(a.conc, a.scen, a.links, T, N, i);
     double live[kGhgRows];  // LINKED: this year's rows
     auto row = [&](int r, int32_t n) -> double {
         if constexpr (LINKED) return live[r];
@@ -58,11 +61,12 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
         c_max = co2_pi - b1 / (2.0 * a1);
         alpha_sat = -b1 * b1 / (4.0 * a1) + d1;
     }
-    a.status[i] = 0;
     for (int32_t n = step_begin; n < step_end; ++n) {
         double f_co2, f_ch4, f_n2o;
         if constexpr (LINKED) {
-            const double c = conc.at(0, n), m = conc.at(1, n), nn = conc.at(2, n);
+            const StepRows<3> now = ahead;
+            if (n + 1 < step_end) ahead = rows_at(conc, n + 1);
+            const double c = now.v[0], m = now.v[1], nn = now.v[2];
             live[kGhgCo2] = c;
             live[kGhgLnCo2] = log(c);
             live[kGhgSqrtCo2] = sqrt(c);
@@ -100,6 +104,7 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
         a.erf_ch4[r] = f_ch4 * adj_ch4;
         a.erf_n2o[r] = f_n2o * adj_n2o;
     }
+    a.status[i] = 0;
 }
 
 }  // namespace ghg

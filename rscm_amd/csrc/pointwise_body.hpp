@@ -187,7 +187,6 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
     cache.params(a.params, a.uniform_rows, N, i, p);
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
-    if (cache.last_step()) a.status[i] = 0;
     for (int32_t n = step_begin; n < step_end; ++n) {
         double in[S::NI], out[S::NO];
 #pragma unroll
@@ -200,6 +199,7 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
             cache.put(o, out[o]);
         }
     }
+    if (cache.last_step()) a.status[i] = 0;   // (last: the byte's store may alias anything, no load moves across it)
     }
 }
 

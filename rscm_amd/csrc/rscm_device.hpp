@@ -219,6 +219,24 @@ struct MemberInputs {
     }
 };
 
+// The NI rows of one model step, asked for together.  The light bodies request the rows of their first step -- and their
+// state -- before they do any arithmetic on their parameters, and in a launch over several steps the rows of step n + 1
+// while step n is computed: a component's step is then ONE trip to memory (parameters, state and inputs in flight
+// together) where it was two or three (parameters; the quotients formed from them; then state and inputs, behind the
+// status byte's store, which may alias anything).  Fused launches of light components are bound by exactly these trips.
+template <int NI>
+struct StepRows {
+    double v[NI];
+};
+template <int SRC, int NI>
+__device__ __forceinline__ StepRows<NI> rows_at(const MemberInputs<SRC, NI>& in, int32_t n)
+{
+    StepRows<NI> r;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) r.v[k] = in.at(k, n);
+    return r;
+}
+
 // The same rows with every address formed once, up front (pointer + stride per row in vector registers):
 // for kernels that read their inputs inside long multi-step loops and are short of SCALAR registers
 // (OceanCarbon's convolution keeps a 47-entry window of the response table there).
