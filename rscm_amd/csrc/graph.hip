@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kUdebBlock) void graph_kernel(const GraphHeavy hv, 
         for (int32_t k = 0; k < n_ops; ++k, stamp(ops[k - 1].kind & 31)) {
             const GroupOp& op = ops[k];
             if (op.kind == kKindUdeb) {
-                ud.template step<true, UFAST>(hv.udeb, b);
+                // (slots 28 / 29: the step up to its sub-step loop, the loop; the rest of the step goes to the kind's slot)
+                ud.template step<true, UFAST>(hv.udeb, b, [&](int where) { stamp(28 + where); });
             } else if (op.kind == kKindOceanCarbon) {
                 ocean::ocean_recur_run<60, 2>(hv.ocean, hv.ocean.irf, hv.ocean.mode_table, ib, b, b + 1, hv.ocean.rebuild != 0 && b == step_begin);
             } else if (b > step_begin) {   // the slots hold what the previous step left

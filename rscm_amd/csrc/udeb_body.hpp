@@ -518,8 +518,12 @@ struct Udeb1 {
 
     // model step n -> n + 1.  CHECK_DEAD = false: the caller has dealt with members the reference refuses to build
     // (nan_rows) and calls step() only for the others.
-    template <bool CHECK_DEAD = true, bool FAST = false>
-    __device__ __forceinline__ void step(const UdebArgs& a, int32_t n)
+    // probe(0) / probe(1): called where the sub-step loop begins and ends (the whole-graph launch's diagnostic cycle stamps)
+    struct NoProbe {
+        __device__ __forceinline__ void operator()(int) const {}
+    };
+    template <bool CHECK_DEAD = true, bool FAST = false, class Probe = NoProbe>
+    __device__ __forceinline__ void step(const UdebArgs& a, int32_t n, const Probe& probe = Probe())
     {
         const size_t r0 = (size_t)n * N + i, r1 = r0 + (size_t)N;
         if (CHECK_DEAD && status != 0) {  // every output NaN
@@ -530,7 +534,12 @@ struct Udeb1 {
         }
         double* st[4] = {a.st0, a.st1, a.st2, a.st3};
         const double* tables = a.tables;  // kernarg segment
+        // everything the step reads at its start that does not depend on anything else, requested together (one wavefront per
+        // SIMD: each dependent trip to memory is exposed in full); the history rows below need k_full first
         const double erf_start = F[(size_t)n * f_stride], erf_end = F[(size_t)(n + 1) * f_stride];
+        const double bound_lo = a.bounds[n], bound_hi = a.bounds[n + 1];
+        const int32_t k_full = a.win_kfull[n];
+        const double part_w = a.win_partw[n];
         // warm start (mod.rs:436-446)
         {
             const double prev0 = st[0][r0];
@@ -543,7 +552,7 @@ struct Udeb1 {
                 gr_sh = land_sh;
             }
         }
-        const double dt_year = a.bounds[n + 1] - a.bounds[n];
+        const double dt_year = bound_hi - bound_lo;
         const double dt_sub = dt_year / steps;
         // ---- time-varying ECS (adjusted_ecs) and the LAMCALC re-solve
         const double erf_mid = (erf_start + erf_end) / 2.0;
@@ -556,8 +565,6 @@ struct Udeb1 {
             // window has moved past are read back and subtracted: 0-2 loads a year instead of a
             // 300-year walk); the reference re-sums newest to oldest, which this matches to
             // rounding.
-            const int32_t k_full = a.win_kfull[n];
-            const double part_w = a.win_partw[n];
             const double* hcol = a.hist + i;
             win_sum += hist_last;
             for (; win_lo < k_full; ++win_lo) win_sum -= hcol[(size_t)win_lo * N];
@@ -613,6 +620,7 @@ struct Udeb1 {
         const double r_land_nh = 1.0 / (lam_l * p.fgnl + p.k_lo), r_land_sh = 1.0 / (lam_l * p.fgsl + p.k_lo);
         const double gfac_nh = (a.land_hc && !(p.fgnl < 1e-15)) ? p.k_lg / (p.fgnl * c_ground) * dt_sub : 0.0;
         const double gfac_sh = (a.land_hc && !(p.fgsl < 1e-15)) ? p.k_lg / (p.fgsl * c_ground) * dt_sub : 0.0;
+        probe(0);
         for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f0 = adj * p.q0, f1 = adj * p.q1, f2 = adj * p.q2, f3 = adj * p.q3;
@@ -651,6 +659,7 @@ struct Udeb1 {
             up_nh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh_nh, 1.0)), w_min);
             up_sh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh_sh, 1.0)), w_min);
         }
+        probe(1);
         // ---- end of year
         const double sst_nh = col[0], sst_sh = park[0][lane];
         const double air_nh = sst_to_air(airmap, sst_nh), air_sh = sst_to_air(airmap, sst_sh);
@@ -682,7 +691,7 @@ struct Udeb1 {
 #pragma unroll
             for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
             total += rho_c * p.dz_mix * sst_sh;
-#pragma unroll 1
+#pragma unroll 7
             for (int l = 1; l < NL; ++l) total += rho_c * p.dz * park[l][lane];
             a.ohc[r1] = total / 2.0;
         }

@@ -14,7 +14,9 @@ from scripts.bench_magicc_chain import build_chain  # noqa: E402
 
 KINDS = {0: "TwoLayer", 2: "ClimateUDEB", 3: "GhgForcing", 4: "OzoneForcing", 5: "AerosolDirect", 6: "AerosolIndirect", 7: "CH4Chemistry",
          8: "N2OChemistry", 9: "CO2Budget", 10: "TerrestrialCarbon", 11: "OceanCarbon", 13: "FourBoxOHU", 14: "OSPP", 15: "CarbonCycle",
-         16: "CO2ERF", 17: "Aggregate (x3: Sum of 8 + 2 grid transforms)", 31: "ClimateUDEB begin/end (per launch)"}
+         16: "CO2ERF", 17: "Aggregate (x3: Sum of 8 + 2 grid transforms)", 28: "ClimateUDEB: step start to sub-step loop",
+         29: "ClimateUDEB: 12 sub-steps", 31: "ClimateUDEB begin/end (per launch)"}
+KINDS[2] = "ClimateUDEB: end of step (outputs)"
 
 members = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
 years = int(sys.argv[2]) if len(sys.argv) > 2 else 50
