@@ -222,7 +222,9 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
 // traffic (12 pulses written, 12 leaving pulses read, 3 output rows) against 144 k operations and 24 KB.
 // One wavefront per SIMD: the 72 pulses, 21 mode sums, 12 partial convolutions and 12 leaving pulses of a step are
 // ~250 registers; cut to 256 for two wavefronts per SIMD the compiler spills 122 of them (17.3 ms against 16.2 ms at
-// 262 144 members x 750 years), and the twelve independent sums of a step hide their own latencies.
+// 262 144 members x 750 years), and the twelve independent sums of a step hide their own latencies.  The same cut for the
+// one-step launches of a lock-step graph alone (125 000 members: 1954 wavefronts on 1024 SIMDs, three quarters of a
+// wavefront's time spent waiting on memory): 34-38 us per launch either way, configs[3]'s share 2.65 s against 2.64 s.
 // TWO (two wavefronts per SIMD, with those spills): for launches of a step or two -- a lock-step graph's -- over more
 // wavefronts than the chip has SIMDs.  Such a launch is one trip through the member's 81 doubles of state and back, the
 // wavefronts spend three quarters of it waiting on memory (gpurun_out/r3f: SQ_ACTIVE_INST_VALU 24 % of SQ_WAVE_CYCLES)
