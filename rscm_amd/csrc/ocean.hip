@@ -27,8 +27,6 @@
 // roofline).  exp() of the temperature factor comes from the device
 // math library: results agree with the CPU oracle to its last-place error, and bit for bit when
 // the temperature feedback is off (tests/test_gpu_ocean.py).
-#include <cstdlib>
-
 #include "ocean_body.hpp"
 
 namespace rscm {
@@ -225,14 +223,9 @@ __global__ __launch_bounds__(kBlock) void ocean_kernel(OceanArgs a, const double
 // 262 144 members x 750 years), and the twelve independent sums of a step hide their own latencies.  The same cut for the
 // one-step launches of a lock-step graph alone (125 000 members: 1954 wavefronts on 1024 SIMDs, three quarters of a
 // wavefront's time spent waiting on memory): 34-38 us per launch either way, configs[3]'s share 2.65 s against 2.64 s.
-// TWO (two wavefronts per SIMD, with those spills): for launches of a step or two -- a lock-step graph's -- over more
-// wavefronts than the chip has SIMDs.  Such a launch is one trip through the member's 81 doubles of state and back, the
-// wavefronts spend three quarters of it waiting on memory (gpurun_out/r3f: SQ_ACTIVE_INST_VALU 24 % of SQ_WAVE_CYCLES)
-// and at one per SIMD the second half of the ensemble waits for the first to finish: 34.1 us against 37.5 us per one-step
-// launch at 125 000 members (rocprofv3 kernel trace of scripts/run_configs3_share.py, RSCM_OCEAN_WAVES=1 for the other).
-template <int NEAR, int SRC, bool TWO>
-__global__ __launch_bounds__(kBlock, TWO ? 2 : 1) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table,
-                                                                       const double* __restrict__ mode_table)
+template <int NEAR, int SRC>
+__global__ __launch_bounds__(kBlock, 1) void ocean_recur_kernel(OceanArgs a, const double* __restrict__ irf_table,
+                                                             const double* __restrict__ mode_table)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
@@ -244,11 +237,8 @@ static hipError_t launch_recur(const OceanArgs& a, hipStream_t s)
 {
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     const int src = a.linked ? 2 : a.scen ? 1 : 0;
-    static const int forced = [] { const char* e = getenv("RSCM_OCEAN_WAVES"); return e ? atoi(e) : 0; }();   // A/B runs: 1 or 2
-    const bool two = forced == 2 || (forced != 1 && a.step_end - a.step_begin <= 2 && a.n_members > 65536);
     void (*kern)(OceanArgs, const double*, const double*) =
-        two ? (src == 2 ? ocean_recur_kernel<NEAR, 2, true> : src == 1 ? ocean_recur_kernel<NEAR, 1, true> : ocean_recur_kernel<NEAR, 0, true>)
-            : (src == 2 ? ocean_recur_kernel<NEAR, 2, false> : src == 1 ? ocean_recur_kernel<NEAR, 1, false> : ocean_recur_kernel<NEAR, 0, false>);
+        src == 2 ? ocean_recur_kernel<NEAR, 2> : src == 1 ? ocean_recur_kernel<NEAR, 1> : ocean_recur_kernel<NEAR, 0>;
     hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, s, a, a.irf, a.mode_table);
     return hipGetLastError();
 }
