@@ -33,9 +33,10 @@ RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps
 
 /* Where a whole-graph launch (csrc/graph.hip) spends its time: with enable != 0 the calling thread's following
  * whole-graph launches add, per component kind, the shader cycles their wavefronts spent in that kind's steps to 32
- * device counters (index = RSCM_KIND_*, 31 = ClimateUDEB's begin / end).  Each call returns the counters collected
+ * device counters (index = RSCM_KIND_*; 28 / 29 = ClimateUDEB's step up to its sub-step loop / the loop, the rest of its step under its
+ * kind; 31 = ClimateUDEB's begin / end).  Each call returns the counters collected
  * since the previous one in out32 (may be NULL) and resets them; enable = 0 stops collecting.  Diagnostic only: the
- * stamps cost a few per cent (profiles/r3_graph_stamps.txt). */
+ * stamps cost a few per cent (profiles/r3_graph_stamps.json). */
 RSCM_API int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32);
 
 /* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an
