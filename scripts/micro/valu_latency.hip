@@ -1,7 +1,8 @@
 // Micro-benchmark (gfx950, run on the GPU box): what one wavefront per SIMD pays for DEPENDENT f64 instructions.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_latency scripts/micro/valu_latency.hip && /tmp/valu_latency
 // Prints shader cycles (s_memtime runs at 100 MHz: wall time x the measured clock is used instead) per instruction for
-// chains of 1, 2 and 4 independent streams of v_fma_f64, for v_rcp_f64, and for an LDS write + read of a double.
+// chains of 1, 2 and 4 independent streams of v_fma_f64, for v_rcp_f64, for an LDS write + read of a double, and per row of a
+// Thomas-sweep c' chain with 0-18 independent instructions beside it.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -58,6 +59,34 @@ __global__ __launch_bounds__(64) void rcp_mixed(double* out, int iters, double a
     out[blockIdx.x * 64 + threadIdx.x] = x + y0 + y1 + y2;
 }
 
+// A Thomas-sweep row in miniature: the c' chain (fma -> v_rcp_f64 -> fma -> fma -> fma, with one multiply beside it) and INDEP
+// independent fmas around it.  If the chain's latency is covered, a row costs the sum of its issue slots.
+template <int INDEP>
+__global__ __launch_bounds__(64) void thomas_row(double* out, int iters, double a, double b, double k)
+{
+    double c = 0.25 + 1e-3 * threadIdx.x;
+    double y[INDEP > 0 ? INDEP : 1];
+#pragma unroll
+    for (int j = 0; j < INDEP; ++j) y[j] = 1.0 + j;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double denom = __builtin_fma(-a, c, b);
+            const double r0 = __builtin_amdgcn_rcp(denom);
+            const double e = __builtin_fma(-denom, r0, 1.0);
+            const double u = __builtin_fma(e, e, e);
+            const double t = k * r0;
+            c = __builtin_fma(t, u, t);
+#pragma unroll
+            for (int j = 0; j < INDEP; ++j) y[j] = __builtin_fma(y[j], 0.999, 0.001);
+        }
+    }
+    double acc = c;
+#pragma unroll
+    for (int j = 0; j < INDEP; ++j) acc += y[j];
+    out[blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(64) void lds_swap(double* out, int iters)
 {
     __shared__ double park[32][64];
@@ -110,6 +139,10 @@ int main()
     report("v_rcp_f64, 4 independent chains", time_ms([&] { hipLaunchKernelGGL(rcp_chain<4>, dim3(blocks), dim3(64), 0, 0, out, iters); }), 64.0 * iters);
     report("1 v_rcp_f64 + 3 v_fma_f64 (per group of 4)", time_ms([&] { hipLaunchKernelGGL(rcp_mixed, dim3(blocks), dim3(64), 0, 0, out, iters, 0.999, 0.001); }), 16.0 * iters);
     report("LDS read + write of a double (per pair)", time_ms([&] { hipLaunchKernelGGL(lds_swap, dim3(blocks), dim3(64), 0, 0, out, iters); }), 32.0 * iters);
+    report("Thomas row: c' chain alone (5 VALU + rcp)", time_ms([&] { hipLaunchKernelGGL(thomas_row<0>, dim3(blocks), dim3(64), 0, 0, out, iters / 4, 0.3, 1.5, 0.4); }), 16.0 * (iters / 4));
+    report("Thomas row: chain + 6 independent fma", time_ms([&] { hipLaunchKernelGGL(thomas_row<6>, dim3(blocks), dim3(64), 0, 0, out, iters / 4, 0.3, 1.5, 0.4); }), 16.0 * (iters / 4));
+    report("Thomas row: chain + 12 independent fma", time_ms([&] { hipLaunchKernelGGL(thomas_row<12>, dim3(blocks), dim3(64), 0, 0, out, iters / 4, 0.3, 1.5, 0.4); }), 16.0 * (iters / 4));
+    report("Thomas row: chain + 18 independent fma", time_ms([&] { hipLaunchKernelGGL(thomas_row<18>, dim3(blocks), dim3(64), 0, 0, out, iters / 4, 0.3, 1.5, 0.4); }), 16.0 * (iters / 4));
     // the same with two wavefronts per SIMD
     report("v_fma_f64, 1 chain, 2 wavefronts per SIMD", time_ms([&] { hipLaunchKernelGGL(fma_chain<1>, dim3(2 * blocks), dim3(64), 0, 0, out, iters, 0.999, 0.001); }), 2 * 64.0 * iters);
     hipFree(out);
