@@ -6,8 +6,8 @@ of 1983 per sub-step): 54.0-54.4 ms against 53.9-54.1 ms -- no gain, not kept.""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from rscm_amd import _lib
-if sys.argv[1] == "variant":
-    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.__file__), "librscm_gpu_variant.so")
+if sys.argv[1] != "base":
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.__file__), "librscm_gpu_" + sys.argv[1] + ".so")
 import bench
 e = bench.make_udeb_ensemble(65536, 0)
 ms = []
