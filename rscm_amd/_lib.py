@@ -261,6 +261,7 @@ SIGNATURES = {
     "rscm_ens_run_lockstep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
     "rscm_ens_run_async": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "rscm_gpu_set_lockstep_fusion": (C.c_int, [C.c_int32]),
+    "rscm_gpu_set_udeb_variant": (C.c_int, [C.c_int32]),
     "rscm_gpu_lockstep_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_gpu_graph_stamps": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     "rscm_ens_sync": (C.c_int, [_h]),

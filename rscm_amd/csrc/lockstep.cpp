@@ -46,6 +46,13 @@ int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32)
     GUARD_END
 }
 
+int rscm_gpu_set_udeb_variant(int32_t variant)
+{
+    if (variant != -1 && variant != 0 && variant != 2 && variant != 4) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0, 2 or 4");
+    rscm::set_udeb_variant(variant);
+    return RSCM_OK;
+}
+
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
     if (enabled < 0 || enabled > 4) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..4)", enabled);

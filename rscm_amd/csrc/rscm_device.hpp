@@ -607,6 +607,7 @@ hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t 
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
 bool udeb_layers_supported(int32_t n_layers);  // the layer counts the column kernels are instantiated for
+void set_udeb_variant(int variant);            // which ClimateUDEB kernel the calling thread's launches take (udeb.hip; -1: by size)
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);

@@ -36,7 +36,7 @@
 // year); no such member occurs in the test ensembles.
 #include <cstdlib>
 
-#include "udeb_body.hpp"
+#include "udeb4_body.hpp"
 
 namespace rscm {
 
@@ -72,12 +72,32 @@ __global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
     m.end(a);
 }
 
+// Four wavefronts per 64 members, half a column each (udeb4_body.hpp), two wavefronts per SIMD.
+template <int NL, bool FAST>
+__global__ __launch_bounds__(kUdeb4Block, 2) void udeb4_kernel(UdebArgs a)
+{
+    __shared__ Udeb4Lds lds;
+    Udeb4<NL> m(lds);
+    m.begin(a);
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<FAST>(a, n);
+    m.end(a);
+}
+
 }  // namespace
 
+// 0: one thread per member, 2: a hemisphere per wavefront, 4: half a hemisphere's column per wavefront; -1: by ensemble size
+static thread_local int t_udeb_variant = -1;
+void set_udeb_variant(int variant) { t_udeb_variant = variant; }
+
 template <int NL>
-static void launch_udeb_nl(const UdebArgs& a, bool two_waves, hipStream_t s)
+static void launch_udeb_nl(const UdebArgs& a, int variant, hipStream_t s)
 {
-    if (two_waves) {
+    const bool two_waves = variant == 2;
+    if (variant == 4) {
+        const dim3 grid((unsigned)((a.n_members + 63) / 64));
+        if (a.fast) hipLaunchKernelGGL((udeb4_kernel<NL, true>), grid, dim3(kUdeb4Block), 0, s, a);
+        else hipLaunchKernelGGL((udeb4_kernel<NL, false>), grid, dim3(kUdeb4Block), 0, s, a);
+    } else if (two_waves) {
         const dim3 grid((unsigned)((a.n_members + 63) / 64));
         if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true>), grid, dim3(kUdeb2Block), 0, s, a);
         else hipLaunchKernelGGL((udeb2_kernel<NL, false>), grid, dim3(kUdeb2Block), 0, s, a);
@@ -99,14 +119,17 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     // Up to 32 768 members there are fewer wavefronts than SIMDs either way: the two-wavefront kernel solves a member's
     // two hemispheres at the same time on two SIMDs (half the latency per model step); beyond that the two kernels
     // take the same time per member (profiles/r3_udeb_two_wave_experiment.txt) and the one-thread kernel is kept.
-    // RSCM_UDEB_VARIANT = 0 / 2 forces one of them (A/B runs).
+    // The four-wavefront kernel (udeb4_body.hpp: two wavefronts per SIMD) is opt-in: 73 ms against 54 ms at 65 536 members x 750
+    // years, 9 % ahead only for a few thousand members, and it agrees with the other two to rounding, not to the bit.
+    // RSCM_UDEB_VARIANT = 0 / 2 / 4 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
-    const bool two_waves = forced == 2 || (forced != 0 && a.n_members <= 32768);
+    int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;
+    if (variant != 0 && variant != 2 && variant != 4) variant = a.n_members <= 32768 ? 2 : 0;
     switch (a.n_layers) {   // the column loops are unrolled, the column lives in registers: one instance per supported layer count
-        case 20: launch_udeb_nl<20>(a, two_waves, s); break;
-        case 30: launch_udeb_nl<30>(a, two_waves, s); break;
-        case 40: launch_udeb_nl<40>(a, two_waves, s); break;
-        case 50: launch_udeb_nl<50>(a, two_waves, s); break;
+        case 20: launch_udeb_nl<20>(a, variant, s); break;
+        case 30: launch_udeb_nl<30>(a, variant, s); break;
+        case 40: launch_udeb_nl<40>(a, variant, s); break;
+        case 50: launch_udeb_nl<50>(a, variant, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -162,6 +162,44 @@ def test_udeb_gpu_ensemble_vs_oracle(ra, orc):
         assert np.array_equal(again[k], got[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("n_layers", [20, 50])
+def test_udeb_gpu_four_wavefront_kernel(ra, orc, n_layers):
+    """The opt-in kernel with four wavefronts per 64 members (csrc/udeb4_body.hpp: a hemisphere's column cut in the middle, the two
+    halves eliminated towards the cut by two wavefronts, two wavefronts per SIMD; rscm_gpu_set_udeb_variant(4)): the same
+    tridiagonal systems solved in another order, so the bar is the oracle's 1e-9 like every kernel's, and against the default
+    kernel the agreement is to rounding, not to the bit.  Launch boundaries (resume from the stored half columns) change nothing,
+    members the reference refuses to build come out flagged and NaN, a ragged last workgroup is handled."""
+    from rscm_amd import _lib as L
+    years = np.arange(1850.0, 1951.0)
+    b = np.append(years, 1951.0)
+    n = 257
+    P = _ensemble_params(orc, n, seed=4, n_layers=float(n_layers))
+    P[orc.UDEB_PARAM_NAMES.index("prescribed_efficacy_co2"), 5] = -1.0   # refused by from_parameters: status 2 for this member alone
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0),
+                  3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0),
+                  -1.5 * np.ones(len(years))])
+    scen = (np.arange(n) % 3).astype(np.int32)
+    want, wst = orc.udeb_run(b, P, F, scen=scen, threads=8)
+    default, dst = _gpu(ra, b, P, F, scen=scen)
+    L.check(L.load().rscm_gpu_set_udeb_variant(4))
+    try:
+        got, st = _gpu(ra, b, P, F, scen=scen)
+        again, _ = _gpu(ra, b, P, F, scen=scen, chunks=(1, 37))
+        fast, _ = _gpu(ra, b, P, F, scen=scen, mode=ra.MODE_FAST)
+    finally:
+        L.check(L.load().rscm_gpu_set_udeb_variant(-1))
+    assert (st == wst).all() and (dst == wst).all() and st[5] == 2 and (st != 0).sum() == 1
+    _assert_close(got, want, f"four-wavefront kernel, {n_layers} layers")
+    _assert_close(fast, want, f"four-wavefront kernel, FAST, {n_layers} layers")
+    worst = 0.0
+    for k in NAMES:
+        assert np.array_equal(again[k], got[k], equal_nan=True), k
+        assert np.isnan(got[k][1:, 5]).all()
+        worst = max(worst, float(np.nanmax(np.abs(got[k] - default[k]) / np.maximum(1.0, np.abs(default[k])))))
+    print(f"four-wavefront kernel vs the default one, {n_layers} layers: max relative deviation {worst:.2e}")
+    assert worst < 1e-11
+
+
 def test_udeb_gpu_failed_construction_is_flagged(ra, orc):
     years = np.arange(1850.0, 1871.0)
     b = np.append(years, 1871.0)
