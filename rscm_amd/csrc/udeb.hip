@@ -119,8 +119,8 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     // Up to 32 768 members there are fewer wavefronts than SIMDs either way: the two-wavefront kernel solves a member's
     // two hemispheres at the same time on two SIMDs (half the latency per model step); beyond that the two kernels
     // take the same time per member (profiles/r3_udeb_two_wave_experiment.txt) and the one-thread kernel is kept.
-    // The four-wavefront kernel (udeb4_body.hpp: two wavefronts per SIMD) is opt-in: 73 ms against 54 ms at 65 536 members x 750
-    // years, 9 % ahead only for a few thousand members, and it agrees with the other two to rounding, not to the bit.
+    // The four-wavefront kernel (udeb4_body.hpp: two wavefronts per SIMD) is opt-in: 71 ms against 54 ms at 65 536 members x 750
+    // years, 11 % ahead only for a few thousand members, and it agrees with the other two to rounding, not to the bit.
     // RSCM_UDEB_VARIANT = 0 / 2 / 4 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
     int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;

@@ -441,6 +441,12 @@ struct Udeb4 {
                 gr = land;
             }
         }
+        // The half column waits in this lane's c' slots (unused between the solves) while the year's constants are formed:
+        // LAMCALC and the parameter block need the registers, and what does not fit goes to scratch memory -- 60 trips to
+        // memory per model step that one or two resident wavefronts cannot hide.
+        double* __restrict__ ncp_lds = &lds.ncp[hemi][0][lane];
+#pragma unroll
+        for (int l = 0; l < H; ++l) ncp_lds[(size_t)l * 64] = col[l];
         // ---- time-varying ECS (adjusted_ecs) and the LAMCALC re-solve: both hemispheres' top wavefronts, same values
         const double erf_mid = (erf_start + erf_end) / 2.0;
         double cum_t = 0.0;
@@ -492,7 +498,13 @@ struct Udeb4 {
         // what the sub-step loop reads of the parameters
         const double w0 = p.w0, f_var = p.f_var, pi_ratio = p.pi_ratio, max_temp = p.max_temp;
         const double fgno = p.fgno, fgnl = p.fgnl, fgso = p.fgso, fgsl = p.fgsl;
-        double* __restrict__ ncp_lds = &lds.ncp[hemi][0][lane];
+        {   // (an opaque offset: the compiler would otherwise forward the stored values to these loads and keep them in registers)
+            int32_t back = 0;
+            asm volatile("" : "+v"(back));
+            const double* parked = ncp_lds + back;
+#pragma unroll
+            for (int l = 0; l < H; ++l) col[l] = parked[(size_t)l * 64];
+        }
         double t_air = 0.0, t_air_o = 0.0;
         for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
