@@ -638,7 +638,9 @@ struct Udeb1 {
                                                            sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
                                                            sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
                                                            sh ? up_sh : up_nh);
-                // exchange the solved column with the parked hemisphere.  (Tried: the exchange layer by layer inside the back
+                // exchange the solved column with the parked hemisphere.  (Tried: both columns in registers and the c' array of the solve
+                // in progress in the LDS slots instead -- as many LDS instructions, none of them between two solves: the register
+                // allocator answers with 505 spilled VGPRs and 652 spilled SGPRs.  Tried: the exchange layer by layer inside the back
                 // substitution, so that the LDS traffic runs under it -- the compiler interleaves it as written, the yearly code
                 // starts to spill, and 65 536 members x 750 years take 58.8 ms instead of 54.8.)
 #pragma unroll
