@@ -162,7 +162,7 @@ def test_udeb_gpu_ensemble_vs_oracle(ra, orc):
         assert np.array_equal(again[k], got[k], equal_nan=True), k
 
 
-@pytest.mark.parametrize("n_layers", [20, 50])
+@pytest.mark.parametrize("n_layers", [20, 30, 40, 50])
 def test_udeb_gpu_four_wavefront_kernel(ra, orc, n_layers):
     """The opt-in kernel with four wavefronts per 64 members (csrc/udeb4_body.hpp: a hemisphere's column cut in the middle, the two
     halves eliminated towards the cut by two wavefronts, two wavefronts per SIMD; rscm_gpu_set_udeb_variant(4)): the same
