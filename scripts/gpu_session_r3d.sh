@@ -4,6 +4,8 @@ set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
 bash scripts/gpu_profile_bench.sh r3_bench > gpurun_out/r3d_bench.log 2>&1 || { tail -5 gpurun_out/r3d_bench.log; exit 1; }
+# (here, on the box: the kernel trace of the whole bench is too large to travel back, its per-(kernel, grid) table and the timed region's launches are what is kept)
+python3 scripts/summarize_bench_profile.py r3_bench gpurun_out/r3_bench_kernel_trace.txt > /dev/null || exit 1
 echo "bench done"
 bash scripts/gpu_profile.sh r3_coupled_1e6 1000000 0 1 > gpurun_out/r3d_coupled.log 2>&1 || { tail -5 gpurun_out/r3d_coupled.log; exit 1; }
 echo "coupled done"
