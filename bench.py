@@ -9,10 +9,16 @@ Inputs (parameters, forcing, initial state) are resident in HBM before the timed
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no launcher: the N ranks are started here)
 
 One process per GPU; members are sharded in contiguous blocks (weak scaling: --members per GPU);
-the only collectives are the contract's barrier and the max-over-ranks of the wall time.
-Rank 0 prints ONE JSON line.
+the only collectives are the contract's barrier and the max-over-ranks of the wall time (plus, outside
+the timed region, an all-reduce of ones and an all-gather of each rank's own times for the `collective`
+and `per_rank` objects of the line).  Rank 0 prints ONE JSON line.
+
+Started with --gpus N > 1 and no launcher environment (no RANK / WORLD_SIZE), this process becomes a
+launcher: it never imports torch.cuda nor loads librscm_gpu.so, starts N children of itself with RANK,
+LOCAL_RANK, WORLD_SIZE and MASTER_* set, relays rank 0's line and exits non-zero if any rank failed.
 """
 import argparse
 import json
@@ -268,10 +274,60 @@ def timed_passes(ens, steps, warmup, torch, dist, world, tstream):
     return wall, kernel_ms
 
 
-def cpu_baseline(threads, target_seconds=12.0):
+def rank_report(kernel_ms, wall, steps, torch, dist):
+    """Outside the timed region: who took part in the collectives (an all-reduce of ones) and every rank's own
+    kernel time, so that a straggler shows in a timed region of a few tens of milliseconds."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return ({"backend": None, "world": 1, "rccl_ranks_seen": 0, "note": "single process, no process group"},
+                {"kernel_ms": [kernel_ms], "weak_efficiency": [kernel_ms / (wall / steps * 1e3)]})
+    dev = _coll_device(torch, dist)
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    kms = [float(x.item()) for x in every]
+    backend = dist.get_backend()
+    coll = {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world": dist.get_world_size(),
+            "rccl_ranks_seen": int(round(float(ones.item()))) if backend == "nccl" else 0,
+            "ranks_seen": int(round(float(ones.item()))), "tensors_on": dev}
+    return coll, {"kernel_ms": kms, "weak_efficiency": [k / (wall / steps * 1e3) for k in kms],
+                  "note": "kernel_ms: HIP events around each rank's own K launches / K; weak_efficiency: that over the "
+                          "max-over-ranks wall time per step (barrier to barrier), i.e. 1 - the share of the step a rank "
+                          "spent waiting for the slowest one and for the barriers"}
+
+
+def host_description():
+    """What the CPU leg ran on: logical cores of the host, the cores this process may use, the cgroup's CPU quota if one is
+    set (a leased box may expose all of the host's cores and throttle to a share of them), the CPU model string."""
+    info = {"host_cores": os.cpu_count() or 1}
+    try:
+        info["affinity_cores"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity_cores"] = info["host_cores"]
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        info["cgroup_cpu_quota_cores"] = None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        info["cgroup_cpu_quota_cores"] = None
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    info["cpu_model"] = model
+    return info
+
+
+def cpu_baseline(threads=None, target_seconds=12.0):
     """The CPU oracle (a port of the reference algorithm) on a bounded sample of the same
-    workload, on this host's cores."""
+    workload, on ALL of this host's cores (one thread per core this process may run on)."""
     from oracle import cbind
+    host = host_description()
+    threads = threads or host["affinity_cores"]
     t = np.arange(T0, T1 + 1, dtype=np.float64)
     b = cbind.bounds_from_values(t)
     F = f_syn(t)
@@ -284,19 +340,28 @@ def cpu_baseline(threads, target_seconds=12.0):
     t0 = time.perf_counter()
     cbind.two_layer_run(b, params(probe), F, 0.0, 0.0, threads=threads)
     dt = time.perf_counter() - t0
-    n = int(min(max(probe, probe * target_seconds / max(dt, 1e-3)), 400_000))
+    # one pass holds 12 KB of output per member on the host: at most 5e5 members (6 GB), repeated to fill the budget
+    n = int(min(max(probe, probe * target_seconds / max(dt, 1e-3)), 500_000))
     n -= n % threads
+    P = params(n)
+    cbind.two_layer_run(b, P[:, :probe], F, 0.0, 0.0, threads=threads)   # threads and pages warm
+    reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    cbind.two_layer_run(b, params(n), F, 0.0, 0.0, threads=threads)
-    dt = time.perf_counter() - t0
-    n1 = max(256, n // (4 * threads))
+    while reps == 0 or (dt < 0.6 * target_seconds and reps < 64):
+        cbind.two_layer_run(b, P, F, 0.0, 0.0, threads=threads)
+        reps += 1
+        dt = time.perf_counter() - t0
+    n1 = max(256, min(n // (4 * threads) if threads < 64 else 4096, 8192))
     t0 = time.perf_counter()
     cbind.two_layer_run(b, params(n1), F, 0.0, 0.0, threads=1)
     dt1 = time.perf_counter() - t0
-    return {"value": n * (T1 - T0) / dt, "unit": "member-years/s", "cores": threads,
+    return {"value": n * reps * (T1 - T0) / dt, "unit": "member-years/s", "cores": threads,
+            "host_cores": host["host_cores"], "threads_used": threads, "affinity_cores": host["affinity_cores"],
+            "cgroup_cpu_quota_cores": host["cgroup_cpu_quota_cores"], "cpu_model": host["cpu_model"],
             "kind": "port", "single_thread_value": n1 * (T1 - T0) / dt1,
-            "sample": f"{n} members x {T1 - T0} years, oracle/rscm_oracle.c two_layer_run "
-                      f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads"}
+            "sample": f"{reps} pass(es) over {n} members x {T1 - T0} years, oracle/rscm_oracle.c two_layer_run "
+                      f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads (one per core this process may run on; "
+                      f"the host has {host['host_cores']})"}
 
 
 def linked_graph_extra(members, device, stream, years):
@@ -579,7 +644,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(min(os.cpu_count() or 1, 16))
+            cpu = cpu_baseline()
         except Exception as exc:  # noqa: BLE001 -- the GPU figure must not be lost to the CPU leg
             cpu = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             print(f"bench.py: cpu_baseline failed: {exc}", file=sys.stderr)

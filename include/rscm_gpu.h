@@ -52,6 +52,10 @@ extern "C" {
 #endif
 
 #define RSCM_GPU_ABI_VERSION 1
+/* Bumped whenever an entry point is added or a mode changes what a kind computes while the major version stays:
+ *   1  rscm_sampler_create_graph; four hooks moved to rscm_gpu_internal.h; RSCM_MODE_FAST acts on ClimateUDEB
+ *   2  RSCM_MODE_FAST acts on the coupled chain and on CarbonCycle; rscm_gpu_abi_minor itself                 */
+#define RSCM_GPU_ABI_MINOR 2
 
 #if defined(__GNUC__)
 #define RSCM_API __attribute__((visibility("default")))
@@ -344,12 +348,21 @@ extern "C" {
                              convolution with fused multiply-adds where the fit does not apply).
                              RSCM_KIND_UDEB: one refinement term of the column solve's row reciprocals instead
                              of two (1.4e-13 from the oracle instead of 5e-14; the same 1e-9 bar,
-                             tests/test_gpu_udeb.py).  The other kinds have one arithmetic.  */
+                             tests/test_gpu_udeb.py).
+                             RSCM_KIND_COUPLED and RSCM_KIND_CARBON_CYCLE (ABI minor 2): the carbon box's RK4 step
+                             in closed form -- its equation is linear over a model step, so the four stages
+                             collapse to C += h phi(h/lifetime) (A - C/lifetime) -- with 1/lifetime =
+                             exp(-alpha T)/tau (no division), the uptake integral from the concentration
+                             increments, cumulative emissions in the reference's own association (bit-exact),
+                             and the two-layer half as in the two-layer kind; within 1e-11 of the oracle on
+                             bounded members (measured 3e-13; tests/test_gpu_parity.py).
+                             The other kinds have one arithmetic.  */
 
 typedef struct rscm_ens rscm_ens;
 
 /* ---- library ------------------------------------------------------------------------------ */
 RSCM_API int rscm_gpu_abi_version(void);
+RSCM_API int rscm_gpu_abi_minor(void);  /* RSCM_GPU_ABI_MINOR the library was built with */
 /* Thread-local text of the last error raised by any call on this thread ("" if none). */
 RSCM_API const char* rscm_gpu_last_error(void);
 RSCM_API int rscm_gpu_device_count(int32_t* out);

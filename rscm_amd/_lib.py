@@ -229,6 +229,7 @@ _h = C.c_void_p
 # name -> (restype, argtypes); must list every symbol include/rscm_gpu.h declares
 SIGNATURES = {
     "rscm_gpu_abi_version": (C.c_int, []),
+    "rscm_gpu_abi_minor": (C.c_int, []),
     "rscm_gpu_last_error": (C.c_char_p, []),
     "rscm_gpu_device_count": (C.c_int, [_ip]),
     "rscm_gpu_mem_info": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -346,8 +347,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library diverge
         fn.restype = res
         fn.argtypes = args
-    if lib.rscm_gpu_abi_version() != 1:
-        raise RscmGpuUnavailable("ABI version mismatch")
+    if lib.rscm_gpu_abi_version() != 1 or lib.rscm_gpu_abi_minor() < 2:
+        raise RscmGpuUnavailable("ABI version mismatch (this front end needs version 1, minor >= 2): rebuild librscm_gpu.so")
     _LIB = lib
     return lib
 

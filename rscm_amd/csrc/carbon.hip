@@ -25,7 +25,15 @@ __global__ __launch_bounds__(kBlock) void carbon_cycle_kernel(CarbonArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    carbon::carbon_cycle_body<SRC>(a, i, a.step_begin, a.step_end);
+    carbon::carbon_cycle_body<0, SRC>(a, i, a.step_begin, a.step_end);
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kBlock) void carbon_cycle_fast_kernel(CarbonArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    carbon::carbon_cycle_body<1, SRC>(a, i, a.step_begin, a.step_end);
 }
 
 template <int SRC>
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
 
 }  // namespace
 
-hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s)
+hipError_t launch_carbon(const CarbonArgs& a, int mode, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
@@ -55,7 +63,8 @@ hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s)
     } else if (a.kind == kKindTerrestrialCarbon) {
         RSCM_LAUNCH_BY_SOURCE(terrestrial_kernel, a, grid, dim3(kBlock), s, a);
     } else if (a.kind == kKindCarbonCycle) {
-        RSCM_LAUNCH_BY_SOURCE(carbon_cycle_kernel, a, grid, dim3(kBlock), s, a);
+        if (mode != 0) RSCM_LAUNCH_BY_SOURCE(carbon_cycle_fast_kernel, a, grid, dim3(kBlock), s, a);
+        else RSCM_LAUNCH_BY_SOURCE(carbon_cycle_kernel, a, grid, dim3(kBlock), s, a);
     } else {
         return hipErrorInvalidValue;
     }

@@ -20,8 +20,8 @@
 // two_layer.hip (three-instruction quotient + exponent-window tags, full IEEE division replay
 // when a tag falls outside).  exp/log come from the device math library and may differ from
 // glibc's by an ulp, so this kind is tolerance-parity (tests/test_gpu_parity.py), not bit-parity.
-#include "rk4_device.hpp"
-#include "rscm_device.hpp"
+#include "carbon_body.hpp"
+#include "two_layer_body.hpp"
 
 namespace rscm {
 
@@ -121,6 +121,73 @@ __device__ __forceinline__ int32_t year(const CPConst& p, double emis, int32_t m
     return acc;
 }
 
+// RSCM_MODE_FAST: one member, the whole axis.  CarbonCycle as the collapsed linear RK4 step of carbon_body.hpp
+// (no division, one exp per year), CO2ERF and the Sum aggregate in their one arithmetic (a division by the
+// pre-industrial concentration and a log per year), TwoLayer with the heat capacities folded into its
+// coefficients and FMA stages (two_layer_body.hpp, rk4_step_fast) -- the very functions the linked components
+// call in this mode, so "four linked ensembles == the fused kind, bit for bit" holds per mode.
+template <bool LDS>
+__global__ __launch_bounds__(kBlock) void coupled_fast_kernel(CoupledArgs a)
+{
+    extern __shared__ double lds_emis[];
+    const int32_t len = a.step_end - a.step_begin;
+    if constexpr (LDS) {
+        const int32_t total = a.n_scen * len;
+        for (int32_t idx = threadIdx.x; idx < total; idx += kBlock) {
+            const int32_t s = idx / len, k = idx - s * len;
+            lds_emis[idx] = a.emissions[(size_t)s * a.n_times + a.step_begin + k];
+        }
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n_members) return;
+    const int64_t N = a.n_members;
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
+
+    double inv_cs;
+    const tl::TLFast tp = tl::make_fast(P(0), P(1), P(2), P(3), P(4), P(5), inv_cs);
+    const double rtau = 1.0 / P(6), conc_pi = P(7), alpha = P(8), erf_scale = P(9) / kLn2;
+    const int32_t scen = a.scen ? a.scen[i] : 0;
+    const double* eglob = a.emissions + (size_t)scen * a.n_times;
+    const int32_t el0 = scen * len - a.step_begin;
+    auto emissions_at = [&](int32_t n) -> double {
+        if constexpr (LDS) return lds_emis[el0 + n];
+        else return eglob[n];
+    };
+
+    const size_t r0 = (size_t)a.step_begin * N + i;
+    double ts = a.ts[r0], td = a.td[r0], conc = a.conc[r0], cum_u = a.cum_uptake[r0], cum_e = a.cum_emis[r0];
+    size_t r = r0 + (size_t)N;
+    const int32_t last = a.step_end - 1;
+    double emis_next = emissions_at(a.step_begin);
+    int32_t mc_next = a.nsub_cc[a.step_begin], mt_next = a.nsub_tl[a.step_begin];
+    const double hc = a.h_cc, sixth_c = a.h_cc / 6.0;
+    const double ht = a.h_tl, half_t = a.h_tl / 2.0, third_t = a.h_tl / 3.0, sixth_t = a.h_tl / 6.0;
+
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) {
+        const double emis = emis_next;
+        const int32_t mc = mc_next, mt = mt_next;
+        const int32_t np = n < last ? n + 1 : n;
+        emis_next = emissions_at(np);
+        mc_next = a.nsub_cc[np];
+        mt_next = a.nsub_tl[np];
+        carbon::carbon_cycle_year_fast(rtau, alpha, conc_pi, emis, ts, mc, hc, sixth_c, conc, cum_u, cum_e);
+        const double erf_co2 = erf_scale * log(1.0 + (conc - conc_pi) / conc_pi);
+        const double erf = (erf_co2 != erf_co2) ? erf_co2 : 0.0 + erf_co2;
+        const double erf_cs = erf * inv_cs;
+        for (int32_t s = 0; s < mt; ++s) tl::rk4_step_fast(tp, erf_cs, ht, half_t, third_t, sixth_t, ts, td);
+        a.conc[r] = conc;
+        a.cum_uptake[r] = cum_u;
+        a.cum_emis[r] = cum_e;
+        a.erf_co2[r] = erf_co2;
+        a.erf_total[r] = erf;
+        a.ts[r] = ts;
+        a.td[r] = td;
+        r += (size_t)N;
+    }
+    a.status[i] = (is_finite(ts) && is_finite(td) && is_finite(conc) && is_finite(cum_u) && is_finite(cum_e)) ? 0 : 1;
+}
+
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void coupled_kernel(CoupledArgs a)
 {
@@ -201,12 +268,13 @@ __global__ __launch_bounds__(kBlock) void coupled_kernel(CoupledArgs a)
 
 }  // namespace
 
-hipError_t launch_coupled(const CoupledArgs& a, int /*mode*/, hipStream_t s)
+hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
     const size_t lds = a.lds_forcing ? (size_t)a.n_scen * (a.step_end - a.step_begin) * sizeof(double) : 0;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
-    void (*kern)(CoupledArgs) = a.lds_forcing ? coupled_kernel<true> : coupled_kernel<false>;
+    void (*kern)(CoupledArgs) = mode != 0 ? (a.lds_forcing ? coupled_fast_kernel<true> : coupled_fast_kernel<false>)
+                                          : (a.lds_forcing ? coupled_kernel<true> : coupled_kernel<false>);
     if (lds > (size_t)kMaxStaticLds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

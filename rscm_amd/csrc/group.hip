@@ -93,7 +93,10 @@ __device__ __forceinline__ void run_kind(const GroupOp& op, int64_t i, int32_t b
     if constexpr (KIND == 0) {
         if (op.variant == 0) tl::two_layer_body<0, false, true>(op.u.tl, nullptr, i, b, b + 1, cache);
         else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, b, b + 1, cache);
-    } else if constexpr (KIND == kKindCarbonCycle) carbon::carbon_cycle_body<2>(op.u.carbon, i, b, b + 1, cache);
+    } else if constexpr (KIND == kKindCarbonCycle) {
+        if (op.variant == 0) carbon::carbon_cycle_body<0, 2>(op.u.carbon, i, b, b + 1, cache);
+        else carbon::carbon_cycle_body<1, 2>(op.u.carbon, i, b, b + 1, cache);
+    }
     else if constexpr (KIND == kKindCo2Budget) carbon::co2_budget_body<2>(op.u.carbon, i, b, b + 1, cache);
     else pw::pointwise_body<KIND, 2>(op.u.pw, i, b, b + 1, cache);   // CO2ERF, aggregate, AerosolIndirect, FourBoxOHU, OSPP
 }

@@ -40,7 +40,9 @@ __device__ __forceinline__ void run_op(const GroupOp& op, int64_t i, int32_t b, 
         case kKindN2oChemistry: if constexpr (FULL) chem::n2o_body<2>(op.u.chem, i, b, e); break;
         case kKindCo2Budget: carbon::co2_budget_body<2>(op.u.carbon, i, b, e, cache); break;
         case kKindTerrestrialCarbon: if constexpr (FULL) carbon::terrestrial_body<2>(op.u.carbon, i, b, e); break;
-        case kKindCarbonCycle: carbon::carbon_cycle_body<2>(op.u.carbon, i, b, e, cache); break;
+        case kKindCarbonCycle: if (op.variant == 0) carbon::carbon_cycle_body<0, 2>(op.u.carbon, i, b, e, cache);
+            else carbon::carbon_cycle_body<1, 2>(op.u.carbon, i, b, e, cache);
+            break;
         default: break;
     }
 }

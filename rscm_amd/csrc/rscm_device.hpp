@@ -611,7 +611,7 @@ void set_udeb_variant(int variant);            // which ClimateUDEB kernel the c
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
-hipError_t launch_carbon(const CarbonArgs& a, hipStream_t s);
+hipError_t launch_carbon(const CarbonArgs& a, int mode, hipStream_t s);   // mode: CarbonCycle only (the other two kinds have one arithmetic)
 hipError_t launch_ocean(const OceanArgs& a, hipStream_t s);
 hipError_t launch_halocarbon(const HaloArgs& a, hipStream_t s);
 hipError_t launch_sampler_propose(const SamplerArgs& a, hipStream_t s);

@@ -503,6 +503,7 @@ int window_flush(WindowDeferral* d, hipStream_t stream)
 extern "C" {
 
 int rscm_gpu_abi_version(void) { return RSCM_GPU_ABI_VERSION; }
+int rscm_gpu_abi_minor(void) { return RSCM_GPU_ABI_MINOR; }
 
 const char* rscm_gpu_last_error(void) { return g_last_error.c_str(); }
 
@@ -1425,11 +1426,11 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.status = h->d_status;
         if (op_out) {  // the arguments go into the fused launch's table instead (csrc/group.hip)
             op_out->kind = h->kind;
-            op_out->variant = 0;
+            op_out->variant = h->kind == RSCM_KIND_CARBON_CYCLE ? h->mode : 0;
             op_out->u.carbon = a;
             return RSCM_OK;
         }
-        HIPCHK(rscm::launch_carbon(a, h->stream));
+        HIPCHK(rscm::launch_carbon(a, h->mode, h->stream));
     } else if (h->kind == RSCM_KIND_CH4_CHEMISTRY || h->kind == RSCM_KIND_N2O_CHEMISTRY) {
         rscm::ChemArgs a{};
         a.n_members = h->N;

@@ -73,6 +73,32 @@ __device__ __forceinline__ void rhs_fast(const TLFast& p, double erf_cs, double 
     dtd = p.ed * diff;
 }
 
+// One FAST RK4 step: stages as FMAs, combination y + h/6*(k1+k4) + h/3*(k2+k3).  Shared with the FAST coupled
+// chain (coupled.hip) so the chain assembled from linked components carries the fused kernel's bits in this mode too.
+__device__ __forceinline__ void rk4_step_fast(const TLFast& p, double erf_cs, double h, double half_step, double third,
+                                              double sixth, double& ts, double& td)
+{
+    double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
+    rhs_fast(p, erf_cs, ts, td, k1s, k1d);
+    rhs_fast(p, erf_cs, __builtin_fma(k1s, half_step, ts), __builtin_fma(k1d, half_step, td), k2s, k2d);
+    rhs_fast(p, erf_cs, __builtin_fma(k2s, half_step, ts), __builtin_fma(k2d, half_step, td), k3s, k3d);
+    rhs_fast(p, erf_cs, __builtin_fma(k3s, h, ts), __builtin_fma(k3d, h, td), k4s, k4d);
+    ts = __builtin_fma(k2s + k3s, third, __builtin_fma(k1s + k4s, sixth, ts));
+    td = __builtin_fma(k2d + k3d, third, __builtin_fma(k1d + k4d, sixth, td));
+}
+
+// the folded coefficients of a member, formed the same way wherever FAST two-layer arithmetic runs
+__device__ __forceinline__ TLFast make_fast(double lambda0, double a, double efficacy, double eta, double cs, double cd, double& inv_cs)
+{
+    inv_cs = 1.0 / cs;
+    TLFast p;
+    p.l0 = lambda0 * inv_cs;
+    p.a = a * inv_cs;
+    p.ee = efficacy * eta * inv_cs;
+    p.ed = eta / cd;
+    return p;
+}
+
 // Per-member Gaussian log-likelihood accumulated while stepping (STORE == false): same
 // expression and summation order as loglik_kernel in ensemble_ops.hip -- per-variable partial
 // sums in time order, then the total in the caller's group order (likelihood.rs:186-250).
@@ -203,12 +229,8 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             }
         }
     } else {
-        const double inv_cs = 1.0 / cs;
-        TLFast p;
-        p.l0 = lambda0 * inv_cs;
-        p.a = pa * inv_cs;
-        p.ee = efficacy * eta * inv_cs;
-        p.ed = eta / cd;
+        double inv_cs;
+        const TLFast p = make_fast(lambda0, pa, efficacy, eta, cs, cd, inv_cs);
         const double third = h / 3.0;
         for (int32_t n = step_begin; n < step_end; ++n) {
             const double erf = erf_next * inv_cs;
@@ -216,18 +238,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
             const int32_t np = n < last ? n + 1 : n;
             erf_next = forcing_ahead(n, np, erf_next);
             m_next = a.nsub[np];
-            for (int32_t s = 0; s < m; ++s) {
-                double k1s, k1d, k2s, k2d, k3s, k3d, k4s, k4d;
-                rhs_fast(p, erf, ts, td, k1s, k1d);
-                rhs_fast(p, erf, __builtin_fma(k1s, half_step, ts), __builtin_fma(k1d, half_step, td),
-                         k2s, k2d);
-                rhs_fast(p, erf, __builtin_fma(k2s, half_step, ts), __builtin_fma(k2d, half_step, td),
-                         k3s, k3d);
-                rhs_fast(p, erf, __builtin_fma(k3s, h, ts), __builtin_fma(k3d, h, td), k4s, k4d);
-                // y + h/6*(k1+k4) + h/3*(k2+k3)
-                ts = __builtin_fma(k2s + k3s, third, __builtin_fma(k1s + k4s, sixth, ts));
-                td = __builtin_fma(k2d + k3d, third, __builtin_fma(k1d + k4d, sixth, td));
-            }
+            for (int32_t s = 0; s < m; ++s) rk4_step_fast(p, erf, h, half_step, third, sixth, ts, td);
             if constexpr (STORE) {
                 *out_ts = ts;
                 *out_td = td;

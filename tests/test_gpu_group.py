@@ -51,7 +51,8 @@ def _fusion_back_on():
     _fusion(True)
 
 
-def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra, mode):
     from rscm_amd import _lib as L
     from rscm_amd.ensemble import run_lockstep
     t = axis_values(1750, 1950)
@@ -59,6 +60,7 @@ def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra):
     T, n = len(t), 1000
     P, E = coupled_params(n), emissions_syn(t)
     with ra.Ensemble(ra.KIND_COUPLED, n, b) as e:
+        e.set_mode(mode)
         e.set_params(P)
         e.set_forcing(E)
         for v, x in ((1, 0.0), (2, 0.0), (3, 278.0), (4, 0.0), (5, 0.0)):
@@ -71,6 +73,7 @@ def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra):
     try:
         for x in (cc, ce, ag, tl):
             x.set_stream(stream.value)
+            x.set_mode(mode)
         cc.set_params(P[[6, 7, 8]])
         ce.set_params(P[[9, 7]])
         ag.set_params(np.zeros((9, n)))
@@ -113,7 +116,7 @@ def test_fused_coupled_chain_is_one_launch_and_keeps_the_bits(ra):
         for x in (cc, ce, ag, tl):
             x.run(8)
         run_lockstep((cc, ce, ag, tl), 100)
-        tl.set_mode(ra.MODE_EXACT)
+        tl.set_mode(mode)   # (setting the mode it has already: the cached op table stays valid)
         run_lockstep((cc, ce, ag, tl))
         again = collect()
         for v in range(1, 8):

@@ -72,12 +72,15 @@ def _coupled_graph(ra, t, P, E, stream):
     return cc, ce, ag, tl
 
 
-def test_linked_graph_reproduces_fused_coupled_chain(ra):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_linked_graph_reproduces_fused_coupled_chain(ra, mode):
+    """Either arithmetic: RSCM_MODE_FAST changes CarbonCycle and TwoLayer, in the fused kind and as linked components alike."""
     t = axis_values(1750, 2100)
     N = 3000
     P = coupled_params(N)
     E = emissions_syn(t)
     with ra.Ensemble(ra.KIND_COUPLED, N, _bounds(t)) as f:
+        f.set_mode(mode)
         f.set_params(P)
         f.set_forcing(E)
         for var, v in (("Atmospheric Concentration|CO2", 278.0), ("Cumulative Land Uptake", 0.0),
@@ -90,6 +93,8 @@ def test_linked_graph_reproduces_fused_coupled_chain(ra):
     s = Stream()
     cc, ce, ag, tl = _coupled_graph(ra, t, P, E, s)
     try:
+        for e in (cc, ce, ag, tl):
+            e.set_mode(mode)
         for n in range(len(t) - 1):  # Model::step: every component once, in graph order
             for e in (cc, ce, ag, tl):
                 e.run(n + 1, sync=False)

@@ -11,7 +11,12 @@ Parity bars (stated here, as the task requires):
     approach a finite-time singularity where any rounding difference is amplified without
     bound; they are compared by status flag only.
   * coupled kind: exp/log come from the device math library (<= 1 ulp from glibc), so
-    |gpu - oracle| <= 1e-11 * max(1, |oracle|) on bounded members, either mode.
+    |gpu - oracle| <= 1e-11 * max(1, |oracle|) on bounded members in RSCM_MODE_EXACT (the reference's
+    expression order) and in RSCM_MODE_FAST (closed-form RK4 step of the linear carbon box, folded heat
+    capacities, FMAs; measured 3e-13) alike -- every coupled test below runs in both.  Cumulative
+    emissions stay bit-exact in either mode.
+  * which kinds have a FAST arithmetic at all: two-layer, coupled, CarbonCycle, ClimateUDEB, OceanCarbon
+    (include/rscm_gpu.h, RSCM_MODE_FAST); for every other kind the mode is accepted and changes nothing.
   * integer/index work (time indexing, scenario selection, status flags, LHS strata): exact.
 """
 import os
@@ -299,14 +304,15 @@ CP_INIT = {"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0,
            "Cumulative Emissions|CO2": 0.0}
 
 
-def test_coupled_vs_oracle(ra, orc):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_coupled_vs_oracle(ra, orc, mode):
     t = axis_values()
     P = coupled_params(777)
     E = emissions_syn(t)
     want = orc.coupled_run(orc.bounds_from_values(t), P, E,
                            dict(ts=0.0, td=0.0, conc=278.0, cum_uptake=0.0, cum_emis=0.0),
                            threads=8)
-    got, st = _cp_gpu(ra, t, P, E, CP_INIT)
+    got, st = _cp_gpu(ra, t, P, E, CP_INIT, mode=mode)
     bounded = _bounded(want["ts"])
     assert bounded.mean() > 0.5
     for k, name in CP_NAMES.items():
@@ -318,9 +324,10 @@ def test_coupled_vs_oracle(ra, orc):
     assert_bit_equal(got["Cumulative Emissions|CO2"], want["cum_emis"])
 
 
-def test_coupled_golden_fixture(ra):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_coupled_golden_fixture(ra, mode):
     g = np.load(os.path.join(GOLDEN, "coupled_golden.npz"))
-    got, _ = _cp_gpu(ra, g["time_values"], g["params"], g["emissions"], CP_INIT)
+    got, _ = _cp_gpu(ra, g["time_values"], g["params"], g["emissions"], CP_INIT, mode=mode)
     for k, name in CP_NAMES.items():
         assert _close(got[name][1:], g[k][1:], FAST_RTOL).all(), name
 
@@ -500,7 +507,8 @@ def test_full_size_properties(ra, orc, n_members):
         assert np.isfinite(base).all()
 
 
-def test_coupled_full_size_properties(ra, orc):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_coupled_full_size_properties(ra, orc, mode):
     """BASELINE.json configs[2]: the coupled chain CarbonCycle -> CO2ERF -> Sum -> TwoLayer at
     1e6 members x 751 points (42 GB of series on the device), through properties plus an oracle
     spot check:
@@ -518,6 +526,7 @@ def test_coupled_full_size_properties(ra, orc):
     rng = np.random.default_rng(23)
     pick = np.sort(rng.choice(n, 256, replace=False))
     with ra.Ensemble(ra.KIND_COUPLED, n, b) as e:
+        e.set_mode(mode)
         e.set_params(P)
         e.set_forcing(E)
         for k, v in CP_INIT.items():
@@ -533,7 +542,7 @@ def test_coupled_full_size_properties(ra, orc):
         for (name, r), want_row in first.items():
             assert_bit_equal(e.get_series(name, r, r + 1)[0], want_row, f"second run {name} row {r}")
     assert status.mean() < 0.5
-    small, _ = _cp_gpu(ra, t, np.ascontiguousarray(P[:, :777]), E, CP_INIT)
+    small, _ = _cp_gpu(ra, t, np.ascontiguousarray(P[:, :777]), E, CP_INIT, mode=mode)
     for name in CP_NAMES.values():
         assert_bit_equal(head[name], small[name], f"first 777 members of 1e6 vs a 777-member run: {name}")
     want = orc.coupled_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), E,
@@ -894,8 +903,9 @@ def test_summary_series_equals_row_summaries(ra, orc):
         assert np.allclose(part["mean"], np.nanmean(row, axis=1), rtol=1e-12) and np.array_equal(part["max"], np.nanmax(row, axis=1))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("seed", range(10))
-def test_coupled_chain_fuzz(ra, orc, seed):
+def test_coupled_chain_fuzz(ra, orc, seed, mode):
     """Seeded random configurations of the fused coupled chain -- axis length, irregular step
     lengths, the two RK4 step sizes, scenarios (LDS and L2 paths) with or without a map, member-wise
     initial values, launch chunking -- against the oracle: 1e-11 on bounded members (device exp /
@@ -916,6 +926,7 @@ def test_coupled_chain_fuzz(ra, orc, seed):
     want = orc.coupled_run(b, P, E, init, scen=scen, h_tl=h_tl, h_cc=h_cc, threads=8)
     cuts = sorted(set(int(x) for x in rng.integers(0, T, int(rng.integers(0, 3)))))
     with ra.Ensemble(ra.KIND_COUPLED, n, b) as e:
+        e.set_mode(mode)
         e.set_step_size(0, h_tl)
         e.set_step_size(1, h_cc)
         e.set_params(P)
@@ -929,7 +940,7 @@ def test_coupled_chain_fuzz(ra, orc, seed):
         e.run()
         got = {key: e.get_series(name) for key, name in CP_NAMES.items()}
         st = e.status()
-    what = f"seed {seed} (T={T}, n={n}, S={S}, h_tl={h_tl}, h_cc={h_cc}, cuts={cuts})"
+    what = f"seed {seed} mode {mode} (T={T}, n={n}, S={S}, h_tl={h_tl}, h_cc={h_cc}, cuts={cuts})"
     bounded = _bounded(want["ts"])
     for key in CP_NAMES:
         g, w = got[key], want[key]
