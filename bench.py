@@ -475,6 +475,95 @@ def end_to_end_extra(members, device, mode, stream, years):
             "note": "H2D params + run + D2H of both series into pinned buffers, best of 3"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks as children of this process (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1 and a free MASTER_PORT in their environment), relay rank 0's JSON line, pass the other
+    ranks' output on to stderr, and return non-zero if any rank failed (the others are then ended by their exact PIDs)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's cross-process buffers need it on this host driver
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE, stderr=None if r == 0 else subprocess.PIPE, text=True))
+    import threading
+    outs = [None] * n
+
+    def drain(r):
+        outs[r] = procs[r].communicate()
+
+    threads = [threading.Thread(target=drain, args=(r,), daemon=True) for r in range(n)]
+    for th in threads:
+        th.start()
+    failed = None
+    while any(th.is_alive() for th in threads):
+        for r, pr in enumerate(procs):
+            code = pr.poll()
+            if code not in (None, 0) and failed is None:
+                failed = (r, code)
+                for other in procs:   # one rank down: the others would wait in a collective until its timeout
+                    if other.poll() is None:
+                        other.terminate()
+        for th in threads:
+            th.join(timeout=0.2)
+    for r, pr in enumerate(procs):
+        if pr.returncode != 0 and failed is None:
+            failed = (r, pr.returncode)
+    for r in range(1, n):
+        so, se = outs[r] or ("", "")
+        if (so or se) and (failed is not None):
+            sys.stderr.write(f"---- rank {r} (exit {procs[r].returncode})\n{(so or '')[-2000:]}{(se or '')[-4000:]}\n")
+    line = (outs[0] or ("", None))[0] or ""
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with {failed[1]}\n{line[-2000:]}\n")
+        return 1
+    # rank 0's stdout may carry library chatter ("[Gloo] Rank 0 is connected ..."): the contract is ONE JSON line on stdout
+    rows = [x for x in line.splitlines() if x.strip()]
+    result = next((x for x in reversed(rows) if x.lstrip().startswith("{")), None)
+    for x in rows:
+        if x is not result:
+            sys.stderr.write(x + "\n")
+    if result is None:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        return 1
+    sys.stdout.write(result + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def rendezvous_only(args, rank, world, torch, dist):
+    """--rendezvous-only: everything of the N > 1 procedure that is not GPU work, on the CPU over gloo -- process group, barriers,
+    max-over-ranks of a wall time, the rank report -- so that the launcher and the collectives' plumbing are covered where there is
+    no GPU.  Prints a line marked as carrying no measurement."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))   # the slowest rank sets the wall time
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    collective, per_rank = rank_report(10.0 * (rank + 1), wall, 1, torch, dist)
+    if rank == 0:
+        print(json.dumps({"metric": "ensemble-member-years/sec, two-layer 1750-2500 f64", "value": None, "unit": "member-years/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rendezvous_only": True,
+                          "collective": collective, "per_rank": per_rank, "wall_s": wall}))
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -484,16 +573,25 @@ def main():
     ap.add_argument("--mode", choices=["exact", "fast"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary 1e6-member / fast-mode lines")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="no GPU work: the ranks meet over gloo, run the contract's barrier / max-over-ranks / rank report and rank 0 "
+                         "prints a line with value null (tests/test_distributed_cpu.py checks the launcher and the N > 1 plumbing with it)")
     args = ap.parse_args()
 
+    # No launcher environment and more than one GPU asked for: this process starts the ranks itself and never touches the GPU
+    # (decided from argv and the environment alone, before torch.cuda or librscm_gpu.so are loaded).
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
 
     import torch
     import torch.distributed as dist
+    if args.rendezvous_only:
+        raise SystemExit(rendezvous_only(args, rank, world, torch, dist))
     from rscm_amd import _lib
     _lib.load()  # no CPU fallback: fail here if the HIP extension is missing
     if not torch.cuda.is_available():
@@ -529,6 +627,7 @@ def main():
     n_fail = int(ens.status().sum())
     s_mid = ens.summary("Surface Temperature", 270)  # year 2020
     ens.close()
+    collective, per_rank = rank_report(kernel_ms, wall, args.steps, torch, dist)
 
     total_member_years = float(world) * args.members * years * args.steps
     value = total_member_years / wall
@@ -676,6 +775,8 @@ def main():
             },
             "roofline": roofline_hbm,
             "roofline_fp64_valu": roofline_valu,
+            "collective": collective,
+            "per_rank": per_rank,
             "cpu_baseline": cpu,
             "check": {"failed_members_rank0": n_fail, "Ts_2020_mean_rank0": s_mid["mean"],
                       "finite_members_2020_rank0": s_mid["count"]},

@@ -282,8 +282,10 @@ extern "C" {
 
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
- * Rows marked [u] are structural and must be equal for every member; the device supports
- * n_layers = 20, 30, 40 or 50 (the column solve is unrolled per layer count) and ocean_temp_profile = 2 (CMIP5). */
+ * Rows marked [u] are structural and must be equal for every member.  n_layers: any count >= 2 as in the reference
+ * (climate/udeb/mod.rs:162-165; at most 4096 here) -- 20, 30, 40 and 50 layers run the register-resident, unrolled column
+ * solve, every other count a slower kernel with the columns in HBM (same arithmetic, same parity bar);
+ * ocean_temp_profile = 2 (CMIP5) only. */
 #define RSCM_UD_NPARAMS 37
 #define RSCM_UD_P_N_LAYERS 0              /* [u] */
 #define RSCM_UD_P_MIXED_LAYER_DEPTH 1     /* [u] */

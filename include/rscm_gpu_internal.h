@@ -40,8 +40,8 @@ RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps
 RSCM_API int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32);
 
 /* Which ClimateUDEB kernel the calling thread's launches take (csrc/udeb.hip): 0 one thread per member, 2 a hemisphere per
- * wavefront, 4 half a hemisphere's column per wavefront (two wavefronts per SIMD); -1 (default): chosen by ensemble size.
- * Kernels 0 and 2 carry the same bits; kernel 4 solves the same system in another order (agrees to rounding). */
+ * wavefront; -1 (default): chosen by ensemble size.  The two carry the same bits.  (Layer counts other than 20 / 30 / 40 / 50
+ * always take the any-count kernel.)  The setting is per calling THREAD: launches issued from another thread do not see it. */
 RSCM_API int rscm_gpu_set_udeb_variant(int32_t variant);
 
 /* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an

@@ -109,6 +109,10 @@ struct rscm_ens {
 
     // ClimateUDEB internal state
     double* d_ocean = nullptr;    // [2][NL][N]
+    int32_t udeb_ocean_layers = 0;   // layers d_ocean has room for
+    double* d_udeb_work = nullptr;   // [NL][N]  the any-layer-count kernel's c' array (udeb_any_body.hpp)
+    double* d_udeb_tables = nullptr; // [NL][6]  its geometry table
+    int32_t udeb_work_layers = 0;
     double* d_scal = nullptr;     // [kUdebScalars][N]
     double* d_hist = nullptr;     // [T][N]
     double* d_tables = nullptr;   // geometry tables
@@ -194,6 +198,43 @@ struct rscm_ens {
         return var >= RSCM_CP_VAR_TS && var <= RSCM_CP_VAR_CUM_EMIS;
     }
 };
+
+// Parameter rows from which the HOST derives state when rscm_ens_set_params / rscm_ens_sample_lhs configure an ensemble
+// (ClimateUDEB's geometry tables and look-back windows, OceanCarbon's impulse-response table and mode fit, GhgForcing's
+// method switch, the N2O look-back): marked [u] in rscm_gpu.h.  They must hold ONE value for all members, and nothing that
+// writes parameters on the device (the samplers' proposals) may touch them -- the derived tables would silently stay those
+// of the base value, where the reference rebuilds the component for every parameter vector (model_runner.rs:257-266).
+// Returns the row's name for the error text, or nullptr.
+inline const char* structural_row(int32_t kind, int32_t row)
+{
+    if (kind == RSCM_KIND_UDEB) {
+        switch (row) {
+            case RSCM_UD_P_N_LAYERS: return "n_layers";
+            case RSCM_UD_P_MIXED_LAYER_DEPTH: return "mixed_layer_depth";
+            case RSCM_UD_P_LAYER_THICKNESS: return "layer_thickness";
+            case RSCM_UD_P_DEPTH_DEPENDENT_AREA: return "depth_dependent_area";
+            case RSCM_UD_P_LAND_HC_ENABLED: return "land_heat_capacity_enabled";
+            case RSCM_UD_P_EFFICACY_APPLY: return "efficacy_apply";
+            case RSCM_UD_P_OCEAN_TEMP_PROFILE: return "ocean_temp_profile";
+            case RSCM_UD_P_STEPS_PER_YEAR: return "steps_per_year";
+            case RSCM_UD_P_FEEDBACK_CUMT_PERIOD: return "feedback_cumt_period";
+            default: return nullptr;
+        }
+    }
+    if (kind == RSCM_KIND_OCEAN_CARBON) {
+        switch (row) {
+            case RSCM_OC_P_MODEL: return "model";
+            case RSCM_OC_P_IRF_SCALE: return "irf_scale";
+            case RSCM_OC_P_STEPS_PER_YEAR: return "steps_per_year";
+            case RSCM_OC_P_MAX_HISTORY_MONTHS: return "max_history_months";
+            case RSCM_OC_P_IRF_SWITCH_TIME: return "irf_switch_time";
+            default: return nullptr;
+        }
+    }
+    if (kind == RSCM_KIND_GHG_FORCING && row == RSCM_GH_P_METHOD) return "method";
+    if (kind == RSCM_KIND_N2O_CHEMISTRY && row == 4) return "stratospheric delay (sets the look-back)";
+    return nullptr;
+}
 
 inline int set_device(const rscm_ens* h)
 {

@@ -48,7 +48,7 @@ int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32)
 
 int rscm_gpu_set_udeb_variant(int32_t variant)
 {
-    if (variant != -1 && variant != 0 && variant != 2 && variant != 4) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0, 2 or 4");
+    if (variant != -1 && variant != 0 && variant != 2) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0 or 2");
     rscm::set_udeb_variant(variant);
     return RSCM_OK;
 }

@@ -356,6 +356,8 @@ struct UdebArgs {
     // rows [NL][6] = {af_top, af_bot, af_diff, 1 - rel_depth, G_nh, G_sh}, NL = n_layers <= 50 (udeb_tables.hpp): passed BY
     // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
     double tables[6 * 50];
+    const double* tables_dev;  // the same rows in device memory, any NL: the any-layer-count kernel (udeb_any_body.hpp); else nullptr
+    double* work;              // [NL][N] the Thomas sweep's c' array of that kernel; else nullptr
     double* ocean;          // [2][NL][N] layer temperatures
     double* scal;           // [10][N] upwelling, land, ground, alpha_eff, hemi exchange (x2 hemispheres)
     double* hist;           // [T][N] year-weighted global temperature history
@@ -606,7 +608,7 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
-bool udeb_layers_supported(int32_t n_layers);  // the layer counts the column kernels are instantiated for
+bool udeb_layers_unrolled(int32_t n_layers);  // the layer counts the register-resident column kernels are instantiated for
 void set_udeb_variant(int variant);            // which ClimateUDEB kernel the calling thread's launches take (udeb.hip; -1: by size)
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);

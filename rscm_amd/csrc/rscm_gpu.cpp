@@ -356,8 +356,10 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             if (row(j, i) != row(j, 0))
                 return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d must be the same for every member", j);
     const double nl = row(RSCM_UD_P_N_LAYERS, 0), steps = row(RSCM_UD_P_STEPS_PER_YEAR, 0);
-    if (nl != std::floor(nl) || !rscm::udeb_layers_supported((int32_t)nl))
-        return fail(RSCM_ERR_INVALID, "ClimateUDEB on the device supports n_layers = 20, 30, 40 or 50 (the column solve is unrolled per layer count), got %g", nl);
+    // mod.rs:162-165: "invalid n_layers: must be >= 2".  20 / 30 / 40 / 50 layers have a register-resident, unrolled column solve;
+    // every other count runs the any-count kernel (columns in HBM; csrc/udeb_any_body.hpp).  The upper bound is this library's.
+    if (nl != std::floor(nl) || nl < 2.0) return fail(RSCM_ERR_INVALID, "invalid n_layers: must be >= 2, got %g", nl);
+    if (nl > 4096.0) return fail(RSCM_ERR_INVALID, "n_layers = %g: the device path takes at most 4096 ocean layers", nl);
     if (h->udeb_ready && (int32_t)nl != h->udeb_n_layers && h->time_index > 0)
         return fail(RSCM_ERR_STATE, "n_layers changes the ocean columns (internal state) at time index %d: rewind first", h->time_index);
     if (row(RSCM_UD_P_OCEAN_TEMP_PROFILE, 0) != 2.0)
@@ -401,7 +403,37 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
         HIPCHK(hipMemcpyAsync(h->d_win_partw, partw.data(), partw.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    if (!h->d_ocean) HIPCHK(hipMalloc(&h->d_ocean, (size_t)2 * 50 * h->N * sizeof(double)));  // room for the largest supported column
+    {   // the columns: room for 50 layers at least (any of the unrolled kernels), more if asked for
+        const int32_t want = std::max(50, h->udeb_n_layers);
+        if (want > h->udeb_ocean_layers) {
+            (void)hipFree(h->d_ocean);
+    (void)hipFree(h->d_udeb_work);
+    (void)hipFree(h->d_udeb_tables);
+            h->d_ocean = nullptr;
+            h->udeb_ocean_layers = 0;
+            const hipError_t e = hipMalloc(&h->d_ocean, (size_t)2 * want * h->N * sizeof(double));
+            if (e != hipSuccess)
+                return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "ocean columns of %d layers x %lld members: %s", want,
+                            (long long)h->N, hipGetErrorString(e));
+            h->udeb_ocean_layers = want;
+        }
+    }
+    if (!rscm::udeb_layers_unrolled(h->udeb_n_layers)) {   // the any-count kernel: its c' array and its table live in device memory
+        if (h->udeb_n_layers > h->udeb_work_layers) {
+            (void)hipFree(h->d_udeb_work);
+            (void)hipFree(h->d_udeb_tables);
+            h->d_udeb_work = h->d_udeb_tables = nullptr;
+            h->udeb_work_layers = 0;
+            const hipError_t e = hipMalloc(&h->d_udeb_work, (size_t)h->udeb_n_layers * h->N * sizeof(double));
+            if (e != hipSuccess)
+                return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "work array of %d layers x %lld members: %s",
+                            h->udeb_n_layers, (long long)h->N, hipGetErrorString(e));
+            HIPCHK(hipMalloc(&h->d_udeb_tables, (size_t)6 * h->udeb_n_layers * sizeof(double)));
+            h->udeb_work_layers = h->udeb_n_layers;
+        }
+        HIPCHK(hipMemcpyAsync(h->d_udeb_tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     h->udeb_ready = true;
     return RSCM_OK;
 }
@@ -1504,9 +1536,15 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.bounds = h->d_bounds;
         a.win_kfull = h->d_win_kfull;
         a.win_partw = h->d_win_partw;
-        if (h->udeb_tables.size() != (size_t)6 * h->udeb_n_layers || h->udeb_tables.size() > sizeof(a.tables) / sizeof(double))
-            return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
-        memcpy(a.tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double));
+        if (h->udeb_tables.size() != (size_t)6 * h->udeb_n_layers) return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
+        if (rscm::udeb_layers_unrolled(h->udeb_n_layers)) {   // by value, in the kernel-argument segment
+            memcpy(a.tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double));
+        } else {
+            if (!h->d_udeb_tables || !h->d_udeb_work || h->udeb_work_layers < h->udeb_n_layers)
+                return fail(RSCM_ERR_STATE, "ClimateUDEB work arrays for %d layers not allocated", h->udeb_n_layers);
+            a.tables_dev = h->d_udeb_tables;
+            a.work = h->d_udeb_work;
+        }
         a.ocean = h->d_ocean;
         a.scal = h->d_scal;
         a.hist = h->d_hist;
@@ -2109,29 +2147,19 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
         return fail(RSCM_ERR_INVALID, "member block [%lld, %lld) outside the global ensemble of %lld",
                     (long long)member_offset, (long long)(member_offset + h->N), (long long)n_total);
     if (int rc = set_device(h)) return rc;
-    if (h->kind == RSCM_KIND_UDEB) {
-        static const int structural[] = {RSCM_UD_P_N_LAYERS, RSCM_UD_P_MIXED_LAYER_DEPTH, RSCM_UD_P_LAYER_THICKNESS,
-                                         RSCM_UD_P_DEPTH_DEPENDENT_AREA, RSCM_UD_P_LAND_HC_ENABLED,
-                                         RSCM_UD_P_EFFICACY_APPLY, RSCM_UD_P_OCEAN_TEMP_PROFILE, RSCM_UD_P_STEPS_PER_YEAR,
-                                         RSCM_UD_P_FEEDBACK_CUMT_PERIOD};
-        for (int j : structural)
-            if (low[j] != high[j])
-                return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d is structural: low must equal high", j);
+    if (h->kind != RSCM_KIND_N2O_CHEMISTRY)   // (N2O's delay may vary over the members: the look-back is sized for the largest)
+        for (int32_t j = 0; j < h->P; ++j)
+            if (const char* name = structural_row(h->kind, j))
+                if (low[j] != high[j])
+                    return fail(RSCM_ERR_INVALID, "parameter row %d (%s) is structural: low must equal high", j, name);
+    if (h->kind == RSCM_KIND_UDEB)
         if (int rc = configure_udeb(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
-    }
-    if (h->kind == RSCM_KIND_OCEAN_CARBON) {
-        static const int structural[] = {RSCM_OC_P_MODEL, RSCM_OC_P_IRF_SCALE, RSCM_OC_P_STEPS_PER_YEAR,
-                                         RSCM_OC_P_MAX_HISTORY_MONTHS, RSCM_OC_P_IRF_SWITCH_TIME};
-        for (int j : structural)
-            if (low[j] != high[j])
-                return fail(RSCM_ERR_INVALID, "OceanCarbon parameter row %d is structural: low must equal high", j);
+    if (h->kind == RSCM_KIND_OCEAN_CARBON)
         if (int rc = configure_ocean(h, 1, [&](int j, int64_t) { return low[j]; })) return rc;
-    }
     if (h->kind == RSCM_KIND_N2O_CHEMISTRY) h->lookback = (int32_t)std::min(std::max(1.0, high[4]), 1e6) + 1;
     if (h->kind == RSCM_KIND_GHG_FORCING) {
         const double m = low[RSCM_GH_P_METHOD];
-        if (m != high[RSCM_GH_P_METHOD] || (m != 0.0 && m != 1.0))
-            return fail(RSCM_ERR_INVALID, "GhgForcing method is structural: low must equal high and be 0 or 1");
+        if (m != 0.0 && m != 1.0) return fail(RSCM_ERR_INVALID, "GhgForcing method must be 0 or 1");
         h->ghg_method = (int32_t)m;
     }
     double* d_lh = nullptr;

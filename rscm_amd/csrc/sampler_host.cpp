@@ -172,6 +172,9 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
         return fail(RSCM_ERR_INVALID, "bad parameter description");
     for (int32_t d = 0; d < n_dims; ++d) {
         if (param_rows[d] < 0 || param_rows[d] >= h->P) return fail(RSCM_ERR_INVALID, "dimension %d: parameter row %d out of range", d, param_rows[d]);
+        if (const char* name = structural_row(h->kind, param_rows[d]))
+            return fail(RSCM_ERR_INVALID, "dimension %d: parameter row %d (%s) is structural -- the host derives tables from it when the "
+                        "parameters are set -- and cannot be sampled on the device", d, param_rows[d], name);
         for (int32_t e2 = 0; e2 < d; ++e2)
             if (param_rows[e2] == param_rows[d]) return fail(RSCM_ERR_INVALID, "parameter row %d sampled twice", param_rows[d]);
         if (prior_kind[d] < 0 || prior_kind[d] > 2) return fail(RSCM_ERR_INVALID, "dimension %d: unknown prior kind %d", d, prior_kind[d]);
@@ -323,6 +326,9 @@ int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32
         if (param_owner[d] < 0 || param_owner[d] >= n_handles) return fail(RSCM_ERR_INVALID, "dimension %d: owner %d out of range", d, param_owner[d]);
         const rscm_ens* h = handles[param_owner[d]];
         if (param_rows[d] < 0 || param_rows[d] >= h->P) return fail(RSCM_ERR_INVALID, "dimension %d: parameter row %d out of range", d, param_rows[d]);
+        if (const char* name = structural_row(h->kind, param_rows[d]))
+            return fail(RSCM_ERR_INVALID, "dimension %d: parameter row %d (%s) of handle %d is structural -- the host derives tables from it "
+                        "when the parameters are set -- and cannot be sampled on the device", d, param_rows[d], name, param_owner[d]);
         for (int32_t e2 = 0; e2 < d; ++e2)
             if (param_owner[e2] == param_owner[d] && param_rows[e2] == param_rows[d])
                 return fail(RSCM_ERR_INVALID, "parameter row %d of handle %d sampled twice", param_rows[d], param_owner[d]);
@@ -340,6 +346,12 @@ int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32
         if (obs_var[j] < 1 || obs_var[j] >= h->V) return fail(RSCM_ERR_INVALID, "observation %d: variable %d has no stored series", j, obs_var[j]);
         if (obs_tidx[j] < 0 || obs_tidx[j] >= h->T) return fail(RSCM_ERR_INVALID, "observation %d: time index %d out of range", j, obs_tidx[j]);
         last_step = std::max(last_step, obs_tidx[j]);
+        // one contiguous run per (owner, variable), as rscm_sampler_create_sharded and the host likelihood require: the kernel closes a
+        // partial sum at every change of group, so an interleaved order would change the association of the sum (likelihood.rs:206-248)
+        if (j > 0 && (obs_owner[j] != obs_owner[j - 1] || obs_var[j] != obs_var[j - 1]))
+            for (int32_t e2 = 0; e2 < j - 1; ++e2)
+                if (obs_owner[e2] == obs_owner[j] && obs_var[e2] == obs_var[j])
+                    return fail(RSCM_ERR_INVALID, "observation %d: the observations of (handle %d, variable %d) must be contiguous", j, obs_owner[j], obs_var[j]);
     }
     if (int rc = set_device(lead)) return rc;
     if (!lead->d_loglik) HIPCHK(hipMalloc(&lead->d_loglik, (size_t)lead->N * sizeof(double)));
@@ -413,7 +425,8 @@ int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32
         for (int32_t j = 0; j < n_obs; ++j) {
             const rscm_ens* h = handles[obs_owner[j]];
             ptrs[(size_t)j] = h->series(obs_var[j]) + (size_t)obs_tidx[j] * h->N;
-            grp[(size_t)j] = obs_owner[j] * 256 + obs_var[j];
+            // the group id: the index of the run's first observation (unique per (owner, variable) whatever the variable count)
+            grp[(size_t)j] = (j > 0 && obs_owner[j] == obs_owner[j - 1] && obs_var[j] == obs_var[j - 1]) ? grp[(size_t)j - 1] : j;
         }
         if (n_obs > 0) {
             memcpy(blob.data(), ptrs.data(), sz_ptr);

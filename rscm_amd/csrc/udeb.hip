@@ -36,7 +36,7 @@
 // year); no such member occurs in the test ensembles.
 #include <cstdlib>
 
-#include "udeb4_body.hpp"
+#include "udeb_any_body.hpp"
 
 namespace rscm {
 
@@ -72,20 +72,18 @@ __global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
     m.end(a);
 }
 
-// Four wavefronts per 64 members, half a column each (udeb4_body.hpp), two wavefronts per SIMD.
-template <int NL, bool FAST>
-__global__ __launch_bounds__(kUdeb4Block, 2) void udeb4_kernel(UdebArgs a)
+// Any other layer count (>= 2): columns in HBM, plain loops (udeb_any_body.hpp).  256 threads: nothing lives in registers across rows.
+template <bool FAST>
+__global__ __launch_bounds__(256) void udeb_any_kernel(UdebArgs a)
 {
-    __shared__ Udeb4Lds lds;
-    Udeb4<NL> m(lds);
-    m.begin(a);
-    for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<FAST>(a, n);
-    m.end(a);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_members) return;
+    udeb::udeb_any_member<FAST>(a, i);
 }
 
 }  // namespace
 
-// 0: one thread per member, 2: a hemisphere per wavefront, 4: half a hemisphere's column per wavefront; -1: by ensemble size
+// 0: one thread per member, 2: a hemisphere per wavefront; -1: by ensemble size
 static thread_local int t_udeb_variant = -1;
 void set_udeb_variant(int variant) { t_udeb_variant = variant; }
 
@@ -93,11 +91,7 @@ template <int NL>
 static void launch_udeb_nl(const UdebArgs& a, int variant, hipStream_t s)
 {
     const bool two_waves = variant == 2;
-    if (variant == 4) {
-        const dim3 grid((unsigned)((a.n_members + 63) / 64));
-        if (a.fast) hipLaunchKernelGGL((udeb4_kernel<NL, true>), grid, dim3(kUdeb4Block), 0, s, a);
-        else hipLaunchKernelGGL((udeb4_kernel<NL, false>), grid, dim3(kUdeb4Block), 0, s, a);
-    } else if (two_waves) {
+    if (two_waves) {
         const dim3 grid((unsigned)((a.n_members + 63) / 64));
         if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true>), grid, dim3(kUdeb2Block), 0, s, a);
         else hipLaunchKernelGGL((udeb2_kernel<NL, false>), grid, dim3(kUdeb2Block), 0, s, a);
@@ -108,7 +102,8 @@ static void launch_udeb_nl(const UdebArgs& a, int variant, hipStream_t s)
     }
 }
 
-bool udeb_layers_supported(int32_t n_layers)
+// the layer counts with an unrolled, register-resident column solve; every other count >= 2 runs the any-count kernel
+bool udeb_layers_unrolled(int32_t n_layers)
 {
     return n_layers == 20 || n_layers == 30 || n_layers == 40 || n_layers == 50;
 }
@@ -119,18 +114,25 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     // Up to 32 768 members there are fewer wavefronts than SIMDs either way: the two-wavefront kernel solves a member's
     // two hemispheres at the same time on two SIMDs (half the latency per model step); beyond that the two kernels
     // take the same time per member (profiles/r3_udeb_two_wave_experiment.txt) and the one-thread kernel is kept.
-    // The four-wavefront kernel (udeb4_body.hpp: two wavefronts per SIMD) is opt-in: 71 ms against 54 ms at 65 536 members x 750
-    // years, 11 % ahead only for a few thousand members, and it agrees with the other two to rounding, not to the bit.
-    // RSCM_UDEB_VARIANT = 0 / 2 / 4 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
+    // (A third kernel -- four wavefronts per 64 members, each hemisphere's column cut in the middle, two wavefronts per SIMD -- was built
+    // in round 3 and removed in round 4: 71 ms against 54 ms at 65 536 members x 750 years, ahead only below ~4096 members, and its
+    // twisted factorisation agrees with these two to rounding, not to the bit -- selecting it by ensemble size would have made a
+    // member's bits depend on how many members run beside it.  profiles/r3_udeb4_65536.txt, DESIGN.md section 8, commit 03abd7b.)
+    // RSCM_UDEB_VARIANT = 0 / 2 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
     int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;
-    if (variant != 0 && variant != 2 && variant != 4) variant = a.n_members <= 32768 ? 2 : 0;
+    if (variant != 0 && variant != 2) variant = a.n_members <= 32768 ? 2 : 0;
     switch (a.n_layers) {   // the column loops are unrolled, the column lives in registers: one instance per supported layer count
         case 20: launch_udeb_nl<20>(a, variant, s); break;
         case 30: launch_udeb_nl<30>(a, variant, s); break;
         case 40: launch_udeb_nl<40>(a, variant, s); break;
         case 50: launch_udeb_nl<50>(a, variant, s); break;
-        default: return hipErrorInvalidValue;
+        default: {   // every other count the reference accepts (>= 2): the completeness path
+            if (a.n_layers < 2 || !a.tables_dev || !a.work) return hipErrorInvalidValue;
+            const dim3 grid((unsigned)((a.n_members + 255) / 256));
+            if (a.fast) hipLaunchKernelGGL(udeb_any_kernel<true>, grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(udeb_any_kernel<false>, grid, dim3(256), 0, s, a);
+        }
     }
     return hipGetLastError();
 }

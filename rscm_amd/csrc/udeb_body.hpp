@@ -881,10 +881,14 @@ struct Udeb2 {
             const double part_w = a.win_partw[n];
             const double* hcol = a.hist + i;
             win_sum += hist_last;
-            for (; win_lo < k_full; ++win_lo) win_sum -= hcol[(size_t)win_lo * N];
+            // Entry n-1 is the one the hemisphere-0 wavefront stored AFTER the previous year's last barrier: the other wavefront may
+            // get here before that store has landed.  Both wavefronts hold its value (hist_last), so neither reads it back -- a
+            // window shorter than the previous model step (k_full == n) would otherwise race on it.
+            auto hist_at = [&](int32_t k) -> double { return k == n - 1 ? hist_last : hcol[(size_t)k * N]; };
+            for (; win_lo < k_full; ++win_lo) win_sum -= hist_at(win_lo);
             if (p.fb_cumt != 0.0) {
                 cum_t = win_sum;
-                if (part_w > 0.0) cum_t += hcol[(size_t)(k_full - 1) * N] * part_w;
+                if (part_w > 0.0) cum_t += hist_at(k_full - 1) * part_w;
             }
         }
         const double cumt_2x = p.ecs * p.fb_period;

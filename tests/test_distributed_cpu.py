@@ -24,3 +24,51 @@ def test_two_rank_gloo_sharding(n_total, tmp_path):
         assert x["world"] == 2
         assert x["ll_ok"] and x["st_ok"] and x["sum_ok"] and x["params_ok"] and x["single_gather"]
         assert x["reduce"] == {"count": 4, "mean": 0.5, "min": -1.0, "max": 1.0}
+
+
+def _bench(*argv, env_extra=None, strip=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in strip}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no RANK / WORLD_SIZE in the environment becomes the launcher: N children of itself, rank 0's
+    line relayed as the ONLY thing on stdout.  --rendezvous-only: the ranks meet over gloo and run the contract's barrier, the
+    max-over-ranks all-reduce and the rank report, with no GPU work (there is none here)."""
+    r = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--rendezvous-only")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(rows) == 1, r.stdout
+    line = json.loads(rows[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["value"] is None and line["rendezvous_only"]
+    assert line["collective"] == {"backend": "gloo", "world": 2, "rccl_ranks_seen": 0, "ranks_seen": 2, "tensors_on": "cpu"}
+    assert line["per_rank"]["kernel_ms"] == [10.0, 20.0]            # every rank's own figure reached rank 0, in rank order
+    eff = line["per_rank"]["weak_efficiency"]
+    assert len(eff) == 2 and eff[0] < eff[1] <= 1.0 + 1e-9          # the rank that waited shows
+
+
+def test_bench_under_a_launcher_keeps_the_launchers_ranks():
+    """With RANK / WORLD_SIZE set (torch.distributed.run's environment) bench.py is a rank, not a launcher."""
+    cmd_env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"]
+    r = subprocess.run(cmd, env=dict(os.environ, **cmd_env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.lstrip().startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["collective"]["ranks_seen"] == 2
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that fails (here: no GPU for the real run) makes the launcher exit non-zero, print no result line and name the rank."""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline", "--members", "2000",
+               env_extra={"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"})   # (on a one-GPU box: both ranks on its GPU)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present: the real two-rank run succeeded")
+    assert r.stdout.strip() == ""
+    assert "exited with" in r.stderr
+
+
+def test_bench_world_size_mismatch_is_refused():
+    r = _bench("--gpus", "2", "--rendezvous-only", env_extra={"RANK": "0", "WORLD_SIZE": "1"}, strip=())
+    assert r.returncode != 0 and "disagree" in (r.stderr + r.stdout)

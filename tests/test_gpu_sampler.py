@@ -173,6 +173,33 @@ def test_device_sampler_on_climate_udeb(setup):
     runner.close()
 
 
+def test_samplers_refuse_structural_parameters(setup):
+    """A [u] row of rscm_gpu.h (here ClimateUDEB's mixed_layer_depth: the host builds the column geometry from it when the
+    parameters are set) cannot be a sampled dimension of the device sampler -- its proposals are written on the device and
+    would be scored with the base value's tables, silently -- nor vary over the members of the host sampler's batches.  Both
+    say so; the reference rebuilds the component per parameter vector (model_runner.rs:257-266)."""
+    cal, _ = setup
+    from rscm_amd import core
+    from rscm_amd.magicc import ClimateUDEBBuilder
+    years = np.arange(1850.0, 1871.0)
+    axis = core.TimeAxis.from_values(years)
+    b = (core.ModelBuilder().with_time_axis(axis)
+         .with_rust_component(ClimateUDEBBuilder.from_parameters({"ecs": 3.0}).build())
+         .with_exogenous_variable("Effective Radiative Forcing", core.Timeseries(np.full(len(years), 2.0), axis, "W/m^2", core.InterpolationStrategy.Previous))
+         .with_initial_values({"Surface Temperature": 0.0}))
+    runner = cal.ModelRunner(b, ["ecs", "mixed_layer_depth"], ["Sea Surface Temperature"])
+    target = cal.Target()
+    target.add_observation("Sea Surface Temperature", 1860.0, 0.5, 0.1)
+    params = cal.ParameterSet().add("ecs", cal.Uniform(1.5, 6.0)).add("mixed_layer_depth", cal.Uniform(40.0, 80.0))
+    dev = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    with pytest.raises(Exception, match="structural"):
+        dev.run(1, cal.WalkerInit.from_prior(), n_walkers=64, seed=1)
+    host = cal.EnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    with pytest.raises(Exception, match="same for every member"):
+        host.log_posterior_batch(params.sample_random(8, np.random.default_rng(0)))
+    runner.close()
+
+
 def test_device_sampler_lognormal_and_bound_priors(setup):
     """No observations: the device sampler must reproduce a LogNormal prior and a Normal truncated
     by Bound; its initial scores are the host prior's."""

@@ -97,7 +97,7 @@ def _ensemble_params(orc, n, seed=0, **fixed):
 def test_udeb_gpu_other_layer_counts(ra, orc, n_layers, n_members):
     """n_layers is a parameter of the reference (parameters/climate_udeb.rs:41, validated >= 2 at climate/udeb/mod.rs:164);
     the device unrolls the column solve per layer count and is instantiated for 20, 30, 40 and 50 layers.  Same bar against
-    the oracle as at 50 layers (the oracle takes any count); other counts are refused with the list."""
+    the oracle as at 50 layers (the oracle takes any count); every other count: test_udeb_gpu_any_layer_count."""
     years = np.arange(1850.0, 1931.0)
     b = np.append(years, 1931.0)
     P = _ensemble_params(orc, n_members, seed=n_layers, n_layers=float(n_layers))
@@ -108,11 +108,46 @@ def test_udeb_gpu_other_layer_counts(ra, orc, n_layers, n_members):
     got, st = _gpu(ra, b, P, F, scen=scen, chunks=(1, 29))
     assert not st.any() and not wst.any()
     _assert_close({k: v[:, pick] for k, v in got.items()}, want, f"{n_layers} layers")
-    if n_members <= 512:
-        with pytest.raises(ra.RscmGpuError, match="20, 30, 40 or 50"):
-            Q = P.copy()
-            Q[orc.UDEB_PARAM_NAMES.index("n_layers")] = 25.0
-            _gpu(ra, b, Q, F, scen=scen)
+
+
+@pytest.mark.parametrize("n_layers", [2, 3, 7, 25, 64])
+def test_udeb_gpu_any_layer_count(ra, orc, n_layers):
+    """Every n_layers >= 2 the reference accepts (parameters/climate_udeb.rs:41; from_parameters refuses < 2, mod.rs:162-165) runs on
+    the device: counts without an unrolled kernel take the any-count kernel (csrc/udeb_any_body.hpp: columns in HBM, plain loops over
+    the layers, the same row arithmetic).  Same 1e-9 bar against the oracle; both arithmetic modes; launch boundaries (resume from
+    the stored columns and scalars) change nothing; a member the reference refuses to build is flagged and NaN; more than 50 layers
+    means the initial profile's last value below layer 50, as in the oracle."""
+    years = np.arange(1850.0, 1931.0)
+    b = np.append(years, 1931.0)
+    n = 300   # a ragged last workgroup of the 256-thread kernel
+    P = _ensemble_params(orc, n, seed=100 + n_layers, n_layers=float(n_layers))
+    P[orc.UDEB_PARAM_NAMES.index("prescribed_efficacy_co2"), 7] = -1.0
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0), 3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0)])
+    scen = (np.arange(n) % 2).astype(np.int32)
+    want, wst = orc.udeb_run(b, P, F, scen=scen, threads=8)
+    got, st = _gpu(ra, b, P, F, scen=scen)
+    assert (st == wst).all() and st[7] == 2 and (st != 0).sum() == 1
+    _assert_close(got, want, f"{n_layers} layers")
+    assert all(np.isnan(got[k][1:, 7]).all() for k in NAMES)
+    again, _ = _gpu(ra, b, P, F, scen=scen, chunks=(1, 29))
+    for k in NAMES:
+        assert np.array_equal(again[k], got[k], equal_nan=True), k
+    fast, _ = _gpu(ra, b, P, F, scen=scen, mode=ra.MODE_FAST)
+    _assert_close(fast, want, f"{n_layers} layers, FAST")
+
+
+def test_udeb_gpu_layer_count_errors(ra, orc):
+    """n_layers < 2 is refused with the reference's message (mod.rs:162-165), a fractional count too; the count is structural."""
+    years = np.arange(1850.0, 1861.0)
+    b = np.append(years, 1861.0)
+    F = np.zeros((1, len(years)))
+    for bad in (1.0, 0.0, 2.5):
+        with pytest.raises(ra.RscmGpuError, match="n_layers"):
+            _gpu(ra, b, _ensemble_params(orc, 8, n_layers=bad), F)
+    Q = _ensemble_params(orc, 8, n_layers=25.0)
+    Q[orc.UDEB_PARAM_NAMES.index("n_layers"), 3] = 26.0
+    with pytest.raises(ra.RscmGpuError, match="same for every member"):
+        _gpu(ra, b, Q, F)
 
 
 @pytest.mark.parametrize("n_members", [257, 40000])   # the two-wavefront kernel and the one-thread kernel
@@ -162,42 +197,28 @@ def test_udeb_gpu_ensemble_vs_oracle(ra, orc):
         assert np.array_equal(again[k], got[k], equal_nan=True), k
 
 
-@pytest.mark.parametrize("n_layers", [20, 30, 40, 50])
-def test_udeb_gpu_four_wavefront_kernel(ra, orc, n_layers):
-    """The opt-in kernel with four wavefronts per 64 members (csrc/udeb4_body.hpp: a hemisphere's column cut in the middle, the two
-    halves eliminated towards the cut by two wavefronts, two wavefronts per SIMD; rscm_gpu_set_udeb_variant(4)): the same
-    tridiagonal systems solved in another order, so the bar is the oracle's 1e-9 like every kernel's, and against the default
-    kernel the agreement is to rounding, not to the bit.  Launch boundaries (resume from the stored half columns) change nothing,
-    members the reference refuses to build come out flagged and NaN, a ragged last workgroup is handled."""
-    from rscm_amd import _lib as L
-    years = np.arange(1850.0, 1951.0)
-    b = np.append(years, 1951.0)
-    n = 257
-    P = _ensemble_params(orc, n, seed=4, n_layers=float(n_layers))
-    P[orc.UDEB_PARAM_NAMES.index("prescribed_efficacy_co2"), 5] = -1.0   # refused by from_parameters: status 2 for this member alone
-    F = np.stack([np.where(years >= 1851, 3.71, 0.0),
-                  3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0),
-                  -1.5 * np.ones(len(years))])
-    scen = (np.arange(n) % 3).astype(np.int32)
-    want, wst = orc.udeb_run(b, P, F, scen=scen, threads=8)
-    default, dst = _gpu(ra, b, P, F, scen=scen)
-    L.check(L.load().rscm_gpu_set_udeb_variant(4))
-    try:
-        got, st = _gpu(ra, b, P, F, scen=scen)
-        again, _ = _gpu(ra, b, P, F, scen=scen, chunks=(1, 37))
-        fast, _ = _gpu(ra, b, P, F, scen=scen, mode=ra.MODE_FAST)
-    finally:
-        L.check(L.load().rscm_gpu_set_udeb_variant(-1))
-    assert (st == wst).all() and (dst == wst).all() and st[5] == 2 and (st != 0).sum() == 1
-    _assert_close(got, want, f"four-wavefront kernel, {n_layers} layers")
-    _assert_close(fast, want, f"four-wavefront kernel, FAST, {n_layers} layers")
-    worst = 0.0
-    for k in NAMES:
-        assert np.array_equal(again[k], got[k], equal_nan=True), k
-        assert np.isnan(got[k][1:, 5]).all()
-        worst = max(worst, float(np.nanmax(np.abs(got[k] - default[k]) / np.maximum(1.0, np.abs(default[k])))))
-    print(f"four-wavefront kernel vs the default one, {n_layers} layers: max relative deviation {worst:.2e}")
-    assert worst < 1e-11
+@pytest.mark.parametrize("n_members", [96, 40000])   # the two-wavefront kernel (a hemisphere per wavefront) and the one-thread kernel
+def test_udeb_gpu_feedback_window_shorter_than_a_model_step(ra, orc, n_members):
+    """feedback_cumt_period = 0.5 yr on an annual axis with feedback_cumt_sensitivity != 0: the look-back window of adjusted_ecs()
+    ends inside the PREVIOUS model step, so the only history entry it touches is the one stored at the end of that step -- in the
+    two-wavefront kernel by the other wavefront, after the year's last barrier.  Both wavefronts take it from their own register;
+    the result is the oracle's (climate/udeb/mod.rs:399-470)."""
+    years = np.arange(1850.0, 1931.0)
+    b = np.append(years, 1931.0)
+    P = _ensemble_params(orc, n_members, seed=12)
+    P[orc.UDEB_PARAM_NAMES.index("feedback_cumt_period")] = 0.5
+    P[orc.UDEB_PARAM_NAMES.index("feedback_cumt_sensitivity")] = 0.02
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0), 3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0)])
+    scen = (np.arange(n_members) % 2).astype(np.int32)
+    pick = np.arange(n_members) if n_members <= 512 else np.arange(256)
+    want, wst = orc.udeb_run(b, P[:, pick].copy(), F, scen=scen[pick].copy(), threads=8)
+    got, st = _gpu(ra, b, P, F, scen=scen, chunks=(1, 29))
+    assert not st.any() and not wst.any()
+    _assert_close({k: v[:, pick] for k, v in got.items()}, want, "half-year feedback window")
+    base = P.copy()
+    base[orc.UDEB_PARAM_NAMES.index("feedback_cumt_sensitivity")] = 0.0
+    off, _ = _gpu(ra, b, base, F, scen=scen)
+    assert np.nanmax(np.abs(off["sst"] - got["sst"])) > 1e-6   # the window does act in this configuration
 
 
 def test_udeb_gpu_failed_construction_is_flagged(ra, orc):
@@ -227,8 +248,8 @@ def test_udeb_structural_parameters_must_be_uniform(ra, orc):
         with pytest.raises(RscmGpuError, match="same for every member"):
             e.set_params(bad)
         bad = P.copy()
-        bad[0] = 45.0
-        with pytest.raises(RscmGpuError, match="n_layers = 20, 30, 40 or 50"):
+        bad[0] = 1.0
+        with pytest.raises(RscmGpuError, match="n_layers: must be >= 2"):   # the reference's message (mod.rs:162-165)
             e.set_params(bad)
         e.set_params(P)
         e.set_forcing(np.zeros(len(years)))
