@@ -52,7 +52,34 @@ __global__ __launch_bounds__(kBlock) void terrestrial_kernel(CarbonArgs a)
     carbon::terrestrial_body<SRC>(a, i, a.step_begin, a.step_end);
 }
 
+__global__ __launch_bounds__(kBlock) void terrestrial_derive_kernel(const double* __restrict__ params, uint64_t uniform_rows, int64_t n_members,
+                                                                    double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_members) return;
+    auto P = [&](int j) -> double { return param_at(params, uniform_rows, j, n_members, i); };
+    double d[kDerivedRows];
+    carbon::terrestrial_member_constants(P(0), P(8), P(9), P(10), P(11), P(12), P(13), P(14), P(15), P(16), P(17), d);
+#pragma unroll
+    for (int k = 0; k < kDerivedRows; ++k) out[(size_t)k * n_members + i] = d[k];
+}
+
 }  // namespace
+
+uint64_t terrestrial_derive_sources()
+{
+    uint64_t m = 1ull << 0;
+    for (int j = 8; j <= 17; ++j) m |= 1ull << j;
+    return m;
+}
+
+hipError_t launch_terrestrial_derive(const double* params, uint64_t uniform_rows, int64_t n_members, double* out, hipStream_t s)
+{
+    if (n_members <= 0) return hipSuccess;
+    hipLaunchKernelGGL(terrestrial_derive_kernel, dim3((unsigned)((n_members + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, params, uniform_rows,
+                       n_members, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_carbon(const CarbonArgs& a, int mode, hipStream_t s)
 {
@@ -61,6 +88,7 @@ hipError_t launch_carbon(const CarbonArgs& a, int mode, hipStream_t s)
     if (a.kind == kKindCo2Budget) {
         RSCM_LAUNCH_BY_SOURCE(co2_budget_kernel, a, grid, dim3(kBlock), s, a);
     } else if (a.kind == kKindTerrestrialCarbon) {
+        if (!a.derived) return hipErrorInvalidValue;
         RSCM_LAUNCH_BY_SOURCE(terrestrial_kernel, a, grid, dim3(kBlock), s, a);
     } else if (a.kind == kKindCarbonCycle) {
         if (mode != 0) RSCM_LAUNCH_BY_SOURCE(carbon_cycle_fast_kernel, a, grid, dim3(kBlock), s, a);

@@ -188,6 +188,30 @@ __device__ __forceinline__ void implicit_pool_step(double pool, double r_tau, do
     turnover = 0.5 * k_eff * (pool + np);
 }
 
+// parameters/terrestrial_carbon.rs:103-168: the four turnover times follow from the pre-industrial pools and fluxes alone.  Formed
+// once per parameter set (launch_terrestrial_derive) and read back by the body:
+//   [0] f_npp_soil   [1..4] 1 / tau of plant, detritus, soil, humus
+__device__ __forceinline__ void terrestrial_member_constants(double npp_pi, double plant_pi, double det_pi, double soil_pi, double hum_pi, double resp_pi,
+                                                             double f_npp_plant, double f_npp_det, double f_plant_det, double f_det_soil,
+                                                             double f_soil_hum, double (&d)[kDerivedRows])
+{
+    const double f_npp_soil = fmax(1.0 - f_npp_plant - f_npp_det, 0.0);
+    const double net_plant = f_npp_plant * npp_pi - resp_pi;
+    const double tau_plant = net_plant > 1e-10 ? plant_pi / net_plant : 100.0;
+    const double flux_det = f_npp_det * npp_pi + f_plant_det * net_plant;
+    const double tau_det = flux_det > 1e-10 ? det_pi / flux_det : 3.0;
+    const double flux_soil = f_npp_soil * npp_pi + (1.0 - f_plant_det) * net_plant + f_det_soil * (det_pi / tau_det);
+    const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
+    const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
+    const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
+    d[0] = f_npp_soil;
+    d[1] = guarded_rcp(tau_plant);
+    d[2] = guarded_rcp(tau_det);
+    d[3] = guarded_rcp(tau_soil);
+    d[4] = guarded_rcp(tau_hum);
+    d[5] = d[6] = d[7] = 0.0;
+}
+
 template <int SRC>
 __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i, int32_t step_begin, int32_t step_end)
 {
@@ -200,22 +224,13 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
     const size_t r0 = (size_t)step_begin * N + i;
     double plant = a.series[r0], det = a.series[vs + r0], soil = a.series[2 * vs + r0], hum = a.series[3 * vs + r0];
     StepRows<3> ahead = rows_at(in, step_begin);
+    double mc[kDerivedRows];   // the member's constants (launch_terrestrial_derive), in flight with the parameters
+    params_block<kDerivedRows>(a.derived, a.derived_uniform ? ~0ull : 0ull, N, i, mc);
     const double npp_pi = P(0), co2_pi = P(1), beta = P(2), npp_ts = P(3), resp_ts = P(4), det_ts = P(5), soil_ts = P(6),
-                 hum_ts = P(7), plant_pi = P(8), det_pi = P(9), soil_pi = P(10), hum_pi = P(11), resp_pi = P(12),
-                 f_npp_plant = P(13), f_npp_det = P(14), f_plant_det = P(15), f_det_soil = P(16), f_soil_hum = P(17);
+                 hum_ts = P(7), resp_pi = P(12), f_npp_plant = P(13), f_npp_det = P(14), f_plant_det = P(15), f_det_soil = P(16),
+                 f_soil_hum = P(17);
     const bool fert_on = P(18) != 0.0, temp_on = P(19) != 0.0;
-    // parameters/terrestrial_carbon.rs:103-168, once per member
-    const double f_npp_soil = fmax(1.0 - f_npp_plant - f_npp_det, 0.0);
-    const double net_plant = f_npp_plant * npp_pi - resp_pi;
-    const double tau_plant = net_plant > 1e-10 ? plant_pi / net_plant : 100.0;
-    const double flux_det = f_npp_det * npp_pi + f_plant_det * net_plant;
-    const double tau_det = flux_det > 1e-10 ? det_pi / flux_det : 3.0;
-    const double flux_soil = f_npp_soil * npp_pi + (1.0 - f_plant_det) * net_plant + f_det_soil * (det_pi / tau_det);
-    const double tau_soil = flux_soil > 1e-10 ? soil_pi / flux_soil : 50.0;
-    const double flux_hum = f_soil_hum * (soil_pi / tau_soil);
-    const double tau_hum = flux_hum > 1e-10 ? hum_pi / flux_hum : 1000.0;
-    const double r_tau_plant = guarded_rcp(tau_plant), r_tau_det = guarded_rcp(tau_det), r_tau_soil = guarded_rcp(tau_soil),
-                 r_tau_hum = guarded_rcp(tau_hum);
+    const double f_npp_soil = mc[0], r_tau_plant = mc[1], r_tau_det = mc[2], r_tau_soil = mc[3], r_tau_hum = mc[4];
     for (int32_t n = step_begin; n < step_end; ++n) {
         const double dt = a.bounds[n + 1] - a.bounds[n];
         const StepRows<3> now = ahead;

@@ -78,6 +78,10 @@ struct rscm_ens {
     double* d_params = nullptr;  // [P][N]
     int32_t ag_rows_set = 0;     // aggregate kind: 1 + the highest contributor row rscm_ens_set_forcing has ever been given data for
     uint64_t uniform_rows = 0;   // bit j: parameter row j (< 64) holds one value for every member (the kernels then read element 0: param_at)
+    // member constants of the kinds that have them (GhgForcing, TerrestrialCarbon; rscm_device.hpp, launch_*_derive): [kDerivedRows][N],
+    // re-formed by ensure_derived() at the next run after anything wrote the parameter block
+    double* d_derived = nullptr;
+    bool derived_dirty = true;
     bool params_exposed = false; // rscm_ens_params_devptr handed the block out: uniform_rows stays 0 for the life of the handle
     double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
     double* d_forcing = nullptr; // [S][n_inputs][T]
@@ -246,6 +250,7 @@ inline int set_device(const rscm_ens* h)
 // launches of several handles out of the same pieces.
 extern "C" {
 int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end);
+int ensure_derived(rscm_ens* h);   // (called by step_check: every run starts with current member constants)
 int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out);
 // op_out: nothing is launched, the arguments go into a fused launch's table (kind -1: this handle cannot be fused);

@@ -31,11 +31,39 @@ __global__ __launch_bounds__(kBlock) void ghg_kernel(GhgArgs a, const double* __
     ghg::ghg_body<METHOD, HAS_SCEN, LINKED>(a, tables, i, a.step_begin, a.step_end);
 }
 
+template <int METHOD>
+__global__ __launch_bounds__(kBlock) void ghg_derive_kernel(const double* __restrict__ params, uint64_t uniform_rows, int64_t n_members, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_members) return;
+    auto P = [&](int j) -> double { return param_at(params, uniform_rows, j, n_members, i); };
+    double d[kDerivedRows];
+    ghg::member_constants<METHOD>(P(1), P(2), P(3), P(7), P(8), P(10), d);
+#pragma unroll
+    for (int k = 0; k < kDerivedRows; ++k) out[(size_t)k * n_members + i] = d[k];
+}
+
 }  // namespace
+
+uint64_t ghg_derive_sources(int32_t method)
+{
+    const uint64_t pre_industrial = (1ull << 1) | (1ull << 2) | (1ull << 3);
+    return method == 0 ? pre_industrial : pre_industrial | (1ull << 7) | (1ull << 8) | (1ull << 10);
+}
+
+hipError_t launch_ghg_derive(const double* params, uint64_t uniform_rows, int32_t method, int64_t n_members, double* out, hipStream_t s)
+{
+    if (n_members <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
+    if (method == 0) hipLaunchKernelGGL(ghg_derive_kernel<0>, grid, dim3(kBlock), 0, s, params, uniform_rows, n_members, out);
+    else hipLaunchKernelGGL(ghg_derive_kernel<1>, grid, dim3(kBlock), 0, s, params, uniform_rows, n_members, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    if (!a.derived) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((a.n_members + kBlock - 1) / kBlock));
     const bool scen = a.scen != nullptr;
     if (a.linked) {

@@ -75,6 +75,16 @@ __global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable tab
                                                             int32_t step_end)
 {
     extern __shared__ double lds_slots[];
+    // Every op starts by reading its fields out of this table through the scalar cache, and a step's ops run one after the other:
+    // n_ops first-touch trips to L2 in a row, each exposed (all wavefronts of a one-step launch start together).  One dword of every
+    // 64-byte line the ops in use cover, requested here together and awaited once, leaves the lines in the scalar cache for them.
+    {
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(&table);
+        const int32_t n_lines = (int32_t)(((size_t)n_ops * sizeof(GroupOp) + 63) / 64);
+        uint32_t touched = 0;
+        for (int32_t l = 0; l < n_lines; ++l) touched |= words[(size_t)l * 16];
+        asm volatile("" ::"s"(touched));
+    }
     run_graph<FULL, CACHED>(table.ops, n_ops, n_members, step_begin, step_end, lds_slots);
 }
 

@@ -382,6 +382,8 @@ struct GhgArgs {
     int32_t method;          // 0 = IPCCTAR, 1 = OLBL (uniform over the ensemble)
     const double* params;    // [21][N]
     uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
+    const double* derived;   // [kDerivedRows][N] member constants (launch_derive); row layout in ghg_body.hpp
+    int32_t derived_uniform; // every parameter row they are formed from is uniform: element 0 serves all members (scalar loads)
     const double* tables;    // [S][kGhgRows][T]
     const int32_t* scen;     // [N] or null
     const double* conc;      // [S][3][T] the concentrations themselves (linked launches)
@@ -435,6 +437,8 @@ struct CarbonArgs {
     int32_t kind;            // RSCM_KIND_CO2_BUDGET / RSCM_KIND_TERRESTRIAL_CARBON
     const double* params;    // [P][N]
     uint64_t uniform_rows;   // bit j: parameter row j (< 64) holds one value for all members (param_at)
+    const double* derived;   // TerrestrialCarbon: [kDerivedRows][N] member constants (launch_derive); row layout in carbon_body.hpp
+    int32_t derived_uniform; // every parameter row they are formed from is uniform: element 0 serves all members
     const double* inputs;    // [S][n_inputs][T]
     const int32_t* scen;     // [N] or null
     InputLinks links;        // used when linked != 0
@@ -611,6 +615,15 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
 bool udeb_layers_unrolled(int32_t n_layers);  // the layer counts the register-resident column kernels are instantiated for
 void set_udeb_variant(int variant);            // which ClimateUDEB kernel the calling thread's launches take (udeb.hip; -1: by size)
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
+// Member constants: what a light component's body formed from its parameters alone at the top of EVERY one-step launch (GhgForcing:
+// four powers, three logarithms, two square roots of the pre-industrial concentrations; TerrestrialCarbon: its four turnover times,
+// seven divisions -- parameters/terrestrial_carbon.rs:103-168) is formed once per parameter set by these small kernels, by the same
+// device functions, and stored beside the parameter block: out [kDerivedRows][N].  Which parameter rows they read: *_derive_sources.
+constexpr int kDerivedRows = 8;
+hipError_t launch_ghg_derive(const double* params, uint64_t uniform_rows, int32_t method, int64_t n_members, double* out, hipStream_t s);
+hipError_t launch_terrestrial_derive(const double* params, uint64_t uniform_rows, int64_t n_members, double* out, hipStream_t s);
+uint64_t ghg_derive_sources(int32_t method);      // bit j: parameter row j enters the member constants
+uint64_t terrestrial_derive_sources();
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);
 hipError_t launch_chem(const ChemArgs& a, hipStream_t s);
 hipError_t launch_carbon(const CarbonArgs& a, int mode, hipStream_t s);   // mode: CarbonCycle only (the other two kinds have one arithmetic)

@@ -407,8 +407,6 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
         const int32_t want = std::max(50, h->udeb_n_layers);
         if (want > h->udeb_ocean_layers) {
             (void)hipFree(h->d_ocean);
-    (void)hipFree(h->d_udeb_work);
-    (void)hipFree(h->d_udeb_tables);
             h->d_ocean = nullptr;
             h->udeb_ocean_layers = 0;
             const hipError_t e = hipMalloc(&h->d_ocean, (size_t)2 * want * h->N * sizeof(double));
@@ -744,6 +742,9 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_ocean_mode_state);
     (void)hipFree(h->d_ocean_mode_table);
     (void)hipFree(h->d_ocean);
+    (void)hipFree(h->d_udeb_work);
+    (void)hipFree(h->d_udeb_tables);
+    (void)hipFree(h->d_derived);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
     (void)hipFree(h->d_tables);
@@ -887,6 +888,7 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
             if (same) uni |= 1ull << j;
         }
         h->uniform_rows = h->params_exposed ? 0 : uni;  // a caller holding the device pointer may rewrite any row
+        h->derived_dirty = true;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -1188,6 +1190,28 @@ int rscm_ens_rewind(rscm_ens* h)
 
 // ---- one launch range of one handle, in pieces (rscm_ens_run_lockstep fuses the launches of several handles) ----
 // (1) what must hold before anything is enqueued
+// The member constants of GhgForcing and TerrestrialCarbon (what their bodies used to form from the parameters alone at the top of
+// every launch): one small kernel whenever the parameter block has been written since the last one -- rscm_ens_set_params*,
+// rscm_ens_sample_lhs, a checkpoint restore, a sampler's proposals -- and before EVERY run of a handle whose block the caller may
+// write directly (rscm_ens_params_devptr).
+static bool has_derived(const rscm_ens* h) { return h->kind == RSCM_KIND_GHG_FORCING || h->kind == RSCM_KIND_TERRESTRIAL_CARBON; }
+
+int ensure_derived(rscm_ens* h)
+{
+    if (!has_derived(h) || !h->params_set) return RSCM_OK;
+    if (!h->derived_dirty && !h->params_exposed && h->d_derived) return RSCM_OK;
+    if (int rc = set_device(h)) return rc;
+    if (!h->d_derived) {
+        const hipError_t e = hipMalloc(&h->d_derived, (size_t)rscm::kDerivedRows * h->N * sizeof(double));
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "member constants of %lld members: %s", (long long)h->N, hipGetErrorString(e));
+    }
+    if (h->kind == RSCM_KIND_GHG_FORCING) HIPCHK(rscm::launch_ghg_derive(h->d_params, h->uniform_rows, h->ghg_method, h->N, h->d_derived, h->stream));
+    else HIPCHK(rscm::launch_terrestrial_derive(h->d_params, h->uniform_rows, h->N, h->d_derived, h->stream));
+    h->derived_dirty = false;
+    return RSCM_OK;
+}
+
 int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     NEED(h);
@@ -1217,7 +1241,7 @@ int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
     for (int32_t v = 1; v < h->V; ++v)
         if (h->is_state(v) && !h->initial_set[v])  // builder.rs:704-717 MissingInitialValue
             return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
-    return RSCM_OK;
+    return ensure_derived(h);
 }
 
 // (2) schedule tables and the handle's own window: room for the rows this range writes
@@ -1332,6 +1356,8 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.method = h->ghg_method;
         a.params = h->d_params;
         a.uniform_rows = h->uniform_rows;
+        a.derived = h->d_derived;
+        a.derived_uniform = (h->uniform_rows & rscm::ghg_derive_sources(h->ghg_method)) == rscm::ghg_derive_sources(h->ghg_method) ? 1 : 0;
         a.tables = h->d_ghg_tables;
         a.scen = h->d_scen;
         a.conc = h->d_forcing;
@@ -1444,6 +1470,8 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.kind = h->kind;
         a.params = h->d_params;
         a.uniform_rows = h->uniform_rows;
+        a.derived = h->d_derived;   // (TerrestrialCarbon only; nullptr for the other two kinds)
+        a.derived_uniform = (h->uniform_rows & rscm::terrestrial_derive_sources()) == rscm::terrestrial_derive_sources() ? 1 : 0;
         a.inputs = h->d_forcing;
         a.scen = h->d_scen;
         a.links = links;
@@ -2171,6 +2199,7 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
     (void)hipFree(d_lh);
     if (e != hipSuccess) return fail(RSCM_ERR_DEVICE, "sample_lhs: %s", hipGetErrorString(e));
     h->uniform_rows = 0;   // conservatively: low + u (high - low) need not reproduce low's bits for every u
+    h->derived_dirty = true;
     h->params_set = true;
     return RSCM_OK;
     GUARD_END

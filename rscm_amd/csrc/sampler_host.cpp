@@ -99,6 +99,7 @@ int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
         for (size_t k = 0; k < s->graph.size(); ++k) {
             rscm_ens* g = s->graph[k];
             g->uniform_rows &= ~s->graph_sampled_rows[k];
+            if (s->graph_sampled_rows[k]) g->derived_dirty = true;   // the proposal kernel is about to write its parameter block
             if (int rc = s->graph_clear ? rscm_ens_clear_series(g) : rscm_ens_rewind(g)) return rc;
         }
         HIPCHK(rscm::launch_sampler_propose(a, s->ev->stream));
@@ -114,6 +115,7 @@ int sampler_half_step(rscm_sampler* s, int32_t half, int32_t identity)
         return RSCM_OK;
     }
     s->ev->uniform_rows = 0;  // the proposal kernel writes the evaluator's parameter block
+    s->ev->derived_dirty = true;
     HIPCHK(rscm::launch_sampler_propose(a, s->ev->stream));
     if (s->fused) {
         HIPCHK(launch_loglik(s->ev));

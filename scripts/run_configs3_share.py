@@ -1,7 +1,8 @@
 """BASELINE.json configs[3], one GPU's share at full size (run on the GPU box): the emissions-driven MAGICC
 graph (ten rscm-magicc components, Sum of eight forcings, FourBox transforms), 125 000 members (1e6 / 8 GPUs),
 MONTHLY model steps 1750-2500 (9001 points, 9000 steps), ClimateUDEB and OceanCarbon at their 12 sub-steps per
-model step, series in a 16-row window with annual (every 12th) rows of every variable kept.
+model step, series in a window of --window rows (default 96: 3.5 GB of the 288; the window slides once every ~80 steps) with annual
+(every 12th) rows of every variable kept.
 
     python scripts/run_configs3_share.py [--members 125000] [--years 750] [--exact]
 
@@ -25,10 +26,10 @@ NAMES = ["Sea Surface Temperature", "Atmospheric Concentration|CO2", "Effective 
          "Carbon Flux|Ocean"]
 
 
-def run(members, years, exact):
+def run(members, years, exact, window=16):
     free0, total = L.mem_info(0)
     t0 = time.perf_counter()
-    model = build_chain(members, years, "topological", steps_per_year=12, series_window=16, output_stride=12)
+    model = build_chain(members, years, "topological", steps_per_year=12, series_window=window, output_stride=12)
     if not exact:
         model.set_mode(L.MODE_FAST)
     build_s = time.perf_counter() - t0
@@ -49,12 +50,12 @@ def run(members, years, exact):
                 component_steps=int(ns.value), warm=warm, co2=co2, failed=status), rows
 
 
-def first_64(members, years, exact):
+def first_64(members, years, exact, window=16):
     """Parity anchor at this size: a 64-member ensemble that is GIVEN the first 64 members' parameters of the
     `members`-member one (build_chain draws whole vectors from one seeded generator: replayed here for the big
     ensemble's draws).  Returns the kept (annual) rows of NAMES."""
     import scripts.bench_magicc_chain as mod
-    small = build_chain(64, years, "topological", steps_per_year=12, series_window=16, output_stride=12)
+    small = build_chain(64, years, "topological", steps_per_year=12, series_window=window, output_stride=12)
     rng = np.random.default_rng(20260327)
     ecs = rng.uniform(2.0, 4.5, members)
     kappa = rng.uniform(0.5, 1.2, members)
@@ -82,18 +83,19 @@ def main():
     ap.add_argument("--members", type=int, default=125_000)
     ap.add_argument("--years", type=int, default=750)
     ap.add_argument("--exact", action="store_true", help="RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) convolution")
+    ap.add_argument("--window", type=int, default=96, help="rows of every series kept on the device (36 MB per row at 125 000 members)")
     ap.add_argument("--fusion", type=int, default=1, help="rscm_gpu_set_lockstep_fusion mode (4: the whole-graph launch; include/rscm_gpu_internal.h)")
     args = ap.parse_args()
     L.check(L.load().rscm_gpu_set_lockstep_fusion(args.fusion))
-    big, rows = run(args.members, args.years, args.exact)
-    small_rows = first_64(args.members, args.years, args.exact)
+    big, rows = run(args.members, args.years, args.exact, args.window)
+    small_rows = first_64(args.members, args.years, args.exact, args.window)
     same = {}
     for n in NAMES:
         a, b = rows[n][:, :64], small_rows[n]
         same[n] = bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)) or np.array_equal(a, b, equal_nan=True))
     steps = args.years * 12
     out = {"workload": f"BASELINE configs[3], one GPU's share: MAGICC graph, {args.members} members x {steps} monthly steps "
-                       f"({args.years} years), window 16 rows + annual outputs of all 36 series, mode {'EXACT' if args.exact else 'FAST'}",
+                       f"({args.years} years), window {args.window} rows + annual outputs of all 36 series, mode {'EXACT' if args.exact else 'FAST'}",
            "run_s": big["run_s"], "build_s": big["build_s"], "member_years_per_s": args.members * args.years / big["run_s"],
            "member_model_steps_per_s": args.members * steps / big["run_s"], "ms_per_model_step": big["run_s"] / steps * 1e3,
            "launches": big["launches"], "launches_per_step": big["launches"] / steps, "hbm_allocated_gib": big["hbm_gib"],
