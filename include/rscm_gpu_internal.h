@@ -22,22 +22,15 @@ extern "C" {
  *      all steps, with thread-private LDS slots between the steps;
  *   2  as 1 without the LDS slots;
  *   3  as 1 with every op table sent through device memory instead of the kernel arguments;
- *   4  as 1, and a graph whose heavy components are at most one ClimateUDEB and one OceanCarbon (RSCM_MODE_FAST
- *      recurrence) runs as ONE launch per window chunk (csrc/graph.hip: the ocean columns stay on chip across the
- *      steps).  Bit-identical to mode 1 and measured slower than it on an MI355X: opt-in. */
+ *      (A mode 4 -- ClimateUDEB and OceanCarbon inside the fused launch too, one launch per window chunk with the ocean columns
+ *      resident on chip -- existed in round 3: bit-identical to mode 1 and 17 % slower on an MI355X, removed in round 4;
+ *      DESIGN.md section 8g, profiles/r3_graph_stamps.json, commit f22e743.)
+ * The setting is per calling THREAD: lock-step runs issued from another thread do not see it. */
 RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
 /* Step launches issued by the calling thread's rscm_ens_run_lockstep calls (component kernels + fused
  * groups; HalocarbonChemistry counts as one) and the component steps they carried, since the thread's
  * last call of this function; resets both counters. */
 RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps);
-
-/* Where a whole-graph launch (csrc/graph.hip) spends its time: with enable != 0 the calling thread's following
- * whole-graph launches add, per component kind, the shader cycles their wavefronts spent in that kind's steps to 32
- * device counters (index = RSCM_KIND_*; 28 / 29 = ClimateUDEB's step up to its sub-step loop / the loop, the rest of its step under its
- * kind; 31 = ClimateUDEB's begin / end).  Each call returns the counters collected
- * since the previous one in out32 (may be NULL) and resets them; enable = 0 stops collecting.  Diagnostic only: the
- * stamps cost a few per cent (profiles/r3_graph_stamps.json). */
-RSCM_API int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32);
 
 /* Which ClimateUDEB kernel the calling thread's launches take (csrc/udeb.hip): 0 one thread per member, 2 a hemisphere per
  * wavefront; -1 (default): chosen by ensemble size.  The two carry the same bits.  (Layer counts other than 20 / 30 / 40 / 50

@@ -253,10 +253,8 @@ int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int ensure_derived(rscm_ens* h);   // (called by step_check: every run starts with current member constants)
 int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out);
-// op_out: nothing is launched, the arguments go into a fused launch's table (kind -1: this handle cannot be fused);
-// heavy_out (with op_out): ClimateUDEB and OceanCarbon may join too, their arguments go there (the whole-graph launch)
-int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked, rscm::GroupOp* op_out,
-                rscm::GraphHeavy* heavy_out);
+// op_out: nothing is launched, the arguments go into a fused launch's table (kind -1: this handle cannot be fused)
+int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked, rscm::GroupOp* op_out);
 int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed);
 }

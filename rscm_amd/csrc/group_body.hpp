@@ -1,6 +1,5 @@
-// The per-member body of every light component kind, dispatched on an op of a fused launch's table: shared by the
-// group kernel (csrc/group.hip: the light components of one step, or a whole light graph over many steps) and the
-// whole-graph kernel (csrc/graph.hip: the same with ClimateUDEB and OceanCarbon between them).
+// The per-member body of every light component kind, dispatched on an op of a fused launch's table (csrc/group.hip: the
+// light components of one step, or a whole light graph over many steps).
 #pragma once
 
 #include "carbon_body.hpp"

@@ -1,7 +1,7 @@
 // The lock-step scheduler of component graphs: Model::step for a list of linked ensembles
 // (crates/rscm-core/src/model/runtime.rs:504-527 walks the graph once per step; here the walk is cut into
-// launches -- fused groups of light components, the heavy components' own kernels, or one launch for
-// many steps of the whole graph).
+// launches -- fused groups of light components (one launch for many steps when the whole graph is light), the
+// heavy components' own kernels).
 #include "ens.hpp"
 
 extern "C" {
@@ -14,9 +14,7 @@ struct LockstepSettings {
     bool fuse = true;        // consecutive light components of a step in one launch
     bool cache = true;       // multi-step fused launches keep per-member values in LDS between steps
     bool by_value = true;    // short op lists travel in the kernel arguments
-    bool persistent = false; // whole graphs with heavy components in one launch per window chunk (csrc/graph.hip): opt-in, see there
     int64_t launches = 0, component_steps = 0;  // since the thread's last rscm_gpu_lockstep_stats
-    unsigned long long* stamps = nullptr;       // rscm_gpu_graph_stamps: 32 device counters, or null
 };
 thread_local LockstepSettings t_ls;
 }  // namespace
@@ -29,23 +27,6 @@ int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
     return RSCM_OK;
 }
 
-int rscm_gpu_graph_stamps(int32_t device_id, int32_t enable, uint64_t* out32)
-{
-    GUARD_BEGIN
-    HIPCHK(hipSetDevice(device_id));
-    HIPCHK(hipDeviceSynchronize());
-    if (t_ls.stamps && out32) HIPCHK(hipMemcpy(out32, t_ls.stamps, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    else if (out32) memset(out32, 0, 32 * sizeof(uint64_t));
-    if (enable && !t_ls.stamps) HIPCHK(hipMalloc((void**)&t_ls.stamps, 32 * sizeof(uint64_t)));
-    if (t_ls.stamps) HIPCHK(hipMemset(t_ls.stamps, 0, 32 * sizeof(uint64_t)));
-    if (!enable && t_ls.stamps) {
-        HIPCHK(hipFree(t_ls.stamps));
-        t_ls.stamps = nullptr;
-    }
-    return RSCM_OK;
-    GUARD_END
-}
-
 int rscm_gpu_set_udeb_variant(int32_t variant)
 {
     if (variant != -1 && variant != 0 && variant != 2) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0 or 2");
@@ -55,11 +36,10 @@ int rscm_gpu_set_udeb_variant(int32_t variant)
 
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
-    if (enabled < 0 || enabled > 4) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..4)", enabled);
+    if (enabled < 0 || enabled > 3) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..3)", enabled);
     t_ls.fuse = enabled != 0;
-    t_ls.cache = enabled == 1 || enabled == 3 || enabled == 4;
+    t_ls.cache = enabled == 1 || enabled == 3;
     t_ls.by_value = enabled != 3;
-    t_ls.persistent = enabled == 4;
     return RSCM_OK;
 }
 
@@ -151,44 +131,16 @@ static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t cou
     return next;
 }
 
-// Whether the whole graph -- light components AND its heavy ones -- can run as ONE launch per window chunk
-// (csrc/graph.hip): at most one ClimateUDEB (50 layers) and one OceanCarbon (RSCM_MODE_FAST with the fitted
-// recurrence, 60 explicit lags), at least one of them (a graph without either already runs through the group
-// kernel), everything else a light kind, one ensemble size, one device.
-static bool whole_graph_launch(rscm_ens* const* handles, int32_t n_handles)
-{
-    if (!t_ls.fuse || !t_ls.persistent || n_handles < 2 || n_handles > 64) return false;
-    int32_t n_udeb = 0, n_ocean = 0;
-    for (int32_t k = 0; k < n_handles; ++k) {
-        const rscm_ens* h = handles[k];
-        if (h->N != handles[0]->N || h->device != handles[0]->device) return false;
-        if (h->kind == RSCM_KIND_UDEB) {
-            if (!h->udeb_ready || h->udeb_n_layers != 50) return false;
-            ++n_udeb;
-        } else if (h->kind == RSCM_KIND_OCEAN_CARBON) {
-            if (!h->ocean_ready || h->mode != RSCM_MODE_FAST || !h->ocean_recur_ok || h->ocean_near != 60 || h->ocean_steps != 12) return false;
-            ++n_ocean;
-        } else if (!fusable(h)) {
-            return false;
-        }
-    }
-    return n_udeb <= 1 && n_ocean <= 1 && n_udeb + n_ocean >= 1;
-}
-
 // Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
 // the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
-// with_heavy: the segment is a whole graph that whole_graph_launch() accepted -- the graph kernel instead of the
-// group kernel, ClimateUDEB's and OceanCarbon's arguments beside the table.
-static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len, bool with_heavy)
+static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
 {
     rscm_ens* lead = plan->handles[first];
     bool all_small = true;
     for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
     std::vector<rscm::OpCache> slots;
     int32_t cache_slots = 0;
-    if (len > 1 && (all_small || with_heavy) && t_ls.cache) cache_slots = assign_cache_slots(plan, first, count, slots);
-    rscm::GraphHeavy heavy;
-    memset((void*)&heavy, 0, sizeof heavy);
+    if (len > 1 && all_small && t_ls.cache) cache_slots = assign_cache_slots(plan, first, count, slots);
     for (int32_t k = first; k < first + count; ++k) {
         rscm_ens* h = plan->handles[k];
         if (int rc = step_check(h, n, n + len)) return rc;
@@ -199,12 +151,12 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
     // only what changed since the last launch is uploaded
     // a multi-step launch of a graph whose sequence of kinds has a kernel of its own (csrc/group.hip, group_seq_kernel)
     bool own_kernel = false;
-    if (cache_slots > 0 && !with_heavy && t_ls.by_value && count <= rscm::kGroupTableOps) {
+    if (cache_slots > 0 && t_ls.by_value && count <= rscm::kGroupTableOps) {
         int32_t kinds[rscm::kGroupTableOps];
         for (int32_t k = 0; k < count; ++k) kinds[k] = plan->handles[first + k]->kind;
         own_kernel = rscm::group_seq_available(kinds, count);
     }
-    const bool by_value = (t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0 && !with_heavy) || own_kernel;
+    const bool by_value = (t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0) || own_kernel;
     rscm::GroupTable table;
     if (by_value) memset((void*)&table, 0, sizeof table);
     for (int32_t k = first; k < first + count; ++k) {
@@ -214,11 +166,9 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         if (int rc = step_links(h, n, n + 1, links, linked)) return rc;
         rscm::GroupOp op;
         memset((void*)&op, 0, sizeof op);
-        const bool is_heavy = h->kind == RSCM_KIND_UDEB || h->kind == RSCM_KIND_OCEAN_CARBON;
-        // (a heavy component's arguments carry the launch's whole step range: where it resumes, whether the ocean's mode sums stand there)
-        if (int rc = step_launch(h, n, is_heavy ? n + len : n + 1, links, linked, &op, with_heavy ? &heavy : nullptr)) return rc;
+        if (int rc = step_launch(h, n, n + 1, links, linked, &op)) return rc;
         if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", k, h->kind);
-        if (!is_heavy) clear_step_fields(op);
+        clear_step_fields(op);
         if (cache_slots > 0) {
             op.cache = slots[(size_t)(k - first)];
         } else {
@@ -245,9 +195,7 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         if (!rscm::launch_group_seq(table, count, lead->N, n, n + len, cache_slots, lead->stream, &seq_status))
             return fail(RSCM_ERR_STATE, "no kernel for this sequence of kinds after all");
         HIPCHK(seq_status);
-    } else if (with_heavy)
-        HIPCHK(rscm::launch_graph(heavy, plan->d_ops + first, count, lead->N, n, n + len, cache_slots, t_ls.stamps, lead->stream));
-    else
+    } else
         HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
                                   cache_slots, lead->stream));
     for (int32_t k = first; k < first + count; ++k)
@@ -278,8 +226,7 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
         segments.emplace_back(k, c);
         k += c;
     }
-    const bool whole = whole_graph_launch(handles, n_handles);
-    bool any_fused = whole;
+    bool any_fused = false;
     for (const auto& sgm : segments) any_fused = any_fused || sgm.second > 1;
     LockstepPlan* plan = nullptr;
     if (any_fused) {
@@ -308,7 +255,7 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
         DeferGuard(rscm_ens* const* h, int32_t k, WindowDeferral* d) : hs(h), n(k) { for (int32_t i = 0; i < n; ++i) hs[i]->defer = d; }
         ~DeferGuard() { for (int32_t i = 0; i < n; ++i) hs[i]->defer = nullptr; }
     } guard(handles, n_handles, t_ls.fuse ? &deferral : nullptr);
-    if (whole || (segments.size() == 1 && segments[0].second > 1)) {
+    if (segments.size() == 1 && segments[0].second > 1) {
         // The whole graph is one fused segment: many model steps per launch.  A chunk ends where a windowed
         // handle runs out of rows (its window slides between launches).
         for (int32_t n = step_begin; n < step_end;) {
@@ -319,7 +266,7 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
             }
             t_ls.launches += 1;
             t_ls.component_steps += (int64_t)n_handles * len;
-            if (int rc = fused_segment(plan, 0, n_handles, n, len, whole)) return rc;
+            if (int rc = fused_segment(plan, 0, n_handles, n, len)) return rc;
             if (int rc = window_flush(&deferral, handles[0]->stream)) return rc;
             n += len;
         }
@@ -330,7 +277,7 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
             t_ls.launches += 1;
             t_ls.component_steps += sgm.second;
             if (sgm.second > 1) {
-                if (int rc = fused_segment(plan, sgm.first, sgm.second, n, 1, false)) return rc;
+                if (int rc = fused_segment(plan, sgm.first, sgm.second, n, 1)) return rc;
             } else if (int rc = run_range(handles[sgm.first], n, n + 1, false)) {
                 return rc;
             }

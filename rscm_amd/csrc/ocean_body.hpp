@@ -1,5 +1,4 @@
-// OceanCarbon per-member arithmetic shared by csrc/ocean.hip (its own launches) and csrc/graph.hip (the
-// whole-graph launch): parameters/ocean_carbon.rs:198-250, carbon/ocean.rs:73-215.
+// OceanCarbon per-member arithmetic (csrc/ocean.hip launches it): parameters/ocean_carbon.rs:198-250, carbon/ocean.rs:73-215.
 #pragma once
 
 #include <type_traits>
@@ -39,8 +38,8 @@ __device__ __forceinline__ int32_t ring_add(int32_t r, int32_t k, int32_t R)
 
 // The O(T) recurrence of RSCM_MODE_FAST (csrc/ocean.hip has the derivation) over model steps [step_begin, step_end)
 // for member i: the running mode sums are loaded at the start (or re-formed from the flux history: `rebuild`) and
-// stored at the end, the last NEAR pulses come out of the history ring -- so a call per model step (the whole-graph
-// launch, csrc/graph.hip; one-step launches) carries the same bits as one call over many steps.
+// stored at the end, the last NEAR pulses come out of the history ring -- so a call per model step (the one-step launches
+// of a graph) carries the same bits as one call over many steps.
 template <int NEAR, int SRC>
 __device__ __forceinline__ void ocean_recur_run(const OceanArgs& a, const double* __restrict__ irf_table, const double* __restrict__ mode_table,
                                                 int64_t i, int32_t step_begin, int32_t step_end, bool rebuild)

@@ -582,19 +582,6 @@ struct GroupTable {
     GroupOp ops[kGroupTableOps];
 };
 static_assert(sizeof(GroupTable) <= 3840, "the by-value op table must fit the kernel-argument segment beside the other arguments");
-// The heavy components of a whole-graph launch (csrc/graph.hip): at most one ClimateUDEB and one OceanCarbon (the
-// RSCM_MODE_FAST recurrence); their ops in the table carry only the kind.  By value in the kernel arguments, like
-// the stand-alone kernels take them (ClimateUDEB's geometry tables are read from there with scalar loads).
-struct GraphHeavy {
-    UdebArgs udeb;
-    OceanArgs ocean;
-    int32_t has_udeb, has_ocean;
-};
-static_assert(sizeof(GraphHeavy) <= 3968, "the whole-graph launch's arguments must fit the 4 KiB kernel-argument segment");
-// stamps: null, or 32 device counters that collect shader cycles per component kind (diagnostic runs)
-hipError_t launch_graph(const GraphHeavy& hv, const GroupOp* d_ops, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
-                        int32_t cache_slots, unsigned long long* stamps, hipStream_t s);
-
 // all_small: every op is one of the kinds group_kind_is_small accepts (the low-register variant of the kernel)
 bool group_kind_is_small(int32_t kind);
 // cache_slots > 0 (all_small only): the ops carry LDS slots (OpCache), cache_slots doubles per thread in all.

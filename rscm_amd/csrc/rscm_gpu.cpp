@@ -1308,7 +1308,7 @@ int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLin
 // (4) the launch itself -- or, with op_out, its arguments for the group kernel (csrc/group.hip) if the kind can
 // be fused with its neighbours (op_out->kind = -1 otherwise; nothing is launched either way)
 int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
-                rscm::GroupOp* op_out, rscm::GraphHeavy* heavy_out)
+                rscm::GroupOp* op_out)
 {
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
@@ -1451,13 +1451,7 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.series = h->series(1);
         a.status = h->d_status;
         if (op_out) {
-            // the whole-graph launch (csrc/graph.hip) runs the O(T) recurrence with 60 explicit lags step by step
-            op_out->kind = -1;
-            if (heavy_out && a.recur && a.near == 60) {
-                heavy_out->ocean = a;
-                heavy_out->has_ocean = 1;
-                op_out->kind = h->kind;
-            }
+            op_out->kind = -1;   // a heavy component: its own launch
             return RSCM_OK;
         }
         HIPCHK(rscm::launch_ocean(a, h->stream));
@@ -1586,11 +1580,6 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.status = h->d_status;
         if (op_out) {
             op_out->kind = -1;
-            if (heavy_out && a.n_layers == 50) {  // the whole-graph launch keeps the columns on chip across its steps
-                heavy_out->udeb = a;
-                heavy_out->has_udeb = 1;
-                op_out->kind = h->kind;
-            }
             return RSCM_OK;
         }
         HIPCHK(rscm::launch_udeb(a, h->stream));
@@ -1652,7 +1641,7 @@ int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
     int32_t linked = 0;
     if (int rc = step_links(h, step_begin, step_end, links, linked)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (int rc = step_launch(h, step_begin, step_end, links, linked, nullptr, nullptr)) return rc;
+    if (int rc = step_launch(h, step_begin, step_end, links, linked, nullptr)) return rc;
     if (int rc = step_finish(h, step_begin, step_end)) return rc;
     if (timed) {
         HIPCHK(hipEventRecord(h->ev1, h->stream));

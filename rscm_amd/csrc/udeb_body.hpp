@@ -1,5 +1,4 @@
-// ClimateUDEB per-member arithmetic shared by the kernels that run it (csrc/udeb.hip: the stand-alone launch;
-// csrc/graph.hip: inside the persistent whole-graph launch): rscm-magicc's 4-box upwelling-diffusion
+// ClimateUDEB per-member arithmetic of the kernels in csrc/udeb.hip: rscm-magicc's 4-box upwelling-diffusion
 // energy-balance model.
 //
 // What it replaces, per model step n (reference file:line):
@@ -415,9 +414,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
 // The two columns never leave the chip in between: the hemisphere being solved is in registers (col[], shared with
 // the solver's d' array), the other one is parked in this lane's LDS slots (park[layer][lane]: 8 NL bytes per lane,
 // each lane touches only its own slots -- no barriers, no bank conflicts) and the two are exchanged after every
-// column solve.  HBM sees the columns once in begin() (resume) and once in end(): ocean[hemi][layer][N].  Used by
-// the stand-alone launch (csrc/udeb.hip) and, with other components' steps between its own, by the whole-graph
-// launch (csrc/graph.hip), where the columns so stay resident across the model steps of a window chunk.
+// column solve.  HBM sees the columns once in begin() (resume) and once in end(): ocean[hemi][layer][N].
 template <int NL>
 struct Udeb1 {
     double (*park)[kUdebBlock];
@@ -518,12 +515,8 @@ struct Udeb1 {
 
     // model step n -> n + 1.  CHECK_DEAD = false: the caller has dealt with members the reference refuses to build
     // (nan_rows) and calls step() only for the others.
-    // probe(0) / probe(1): called where the sub-step loop begins and ends (the whole-graph launch's diagnostic cycle stamps)
-    struct NoProbe {
-        __device__ __forceinline__ void operator()(int) const {}
-    };
-    template <bool CHECK_DEAD = true, bool FAST = false, class Probe = NoProbe>
-    __device__ __forceinline__ void step(const UdebArgs& a, int32_t n, const Probe& probe = Probe())
+    template <bool CHECK_DEAD = true, bool FAST = false>
+    __device__ __forceinline__ void step(const UdebArgs& a, int32_t n)
     {
         const size_t r0 = (size_t)n * N + i, r1 = r0 + (size_t)N;
         if (CHECK_DEAD && status != 0) {  // every output NaN
@@ -620,7 +613,6 @@ struct Udeb1 {
         const double r_land_nh = 1.0 / (lam_l * p.fgnl + p.k_lo), r_land_sh = 1.0 / (lam_l * p.fgsl + p.k_lo);
         const double gfac_nh = (a.land_hc && !(p.fgnl < 1e-15)) ? p.k_lg / (p.fgnl * c_ground) * dt_sub : 0.0;
         const double gfac_sh = (a.land_hc && !(p.fgsl < 1e-15)) ? p.k_lg / (p.fgsl * c_ground) * dt_sub : 0.0;
-        probe(0);
         for (int32_t step_idx = 1; step_idx <= a.steps_per_year; ++step_idx) {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f0 = adj * p.q0, f1 = adj * p.q1, f2 = adj * p.q2, f3 = adj * p.q3;
@@ -661,7 +653,6 @@ struct Udeb1 {
             up_nh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh_nh, 1.0)), w_min);
             up_sh = fmax(p.w0 * (1.0 - p.f_var * fmin(global_temp * inv_thresh_sh, 1.0)), w_min);
         }
-        probe(1);
         // ---- end of year
         const double sst_nh = col[0], sst_sh = park[0][lane];
         const double air_nh = sst_to_air(airmap, sst_nh), air_sh = sst_to_air(airmap, sst_sh);

@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--years", type=int, default=750)
     ap.add_argument("--exact", action="store_true", help="RSCM_MODE_EXACT: OceanCarbon's literal O(T^2) convolution")
     ap.add_argument("--window", type=int, default=96, help="rows of every series kept on the device (36 MB per row at 125 000 members)")
-    ap.add_argument("--fusion", type=int, default=1, help="rscm_gpu_set_lockstep_fusion mode (4: the whole-graph launch; include/rscm_gpu_internal.h)")
+    ap.add_argument("--fusion", type=int, default=1, help="rscm_gpu_set_lockstep_fusion mode 0..3 (include/rscm_gpu_internal.h)")
     args = ap.parse_args()
     L.check(L.load().rscm_gpu_set_lockstep_fusion(args.fusion))
     big, rows = run(args.members, args.years, args.exact, args.window)

@@ -398,50 +398,3 @@ def test_windowed_graph_in_fast_mode(ra):
         assert np.isfinite(got).all() and err.max() <= 2e-8, (name, err.max())
     other.close()
     full.close()
-
-
-def test_whole_graph_launch_equals_the_per_step_launches(ra):
-    """rscm_gpu_set_lockstep_fusion(4): the MAGICC graph in RSCM_MODE_FAST -- eleven light components, ClimateUDEB and
-    OceanCarbon -- as ONE launch per window chunk (csrc/graph.hip: thread i runs Model::run's loop for member i, the
-    ocean columns stay on chip across the steps) against the default four launches per step: every kept row of every
-    series bit for bit, with windowed and with full storage, over launch boundaries that fall inside a chunk, and a
-    handful of launches instead of five per step."""
-    import ctypes as C
-    from rscm_amd import _lib as L
-    from rscm_amd.ensemble import run_lockstep
-    mod = _chain()
-    lib = L.load()
-    years, N = 60, 200
-
-    def run(mode, **kw):
-        L.check(lib.rscm_gpu_set_lockstep_fusion(mode))
-        L.check(lib.rscm_gpu_lockstep_stats(None, None))
-        m = mod.build_chain(N, years, "topological", **kw)
-        m.set_mode(L.MODE_FAST)
-        lst = [m.ensembles[name] for name in m._order]
-        run_lockstep(lst, 7)          # launch boundaries at odd places
-        run_lockstep(lst, 8)
-        run_lockstep(lst, 31)
-        m.time_index = 31
-        m.run()
-        a, b = C.c_int64(), C.c_int64()
-        L.check(lib.rscm_gpu_lockstep_stats(C.byref(a), C.byref(b)))
-        stride = kw.get("output_stride", 1)
-        names = sorted({v for v in m._var_home})
-        rows = {v: m.get_series(v, t_stride=stride) for v in names}
-        status = m.ensembles["ClimateUDEB"].status().copy()
-        m.close()
-        return rows, a.value, b.value, status
-
-    try:
-        for kw in (dict(), dict(series_window=12, output_stride=4)):
-            want, launches1, steps1, st1 = run(1, **kw)
-            got, launches4, steps4, st4 = run(4, **kw)
-            assert steps1 == steps4 == 13 * years and launches1 == 4 * years
-            assert launches4 == 4 if not kw else launches4 < launches1 // 10, launches4   # one per call, or one per window chunk
-            assert np.array_equal(st1, st4) and not st1.any()
-            assert set(want) == set(got) and len(want) >= 25
-            for v in want:
-                assert_bit_equal(got[v], want[v], f"whole-graph launch vs four launches per step ({'windowed' if kw else 'full storage'}): {v}")
-    finally:
-        L.check(lib.rscm_gpu_set_lockstep_fusion(1))
