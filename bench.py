@@ -66,18 +66,28 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
            "peak_measured_store_stream": HBM_STORE_STREAM_GBS, "frac_of_measured": gbs / HBM_STORE_STREAM_GBS,
            "traffic_source": (f"{source}: separate rocprofv3 --pmc passes of this launch (FETCH_SIZE x2 + WRITE_SIZE, KiB), "
                               "read from profiles/traffic.json; not re-measured inside bench.py") if source else None,
-           "kernel": "coupled_kernel" if kind == "coupled" else "two_layer_kernel", "kernel_ms": kernel_ms,
+           "kernel": ("coupled_fast_kernel" if mode == "fast" else "coupled_kernel") if kind == "coupled" else "two_layer_kernel",
+           "kernel_ms": kernel_ms,
            "algorithmic_bytes": bytes_per_member_year * my,
            "note": f"algorithmic {bytes_per_member_year:g} B/member-year x members x {years} / launch duration; `bound` is the "
                    "roof the contract prices against, `binding` the one that limits the kernel: arithmetic intensity "
-                   "45-110 f64 op/B against a ridge of ~5 (roofline_fp64_valu)"}
+                   + ("45-110 f64 op/B against a ridge of ~5 (roofline_fp64_valu)" if kind != "coupled" else
+                      "8-28 f64 instructions per byte stored against a ridge of ~5 (roofline_fp64_valu)")}
     # EXACT: the reference's 620 separately rounded add/mul + 80 divisions per member-year; FAST folds the heat
-    # capacities into the coefficients and fuses: 34 instructions per RK4 step (profiles/r2_two_layer_isa_histogram.txt)
-    ops = ALG_OPS_PER_MEMBER_YEAR if mode == "exact" else 340.0
+    # capacities into the coefficients, fuses, and steps (Ts, Ts - Td): 30 instructions per RK4 step (csrc/two_layer_body.hpp)
+    if kind == "coupled":
+        # executed vector instructions per wavefront-year, from the ISA / the SQ_INSTS_VALU counter (profiles/r4_coupled_1e6.txt,
+        # profiles/r4_coupled_fast_1e6.txt): the chain has no algorithmic count in SURVEY.md, so these are as-executed figures
+        ops = 1520.0 if mode == "exact" else 470.0
+        note = ("1520 vector instructions per wavefront-year as executed (EXACT: the reference's expression order, IEEE divisions)"
+                if mode == "exact" else
+                "470 vector instructions per wavefront-year as executed (FAST: 10 x 30 two-layer, 10 x 4 carbon box, exp, log, one division)")
+    else:
+        ops = ALG_OPS_PER_MEMBER_YEAR if mode == "exact" else 300.0
+        note = ("algorithmic 620 add/mul + 80 div per member-year (unfused, div counted as 1)" if mode == "exact" else
+                "300 fused f64 instructions per member-year (10 RK4 steps x 30)")
     tins = ops * my / (kernel_ms * 1e-3) / 1e12
-    valu = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR,
-            "note": ("algorithmic 620 add/mul + 80 div per member-year (unfused, div counted as 1)" if mode == "exact" else
-                     "340 fused f64 instructions per member-year (10 RK4 steps x 34)")}
+    valu = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR, "note": note}
     return hbm, valu
 
 
@@ -189,7 +199,7 @@ def calibration_extra(device, walkers=100_000, iterations=20):
             "walkers": walkers, "acceptance_rate": sampler.acceptance_rate()}
 
 
-def graph_calibration_extra(device, walkers=100_000, iterations=10):
+def graph_calibration_extra(device, walkers=100_000, iterations=10, mode=0):
     """The calibration loop with a GRAPH as the evaluator (rscm_sampler_create_graph): CarbonCycle -> CO2ERF -> Sum -> TwoLayer as
     four linked ensembles, TwoLayer.lambda0 and CarbonCycle.tau sampled (two owners), Ts and CO2 observed 1800..1940 (two owners);
     per half-step the graph runs 190 steps in one launch and is scored on the device."""
@@ -214,7 +224,7 @@ def graph_calibration_extra(device, walkers=100_000, iterations=10):
          .with_exogenous_variable("Effective Radiative Forcing|Other", core.Timeseries(0.2 * np.sin(t / 9.0), axis, "", core.InterpolationStrategy.Linear))
          .with_initial_values({"Cumulative Land Uptake": 0.0, "Cumulative Emissions|CO2": 0.0, "Atmospheric Concentration|CO2": 278.0,
                                "Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}))
-    runner = cal.ModelRunner(b, ["TwoLayer.lambda0", "tau"], ["Surface Temperature", "Atmospheric Concentration|CO2"])
+    runner = cal.ModelRunner(b, ["TwoLayer.lambda0", "tau"], ["Surface Temperature", "Atmospheric Concentration|CO2"], mode=mode)
     truth = runner.run([1.25, 30.0])
     target = cal.Target()
     for yr in range(1800, 1941, 10):
@@ -230,6 +240,7 @@ def graph_calibration_extra(device, walkers=100_000, iterations=10):
     return {"model_evaluations_per_s": walkers * iterations / (sampler.device_ms * 1e-3),
             "device_ms_per_iteration": sampler.device_ms / iterations, "wall_s_per_iteration": dt / iterations,
             "walkers": walkers, "steps_per_evaluation": 190, "acceptance_rate": sampler.acceptance_rate(),
+            "arithmetic_mode": "fast" if mode else "exact",
             "note": "four linked ensembles as the sampler's evaluator; proposals, lock-step run, likelihood and accept step on the device"}
 
 
@@ -655,14 +666,14 @@ def main():
             # the north-star's target size (1e6 members) and the coupled chain carry their own roofline objects
             hbm, valu = two_layer_rooflines(members, years, k2, "fast" if m else "exact", "coupled" if cp else "two_layer", bpy)
             out["roofline"] = hbm
-            if not cp:
-                out["roofline_fp64_valu"] = valu
+            out["roofline_fp64_valu"] = valu
             return out
 
         for label, members, m, cp in (("fast_1e5", args.members, 1, False),
                                       ("exact_1e6", 1_000_000, 0, False),
                                       ("fast_1e6", 1_000_000, 1, False),
-                                      ("coupled_1e6", 1_000_000, 0, True)):
+                                      ("coupled_1e6", 1_000_000, 0, True),
+                                      ("coupled_1e6_fast", 1_000_000, 1, True)):
             side(label, lambda members=members, m=m, cp=cp: two_layer_case(members, m, cp))
 
         def udeb_case(members):
@@ -739,6 +750,7 @@ def main():
         side("calibrate_device_1e5", lambda: calibration_extra(local_rank))
         # ... and with a graph of linked ensembles as the evaluator (rscm_sampler_create_graph)
         side("calibrate_graph_device_1e5", lambda: graph_calibration_extra(local_rank))
+        side("calibrate_graph_device_1e5_fast", lambda: graph_calibration_extra(local_rank, mode=1))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -100,7 +100,7 @@ __device__ __forceinline__ int32_t year(const CPConst& p, double emis, int32_t m
         y.cum_e = rk4_combine(y.cum_e, emis, emis, emis, emis, sixth_c);
     }
     // ---- CO2ERF on C[n+1], then the Sum aggregate over its single contributor
-    erf_co2 = p.erf_scale * log(1.0 + (y.conc - p.conc_pi) / p.conc_pi);
+    erf_co2 = p.erf_scale * log_f64(1.0 + (y.conc - p.conc_pi) / p.conc_pi);
     erf = (erf_co2 != erf_co2) ? erf_co2 : 0.0 + erf_co2;
     // ---- TwoLayer with ERF[n+1]
     const double half_t = ht / 2.0, sixth_t = ht / 6.0;
@@ -124,7 +124,7 @@ __device__ __forceinline__ int32_t year(const CPConst& p, double emis, int32_t m
 // RSCM_MODE_FAST: one member, the whole axis.  CarbonCycle as the collapsed linear RK4 step of carbon_body.hpp
 // (no division, one exp per year), CO2ERF and the Sum aggregate in their one arithmetic (a division by the
 // pre-industrial concentration and a log per year), TwoLayer with the heat capacities folded into its
-// coefficients and FMA stages (two_layer_body.hpp, rk4_step_fast) -- the very functions the linked components
+// coefficients and FMA stages (two_layer_body.hpp, rk4_year_fast) -- the very functions the linked components
 // call in this mode, so "four linked ensembles == the fused kind, bit for bit" holds per mode.
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void coupled_fast_kernel(CoupledArgs a)
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(kBlock) void coupled_fast_kernel(CoupledArgs a)
         mc_next = a.nsub_cc[np];
         mt_next = a.nsub_tl[np];
         carbon::carbon_cycle_year_fast(rtau, alpha, conc_pi, emis, ts, mc, hc, sixth_c, conc, cum_u, cum_e);
-        const double erf_co2 = erf_scale * log(1.0 + (conc - conc_pi) / conc_pi);
+        const double erf_co2 = erf_scale * log_f64(1.0 + (conc - conc_pi) / conc_pi);
         const double erf = (erf_co2 != erf_co2) ? erf_co2 : 0.0 + erf_co2;
         const double erf_cs = erf * inv_cs;
-        for (int32_t s = 0; s < mt; ++s) tl::rk4_step_fast(tp, erf_cs, ht, half_t, third_t, sixth_t, ts, td);
+        tl::rk4_year_fast(tp, erf_cs, mt, ht, half_t, third_t, sixth_t, ts, td);
         a.conc[r] = conc;
         a.cum_uptake[r] = cum_u;
         a.cum_emis[r] = cum_e;

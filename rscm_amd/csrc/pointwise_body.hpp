@@ -2,6 +2,7 @@
 // and group.hip (several linked components of one model step in one launch).  See pointwise.hip.
 #pragma once
 
+#include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
 namespace rscm {
@@ -92,7 +93,7 @@ __device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[2
 // co2_erf.rs:57-60; p = {erf_2xco2, conc_pi}; in = {Atmospheric Concentration|CO2}
 __device__ __forceinline__ void eval(const double (&p)[2], const double (&in)[1], double (&out)[1])
 {
-    out[0] = (p[0] / kLn2) * log(1.0 + (in[0] - p[1]) / p[1]);
+    out[0] = (p[0] / kLn2) * log_f64(1.0 + (in[0] - p[1]) / p[1]);   // (rk4_device.hpp: the coupled chain's logarithm, so that the linked chain carries its bits)
 }
 
 // compute_aggregate, schema.rs:760-802; params = {operation (0 Sum, 1 Mean, 2 Weighted), weights[8]}; up to

@@ -126,6 +126,40 @@ __device__ __forceinline__ double rk4_combine_fused2(double y, double k1, double
     return y + (__builtin_fma(k3, 2.0, __builtin_fma(k2, 2.0, k1)) + k4) * sixth;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ln x for the forcing formulas (CO2ERF in the coupled chain and as a linked component: once per member and model step).
+// The device library's log is 75 instructions, 46 of them separately rounded additions of its double-double arithmetic; this is
+// the classical reduction  x = 2^k m,  m in [sqrt(1/2), sqrt(2)),  f = m - 1,  s = f / (2 + f),
+//     ln m = f - f^2/2 + s (f^2/2 + R(s^2)),   R an odd minimax polynomial (degree 14 in s; W. Kahan's coefficients as published in
+// the freely distributable fdlibm e_log.c, error < 1 ulp), with the quotient as reciprocal estimate + one Newton step + one
+// correction of the quotient: ~40 instructions.  Same accuracy class as the library's (<= 1 ulp), not the same bits: every use sits in a
+// tolerance-parity kind (tests/test_gpu_parity.py: 1e-11).  Zero, negatives, denormals, inf and NaN take the library's log.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double log_f64(double x)
+{
+    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x < __builtin_inf()), 0)) return log(x);
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    int32_t k = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                                 // [sqrt(1/2), sqrt(2))
+    k = low ? k - 1 : k;
+    const double dk = (double)k;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = f * r;
+    const double s = __builtin_fma(__builtin_fma(-d, q, f), r, q);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                         2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
 __device__ __forceinline__ int32_t max3_i32(int32_t a, int32_t b, int32_t c)
 {
     return max(max(a, b), c);  // v_max3_i32
