@@ -686,9 +686,12 @@ def main():
                     # 7 output rows + the history row written, ~1 history entry read back;
                     # the ocean columns stay in registers/LDS for the whole launch
                     "hbm_frac": 72.0 * members * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    # ~25.6e3 f64 VALU instructions per member-year (24 column solves of ~1020 + LAMCALC +
-                    # bookkeeping; scripts/isa_blocks.py) against 39.3 T f64 lane-ops/s
-                    "fp64_valu_frac": 25.6e3 * members * years / (k3 * 1e-3) / 39.3e12}
+                    # 28.7e3 vector instructions per wavefront-year as EXECUTED (SQ_INSTS_VALU of profiles/r3_udeb_65536.txt; 12 % of them are
+                    # not f64 arithmetic: moves between register files, compares, selects) against 39.3 T f64 lane-ops/s; the
+                    # same profile's measured issue utilisation is beside it (0.67 at 65 536 members: one wavefront per SIMD)
+                    "fp64_valu_frac": 28.7e3 * members * years / (k3 * 1e-3) / 39.3e12,
+                    "valu_instructions_per_member_year": 28.7e3, "valu_count_source": "profiles/r3_udeb_65536.txt (SQ_INSTS_VALU / waves / years)",
+                    "measured_valu_issue_utilisation_at_65536": 0.67}
 
         side("udeb_1e5", lambda: udeb_case(100_000))
         side("udeb_65536", lambda: udeb_case(65_536))
