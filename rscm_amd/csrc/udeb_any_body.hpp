@@ -55,10 +55,21 @@ __device__ __forceinline__ double step_hemisphere_any(const UdebP& p, const Year
         // row 1 as an interior row: dz_up = dz/2; as the BOTTOM row (two layers) the reference takes dz for it (ocean_column.rs:191)
         tdu = kap0 * (NL == 2 ? y.dt_dz2 : y.dt_dzdz1);
     }
+    // Row i + 1 -- its temperature and its six table values -- is requested while row i is computed: the sweep is a chain of trips
+    // to L2 and through the scalar cache otherwise (one wavefront per SIMD at 65 536 members: nothing else hides them).
+    double t_ahead = T[N];
+    double r_ahead[kTabCols];
+#pragma unroll
+    for (int k = 0; k < kTabCols; ++k) r_ahead[k] = tab[kTabCols + k];
     for (int32_t i = 1; i < NL; ++i) {   // ---- interior rows and the bottom row: forward sweep
-        const double* row = tab + (size_t)i * kTabCols;
-        const double af_top = row[0], af_bot = row[1], af_diff = row[2], omr = row[3], G = sh ? row[5] : row[4];
-        const double t_i = T[(size_t)i * N];
+        const double af_top = r_ahead[0], af_bot = r_ahead[1], af_diff = r_ahead[2], omr = r_ahead[3], G = sh ? r_ahead[5] : r_ahead[4];
+        const double t_i = t_ahead;
+        if (i + 1 < NL) {
+            t_ahead = T[(size_t)(i + 1) * N];
+            const double* nxt = tab + (size_t)(i + 1) * kTabCols;
+#pragma unroll
+            for (int k = 0; k < kTabCols; ++k) r_ahead[k] = nxt[k];
+        }
         const double tdu_aft = tdu * af_top;
         if (i < NL - 1) {
             const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
@@ -85,8 +96,14 @@ __device__ __forceinline__ double step_hemisphere_any(const UdebP& p, const Year
     // ---- back substitution, clamp (thomas_solve returns the unclamped vector; the state keeps min(x, max_temp))
     double x = dp_prev;
     T[(size_t)(NL - 1) * N] = fmin(x, p.max_temp);
+    double c_ahead = ncp[(size_t)(NL - 2) * N], d_ahead = T[(size_t)(NL - 2) * N];   // (NL >= 2)
     for (int32_t i = NL - 2; i >= 0; --i) {
-        x = __builtin_fma(ncp[(size_t)i * N], x, T[(size_t)i * N]);
+        const double c_i = c_ahead, d_i = d_ahead;
+        if (i > 0) {
+            c_ahead = ncp[(size_t)(i - 1) * N];
+            d_ahead = T[(size_t)(i - 1) * N];
+        }
+        x = __builtin_fma(c_i, x, d_i);
         T[(size_t)i * N] = fmin(x, p.max_temp);
     }
     return fmin(x, p.max_temp);

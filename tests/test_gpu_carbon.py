@@ -202,3 +202,74 @@ def test_terrestrial_zero_and_infinite_turnover_times(ra, orc):
     err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
     assert err.max() <= TOL, f"max deviation {err.max():.3e}"
     assert np.isfinite(want[:, 1:, 40:]).all() and np.isfinite(want[:4, 0]).all()
+
+
+def test_terrestrial_member_constants_follow_the_parameters(ra, orc):
+    """TerrestrialCarbon's turnover times (parameters/terrestrial_carbon.rs:103-168) are formed once per parameter set on the device
+    (launch_terrestrial_derive): a second parameter set on the same handle, uniform rows (scalar loads of element 0) and varied ones
+    all give the oracle's pools."""
+    rng = np.random.default_rng(3)
+    T, n = 120, 130
+    b = _bounds(T)
+    yr = np.arange(T, dtype=float)
+    inputs = np.stack([278.0 * 1.004 ** yr, 0.012 * yr, np.where(yr > 50, 1.5, 0.2)])[None]
+    names = orc.CARBON_PARAM_NAMES[orc.CARBON_TERRESTRIAL]
+    base = np.repeat(orc.carbon_default_params(orc.CARBON_TERRESTRIAL).reshape(-1, 1), n, axis=1)
+    init = np.stack([np.full(n, PI_POOLS[k]) for k in range(4)])
+
+    def varied(seed):
+        r = np.random.default_rng(seed)
+        P = base.copy()
+        for k, (lo, hi) in dict(npp_pi=(55.0, 75.0), plant_pool_pi=(700.0, 1000.0), soil_pool_pi=(1400.0, 1900.0), respiration_pi=(10.0, 14.0),
+                                frac_npp_to_plant=(0.3, 0.5), frac_soil_to_humus=(0.0, 0.05)).items():
+            if k in names:
+                P[names.index(k)] = r.uniform(lo, hi, n)
+        return P
+
+    with ra.Ensemble(ra.KIND_TERRESTRIAL_CARBON, n, b) as e:
+        e.set_forcing(inputs)
+        for v in range(4):
+            e.set_initial(v + 1, init[v])
+        for what, P in (("varied", varied(1)), ("another set", varied(2)), ("uniform", base), ("varied again", varied(1))):
+            e.set_params(P)
+            e.rewind()
+            e.run()
+            got = np.stack([e.get_series(v) for v in range(1, 6)])
+            want = orc.carbon_run(orc.CARBON_TERRESTRIAL, b, P, inputs, init, threads=4)
+            ok = ~np.isnan(want)
+            assert (np.isnan(got) == np.isnan(want)).all(), what
+            err = np.abs(got[ok] - want[ok]) / np.maximum(1.0, np.abs(want[ok]))
+            assert err.max() <= TOL, f"{what}: max deviation {err.max():.3e}"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_carbon_cycle_kind_on_its_own_in_both_modes(ra, orc, mode):
+    """RSCM_KIND_CARBON_CYCLE stand-alone (table inputs: emissions and a prescribed temperature) against the oracle's single-step
+    solve chained over the axis, in RSCM_MODE_EXACT (the reference's expression order) and RSCM_MODE_FAST (the closed-form RK4 step of
+    the linear box, carbon_body.hpp): 1e-11 on concentration and cumulative uptake, cumulative emissions bit for bit in either."""
+    rng = np.random.default_rng(9)
+    T, n = 90, 200
+    b = 1750.0 + np.concatenate([[0.0], np.cumsum(np.where(np.arange(T) % 4 == 1, 0.5, 1.0))])   # steps of 1 and 1/2 year: 10 and 5 sub-steps
+    E = np.abs(rng.normal(4.0, 2.0, T))
+    temp = np.cumsum(rng.normal(0.02, 0.05, T))
+    P = np.stack([rng.uniform(15.0, 40.0, n), np.full(n, 278.0), rng.uniform(0.0, 0.1, n)])
+    with ra.Ensemble(ra.KIND_CARBON_CYCLE, n, b) as e:
+        e.set_mode(mode)
+        e.set_params(P)
+        e.set_forcing(np.stack([E, temp]))
+        for v, x in ((1, 278.0), (2, 0.0), (3, 0.0)):
+            e.set_initial(v, x)
+        e.run(7)
+        e.run()
+        got = np.stack([e.get_series(v) for v in (1, 2, 3)])
+        assert not e.status().any()
+    want = np.empty_like(got)
+    want[:, 0] = got[:, 0]
+    for i in range(n):
+        y = np.array([278.0, 0.0, 0.0])
+        for k in range(T - 1):
+            y = orc.carbon_cycle_solve(P[:, i], E[k], temp[k], b[k], b[k + 1], 0.1, y)
+            want[:, k + 1, i] = y
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err[:2].max() <= 1e-11, f"mode {mode}: {err[:2].max():.3e}"
+    assert np.array_equal(got[2].view(np.uint64), want[2].view(np.uint64)), "cumulative emissions"

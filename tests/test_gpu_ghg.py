@@ -220,3 +220,47 @@ def test_udeb_runs_on_a_monthly_axis(ra, orc):
     want, st = orc.udeb_run(b, P, erf)
     assert st[0] == 0
     assert np.abs(got[1:] - want["sst"][1:, 0]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("method", ["Ipcctar", "Olbl"])
+def test_member_constants_follow_every_way_of_writing_the_parameters(ra, orc, method):
+    """GhgForcing's member constants (ln C0, sqrt M0, sqrt N0, the pre-industrial powers and overlap: formed once per parameter set by
+    launch_ghg_derive and stored beside the parameter block) must be re-formed after ANY write of the block: a second
+    rscm_ens_set_params on the same handle, rows that go from uniform to varied and back, rscm_ens_sample_lhs, and values written
+    straight through rscm_ens_params_devptr (then before every run).  Each run is held against the oracle with the parameters the
+    device block holds at that moment."""
+    import ctypes as C
+    from rscm_amd import _lib as L
+    T, n = 120, 257
+    yr = np.arange(T)
+    conc = np.stack([278.0 * 1.006 ** yr, 722.0 + 6.0 * yr, 270.0 + 0.4 * yr])[None]
+    b = np.arange(T + 1, dtype=float) + 1750.0
+    P1 = _ensemble(orc, n, method, seed=11)
+    P2 = _ensemble(orc, n, method, seed=12)
+    U = np.repeat(P1[:, :1], n, axis=1).copy()   # every row uniform: the constants come through scalar loads
+    with ra.Ensemble(ra.KIND_GHG_FORCING, n, b) as e:
+        e.set_forcing(conc)
+
+        def check(P, what):
+            e.rewind()
+            e.run()
+            got = {k: e.get_series(v) for k, v in NAMES.items()}
+            _assert_close(got, orc.ghg_run(T, np.ascontiguousarray(P), conc), f"{method}: {what}")
+
+        e.set_params(P1)
+        check(P1, "first parameter set")
+        e.set_params(P2)
+        check(P2, "second parameter set on the same handle")
+        e.set_params(U)
+        check(U, "uniform rows")
+        e.set_params(P1)
+        check(P1, "varied again")
+        lo, hi = P1.min(axis=1), P1.max(axis=1)
+        e.sample_lhs(5, lo, hi)
+        check(e.get_params(), "device Latin hypercube")
+        ptr = C.c_void_p()
+        L.check(e._lib.rscm_ens_params_devptr(e._h, C.byref(ptr)))
+        for P in (P2, P1):   # written behind the library's back, twice: the constants are re-formed before every run of such a handle
+            Pc = np.ascontiguousarray(P)
+            L.check(e._lib.rscm_gpu_copy_to_device(0, ptr, Pc.ctypes.data_as(C.c_void_p), Pc.nbytes))
+            check(P, "written through the device pointer")
