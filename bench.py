@@ -285,6 +285,32 @@ def timed_passes(ens, steps, warmup, torch, dist, world, tstream):
     return wall, kernel_ms
 
 
+def loss_gather_report(ens, members, world, dist):
+    """Outside the timed region, only with a process group: BASELINE configs[4]'s exchange -- every rank scores its members on the
+    device (Gaussian log-likelihood against 18 Surface Temperature observations 1850..2020) and the ranks all-gather the per-member
+    losses from device memory (rscm_amd.distributed.gather_members: RCCL over xGMI with the nccl backend, 8 B per member).  Timed with
+    the host clock, barrier to return; a failure is reported in the line, it never costs the headline."""
+    forced = os.environ.get("RSCM_BENCH_FORCE_DIST") == "1"   # rehearsal: a one-rank RCCL group on a one-GPU box
+    if not (dist.is_available() and dist.is_initialized()) or (world < 2 and not forced):
+        return None
+    try:
+        from rscm_amd.distributed import gather_members
+        if forced:
+            os.environ["RSCM_FORCE_DISTRIBUTED"] = "1"
+        tidx = np.arange(1850, 2021, 10) - T0
+        obs = 1.0 + 0.004 * tidx
+        dist.barrier()
+        t0 = time.perf_counter()
+        local = ens.loglik(["Surface Temperature"] * len(tidx), tidx, obs, np.full(len(tidx), 0.1), on_device=True)
+        full = gather_members(local, world * members)
+        dt = time.perf_counter() - t0
+        return {"what": "per-member log-likelihood scored on the device, all-gathered over the ranks from device memory",
+                "ms": dt * 1e3, "bytes_per_rank": 8 * members, "members_gathered": int(full.size),
+                "finite": int(np.isfinite(full).sum())}
+    except Exception as exc:  # noqa: BLE001 -- reported, not hidden
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def rank_report(kernel_ms, wall, steps, torch, dist):
     """Outside the timed region: who took part in the collectives (an all-reduce of ones) and every rank's own
     kernel time, so that a straggler shows in a timed region of a few tens of milliseconds."""
@@ -637,8 +663,11 @@ def main():
     wall, kernel_ms = timed_passes(ens, args.steps, args.warmup, torch, dist, world, tstream)
     n_fail = int(ens.status().sum())
     s_mid = ens.summary("Surface Temperature", 270)  # year 2020
+    gather = loss_gather_report(ens, args.members, world, dist)
     ens.close()
     collective, per_rank = rank_report(kernel_ms, wall, args.steps, torch, dist)
+    if gather is not None:
+        collective["loss_gather"] = gather
 
     total_member_years = float(world) * args.members * years * args.steps
     value = total_member_years / wall

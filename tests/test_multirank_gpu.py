@@ -100,4 +100,6 @@ def test_bench_two_ranks_with_and_without_a_launcher():
         assert two["collective"]["world"] == 2 and two["collective"]["ranks_seen"] == 2
         assert len(two["per_rank"]["kernel_ms"]) == 2 and min(two["per_rank"]["kernel_ms"]) > 0
         assert two["config"]["members_per_gpu"] == 20000
+        g = two["collective"]["loss_gather"]   # configs[4]'s exchange: per-member losses scored on the device, all-gathered over the ranks
+        assert "error" not in g and g["members_gathered"] == 40000 and g["finite"] > 0.9 * 40000 and g["ms"] > 0
         assert two["check"]["failed_members_rank0"] < 0.1 * 20000
