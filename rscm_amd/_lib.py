@@ -261,6 +261,8 @@ SIGNATURES = {
     "rscm_ens_run": (C.c_int, [_h, C.c_int32, C.c_int32]),
     "rscm_ens_run_lockstep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
     "rscm_ens_run_async": (C.c_int, [_h, C.c_int32, C.c_int32]),
+    # test / A-B hooks (include/rscm_gpu_internal.h).  Their state is PER CALLING THREAD: a switch set from one Python thread does
+    # not reach lock-step runs or ClimateUDEB launches issued from another, and the launch counters are the calling thread's own.
     "rscm_gpu_set_lockstep_fusion": (C.c_int, [C.c_int32]),
     "rscm_gpu_set_udeb_variant": (C.c_int, [C.c_int32]),
     "rscm_gpu_lockstep_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

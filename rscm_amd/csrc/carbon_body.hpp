@@ -236,7 +236,7 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
         const StepRows<3> now = ahead;
         if (n + 1 < step_end) ahead = rows_at(in, n + 1);
         const double co2 = now.v[0], temperature = now.v[1], landuse = now.v[2];
-        const double fert = (!fert_on || co2 <= 0.0) ? 1.0 : fmax(1.0 + beta * log(co2 / co2_pi), 0.1);
+        const double fert = (!fert_on || co2 <= 0.0) ? 1.0 : fmax(1.0 + beta * log_f64(co2 / co2_pi), 0.1);
         auto tf = [&](double sens) -> double { return temp_on ? exp(sens * temperature) : 1.0; };
         const double npp = npp_pi * fert * tf(npp_ts);
         const double respiration = resp_pi * fert * tf(resp_ts);

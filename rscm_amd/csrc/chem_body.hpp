@@ -13,7 +13,7 @@ constexpr int kPratherIterations = 4;
 // x^y for x >= 1 as exp(y ln x): the lifetime ratios are in [1, ~10] and |y| < 1, so the product
 // y ln x is O(1) and carries ~1 ulp of ln's error into an exponent of that size -- a relative
 // error of ~1e-16 in the power, at a third of the instructions of the general pow().
-__device__ __forceinline__ double pow_ratio(double x, double y) { return exp(y * log(x)); }
+__device__ __forceinline__ double pow_ratio(double x, double y) { return exp(y * log_f64(x)); }
 
 template <int SRC>
 __device__ __forceinline__ void ch4_body(const ChemArgs& a, int64_t i, int32_t step_begin, int32_t step_end)

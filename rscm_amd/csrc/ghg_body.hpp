@@ -1,6 +1,7 @@
 // Device code of GhgForcing, shared by ghg.hip and group.hip (see ghg.hip).
 #pragma once
 
+#include "rk4_device.hpp"
 #include "rscm_device.hpp"
 
 namespace rscm {
@@ -10,14 +11,14 @@ namespace ghg {
 // m75*n75 = (M N)^0.75, m_m152*n152 = M (M N)^1.52
 __device__ __forceinline__ double overlap_split(double m75, double n75, double m_m152, double n152)
 {
-    return 0.47 * log(1.0 + 2.01e-5 * (m75 * n75) + 5.31e-15 * (m_m152 * n152));
+    return 0.47 * log_f64(1.0 + 2.01e-5 * (m75 * n75) + 5.31e-15 * (m_m152 * n152));
 }
 
 // x^0.75 and x^1.52 of one x > 0 from ONE logarithm: exp(y ln x) with |y ln x| <= ~12 keeps ~1.5e-15 relative accuracy at a third
 // of the instructions of two general pow() calls (the pointwise kinds and the chemistry do the same, pointwise_body.hpp).
 __device__ __forceinline__ void powers_75_152(double x, double& p75, double& p152)
 {
-    const double lx = log(x);
+    const double lx = log_f64(x);
     p75 = exp(0.75 * lx);
     p152 = exp(1.52 * lx);
 }
@@ -29,7 +30,7 @@ __device__ __forceinline__ void powers_75_152(double x, double& p75, double& p15
 template <int METHOD>
 __device__ __forceinline__ void member_constants(double co2_pi, double ch4_pi, double n2o_pi, double a1, double b1, double d1, double (&d)[kDerivedRows])
 {
-    d[0] = log(co2_pi);
+    d[0] = log_f64(co2_pi);
     d[1] = sqrt(ch4_pi);
     d[2] = sqrt(n2o_pi);
     d[3] = d[4] = d[5] = d[6] = d[7] = 0.0;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
             if (n + 1 < step_end) ahead = rows_at(conc, n + 1);
             const double c = now.v[0], m = now.v[1], nn = now.v[2];
             live[kGhgCo2] = c;
-            live[kGhgLnCo2] = log(c);
+            live[kGhgLnCo2] = log_f64(c);
             live[kGhgSqrtCo2] = sqrt(c);
             live[kGhgSqrtCh4] = sqrt(m);
             live[kGhgSqrtN2o] = sqrt(nn);

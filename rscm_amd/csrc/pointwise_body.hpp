@@ -33,9 +33,9 @@ __device__ __forceinline__ void eval(const double (&p)[13], const double (&in)[6
     const double delta_eesc = in[0] - p[0];
     // x^y for x > 0 as exp(y ln x): |y ln x| is O(1..10) here, so the power keeps ~1e-15 relative
     // accuracy at a third of the instructions of the general pow()
-    out[0] = delta_eesc <= 0.0 ? 0.0 : p[1] * exp(p[2] * log(delta_eesc / 100.0));
+    out[0] = delta_eesc <= 0.0 ? 0.0 : p[1] * exp(p[2] * log_f64(delta_eesc / 100.0));
     const double ch4 = in[1];
-    const double ch4_term = (ch4 > 0.0 && p[8] > 0.0) ? p[4] * log(ch4 / p[8]) : 0.0;
+    const double ch4_term = (ch4 > 0.0 && p[8] > 0.0) ? p[4] * log_f64(ch4 / p[8]) : 0.0;
     const double delta_nox = in[2] - p[9], delta_co = in[3] - p[10], delta_nmvoc = in[4] - p[11];
     const double precursor = p[5] * delta_nox + p[6] * delta_co + p[7] * delta_nmvoc;
     out[1] = p[3] * (ch4_term + precursor);
@@ -67,7 +67,7 @@ __device__ __forceinline__ void eval(const double (&p)[9], const double (&in)[2]
     const double burden = p[2] * in[0] + p[3] * in[1];
     const double burden_pi = p[2] * p[4] + p[3] * p[5];
     const double delta = burden - burden_pi;
-    out[0] = delta <= 0.0 ? 0.0 : p[0] * log(1.0 + delta / p[1]);
+    out[0] = delta <= 0.0 ? 0.0 : p[0] * log_f64(1.0 + delta / p[1]);
 }
 
 // four_box_ocean_heat_uptake.rs:85-112; in = {ERF|Aggregated}; out = FourBox {NO, NL, SO, SL}

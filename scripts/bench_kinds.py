@@ -91,6 +91,9 @@ out["halocarbon"] = case("halocarbon", L.KIND_HALOCARBON, 100_000, L.HC_DEFAULTS
                          "41 species: series written once, read once for the aggregates")
 out["carbon_cycle"] = case("carbon_cycle", L.KIND_CARBON_CYCLE, 1_000_000, (25.0, 278.0, 0.05), dict(tau=(15.0, 40.0), alpha_temperature=(0.0, 0.1)), L.CC_PARAM_NAMES,
                            np.stack([0.02 * yr, 0.004 * yr]), {1: 278.0, 2: 0.0, 3: 0.0}, 24, "RK4, 10 sub-steps: 1 exp + 40 divisions per member-year")
+out["carbon_cycle_fast"] = case("carbon_cycle_fast", L.KIND_CARBON_CYCLE, 1_000_000, (25.0, 278.0, 0.05), dict(tau=(15.0, 40.0), alpha_temperature=(0.0, 0.1)),
+                                L.CC_PARAM_NAMES, np.stack([0.02 * yr, 0.004 * yr]), {1: 278.0, 2: 0.0, 3: 0.0}, 24,
+                                "RSCM_MODE_FAST: the RK4 step of the linear box in closed form, 1 exp, no division", mode=1)
 out["co2_erf"] = case("co2_erf", L.KIND_CO2_ERF, 1_000_000, (3.7, 278.0), dict(erf_2xco2=(3.0, 4.5)), L.CE_PARAM_NAMES, ramp(278.0, 1.001)[None], {}, 8,
                       "one log per member-year")
 agg_in = np.full((8, T), np.nan)
