@@ -401,13 +401,13 @@ def cpu_baseline(threads=None, target_seconds=12.0):
                       f"the host has {host['host_cores']})"}
 
 
-def linked_graph_extra(members, device, stream, years):
+def linked_graph_extra(members, device, stream, years, mode=0):
     import time
     import rscm_amd
     from rscm_amd.ensemble import run_lockstep
     t = np.arange(T0, T1 + 1, dtype=np.float64)
     bounds = np.append(t, t[-1] + 1.0)
-    fused = make_ensemble(members, device, 0, 1, 0, stream, coupled=True)
+    fused = make_ensemble(members, device, 0, 1, mode, stream, coupled=True)
     P = fused.get_params()
     fused_best = float("inf")   # the fused coupled kernel on the same card, minutes apart at most: the yardstick
     for _ in range(3):
@@ -424,6 +424,7 @@ def linked_graph_extra(members, device, stream, years):
     cc, ce, ag, tl = (rscm_amd.Ensemble(k, members, bounds, device=device) for k in kinds)
     for e in (cc, ce, ag, tl):
         e.set_stream(stream)
+        e.set_mode(mode)
     cc.set_params(P[[6, 7, 8]])
     ce.set_params(P[[9, 7]])
     ag.set_params(np.zeros((9, members)))
@@ -457,7 +458,7 @@ def linked_graph_extra(members, device, stream, years):
             "component_steps": int(ns.value) // 3,
             "fused_coupled_kernel_ms": fused_best * 1e3, "ratio_to_fused_coupled_kernel": best / fused_best,
             # the same 7 series written per member-year as the fused kernel (56 B); the LDS slots keep the reads out of HBM
-            "hbm_frac": 56.0 * members * years / best / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac": 56.0 * members * years / best / 1e9 / HBM_PEAK_GBS, "arithmetic_mode": "fast" if mode else "exact",
             "note": "CarbonCycle, CO2ERF, Sum, TwoLayer as four linked ensembles in lock-step; all four are light "
                     "components, so the run is one fused group launch (csrc/group.hip) that keeps parameters, states "
                     "and linked values in LDS between the model steps"}
@@ -740,6 +741,7 @@ def main():
         # the same coupled chain assembled from four linked ensembles and stepped in graph order
         # (rscm_ens_link_input / rscm_ens_run_lockstep): what an arbitrary component graph costs
         side("coupled_linked_1e6", lambda: linked_graph_extra(1_000_000, local_rank, stream, years))
+        side("coupled_linked_1e6_fast", lambda: linked_graph_extra(1_000_000, local_rank, stream, years, mode=1))
 
         # BASELINE.json configs[3]: the emissions-driven MAGICC graph (ten rscm-magicc components, Sum of
         # eight forcings, FourBox transforms) as linked ensembles, ClimateUDEB / OceanCarbon at 12 sub-steps

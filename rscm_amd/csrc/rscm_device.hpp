@@ -356,6 +356,8 @@ struct UdebArgs {
     // rows [NL][6] = {af_top, af_bot, af_diff, 1 - rel_depth, G_nh, G_sh}, NL = n_layers <= 50 (udeb_tables.hpp): passed BY
     // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
     double tables[6 * 50];
+    const double* derived;     // [kDerivedRows][N] member constants: the base LAMCALC solve (launch_udeb_derive; udeb_body.hpp)
+    int32_t derived_uniform;   // every parameter row it is formed from is uniform: element 0 serves all members
     const double* tables_dev;  // the same rows in device memory, any NL: the any-layer-count kernel (udeb_any_body.hpp); else nullptr
     double* work;              // [NL][N] the Thomas sweep's c' array of that kernel; else nullptr
     double* ocean;          // [2][NL][N] layer temperatures
@@ -609,6 +611,8 @@ hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 constexpr int kDerivedRows = 8;
 hipError_t launch_ghg_derive(const double* params, uint64_t uniform_rows, int32_t method, int64_t n_members, double* out, hipStream_t s);
 hipError_t launch_terrestrial_derive(const double* params, uint64_t uniform_rows, int64_t n_members, double* out, hipStream_t s);
+hipError_t launch_udeb_derive(const double* params, uint64_t uniform_rows, int64_t n_members, double* out, hipStream_t s);
+uint64_t udeb_derive_sources();
 uint64_t ghg_derive_sources(int32_t method);      // bit j: parameter row j enters the member constants
 uint64_t terrestrial_derive_sources();
 hipError_t launch_pointwise(const PointwiseArgs& a, hipStream_t s);

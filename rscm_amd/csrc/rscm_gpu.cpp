@@ -1190,11 +1190,14 @@ int rscm_ens_rewind(rscm_ens* h)
 
 // ---- one launch range of one handle, in pieces (rscm_ens_run_lockstep fuses the launches of several handles) ----
 // (1) what must hold before anything is enqueued
-// The member constants of GhgForcing and TerrestrialCarbon (what their bodies used to form from the parameters alone at the top of
-// every launch): one small kernel whenever the parameter block has been written since the last one -- rscm_ens_set_params*,
+// The member constants of GhgForcing, TerrestrialCarbon and ClimateUDEB (what their bodies used to form from the parameters alone at the
+// top of every launch; ClimateUDEB: the base LAMCALC solve): one small kernel whenever the parameter block has been written since the last one -- rscm_ens_set_params*,
 // rscm_ens_sample_lhs, a checkpoint restore, a sampler's proposals -- and before EVERY run of a handle whose block the caller may
 // write directly (rscm_ens_params_devptr).
-static bool has_derived(const rscm_ens* h) { return h->kind == RSCM_KIND_GHG_FORCING || h->kind == RSCM_KIND_TERRESTRIAL_CARBON; }
+static bool has_derived(const rscm_ens* h)
+{
+    return h->kind == RSCM_KIND_GHG_FORCING || h->kind == RSCM_KIND_TERRESTRIAL_CARBON || h->kind == RSCM_KIND_UDEB;
+}
 
 int ensure_derived(rscm_ens* h)
 {
@@ -1207,6 +1210,7 @@ int ensure_derived(rscm_ens* h)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "member constants of %lld members: %s", (long long)h->N, hipGetErrorString(e));
     }
     if (h->kind == RSCM_KIND_GHG_FORCING) HIPCHK(rscm::launch_ghg_derive(h->d_params, h->uniform_rows, h->ghg_method, h->N, h->d_derived, h->stream));
+    else if (h->kind == RSCM_KIND_UDEB) HIPCHK(rscm::launch_udeb_derive(h->d_params, h->uniform_rows, h->N, h->d_derived, h->stream));
     else HIPCHK(rscm::launch_terrestrial_derive(h->d_params, h->uniform_rows, h->N, h->d_derived, h->stream));
     h->derived_dirty = false;
     return RSCM_OK;
@@ -1552,6 +1556,8 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.fast = h->mode == RSCM_MODE_FAST ? 1 : 0;
         a.params = h->d_params;
         a.uniform_rows = h->uniform_rows;
+        a.derived = h->d_derived;
+        a.derived_uniform = (h->uniform_rows & rscm::udeb_derive_sources()) == rscm::udeb_derive_sources() ? 1 : 0;
         a.erf = h->d_forcing;
         a.link = linked ? links.row[0] : nullptr;
         a.scen = linked ? nullptr : h->d_scen;

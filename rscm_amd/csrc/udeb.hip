@@ -81,7 +81,39 @@ __global__ __launch_bounds__(256) void udeb_any_kernel(UdebArgs a)
     udeb::udeb_any_member<FAST>(a, i);
 }
 
+// The base LAMCALC solve of every member, once per parameter set (rscm_gpu.cpp, ensure_derived): rows of `out` as in udeb_body.hpp.
+__global__ __launch_bounds__(256) void udeb_derive_kernel(const double* __restrict__ params, uint64_t uniform_rows, int64_t n_members,
+                                                          double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_members) return;
+    auto P = [&](int j) -> double { return param_at(params, uniform_rows, j, n_members, i); };
+    udeb::UdebP p;
+    udeb::fill_lamcalc_inputs(p, P(10), P(11), P(12), P(16), P(17), P(18), P(19), P(20), P(28), P(29), P(30), P(31));
+    const udeb::LamResult r = udeb::lamcalc(p, p.ecs);
+    out[i] = r.lam_o;
+    out[(size_t)n_members + i] = r.lam_l;
+    out[(size_t)2 * n_members + i] = r.eff;
+    out[(size_t)3 * n_members + i] = r.ok ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 4; k < kDerivedRows; ++k) out[(size_t)k * n_members + i] = 0.0;
+}
+
 }  // namespace
+
+uint64_t udeb_derive_sources()
+{
+    uint64_t m = 0;
+    for (int j : {10, 11, 12, 16, 17, 18, 19, 20, 28, 29, 30, 31}) m |= 1ull << j;
+    return m;
+}
+
+hipError_t launch_udeb_derive(const double* params, uint64_t uniform_rows, int64_t n_members, double* out, hipStream_t s)
+{
+    if (n_members <= 0) return hipSuccess;
+    hipLaunchKernelGGL(udeb_derive_kernel, dim3((unsigned)((n_members + 255) / 256)), dim3(256), 0, s, params, uniform_rows, n_members, out);
+    return hipGetLastError();
+}
 
 // 0: one thread per member, 2: a hemisphere per wavefront; -1: by ensemble size
 static thread_local int t_udeb_variant = -1;
@@ -111,6 +143,7 @@ bool udeb_layers_unrolled(int32_t n_layers)
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
 {
     if (a.step_end <= a.step_begin || a.n_members <= 0) return hipSuccess;
+    if (!a.derived) return hipErrorInvalidValue;
     // Up to 32 768 members there are fewer wavefronts than SIMDs either way: the two-wavefront kernel solves a member's
     // two hemispheres at the same time on two SIMDs (half the latency per model step); beyond that the two kernels
     // take the same time per member (profiles/r3_udeb_two_wave_experiment.txt) and the one-thread kernel is kept.

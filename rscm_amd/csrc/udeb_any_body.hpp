@@ -135,7 +135,7 @@ __device__ __forceinline__ void udeb_any_member(const UdebArgs& a, int64_t i)
     if (!is_finite(p.prescribed_eff) || p.prescribed_eff <= 0.0) status = 2;
     LamResult base = LamResult{0.0, 0.0, 1.0, false};
     if (status == 0) {
-        base = lamcalc(p, p.ecs);
+        base = base_lamcalc_from_block(a.derived, a.derived_uniform, N, i);
         if (!base.ok) status = 4;
     }
     a.status[i] = (uint8_t)status;

@@ -215,6 +215,33 @@ __device__ __forceinline__ LamResult lamcalc(const UdebP& p, double ecs)
     return out;
 }
 
+// The base LAMCALC solve (from_parameters, mod.rs:161-227) depends on the parameters alone: formed once per parameter set by
+// launch_udeb_derive (udeb.hip) -- this very function on the same inputs -- and read back at the top of every launch instead of iterating
+// again (a one-step launch of a graph paid the secant iteration every model step).  Rows of the block: [0] lambda_ocean
+// [1] lambda_land [2] CO2 efficacy [3] 1.0 if the iteration converged.
+__device__ __forceinline__ LamResult base_lamcalc_from_block(const double* __restrict__ derived, int32_t uniform, int64_t N, int64_t i)
+{
+    const uint64_t u = uniform ? 0xFull : 0ull;
+    LamResult r;
+    r.lam_o = param_at(derived, u, 0, N, i);
+    r.lam_l = param_at(derived, u, 1, N, i);
+    r.eff = param_at(derived, u, 2, N, i);
+    r.ok = param_at(derived, u, 3, N, i) != 0.0;
+    return r;
+}
+
+// what lamcalc() reads of a member's parameters (the derive kernel fills just this)
+__device__ __forceinline__ void fill_lamcalc_inputs(UdebP& p, double ecs, double rf_2x, double rlo, double k_lo, double k_ns, double amplify,
+                                                    double nh_land, double sh_land, double rf0, double rf1, double rf2, double rf3)
+{
+    p.ecs = ecs; p.rf_2x = rf_2x; p.rlo = rlo; p.k_lo = k_lo; p.k_ns = k_ns; p.amplify = amplify; p.nh_land = nh_land; p.sh_land = sh_land;
+    p.rf0 = rf0; p.rf1 = rf1; p.rf2 = rf2; p.rf3 = rf3;
+    p.fgnl = p.nh_land / 2.0; p.fgno = 0.5 - p.fgnl; p.fgsl = p.sh_land / 2.0; p.fgso = 0.5 - p.fgsl;
+    const double rf_sum = p.rf0 * p.fgno + p.rf1 * p.fgnl + p.rf2 * p.fgso + p.rf3 * p.fgsl;   // compute_qfrac
+    if (fabs(rf_sum) <= 1e-15) { p.q0 = p.q1 = p.q2 = p.q3 = 1.0; }
+    else { p.q0 = p.rf0 / rf_sum; p.q1 = p.rf1 / rf_sum; p.q2 = p.rf2 / rf_sum; p.q3 = p.rf3 / rf_sum; }
+}
+
 // The scalar model code between the column solves (mod.rs:487-560), shared by the two kernels (so that they carry the same
 // bits).  ClimateUDEB is a tolerance-parity kind: a quotient by a value that is fixed for the launch or for the year is a
 // product with its reciprocal, formed once -- six IEEE divisions (58 cycles each) less per sub-step.
@@ -458,7 +485,7 @@ struct Udeb1 {
         if (!is_finite(p.prescribed_eff) || p.prescribed_eff <= 0.0) status = 2;
         base = LamResult{0.0, 0.0, 1.0, false};
         if (status == 0) {
-            base = lamcalc(p, p.ecs);
+            base = base_lamcalc_from_block(a.derived, a.derived_uniform, N, i);
             if (!base.ok) status = 4;
         }
         a.status[i] = (uint8_t)status;
@@ -796,7 +823,7 @@ struct Udeb2 {
         if (!is_finite(p.prescribed_eff) || p.prescribed_eff <= 0.0) status = 2;
         base = LamResult{0.0, 0.0, 1.0, false};
         if (status == 0) {
-            base = lamcalc(p, p.ecs);
+            base = base_lamcalc_from_block(a.derived, a.derived_uniform, N, i);
             if (!base.ok) status = 4;
         }
         if (live && hemi == 0) a.status[i] = (uint8_t)status;
