@@ -22,7 +22,8 @@ extern "C" {
  *      all steps, with thread-private LDS slots between the steps;
  *   2  as 1 without the LDS slots;
  *   3  as 1 with every op table sent through device memory instead of the kernel arguments;
- *      (A mode 4 -- ClimateUDEB and OceanCarbon inside the fused launch too, one launch per window chunk with the ocean columns
+ *   4  as 1 without cutting a one-step segment's independent ops over two wavefronts (csrc/group.hip, group_split_kernel): A/B.
+ *      (Round 3's mode 4 -- ClimateUDEB and OceanCarbon inside the fused launch too, one launch per window chunk with the ocean columns
  *      resident on chip -- existed in round 3: bit-identical to mode 1 and 17 % slower on an MI355X, removed in round 4;
  *      DESIGN.md section 8g, profiles/r3_graph_stamps.json, commit f22e743.)
  * The setting is per calling THREAD: lock-step runs issued from another thread do not see it. */
@@ -31,6 +32,9 @@ RSCM_API int rscm_gpu_set_lockstep_fusion(int32_t enabled);
  * groups; HalocarbonChemistry counts as one) and the component steps they carried, since the thread's
  * last call of this function; resets both counters. */
 RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps);
+/* How many of the calling thread's fused launches since its last call of this function ran two independent sets of ops on two
+ * wavefronts per 64 members (group_split_kernel); resets the counter. */
+RSCM_API int rscm_gpu_lockstep_split_launches(int64_t* out);
 
 /* Which ClimateUDEB kernel the calling thread's launches take (csrc/udeb.hip): 0 one thread per member, 2 a hemisphere per
  * wavefront; -1 (default): chosen by ensemble size.  The two carry the same bits.  (Layer counts other than 20 / 30 / 40 / 50

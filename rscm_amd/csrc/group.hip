@@ -89,6 +89,53 @@ __global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable tab
 }
 
 
+// ---- two independent chains of a step on two wavefronts ---------------------------------------------------------
+// A one-step launch of light components is a chain of dependent memory trips, one op after the other: at
+// 125 000 members the eight ops of the MAGICC graph's first segment take 33 us of which ~7 us are arithmetic.  Many of those ops do not
+// depend on each other -- the aerosol forcings and the chemistry -> greenhouse-gas forcing branch only meet in the Sum of the forcings.
+// The host (csrc/lockstep.cpp, plan_split) cuts the segment into two sets of ops with no edge between them plus a tail that may read
+// both; here a workgroup of TWO wavefronts serves 64 members: wavefront 0 runs the first set for them, wavefront 1 the second, at the
+// same time; after a workgroup barrier (release / acquire at workgroup scope: both wavefronts sit on one CU and share its L1) wavefront 0
+// runs the tail.  Every op still executes the same body on the same operands, in an order the graph's edges allow: the same bits
+// (tests/test_gpu_group.py).  Twice the wavefronts of the plain launch must be resident (3908 at 125 000 members: they are, at <= 128
+// registers); no lane leaves before the barrier.
+template <bool FULL, class Ops>
+__device__ __forceinline__ void split_range(const Ops& ops, int32_t begin, int32_t end, int64_t i, int32_t step, bool live)
+{
+    if (!live) return;
+    for (int32_t k = begin; k < end; ++k) run_op<FULL>(ops[k], i, step, step + 1, NoCache());
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(128) void group_split_kernel(const GroupTable table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members,
+                                                          int32_t step)
+{
+    {   // the table's lines up front, as in group_kernel_args
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(&table);
+        const int32_t n_lines = (int32_t)(((size_t)n_ops * sizeof(GroupOp) + 63) / 64);
+        uint32_t touched = 0;
+        for (int32_t l = 0; l < n_lines; ++l) touched |= words[(size_t)l * 16];
+        asm volatile("" ::"s"(touched));
+    }
+    const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));   // wave-uniform, and said so: the op index stays scalar
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool live = i < n_members;
+    // ONE call site of the bodies (a second one takes the uses of the by-value table past the point where the compiler stops treating its
+    // stack copy as read-only and keeps the copy: 2.4 KB of scratch per lane): phase 0 = this wavefront's set, phase 1 = the tail.
+    for (int32_t phase = 0; phase < 2; ++phase) {
+        int32_t begin, end;
+        if (phase == 0) {
+            begin = wave == 0 ? 0 : n_first;
+            end = wave == 0 ? n_first : n_first + n_second;
+        } else {
+            __syncthreads();
+            begin = n_first + n_second;
+            end = wave == 0 ? n_ops : begin;
+        }
+        split_range<FULL>(table.ops, begin, end, i, step, live);
+    }
+}
+
 // ---- a kernel per graph: the op KINDS fixed at compile time -------------------------------------------------
 // The interpreter above pays, per op and model step, for what it cannot know: the switch on the kind, the op's
 // fields re-read through the scalar cache (a dynamic index into the table), the slot records of its LDS cache --
@@ -201,6 +248,16 @@ bool launch_group_seq(const GroupTable& table, int32_t n_ops, int64_t n_members,
     else return false;
     *status = hipGetLastError();
     return true;
+}
+
+hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
+                              hipStream_t s)
+{
+    if (n_first < 1 || n_second < 1 || n_first + n_second > n_ops || n_ops > kGroupTableOps || n_members <= 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n_members + 63) / 64));
+    if (all_small) hipLaunchKernelGGL(group_split_kernel<false>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
+    else hipLaunchKernelGGL(group_split_kernel<true>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
+    return hipGetLastError();
 }
 
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,

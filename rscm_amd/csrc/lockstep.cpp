@@ -2,6 +2,9 @@
 // (crates/rscm-core/src/model/runtime.rs:504-527 walks the graph once per step; here the walk is cut into
 // launches -- fused groups of light components (one launch for many steps when the whole graph is light), the
 // heavy components' own kernels).
+#include <algorithm>
+#include <cstdlib>
+
 #include "ens.hpp"
 
 extern "C" {
@@ -14,7 +17,9 @@ struct LockstepSettings {
     bool fuse = true;        // consecutive light components of a step in one launch
     bool cache = true;       // multi-step fused launches keep per-member values in LDS between steps
     bool by_value = true;    // short op lists travel in the kernel arguments
+    bool split = true;       // independent ops of a one-step segment on two wavefronts (group_split_kernel)
     int64_t launches = 0, component_steps = 0;  // since the thread's last rscm_gpu_lockstep_stats
+    int64_t split_launches = 0;                 // of those, launches of group_split_kernel
 };
 thread_local LockstepSettings t_ls;
 }  // namespace
@@ -27,6 +32,13 @@ int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps)
     return RSCM_OK;
 }
 
+int rscm_gpu_lockstep_split_launches(int64_t* out)
+{
+    if (out) *out = t_ls.split_launches;
+    t_ls.split_launches = 0;
+    return RSCM_OK;
+}
+
 int rscm_gpu_set_udeb_variant(int32_t variant)
 {
     if (variant != -1 && variant != 0 && variant != 2) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0 or 2");
@@ -36,10 +48,11 @@ int rscm_gpu_set_udeb_variant(int32_t variant)
 
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
-    if (enabled < 0 || enabled > 3) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..3)", enabled);
+    if (enabled < 0 || enabled > 4) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..4)", enabled);
     t_ls.fuse = enabled != 0;
-    t_ls.cache = enabled == 1 || enabled == 3;
+    t_ls.cache = enabled == 1 || enabled == 3 || enabled == 4;
     t_ls.by_value = enabled != 3;
+    t_ls.split = enabled != 4;
     return RSCM_OK;
 }
 
@@ -131,6 +144,95 @@ static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t cou
     return next;
 }
 
+// Two independent sets of ops + a tail for a one-step segment (csrc/group.hip, group_split_kernel).  Ops are tied together -- must run on
+// the same wavefront, in their order -- whenever one reads the row the other writes in this step (a link read at n + 1, whichever of the
+// two comes first in the order: a consumer that runs BEFORE its producer reads what the row held before, and must keep doing so); links
+// read at n touch another row than the one being written and tie nothing.  For every tail start t the ops before it fall into connected
+// sets; two bins are filled greedily by estimated cost; the cut with the shortest critical path wins if it beats the serial chain.
+struct SplitPlan {
+    int32_t order[rscm::kGroupTableOps];
+    int32_t n_first = 0, n_second = 0;
+};
+static int32_t op_cost(int32_t kind)
+{
+    switch (kind) {
+        case RSCM_KIND_TWO_LAYER: return 8;
+        case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: case RSCM_KIND_GHG_FORCING:
+        case RSCM_KIND_TERRESTRIAL_CARBON: return 3;
+        default: return 2;   // one dependent round trip to memory and a few dozen instructions
+    }
+}
+static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, SplitPlan* out)
+{
+    static const bool enabled = [] { const char* e = getenv("RSCM_LOCKSTEP_SPLIT"); return !e || atoi(e) != 0; }();   // 0: A/B runs without it
+    if (!enabled || !t_ls.split || count < 3 || count > rscm::kGroupTableOps) return false;
+    bool tie[rscm::kGroupTableOps][rscm::kGroupTableOps] = {};
+    int32_t cost[rscm::kGroupTableOps], serial = 0;
+    for (int32_t k = 0; k < count; ++k) {
+        const rscm_ens* h = plan->handles[first + k];
+        cost[k] = op_cost(h->kind);
+        serial += cost[k];
+        for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
+            const auto& l = h->links[j];
+            if (!l.src) continue;
+            const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
+            if (!reads_end) continue;
+            for (int32_t q = 0; q < count; ++q)
+                if (plan->handles[first + q] == l.src && q != k) tie[k][q] = tie[q][k] = true;
+        }
+    }
+    int32_t best = serial - 1, best_t = -1, best_bin[rscm::kGroupTableOps] = {};
+    for (int32_t t = 2; t <= count; ++t) {
+        int32_t comp[rscm::kGroupTableOps];
+        for (int32_t k = 0; k < t; ++k) comp[k] = k;
+        for (bool changed = true; changed;) {   // connected sets of the ops before the tail (at most eight ops)
+            changed = false;
+            for (int32_t a = 0; a < t; ++a)
+                for (int32_t b = 0; b < t; ++b)
+                    if (tie[a][b] && comp[a] != comp[b]) {
+                        const int32_t lo = std::min(comp[a], comp[b]), hi = std::max(comp[a], comp[b]);
+                        for (int32_t k = 0; k < t; ++k)
+                            if (comp[k] == hi) comp[k] = lo;
+                        changed = true;
+                    }
+        }
+        int32_t weight[rscm::kGroupTableOps] = {}, bin_of[rscm::kGroupTableOps], load[2] = {0, 0}, n_sets = 0;
+        for (int32_t k = 0; k < t; ++k) weight[comp[k]] += cost[k];
+        for (int32_t c = 0; c < t; ++c) {
+            bin_of[c] = -1;
+            if (weight[c] > 0) ++n_sets;
+        }
+        if (n_sets < 2) continue;
+        for (int32_t placed = 0; placed < n_sets; ++placed) {   // heaviest set first, into the lighter bin
+            int32_t pick = -1;
+            for (int32_t c = 0; c < t; ++c)
+                if (weight[c] > 0 && bin_of[c] < 0 && (pick < 0 || weight[c] > weight[pick])) pick = c;
+            const int32_t b = load[0] <= load[1] ? 0 : 1;
+            bin_of[pick] = b;
+            load[b] += weight[pick];
+        }
+        int32_t tail = 0;
+        for (int32_t k = t; k < count; ++k) tail += cost[k];
+        const int32_t path = std::max(load[0], load[1]) + tail + 1;   // + the barrier
+        if (path < best) {
+            best = path;
+            best_t = t;
+            for (int32_t k = 0; k < t; ++k) best_bin[k] = bin_of[comp[k]];
+        }
+    }
+    if (best_t < 0) return false;
+    int32_t pos = 0;
+    out->n_first = out->n_second = 0;
+    for (int32_t b = 0; b < 2; ++b)
+        for (int32_t k = 0; k < best_t; ++k)
+            if (best_bin[k] == b) {
+                out->order[pos++] = k;
+                ++(b == 0 ? out->n_first : out->n_second);
+            }
+    for (int32_t k = best_t; k < count; ++k) out->order[pos++] = k;
+    return out->n_first > 0 && out->n_second > 0;
+}
+
 // Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
 // the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
 static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
@@ -195,9 +297,19 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         if (!rscm::launch_group_seq(table, count, lead->N, n, n + len, cache_slots, lead->stream, &seq_status))
             return fail(RSCM_ERR_STATE, "no kernel for this sequence of kinds after all");
         HIPCHK(seq_status);
-    } else
-        HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
-                                  cache_slots, lead->stream));
+    } else {
+        SplitPlan split;
+        if (by_value && len == 1 && cache_slots == 0 && plan_split(plan, first, count, &split)) {
+            rscm::GroupTable ordered;
+            memset((void*)&ordered, 0, sizeof ordered);
+            for (int32_t k = 0; k < count; ++k) memcpy((void*)&ordered.ops[k], &table.ops[split.order[k]], sizeof(rscm::GroupOp));
+            HIPCHK(rscm::launch_group_split(ordered, split.n_first, split.n_second, count, lead->N, n, all_small, lead->stream));
+            t_ls.split_launches += 1;
+        } else {
+            HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
+                                      cache_slots, lead->stream));
+        }
+    }
     for (int32_t k = first; k < first + count; ++k)
         if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
     return RSCM_OK;

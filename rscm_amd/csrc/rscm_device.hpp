@@ -591,6 +591,11 @@ bool group_kind_is_small(int32_t kind);
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
                         bool all_small, int32_t cache_slots, hipStream_t s);
 
+// One model step of a by-value table whose first n_first ops and next n_second ops have no edge between them (two wavefronts per 64
+// members run them at the same time), the rest after a workgroup barrier (csrc/group.hip, group_split_kernel).
+hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
+                              hipStream_t s);
+
 // A multi-step launch of a light graph whose sequence of kinds has a kernel of its own (csrc/group.hip: the op table
 // by value, the kinds compile-time): true if one was launched (*status: its launch status), false if the sequence has none.
 bool group_seq_available(const int32_t* kinds, int32_t n_ops);

@@ -264,6 +264,48 @@ def test_fused_magicc_graph_keeps_the_bits(ra, execution_order):
     fused.close()
 
 
+@pytest.mark.parametrize("execution_order", ["reference", "topological"])
+def test_independent_ops_of_a_step_on_two_wavefronts(ra, execution_order):
+    """The fused one-step launches cut a segment's ops into two sets with no edge between them plus a tail (csrc/lockstep.cpp plan_split,
+    csrc/group.hip group_split_kernel: two wavefronts per 64 members run the sets at the same time, a workgroup barrier, then the tail).
+    The MAGICC graph's first segment has such a cut (the aerosol forcings beside the chemistry -> greenhouse-gas branch, the Sum of the
+    forcings as the tail): the launches with the split are counted, and every series equals the run without it (fusion mode 4) and the
+    unfused run (mode 0), bit for bit -- in the reference's breadth-first order too, where a consumer may run before its producer
+    (they are tied to one wavefront).  A ragged last workgroup (N = 203) and windowed series are part of it."""
+    import ctypes as C
+    from rscm_amd import _lib as L
+    mod = _chain()
+    lib = L.load()
+    years, N = 40, 203
+
+    def run(mode, **kw):
+        L.check(lib.rscm_gpu_set_lockstep_fusion(mode))
+        L.check(lib.rscm_gpu_lockstep_split_launches(None))
+        m = mod.build_chain(N, years, execution_order, **kw)
+        m.set_mode(L.MODE_FAST)
+        m.run()
+        n_split = C.c_int64()
+        L.check(lib.rscm_gpu_lockstep_split_launches(C.byref(n_split)))
+        stride = kw.get("output_stride", 1)
+        rows = {v: m.get_series(v, t_stride=stride) for v in sorted(m._var_home) if v != "Surface Temperature"}
+        for v in range(1, 5):
+            rows[f"box {v}"] = m.ensembles["ClimateUDEB"].get_series(v, t_stride=stride)
+        m.close()
+        return rows, n_split.value
+
+    try:
+        for kw in (dict(), dict(series_window=12, output_stride=4)):
+            with_split, n_split = run(1, **kw)
+            without, n_none = run(4, **kw)
+            unfused, _ = run(0, **kw)
+            assert n_none == 0 and n_split >= years, (n_split, n_none)   # at least the first segment of every step
+            for name in with_split:
+                assert_bit_equal(with_split[name], without[name], f"{execution_order} {kw}: split vs unsplit: {name}")
+                assert_bit_equal(with_split[name], unfused[name], f"{execution_order} {kw}: split vs unfused: {name}")
+    finally:
+        L.check(lib.rscm_gpu_set_lockstep_fusion(1))
+
+
 def test_fused_windowed_graph_keeps_the_bits(ra):
     mod = _chain()
     years, N = 70, 128
