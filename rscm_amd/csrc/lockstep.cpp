@@ -155,11 +155,15 @@ struct SplitPlan {
 };
 static int32_t op_cost(int32_t kind)
 {
+    // (one unit ~ a dependent round trip to memory plus a few dozen instructions; the chemistry's Prather passes, the forcing
+    // formulas' logarithms and the RK4 box models weigh by their instruction counts on top)
     switch (kind) {
-        case RSCM_KIND_TWO_LAYER: return 8;
-        case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: case RSCM_KIND_GHG_FORCING:
-        case RSCM_KIND_TERRESTRIAL_CARBON: return 3;
-        default: return 2;   // one dependent round trip to memory and a few dozen instructions
+        case RSCM_KIND_TWO_LAYER: return 12;
+        case RSCM_KIND_CH4_CHEMISTRY: return 6;
+        case RSCM_KIND_N2O_CHEMISTRY: return 5;
+        case RSCM_KIND_CARBON_CYCLE: case RSCM_KIND_GHG_FORCING: case RSCM_KIND_TERRESTRIAL_CARBON: return 4;
+        case RSCM_KIND_OZONE_FORCING: case RSCM_KIND_AEROSOL_DIRECT: return 2;
+        default: return 1;
     }
 }
 static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, SplitPlan* out)
