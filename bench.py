@@ -417,7 +417,6 @@ def linked_graph_extra(members, device, stream, years, mode=0):
         fused.run()
         fused_best = min(fused_best, time.perf_counter() - t0)
     fused.close()
-    import ctypes as C0
     from rscm_amd import _lib as L0
     L0.check(L0.load().rscm_gpu_lockstep_stats(None, None))  # reset the launch counters
     kinds = (rscm_amd.KIND_CARBON_CYCLE, rscm_amd.KIND_CO2_ERF, rscm_amd.KIND_AGGREGATE, rscm_amd.KIND_TWO_LAYER)
