@@ -164,14 +164,75 @@ struct KindSeq {
     static constexpr int kinds[sizeof...(KINDS)] = {KINDS...};
 };
 
-template <class Seq, int... IDX>
-__device__ __forceinline__ void run_seq_step(const GroupTable& table, int64_t i, int32_t b, bool warm, bool last, double* slots,
+// Parameters (P) and stored series (S = V - 1) of the kinds a sequence may hold, and where their blocks live in the op's arguments.
+template <int KIND> struct SeqShape { static constexpr int P = pw::Shape<KIND>::P, S = pw::Shape<KIND>::NO; };
+template <> struct SeqShape<0> { static constexpr int P = 6, S = 2; };
+template <> struct SeqShape<kKindCarbonCycle> { static constexpr int P = 3, S = 3; };
+
+// An op's parameters and latest row, in registers for the whole launch (RegCache, rscm_device.hpp)
+template <int KIND>
+struct OpRegs {
+    double prm[SeqShape<KIND>::P];
+    double st[SeqShape<KIND>::S];
+    __device__ __forceinline__ void load(const GroupOp& op, int64_t i, int32_t step_begin)
+    {
+        const double* params;
+        uint64_t uniform;
+        int64_t N;
+        if constexpr (KIND == 0) { params = op.u.tl.params; uniform = op.u.tl.uniform_rows; N = op.u.tl.n_members; }
+        else if constexpr (KIND == kKindCarbonCycle || KIND == kKindCo2Budget) { params = op.u.carbon.params; uniform = op.u.carbon.uniform_rows; N = op.u.carbon.n_members; }
+        else { params = op.u.pw.params; uniform = op.u.pw.uniform_rows; N = op.u.pw.n_members; }
+#pragma unroll
+        for (int j = 0; j < SeqShape<KIND>::P; ++j) prm[j] = param_at(params, uniform, j, N, i);
+        // the state rows the bodies ask their cache for (the pointwise kinds have outputs only: nothing is read back)
+        const size_t r0 = (size_t)step_begin * N + i;
+        if constexpr (KIND == 0) {
+            st[0] = op.u.tl.ts[r0];
+            st[1] = op.u.tl.td[r0];
+        } else if constexpr (KIND == kKindCarbonCycle || KIND == kKindCo2Budget) {
+            const size_t vs = (size_t)op.u.carbon.rows * N;
+#pragma unroll
+            for (int v = 0; v < SeqShape<KIND>::S; ++v) st[v] = op.u.carbon.series[v * vs + r0];
+        } else {
+#pragma unroll
+            for (int v = 0; v < SeqShape<KIND>::S; ++v) st[v] = 0.0;
+        }
+    }
+};
+
+template <int... K> struct RegPack;
+template <> struct RegPack<> {};
+template <int K0, int... K>
+struct RegPack<K0, K...> {
+    OpRegs<K0> head;
+    RegPack<K...> tail;
+};
+template <int I, int K0, int... K>
+__device__ __forceinline__ auto& pack_get(RegPack<K0, K...>& p)
+{
+    if constexpr (I == 0) return p.head;
+    else return pack_get<I - 1>(p.tail);
+}
+template <class Seq> struct PackOf;
+template <int... K> struct PackOf<KindSeq<K...>> { using type = RegPack<K...>; };
+
+template <class Seq, bool WARM, class Pack, int... IDX>
+__device__ __forceinline__ void run_seq_step(const GroupTable& table, Pack& regs, int64_t i, int32_t b, bool last, double* slots,
                                              std::integer_sequence<int, IDX...>)
 {
-    if (warm) (run_kind<Seq::kinds[IDX]>(table.ops[IDX], i, b, LdsCache<true>{slots, table.ops[IDX].cache, last}), ...);
-    else (run_kind<Seq::kinds[IDX]>(table.ops[IDX], i, b, LdsCache<false>{slots, table.ops[IDX].cache, last}), ...);
+    (run_kind<Seq::kinds[IDX]>(table.ops[IDX], i, b,
+                               RegCache<WARM>{pack_get<IDX>(regs).prm, pack_get<IDX>(regs).st, slots, table.ops[IDX].cache, last}), ...);
 }
 
+template <class Seq, class Pack, int... IDX>
+__device__ __forceinline__ void load_seq_regs(const GroupTable& table, Pack& regs, int64_t i, int32_t step_begin, std::integer_sequence<int, IDX...>)
+{
+    (pack_get<IDX>(regs).load(table.ops[IDX], i, step_begin), ...);
+}
+
+// Parameters and states live in registers from the first step to the last (RegCache): the bodies are inlined into the step loop, so what
+// they form from the parameters alone -- reciprocals, folded coefficients, the refined reciprocals of the speculative divisions -- is
+// loop-invariant and formed once per launch, like in a kernel written for the graph; the LDS slots carry only what ops read of each other.
 template <class Seq>
 __global__ __launch_bounds__(kBlock) void group_seq_kernel(const GroupTable table, int64_t n_members, int32_t step_begin, int32_t step_end)
 {
@@ -180,13 +241,15 @@ __global__ __launch_bounds__(kBlock) void group_seq_kernel(const GroupTable tabl
     if (i >= n_members) return;
     double* slots = lds_slots + threadIdx.x;
     const auto idx = std::make_integer_sequence<int, Seq::n>();
-    run_seq_step<Seq>(table, i, step_begin, false, step_begin + 1 == step_end, slots, idx);   // cold: fills the slots
+    typename PackOf<Seq>::type regs;
+    load_seq_regs<Seq>(table, regs, i, step_begin, idx);
+    run_seq_step<Seq, false>(table, regs, i, step_begin, step_begin + 1 == step_end, slots, idx);   // cold: feedback links come from memory
     for (int32_t b = step_begin + 1; b < step_end; ++b) {
         // the fields of four ops do not fit the scalar registers at once: an opaque zero offset per step keeps their
         // loads inside the step (a few s_load_dwordx16 from the kernel-argument segment) instead of hoisted and spilled
         int32_t opaque = 0;
         asm volatile("" : "+s"(opaque));
-        run_seq_step<Seq>((&table)[opaque], i, b, true, b + 1 == step_end, slots, idx);
+        run_seq_step<Seq, true>((&table)[opaque], regs, i, b, b + 1 == step_end, slots, idx);
     }
 }
 

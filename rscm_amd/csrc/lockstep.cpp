@@ -100,7 +100,7 @@ static bool keeps_slots(int32_t kind)
         default: return false;
     }
 }
-static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t count, std::vector<rscm::OpCache>& out)
+static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t count, std::vector<rscm::OpCache>& out, bool param_slots)
 {
     out.assign((size_t)count, rscm::OpCache{});
     int32_t next = 0;
@@ -120,7 +120,7 @@ static int32_t assign_cache_slots(LockstepPlan* plan, int32_t first, int32_t cou
         const rscm_ens* h = plan->handles[first + k];
         const uint64_t all_rows = h->P >= 64 ? ~0ull : ((1ull << h->P) - 1ull);
         const bool varies = (h->uniform_rows & all_rows) != all_rows;
-        if (keeps_slots(h->kind) && h->kind != RSCM_KIND_AGGREGATE && varies && h->P <= 16 && next + h->P <= kCacheSlotBudget) {
+        if (param_slots && keeps_slots(h->kind) && h->kind != RSCM_KIND_AGGREGATE && varies && h->P <= 16 && next + h->P <= kCacheSlotBudget) {
             out[(size_t)k].param_slot = next;
             next += h->P;
         }
@@ -246,7 +246,16 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
     for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
     std::vector<rscm::OpCache> slots;
     int32_t cache_slots = 0;
-    if (len > 1 && all_small && t_ls.cache) cache_slots = assign_cache_slots(plan, first, count, slots);
+    // a multi-step launch of a graph whose sequence of kinds has a kernel of its own (csrc/group.hip, group_seq_kernel): that kernel keeps
+    // the parameters in registers, so only the series get LDS slots
+    bool own_kernel = false;
+    if (len > 1 && all_small && t_ls.cache && t_ls.by_value && count <= rscm::kGroupTableOps) {
+        int32_t kinds[rscm::kGroupTableOps];
+        for (int32_t k = 0; k < count; ++k) kinds[k] = plan->handles[first + k]->kind;
+        own_kernel = rscm::group_seq_available(kinds, count);
+    }
+    if (len > 1 && all_small && t_ls.cache) cache_slots = assign_cache_slots(plan, first, count, slots, !own_kernel);
+    if (cache_slots <= 0) own_kernel = false;
     for (int32_t k = first; k < first + count; ++k) {
         rscm_ens* h = plan->handles[k];
         if (int rc = step_check(h, n, n + len)) return rc;
@@ -255,13 +264,6 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
     // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
     // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
     // only what changed since the last launch is uploaded
-    // a multi-step launch of a graph whose sequence of kinds has a kernel of its own (csrc/group.hip, group_seq_kernel)
-    bool own_kernel = false;
-    if (cache_slots > 0 && t_ls.by_value && count <= rscm::kGroupTableOps) {
-        int32_t kinds[rscm::kGroupTableOps];
-        for (int32_t k = 0; k < count; ++k) kinds[k] = plan->handles[first + k]->kind;
-        own_kernel = rscm::group_seq_available(kinds, count);
-    }
     const bool by_value = (t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0) || own_kernel;
     rscm::GroupTable table;
     if (by_value) memset((void*)&table, 0, sizeof table);

@@ -181,6 +181,43 @@ struct LdsCache {
     __device__ __forceinline__ bool last_step() const { return last; }
 };
 
+// The same interface with an op's parameters and its own latest row in REGISTERS for the whole launch (csrc/group.hip,
+// group_seq_kernel: a kernel compiled for a sequence of kinds keeps one of these per op across its step loop).  The bodies are
+// inlined into that loop; what they form from the parameters alone -- reciprocals of heat capacities and lifetimes, folded
+// coefficients, h/3 -- is loop-invariant to the compiler and leaves the loop, the state needs no trip through LDS, and only what
+// OTHER ops read goes through the LDS slots (put() writes both).  prm / st point at arrays in the kernel's frame; every index the
+// bodies pass is a literal after inlining, so the arrays are registers.  What comes out is the double that went in: the same bits.
+template <bool WARM, int STRIDE = kBlock>
+struct RegCache {
+    static constexpr bool kOn = true;
+    static constexpr int kCacheStride = STRIDE;
+    const double* prm;   // [P] this member's parameter values, loaded once per launch
+    double* st;          // [V - 1] the op's latest row (its state for the next step)
+    double* col;         // this thread's column of LDS slots
+    OpCache c;
+    bool last;
+    __device__ __forceinline__ double param(const double* __restrict__, uint64_t, int j, int64_t, int64_t) const { return prm[j]; }
+    __device__ __forceinline__ double param_scalar(const double* __restrict__, uint64_t, int j, int64_t, int64_t) const { return prm[j]; }
+    template <int P>
+    __device__ __forceinline__ void params(const double* __restrict__, uint64_t, int64_t, int64_t, double (&p)[P]) const
+    {
+#pragma unroll
+        for (int j = 0; j < P; ++j) p[j] = prm[j];
+    }
+    __device__ __forceinline__ double state(int v, const double*) const { return st[v]; }
+    __device__ __forceinline__ void put(int v, double x) const
+    {
+        st[v] = x;
+        if (c.series_slot >= 0) col[(size_t)(c.series_slot + v) * kCacheStride] = x;
+    }
+    __device__ __forceinline__ bool has_link(int k) const
+    {
+        return c.link_slot[k] >= 0 && (WARM || ((c.link_warm >> k) & 1u) == 0);
+    }
+    __device__ __forceinline__ double link(int k) const { return col[(size_t)c.link_slot[k] * kCacheStride]; }
+    __device__ __forceinline__ bool last_step() const { return last; }
+};
+
 // The NI input rows of member i.  SRC 0: one shared table [NI][T]; 1: per-member scenario of a
 // table [S][NI][T]; 2: linked rows (coalesced [T][N] reads) mixed with table rows.  SRC < 2
 // compiles to the plain table indexing the kernels had before links existed.
