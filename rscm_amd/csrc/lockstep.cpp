@@ -185,7 +185,8 @@ static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, S
                 if (plan->handles[first + q] == l.src && q != k) tie[k][q] = tie[q][k] = true;
         }
     }
-    int32_t best = serial - 1, best_t = -1, best_bin[rscm::kGroupTableOps] = {};
+    // (worth it from ~15 % of the serial chain: the cut doubles the wavefronts that must be resident)
+    int32_t best = serial - std::max(1, (serial * 3 + 19) / 20), best_t = -1, best_bin[rscm::kGroupTableOps] = {};
     for (int32_t t = 2; t <= count; ++t) {
         int32_t comp[rscm::kGroupTableOps];
         for (int32_t k = 0; k < t; ++k) comp[k] = k;
@@ -218,7 +219,7 @@ static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, S
         int32_t tail = 0;
         for (int32_t k = t; k < count; ++k) tail += cost[k];
         const int32_t path = std::max(load[0], load[1]) + tail + 1;   // + the barrier
-        if (path < best) {
+        if (path <= best && (best_t < 0 || path < best)) {
             best = path;
             best_t = t;
             for (int32_t k = 0; k < t; ++k) best_bin[k] = bin_of[comp[k]];

@@ -218,6 +218,13 @@ def test_light_graph_with_lds_slots_matches_the_unfused_run(ra):
             assert_bit_equal(a, w_, f"one launch without the slots: series {k}")
         for k, (a, w_) in enumerate(zip(run(1, pieces=(1, 2, 40)), plain)):
             assert_bit_equal(a, w_, f"with slots, in four launches: series {k}")
+        # One model step per call: every step is a one-step launch of the seven ops.  Whether the scheduler cuts it into two sets of
+        # independent ops on two wavefronts is its cost model's decision (here the two-layer model in the tail outweighs what the
+        # cut would save; tests/test_gpu_group.py::test_independent_ops_of_a_step_on_two_wavefronts has a graph where it cuts):
+        # the bits are the same with the cut allowed (mode 1), forbidden (mode 4) and with one launch per component.
+        for mode in (1, 4):
+            for k, (a, w_) in enumerate(zip(run(mode, pieces=tuple(range(1, T - 1))), plain)):
+                assert_bit_equal(a, w_, f"one step per launch, fusion mode {mode}: series {k}")
     finally:
         for x in graph:
             for k in range(8):
