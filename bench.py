@@ -91,6 +91,17 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
     return hbm, valu
 
 
+def describe_run_plan(roofline, plan):
+    """How one pass was issued (rscm_ens_last_run_plan): `kernel_ms` is the HIP-event time of a whole pass on the launch stream, which
+    forks into and joins the library's second stream -- with a cut it covers blocks x chunks overlapping launches of the kernel."""
+    blocks, chunks = plan
+    roofline["launches_per_pass"] = blocks * chunks
+    if blocks * chunks > 1:
+        roofline["run_plan"] = (f"{blocks} member blocks on two streams x {chunks} chunks of model steps, issued in turn: the same kernel on the same "
+                                "operands, the wavefronts evened out over the SIMDs (include/rscm_gpu.h, rscm_ens_last_run_plan); kernel_ms = "
+                                "HIP events around the whole pass / passes, the launches overlap")
+
+
 def f_syn(t):
     return 4.0 * (1.0 - np.exp(-(t - 1750.0) / 120.0)) + 0.3 * np.sin(2.0 * np.pi * (t - 1750.0) / 11.0)
 
@@ -662,6 +673,7 @@ def main():
     ens = make_ensemble(args.members, local_rank, rank, world, mode, stream)
     wall, kernel_ms = timed_passes(ens, args.steps, args.warmup, torch, dist, world, tstream)
     n_fail = int(ens.status().sum())
+    run_plan = ens.last_run_plan()
     s_mid = ens.summary("Surface Temperature", 270)  # year 2020
     gather = loss_gather_report(ens, args.members, world, dist)
     ens.close()
@@ -672,6 +684,7 @@ def main():
     total_member_years = float(world) * args.members * years * args.steps
     value = total_member_years / wall
     roofline_hbm, roofline_valu = two_layer_rooflines(args.members, years, kernel_ms, args.mode)
+    describe_run_plan(roofline_hbm, run_plan)
 
     extra = {}
 
@@ -688,12 +701,14 @@ def main():
             e2 = make_ensemble(members, local_rank, 0, 1, m, stream, coupled=cp)
             k = max(3, args.steps // 4)
             w2, k2 = timed_passes(e2, k, 1, torch, dist, 1, tstream)
+            plan2 = e2.last_run_plan()
             e2.close()
             bpy = 56.0 if cp else ALG_BYTES_PER_MEMBER_YEAR
             out = {"member_years_per_s": members * years * k / w2, "kernel_ms": k2,
                    "hbm_frac": bpy * members * years / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
             # the north-star's target size (1e6 members) and the coupled chain carry their own roofline objects
             hbm, valu = two_layer_rooflines(members, years, k2, "fast" if m else "exact", "coupled" if cp else "two_layer", bpy)
+            describe_run_plan(hbm, plan2)
             out["roofline"] = hbm
             out["roofline_fp64_valu"] = valu
             return out

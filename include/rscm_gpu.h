@@ -54,8 +54,9 @@ extern "C" {
 #define RSCM_GPU_ABI_VERSION 1
 /* Bumped whenever an entry point is added or a mode changes what a kind computes while the major version stays:
  *   1  rscm_sampler_create_graph; four hooks moved to rscm_gpu_internal.h; RSCM_MODE_FAST acts on ClimateUDEB
- *   2  RSCM_MODE_FAST acts on the coupled chain and on CarbonCycle; rscm_gpu_abi_minor itself                 */
-#define RSCM_GPU_ABI_MINOR 2
+ *   2  RSCM_MODE_FAST acts on the coupled chain and on CarbonCycle; rscm_gpu_abi_minor itself
+ *   3  rscm_ens_last_run_plan                                                                                  */
+#define RSCM_GPU_ABI_MINOR 3
 
 #if defined(__GNUC__)
 #define RSCM_API __attribute__((visibility("default")))
@@ -519,6 +520,13 @@ RSCM_API int rscm_ens_clear_rows_after(rscm_ens* h, int32_t tidx);
 /* Device time of the most recent rscm_ens_run* launch sequence, from HIP events recorded on
  * the launch stream (valid after a sync). */
 RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);
+/* How the most recent rscm_ens_run* was cut into launches (ABI minor 3).  A whole-axis run of the two-layer or the coupled kind over more
+ * members than the chip holds wavefronts at one per SIMD, and over at least ~290 model steps, is issued as TWO member blocks on two
+ * streams (the caller's and one of the handle's own, forked and joined with events), each in chunks of ~96 model steps: the same
+ * kernels on the same operands -- the same bits -- and the wavefronts even out over the SIMDs (1e5 members x 750 years: 2.7 -> 2.3 ms).
+ * member_blocks x step_chunks launches in all; 1 x 1 otherwise.  To the caller the run is one asynchronous operation on its stream
+ * either way.  Environment RSCM_SPLIT_RUNS=0 turns the cut off. */
+RSCM_API int rscm_ens_last_run_plan(rscm_ens* h, int32_t* member_blocks, int32_t* step_chunks);
 
 /* ---- outputs ------------------------------------------------------------------------------ */
 /* Copy series[var][t][m] for t in {t_begin, t_begin+t_stride, ...} < t_end and

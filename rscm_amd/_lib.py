@@ -276,6 +276,7 @@ SIGNATURES = {
     "rscm_ens_set_internal_state": (C.c_int, [_h, _dp, C.c_int64, C.c_int32]),
     "rscm_ens_rewind": (C.c_int, [_h]),
     "rscm_ens_last_run_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
+    "rscm_ens_last_run_plan": (C.c_int, [_h, _ip, _ip]),
     "rscm_ens_get_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                       C.c_int64, _dp]),
     "rscm_ens_series_devptr": (C.c_int, [_h, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -349,8 +350,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library diverge
         fn.restype = res
         fn.argtypes = args
-    if lib.rscm_gpu_abi_version() != 1 or lib.rscm_gpu_abi_minor() < 2:
-        raise RscmGpuUnavailable("ABI version mismatch (this front end needs version 1, minor >= 2): rebuild librscm_gpu.so")
+    if lib.rscm_gpu_abi_version() != 1 or lib.rscm_gpu_abi_minor() < 3:
+        raise RscmGpuUnavailable("ABI version mismatch (this front end needs version 1, minor >= 3): rebuild librscm_gpu.so")
     _LIB = lib
     return lib
 

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void coupled_fast_kernel(CoupledArgs a)
     }
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    const int64_t N = a.n_members;
+    const int64_t N = a.row_stride;
     auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
 
     double inv_cs;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void coupled_kernel(CoupledArgs a)
     }
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    const int64_t N = a.n_members;
+    const int64_t N = a.row_stride;
 
     CPConst p;
     p.lambda0 = param_at(a.params, a.uniform_rows, 0, N, i);

@@ -80,6 +80,11 @@ struct rscm_ens {
     uint64_t uniform_rows = 0;   // bit j: parameter row j (< 64) holds one value for every member (the kernels then read element 0: param_at)
     // member constants of the kinds that have them (GhgForcing, TerrestrialCarbon; rscm_device.hpp, launch_*_derive): [kDerivedRows][N],
     // re-formed by ensure_derived() at the next run after anything wrote the parameter block
+    // whole-axis runs as two member blocks on two streams in chunks of model steps (rscm_gpu.cpp, plan_member_split): the second stream
+    // and the fork / join events, created with the first such run
+    int32_t last_blocks = 1, last_chunks = 1;   // how the last run was cut (rscm_ens_last_run_plan)
+    hipStream_t split_stream = nullptr;
+    hipEvent_t split_fork = nullptr, split_join = nullptr;
     double* d_derived = nullptr;
     bool derived_dirty = true;
     bool params_exposed = false; // rscm_ens_params_devptr handed the block out: uniform_rows stays 0 for the life of the handle

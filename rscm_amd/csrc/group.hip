@@ -179,7 +179,7 @@ struct OpRegs {
         const double* params;
         uint64_t uniform;
         int64_t N;
-        if constexpr (KIND == 0) { params = op.u.tl.params; uniform = op.u.tl.uniform_rows; N = op.u.tl.n_members; }
+        if constexpr (KIND == 0) { params = op.u.tl.params; uniform = op.u.tl.uniform_rows; N = op.u.tl.row_stride; }
         else if constexpr (KIND == kKindCarbonCycle || KIND == kKindCo2Budget) { params = op.u.carbon.params; uniform = op.u.carbon.uniform_rows; N = op.u.carbon.n_members; }
         else { params = op.u.pw.params; uniform = op.u.pw.uniform_rows; N = op.u.pw.n_members; }
 #pragma unroll

@@ -321,7 +321,9 @@ struct MemberInputsEager {
 
 // Stand-alone two-layer run over steps [step_begin, step_end).
 struct TwoLayerArgs {
-    int64_t n_members;
+    int64_t n_members;       // members this launch covers ...
+    int64_t row_stride;      // ... of an ensemble of this many: the stride of the [rows][N] series and [P][N] parameter rows.  Equal
+                             // unless the host launches a BLOCK of members (pointers moved to its first member; rscm_gpu.cpp, split runs)
     int32_t n_times;
     int32_t step_begin, step_end;
     int32_t n_scen;
@@ -354,6 +356,7 @@ struct TwoLayerArgs {
 // Coupled chain CarbonCycle -> CO2ERF -> Sum -> TwoLayer over steps [step_begin, step_end).
 struct CoupledArgs {
     int64_t n_members;
+    int64_t row_stride;      // as in TwoLayerArgs
     int32_t n_times;
     int32_t step_begin, step_end;
     int32_t n_scen;

@@ -7,6 +7,8 @@
 // state the bounds; GhgForcing's linked-input path evaluates the same factors with the device
 // library and is compared with the table path in tests/test_gpu_links.py).
 #include "ens.hpp"
+#include <functional>
+
 #include "udeb_tables.hpp"
 
 namespace {
@@ -745,6 +747,9 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_udeb_work);
     (void)hipFree(h->d_udeb_tables);
     (void)hipFree(h->d_derived);
+    if (h->split_stream) (void)hipStreamDestroy(h->split_stream);
+    if (h->split_fork) (void)hipEventDestroy(h->split_fork);
+    if (h->split_join) (void)hipEventDestroy(h->split_join);
     (void)hipFree(h->d_scal);
     (void)hipFree(h->d_hist);
     (void)hipFree(h->d_tables);
@@ -1311,14 +1316,73 @@ int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLin
 
 // (4) the launch itself -- or, with op_out, its arguments for the group kernel (csrc/group.hip) if the kind can
 // be fused with its neighbours (op_out->kind = -1 otherwise; nothing is launched either way)
+// Whole-axis launches of the two-layer and the coupled kind as TWO member blocks on two streams, each in chunks of model steps issued
+// in turn.  One launch of 1e5 members is 1564 wavefronts on 1024 SIMDs: the SIMDs that got two take twice as long as those that got one,
+// and the launch takes the time of two (issue utilisation 0.66).  Cut into a block that fills the chip once
+// (65 536 members) and the rest, each block on its own stream and in chunks of ~96 model steps, the same kernels resume from the rows they
+// stored (as rscm_ens_run in pieces always could), a block's next chunk is dispatched while the other block's is still running, and the
+// hardware's dispatcher evens out the SIMDs over the chunks: 2.86 -> 2.36 ms at 1e5 members x 750 years, 1.1-1.36x at every size between
+// 1e5 and 3e5, 1.05x at 1e6, never slower with three chunks or more (scripts/multi_stream_two_layer.py).  Same kernels on the same
+// operands: the same bits.  The caller's stream forks into the helper stream and joins it again with events: to the caller this is one
+// asynchronous run on its stream, as before.  RSCM_SPLIT_RUNS=0 turns it off (A/B).
+struct MemberSplit {
+    bool on = false;
+    int64_t first = 0;     // members of the first block
+    int32_t chunk = 0;     // model steps per launch
+};
+static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t step_end, bool linked)
+{
+    static const bool enabled = [] { const char* e = getenv("RSCM_SPLIT_RUNS"); return !e || atoi(e) != 0; }();
+    MemberSplit m;
+    constexpr int32_t kChunk = 96;
+    const int32_t len = step_end - step_begin;
+    if (!enabled || linked || h->windowed || h->rows != h->T || len < 3 * kChunk) return m;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) return m;
+    const int64_t per_round = (int64_t)cus * 4 * 64;   // one wavefront on every SIMD: 65 536 members on an MI355X
+    if (h->N <= per_round) return m;                   // every wavefront has a SIMD to itself already
+    m.first = std::max(per_round, (h->N / 2) / per_round * per_round);
+    const int32_t n_chunks = (len + kChunk - 1) / kChunk;
+    m.chunk = (len + n_chunks - 1) / n_chunks;
+    m.on = true;
+    return m;
+}
+static int member_split_streams(rscm_ens* h)
+{
+    if (!h->split_stream) HIPCHK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+    if (!h->split_fork) HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+    if (!h->split_join) HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
+    return RSCM_OK;
+}
+// issue(begin, end, first_member, count, stream) launches one chunk of one block; the fork and the join around all of them
+static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begin, int32_t step_end,
+                            const std::function<hipError_t(int32_t, int32_t, int64_t, int64_t, hipStream_t)>& issue)
+{
+    if (int rc = member_split_streams(h)) return rc;
+    h->last_blocks = 2;
+    h->last_chunks = (step_end - step_begin + m.chunk - 1) / m.chunk;
+    HIPCHK(hipEventRecord(h->split_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    for (int32_t b = step_begin; b < step_end; b += m.chunk) {
+        const int32_t e = std::min(step_end, b + m.chunk);
+        HIPCHK(issue(b, e, (int64_t)0, m.first, h->stream));
+        HIPCHK(issue(b, e, m.first, h->N - m.first, h->split_stream));
+    }
+    HIPCHK(hipEventRecord(h->split_join, h->split_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->split_join, 0));
+    return RSCM_OK;
+}
+
 int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
                 rscm::GroupOp* op_out)
 {
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
+    if (!op_out) h->last_blocks = h->last_chunks = 1;
     if (h->kind == RSCM_KIND_TWO_LAYER) {
         rscm::TwoLayerArgs a{};
         a.n_members = h->N;
+        a.row_stride = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
         a.step_end = step_end;
@@ -1349,7 +1413,26 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
             op_out->u.tl = a;
             return RSCM_OK;
         }
-        HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
+        const MemberSplit ms = plan_member_split(h, step_begin, step_end, linked != 0);
+        if (ms.on) {
+            const int32_t mode = h->mode;
+            if (int rc = run_member_split(h, ms, step_begin, step_end, [&](int32_t b, int32_t e, int64_t m0, int64_t cnt, hipStream_t st) {
+                    rscm::TwoLayerArgs c = a;
+                    c.n_members = cnt;
+                    c.step_begin = b;
+                    c.step_end = e;
+                    c.lds_forcing = (size_t)h->n_scen * (size_t)(e - b) * sizeof(double) <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
+                    c.params = a.params + m0;
+                    if (a.scen) c.scen = a.scen + m0;
+                    c.ts = a.ts + m0;
+                    c.td = a.td + m0;
+                    c.status = a.status + m0;
+                    return rscm::launch_two_layer(c, mode, st);
+                }))
+                return rc;
+        } else {
+            HIPCHK(rscm::launch_two_layer(a, h->mode, h->stream));
+        }
     } else if (h->kind == RSCM_KIND_GHG_FORCING) {
         rscm::GhgArgs a{};
         a.n_members = h->N;
@@ -1592,6 +1675,7 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
     } else {
         rscm::CoupledArgs a{};
         a.n_members = h->N;
+        a.row_stride = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
         a.step_end = step_end;
@@ -1614,7 +1698,26 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.erf_total = h->series(RSCM_CP_VAR_ERF);
         a.status = h->d_status;
         if (op_out) { op_out->kind = -1; return RSCM_OK; }
-        HIPCHK(rscm::launch_coupled(a, h->mode, h->stream));
+        const MemberSplit ms = plan_member_split(h, step_begin, step_end, false);
+        if (ms.on) {
+            const int32_t mode = h->mode;
+            if (int rc = run_member_split(h, ms, step_begin, step_end, [&](int32_t b, int32_t e, int64_t m0, int64_t cnt, hipStream_t st) {
+                    rscm::CoupledArgs c = a;
+                    c.n_members = cnt;
+                    c.step_begin = b;
+                    c.step_end = e;
+                    c.lds_forcing = (size_t)h->n_scen * (size_t)(e - b) * sizeof(double) <= (size_t)rscm::kMaxLds - 1024 ? 1 : 0;
+                    c.params = a.params + m0;
+                    if (a.scen) c.scen = a.scen + m0;
+                    c.ts = a.ts + m0; c.td = a.td + m0; c.conc = a.conc + m0; c.cum_uptake = a.cum_uptake + m0; c.cum_emis = a.cum_emis + m0;
+                    c.erf_co2 = a.erf_co2 + m0; c.erf_total = a.erf_total + m0;
+                    c.status = a.status + m0;
+                    return rscm::launch_coupled(c, mode, st);
+                }))
+                return rc;
+        } else {
+            HIPCHK(rscm::launch_coupled(a, h->mode, h->stream));
+        }
     }
     return RSCM_OK;
 }
@@ -1714,6 +1817,14 @@ int rscm_ens_run(rscm_ens* h, int32_t step_begin, int32_t step_end)
 {
     if (int rc = rscm_ens_run_async(h, step_begin, step_end)) return rc;
     return rscm_ens_sync(h);
+}
+
+int rscm_ens_last_run_plan(rscm_ens* h, int32_t* member_blocks, int32_t* step_chunks)
+{
+    NEED(h);
+    if (member_blocks) *member_blocks = h->last_blocks;
+    if (step_chunks) *step_chunks = h->last_chunks;
+    return RSCM_OK;
 }
 
 int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms)
@@ -1986,6 +2097,7 @@ hipError_t launch_loglik(rscm_ens* h)
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
     rscm::TwoLayerArgs a{};
     a.n_members = h->N;
+    a.row_stride = h->N;
     a.n_times = h->T;
     a.step_begin = 0;
     a.step_end = len;

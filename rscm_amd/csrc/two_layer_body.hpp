@@ -146,7 +146,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
                                                int32_t step_end, const Cache& cache = Cache())
 {
     const int32_t len = step_end - step_begin;
-    const int64_t N = a.n_members;
+    const int64_t N = a.row_stride;   // the rows' stride (the caller has checked i against a.n_members)
 
     const double lambda0 = cache.param(a.params, a.uniform_rows, 0, N, i);
     const double pa = cache.param(a.params, a.uniform_rows, 1, N, i);

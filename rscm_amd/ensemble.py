@@ -232,6 +232,13 @@ class Ensemble:
         L.check(self._lib.rscm_ens_last_run_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_run_plan(self):
+        """(member blocks, step chunks) the most recent run was cut into: (2, k) when a whole-axis run of the two-layer or the
+        coupled kind was issued as two member blocks on two streams in k chunks of model steps (rscm_ens_last_run_plan), else (1, 1)."""
+        mb, sc = C.c_int32(), C.c_int32()
+        L.check(self._lib.rscm_ens_last_run_plan(self._h, C.byref(mb), C.byref(sc)))
+        return mb.value, sc.value
+
     # -- checkpoint / resume ------------------------------------------------------------------
     def state_vars(self) -> Dict[str, int]:
         """The State variables of the kind (what the stepper reads back at the next step)."""

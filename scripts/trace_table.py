@@ -28,6 +28,26 @@ def main():
         if sum(t) < 50.0:
             continue
         print(f"{n:62s} {g:9d} {v:5d} {len(t):6d} {sum(t) / len(t):9.1f} {min(t):8.1f} {max(t):8.1f} {sum(t) / 1e3:9.2f}")
+    # launches of one kernel may overlap (two member blocks on two streams): per kernel name, the time during which at least one of
+    # its launches was running (the union of the intervals) beside the sum of the durations
+    spans = collections.defaultdict(list)
+    for r in rows:
+        spans[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    print("\n# per kernel name: launches, sum of durations, time with at least one launch running (overlapping launches counted once)")
+    for n, iv in sorted(spans.items(), key=lambda kv: -sum(b - a for a, b in kv[1])):
+        total = sum(b - a for a, b in iv)
+        if total < 50_000:
+            continue
+        iv.sort()
+        busy, cur_a, cur_b = 0, iv[0][0], iv[0][1]
+        for a, b in iv[1:]:
+            if a > cur_b:
+                busy += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        busy += cur_b - cur_a
+        print(f"{n:62s} {len(iv):6d} launches {total / 1e6:10.3f} ms summed {busy / 1e6:10.3f} ms busy")
     big = sorted((r for r in rows if int(r["Grid_Size_X"]) >= big_min), key=lambda r: int(r["Start_Timestamp"]))
     if len(big) > 400:
         s = big[len(big) // 2: len(big) // 2 + 14]

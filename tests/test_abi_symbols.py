@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name)
     assert lib.rscm_gpu_abi_version() == 1
-    assert lib.rscm_gpu_abi_minor() >= 2
+    assert lib.rscm_gpu_abi_minor() >= 3
     assert lib.rscm_gpu_last_error() is not None
 
 

@@ -1023,3 +1023,72 @@ def test_params_devptr_disarms_the_uniform_row_shortcut_for_good(ra):
         L.check(e._lib.rscm_gpu_copy_to_device(0, ptr, Pc.ctypes.data_as(C.c_void_p), Pc.nbytes))
         e.run()
         assert_bit_equal(e.get_series(1), want, "varied parameters written through a cached device pointer")
+
+
+@pytest.mark.parametrize("kind", ["two_layer", "coupled"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mode):
+    """A whole-axis run over more members than the chip holds wavefronts at one per SIMD is issued as two member blocks on two streams in
+    chunks of model steps (rscm_ens_last_run_plan: 2 x 8 for 750 steps).  Runs of fewer than 288 steps are not cut: the same axis in
+    three pieces is the single-launch path, and must give the same bits -- with a scenario map (its pointer moves with the block), a
+    ragged member count, and against the oracle on a sample of members from both blocks."""
+    n = 100_001
+    t = axis_values()
+    b = np.append(t, t[-1] + 1.0)
+    rng = np.random.default_rng(3)
+    scen = rng.integers(0, 2, n).astype(np.int32)
+    if kind == "two_layer":
+        P = two_layer_params(n)
+        F = np.stack([f_syn(t), 0.5 * f_syn(t)])
+        names = ["Surface Temperature", "Deep Ocean Temperature"]
+        init = {"Surface Temperature": 0.0, "Deep Ocean Temperature": 0.0}
+        k = ra.KIND_TWO_LAYER
+    else:
+        P = coupled_params(n)
+        F = np.stack([emissions_syn(t), 0.7 * emissions_syn(t)])
+        names = list(CP_NAMES.values())
+        init = CP_INIT
+        k = ra.KIND_COUPLED
+
+    def run(pieces):
+        with ra.Ensemble(k, n, b) as e:
+            e.set_mode(mode)
+            e.set_params(P)
+            e.set_forcing(F, scen)
+            for name, v in init.items():
+                e.set_initial(name, v)
+            plans = []
+            for c in pieces:
+                e.run(c)
+                plans.append(e.last_run_plan())
+            e.run()
+            plans.append(e.last_run_plan())
+            assert e.finished() and e.last_run_ms() > 0
+            rows = {name: e.get_series(name, 0, 751, 150) for name in names}      # rows 0, 150, ..., 750 of every member
+            sample = {name: e.get_series(name, 0, 751, 1, 65_500, 65_600) for name in names}   # members on both sides of the cut
+            return rows, sample, plans, e.status()
+
+    cut_rows, cut_sample, plans, st_cut = run(())
+    assert plans == [(2, 8)], plans
+    one_rows, one_sample, plans, st_one = run((250, 500))
+    assert plans == [(1, 1)] * 3, plans
+    assert np.array_equal(st_cut, st_one)
+    for name in names:
+        assert_bit_equal(cut_rows[name], one_rows[name], f"{kind} mode {mode}: {name}, every member at six rows")
+        assert_bit_equal(cut_sample[name], one_sample[name], f"{kind} mode {mode}: {name}, 100 members across the cut, every row")
+    pick = np.arange(65_500, 65_600)
+    if kind == "two_layer":
+        want = orc.two_layer_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), F, 0.0, 0.0, scen=scen[pick].copy())
+        got = (cut_sample["Surface Temperature"], cut_sample["Deep Ocean Temperature"])
+        if mode == 0:
+            assert_bit_equal(got[0], want[0])
+            assert_bit_equal(got[1], want[1])
+        else:
+            ok = _bounded(want[0])
+            assert _close(got[0][:, ok], want[0][:, ok], FAST_RTOL).all() and _close(got[1][:, ok], want[1][:, ok], FAST_RTOL).all()
+    else:
+        want = orc.coupled_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), F,
+                               dict(ts=0.0, td=0.0, conc=278.0, cum_uptake=0.0, cum_emis=0.0), scen=scen[pick].copy())
+        ok = _bounded(want["ts"])
+        for key, name in CP_NAMES.items():
+            assert _close(cut_sample[name][1:, ok], want[key][1:, ok], FAST_RTOL).all(), name
