@@ -380,6 +380,7 @@ constexpr int kUdebScalars = 11;
 
 struct UdebArgs {
     int64_t n_members;
+    int64_t row_stride;     // as in TwoLayerArgs: the stride of every [..][N] array when a block of members is launched
     int32_t n_times;
     int32_t step_begin, step_end;
     int32_t n_scen;

@@ -1330,7 +1330,7 @@ struct MemberSplit {
     int64_t first = 0;     // members of the first block
     int32_t chunk = 0;     // model steps per launch
 };
-static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t step_end, bool linked)
+static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t step_end, bool linked, bool halves = false)
 {
     static const bool enabled = [] { const char* e = getenv("RSCM_SPLIT_RUNS"); return !e || atoi(e) != 0; }();
     MemberSplit m;
@@ -1341,7 +1341,7 @@ static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t st
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) return m;
     const int64_t per_round = (int64_t)cus * 4 * 64;   // one wavefront on every SIMD: 65 536 members on an MI355X
     if (h->N <= per_round) return m;                   // every wavefront has a SIMD to itself already
-    m.first = std::max(per_round, (h->N / 2) / per_round * per_round);
+    m.first = halves ? (h->N / 2 + 63) / 64 * 64 : std::max(per_round, (h->N / 2) / per_round * per_round);
     const int32_t n_chunks = (len + kChunk - 1) / kChunk;
     m.chunk = (len + n_chunks - 1) / n_chunks;
     m.on = true;
@@ -1628,6 +1628,7 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         if (!h->udeb_ready) return fail(RSCM_ERR_STATE, "ClimateUDEB parameters not configured");
         rscm::UdebArgs a{};
         a.n_members = h->N;
+        a.row_stride = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
         a.step_end = step_end;
@@ -1671,7 +1672,29 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
             op_out->kind = -1;
             return RSCM_OK;
         }
-        HIPCHK(rscm::launch_udeb(a, h->stream));
+        // (ClimateUDEB runs one wavefront per SIMD, so "rounds" of 65 536 members: halves even out best -- 1e5 members x 750 years
+        // 106 -> 86 ms, 2e5 213 -> 168 ms, nothing to gain at 125 000 = 1.91 rounds; scripts/multi_stream_udeb.py)
+        const MemberSplit ms = plan_member_split(h, step_begin, step_end, linked != 0, /*halves=*/true);
+        if (ms.on) {
+            if (int rc = run_member_split(h, ms, step_begin, step_end, [&](int32_t b, int32_t e, int64_t m0, int64_t cnt, hipStream_t st) {
+                    rscm::UdebArgs c = a;
+                    c.n_members = cnt;
+                    c.step_begin = b;
+                    c.step_end = e;
+                    c.params = a.params + m0;
+                    c.derived = a.derived + m0;
+                    if (a.scen) c.scen = a.scen + m0;
+                    c.ocean = a.ocean + m0; c.scal = a.scal + m0; c.hist = a.hist + m0;
+                    if (a.work) c.work = a.work + m0;
+                    c.st0 = a.st0 + m0; c.st1 = a.st1 + m0; c.st2 = a.st2 + m0; c.st3 = a.st3 + m0;
+                    c.heat_uptake = a.heat_uptake + m0; c.ohc = a.ohc + m0; c.sst = a.sst + m0;
+                    c.status = a.status + m0;
+                    return rscm::launch_udeb(c, st);
+                }))
+                return rc;
+        } else {
+            HIPCHK(rscm::launch_udeb(a, h->stream));
+        }
     } else {
         rscm::CoupledArgs a{};
         a.n_members = h->N;

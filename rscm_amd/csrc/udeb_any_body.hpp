@@ -114,7 +114,7 @@ __device__ __forceinline__ double step_hemisphere_any(const UdebP& p, const Year
 template <bool FAST>
 __device__ __forceinline__ void udeb_any_member(const UdebArgs& a, int64_t i)
 {
-    const int64_t N = a.n_members;
+    const int64_t N = a.row_stride;
     const int32_t NL = a.n_layers;
     UdebP p;
     auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };

@@ -466,7 +466,7 @@ struct Udeb1 {
     {
         lane = threadIdx.x;
         i = member;
-        N = a.n_members;
+        N = a.row_stride;   // the stride of every [..][N] array (the caller has checked `member` against a.n_members)
         auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
         p.dz_mix = P(1); p.dz = P(2); p.kappa = P(3); p.kappa_min = P(4); p.kappa_dkdt = P(5);
         p.w0 = P(6); p.f_var = P(7); p.t_thresh_nh = P(8); p.t_thresh_sh = P(9);
@@ -801,10 +801,10 @@ struct Udeb2 {
         tid = threadIdx.x;
         lane = tid & 63;
         hemi = __builtin_amdgcn_readfirstlane(tid >> 6);
-        N = a.n_members;
+        N = a.row_stride;   // the stride of every [..][N] array; a.n_members: the members this launch covers
         const int64_t i_raw = (int64_t)blockIdx.x * 64 + lane;
-        live = i_raw < N;
-        i = live ? i_raw : N - 1;
+        live = i_raw < a.n_members;
+        i = live ? i_raw : a.n_members - 1;
         auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
         p.dz_mix = P(1); p.dz = P(2); p.kappa = P(3); p.kappa_min = P(4); p.kappa_dkdt = P(5);
         p.w0 = P(6); p.f_var = P(7); p.t_thresh_nh = P(8); p.t_thresh_sh = P(9);

@@ -357,3 +357,49 @@ def test_udeb_fuzz(ra, orc, seed):
     got, st = _gpu(ra, b, P, F, scen=scen, chunks=cuts)
     assert (st == wst).all()
     _assert_close(got, want, f"fuzz seed {seed} ({fixed}, T={T}, n={n}, cuts={cuts})")
+
+
+def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc):
+    """A whole-axis ClimateUDEB run over more than 65 536 members (one wavefront per SIMD) is issued as two halves of the members on two
+    streams in chunks of model steps (rscm_ens_last_run_plan: 2 x 8 for 750 steps; each chunk reloads and stores the ocean columns and
+    the scalars like any resumed run).  The same axis in three pieces of fewer than 288 steps takes the single-launch path: same bits,
+    also the internal state at the end; members on both sides of the cut against the oracle."""
+    n = 70_001
+    years = np.arange(1750.0, 2501.0)
+    b = np.append(years, 2501.0)
+    P = _ensemble_params(orc, n, seed=21)
+    F = np.stack([3.71 * np.minimum((years - 1750.0) / 200.0, 1.0), 1.5 * np.sin((years - 1750.0) / 40.0)])
+    scen = (np.arange(n) % 2).astype(np.int32)
+
+    def run(pieces):
+        with ra.Ensemble(ra.KIND_UDEB, n, b) as e:
+            e.set_params(P)
+            e.set_forcing(F, scen)
+            for k in range(1, 5):
+                e.set_initial(k, 0.0)
+            plans = []
+            for c in pieces:
+                e.run(c)
+                plans.append(e.last_run_plan())
+            e.run()
+            plans.append(e.last_run_plan())
+            rows = {k: e.get_series(v, 0, 751, 125) for k, v in NAMES.items()}
+            sample = {k: e.get_series(v, 0, 751, 1, 34_960, 35_060) for k, v in NAMES.items()}   # the cut is at member 35 008
+            return rows, sample, plans, e.status().copy(), e.checkpoint()
+
+    cut_rows, cut_sample, plans, st_cut, ck_cut = run(())
+    assert plans == [(2, 8)], plans
+    one_rows, one_sample, plans, st_one, ck_one = run((250, 500))
+    assert plans == [(1, 1)] * 3, plans
+    assert np.array_equal(st_cut, st_one) and not st_cut.any()
+    for k in NAMES:
+        assert np.array_equal(cut_rows[k], one_rows[k], equal_nan=True), k
+        assert np.array_equal(cut_sample[k], one_sample[k], equal_nan=True), k
+    for key in ck_cut:   # ocean columns, scalars, history: the internal state
+        a, c = ck_cut[key], ck_one[key]
+        if isinstance(a, np.ndarray):
+            assert np.array_equal(a, c, equal_nan=True), key
+    pick = np.arange(34_960, 35_060)
+    want, wst = orc.udeb_run(b, P[:, pick].copy(), F, scen=scen[pick].copy(), threads=8)
+    assert not wst.any()
+    _assert_close(cut_sample, want, "members across the cut")
