@@ -1050,11 +1050,16 @@ def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mod
         init = CP_INIT
         k = ra.KIND_COUPLED
 
+    source = 1 if (kind == "two_layer" and mode == 1) else 0   # (the two-layer forcing read at n + 1 in one of the four cases)
+
     def run(pieces):
         with ra.Ensemble(k, n, b) as e:
             e.set_mode(mode)
             e.set_params(P)
-            e.set_forcing(F, scen)
+            if kind == "two_layer":
+                e.set_forcing(F, scen, source)
+            else:
+                e.set_forcing(F, scen)
             for name, v in init.items():
                 e.set_initial(name, v)
             plans = []
@@ -1078,7 +1083,7 @@ def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mod
         assert_bit_equal(cut_sample[name], one_sample[name], f"{kind} mode {mode}: {name}, 100 members across the cut, every row")
     pick = np.arange(65_500, 65_600)
     if kind == "two_layer":
-        want = orc.two_layer_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), F, 0.0, 0.0, scen=scen[pick].copy())
+        want = orc.two_layer_run(orc.bounds_from_values(t), np.ascontiguousarray(P[:, pick]), F, 0.0, 0.0, scen=scen[pick].copy(), source=source)
         got = (cut_sample["Surface Temperature"], cut_sample["Deep Ocean Temperature"])
         if mode == 0:
             assert_bit_equal(got[0], want[0])
