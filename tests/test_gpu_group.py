@@ -479,3 +479,84 @@ def test_two_threads_step_two_graphs_with_their_own_fusion_settings(ra):
     chain(2000, 12, 1, w2)
     for k, (x, y) in enumerate(zip(w2["series"], want[1]["series"])):
         assert_bit_equal(x, y, f"fused vs unfused: series {k}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_light_graphs_with_and_without_the_cut(ra, seed):
+    """Random graphs of five to eight light ops -- schema aggregates (Sum / Weighted over links and table rows: NaN contributors are
+    skipped, so rows a consumer reads before its producer has written them do not poison the run) and FourBoxOceanHeatUptake ops --
+    with random links: read at n or at n + 1, to ops earlier OR later in the order (the reference's breadth-first order allows a
+    consumer before its producer; such pairs must stay on one wavefront).  Stepped one model step per call, so every step is a one-step
+    fused launch that the scheduler may cut into two sets of independent ops on two wavefronts: with the cut allowed (mode 1),
+    forbidden (mode 4) and with one launch per op (mode 0) every series carries the same bits."""
+    from rscm_amd import _lib as L
+    from rscm_amd.ensemble import run_lockstep
+    rng = np.random.default_rng(900 + seed)
+    T, n = 25, int(rng.choice([64, 130, 777]))
+    b = np.arange(T + 1, dtype=float) + 1750.0
+    yr = np.arange(T, dtype=float)
+    n_ops = int(rng.integers(5, 9))
+    kinds = [ra.KIND_FOURBOX_OHU if rng.random() < 0.3 else ra.KIND_AGGREGATE for _ in range(n_ops)]
+    stream = C.c_void_p()
+    L.check(L.load().rscm_gpu_stream_create(0, C.byref(stream)))
+    graph = [ra.Ensemble(k, n, b) for k in kinds]
+    linked = []
+    try:
+        for x, k in zip(graph, kinds):
+            x.set_stream(stream.value)
+            if k == ra.KIND_AGGREGATE:
+                w = np.zeros((9, n))
+                w[0] = float(rng.choice([0.0, 2.0]))                      # Sum or Weighted
+                w[1:] = rng.uniform(0.1, 0.4, (8, 1)) * rng.uniform(0.9, 1.1, (8, n))
+                x.set_params(w)
+                rows = np.full((8, T), np.nan)
+                for r in rng.choice(8, int(rng.integers(1, 4)), replace=False):
+                    rows[r] = rng.uniform(0.5, 2.0) * np.sin(yr / rng.uniform(3.0, 9.0)) + 1.0
+                x.set_forcing(rows)
+                x.set_initial(1, 0.25)
+            else:
+                x.set_params(np.repeat(np.array([[0.3], [0.2], [0.35], [0.15]]), n, axis=1) * rng.uniform(0.9, 1.1, (4, n)))
+                x.set_forcing((0.5 + 0.1 * yr)[None])
+        for j, (x, k) in enumerate(zip(graph, kinds)):
+            slots = list(range(8)) if k == ra.KIND_AGGREGATE else [0]
+            for slot in rng.choice(slots, min(len(slots), int(rng.integers(1, 4))), replace=False):
+                src = int(rng.integers(0, n_ops))
+                if src == j:
+                    continue
+                var = 1 if kinds[src] == ra.KIND_AGGREGATE else int(rng.integers(1, 5))
+                x.link_input(int(slot), graph[src], var, ra.SRC_UPSTREAM if rng.random() < 0.6 else ra.SRC_EXOGENOUS)
+                linked.append((x, int(slot)))
+        for x in graph:
+            L.check(L.load().rscm_ens_set_link_order_check(x._h, 0))
+
+        def run(mode):
+            for x in graph:
+                x.rewind()
+                x.clear_series()
+            L.check(L.load().rscm_gpu_set_lockstep_fusion(mode))
+            L.check(L.load().rscm_gpu_lockstep_split_launches(None))
+            for stop in range(1, T):
+                run_lockstep(graph, stop)
+            cut = C.c_int64()
+            L.check(L.load().rscm_gpu_lockstep_split_launches(C.byref(cut)))
+            return [x.get_series(v) for x in graph for v in sorted(v for v in x.var_ids.values() if v > 0)], cut.value
+
+        plain, _ = run(0)
+        with_cut, n_cut = run(1)
+        without, n_none = run(4)
+        assert n_none == 0
+        print(f"seed {seed}: {n_ops} ops {['agg' if k == ra.KIND_AGGREGATE else 'ohu' for k in kinds]}, {len(linked)} links, "
+              f"{n_cut} of {T - 1} steps cut")
+        for k, (a, w_, p_) in enumerate(zip(with_cut, without, plain)):
+            assert_bit_equal(a, p_, f"seed {seed}: with the cut vs one launch per op: series {k}")
+            assert_bit_equal(w_, p_, f"seed {seed}: without the cut vs one launch per op: series {k}")
+    finally:
+        L.check(L.load().rscm_gpu_set_lockstep_fusion(1))
+        for x, slot in linked:
+            try:
+                x.unlink_input(slot)
+            except Exception:
+                pass
+        for x in reversed(graph):
+            x.close()
+        L.check(L.load().rscm_gpu_stream_destroy(0, stream))
