@@ -521,8 +521,8 @@ RSCM_API int rscm_ens_clear_rows_after(rscm_ens* h, int32_t tidx);
  * the launch stream (valid after a sync). */
 RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);
 /* How the most recent rscm_ens_run* was cut into launches (ABI minor 3).  A whole-axis run of the two-layer or the coupled kind over more
- * members than the chip holds wavefronts at one per SIMD, and over at least ~290 model steps, is issued as TWO member blocks on two
- * streams (the caller's and one of the handle's own, forked and joined with events), each in chunks of ~96 model steps: the same
+ * members than the chip holds wavefronts at one per SIMD, and over at least ~190 model steps, is issued as TWO member blocks on two
+ * streams (the caller's and one of the handle's own, forked and joined with events), each in chunks of ~64 model steps: the same
  * kernels on the same operands -- the same bits -- and the wavefronts even out over the SIMDs (1e5 members x 750 years: 2.7 -> 2.3 ms).
  * member_blocks x step_chunks launches in all; 1 x 1 otherwise.  To the caller the run is one asynchronous operation on its stream
  * either way.  Environment RSCM_SPLIT_RUNS=0 turns the cut off. */

@@ -1319,7 +1319,7 @@ int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLin
 // Whole-axis launches of the two-layer and the coupled kind as TWO member blocks on two streams, each in chunks of model steps issued
 // in turn.  One launch of 1e5 members is 1564 wavefronts on 1024 SIMDs: the SIMDs that got two take twice as long as those that got one,
 // and the launch takes the time of two (issue utilisation 0.66).  Cut into a block that fills the chip once
-// (65 536 members) and the rest, each block on its own stream and in chunks of ~96 model steps, the same kernels resume from the rows they
+// (65 536 members) and the rest, each block on its own stream and in chunks of ~64 model steps, the same kernels resume from the rows they
 // stored (as rscm_ens_run in pieces always could), a block's next chunk is dispatched while the other block's is still running, and the
 // hardware's dispatcher evens out the SIMDs over the chunks: 2.86 -> 2.36 ms at 1e5 members x 750 years, 1.1-1.36x at every size between
 // 1e5 and 3e5, 1.05x at 1e6, never slower with three chunks or more (scripts/multi_stream_two_layer.py).  Same kernels on the same
@@ -1333,8 +1333,13 @@ struct MemberSplit {
 static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t step_end, bool linked, bool halves = false)
 {
     static const bool enabled = [] { const char* e = getenv("RSCM_SPLIT_RUNS"); return !e || atoi(e) != 0; }();
+    // (tuning knobs for experiments: model steps per chunk, members of the first block)
+    static const int32_t chunk_env = [] { const char* e = getenv("RSCM_SPLIT_CHUNK"); return e ? atoi(e) : 0; }();
+    static const int64_t first_env = [] { const char* e = getenv("RSCM_SPLIT_FIRST"); return e ? atoll(e) : 0ll; }();
     MemberSplit m;
-    constexpr int32_t kChunk = 96;
+    // two-layer / coupled: 32-64 steps per chunk 2.30 ms at 1e5 members, 96: 2.32, 192: 2.37 (scripts/sweep_split.sh); ClimateUDEB reloads
+    // and stores its columns with every chunk: 96 (88 ms at 1e5 members against 90 with 64)
+    const int32_t kChunk = chunk_env > 0 ? chunk_env : (halves ? 96 : 64);
     const int32_t len = step_end - step_begin;
     if (!enabled || linked || h->windowed || h->rows != h->T || len < 3 * kChunk) return m;
     int cus = 0;
@@ -1342,6 +1347,7 @@ static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t st
     const int64_t per_round = (int64_t)cus * 4 * 64;   // one wavefront on every SIMD: 65 536 members on an MI355X
     if (h->N <= per_round) return m;                   // every wavefront has a SIMD to itself already
     m.first = halves ? (h->N / 2 + 63) / 64 * 64 : std::max(per_round, (h->N / 2) / per_round * per_round);
+    if (first_env > 0 && first_env < h->N) m.first = (first_env + 63) / 64 * 64;
     const int32_t n_chunks = (len + kChunk - 1) / kChunk;
     m.chunk = (len + n_chunks - 1) / n_chunks;
     m.on = true;

@@ -1029,8 +1029,8 @@ def test_params_devptr_disarms_the_uniform_row_shortcut_for_good(ra):
 @pytest.mark.parametrize("mode", [0, 1])
 def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mode):
     """A whole-axis run over more members than the chip holds wavefronts at one per SIMD is issued as two member blocks on two streams in
-    chunks of model steps (rscm_ens_last_run_plan: 2 x 8 for 750 steps).  Runs of fewer than 288 steps are not cut: the same axis in
-    three pieces is the single-launch path, and must give the same bits -- with a scenario map (its pointer moves with the block), a
+    chunks of model steps (rscm_ens_last_run_plan: 2 x 12 for 750 steps).  Runs of fewer than 192 steps are not cut: the same axis in
+    five pieces is the single-launch path, and must give the same bits -- with a scenario map (its pointer moves with the block), a
     ragged member count, and against the oracle on a sample of members from both blocks."""
     n = 100_001
     t = axis_values()
@@ -1074,9 +1074,9 @@ def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mod
             return rows, sample, plans, e.status()
 
     cut_rows, cut_sample, plans, st_cut = run(())
-    assert plans == [(2, 8)], plans
-    one_rows, one_sample, plans, st_one = run((250, 500))
-    assert plans == [(1, 1)] * 3, plans
+    assert plans == [(2, 12)], plans
+    one_rows, one_sample, plans, st_one = run((150, 300, 450, 600))
+    assert plans == [(1, 1)] * 5, plans
     assert np.array_equal(st_cut, st_one)
     for name in names:
         assert_bit_equal(cut_rows[name], one_rows[name], f"{kind} mode {mode}: {name}, every member at six rows")

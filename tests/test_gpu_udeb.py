@@ -362,7 +362,7 @@ def test_udeb_fuzz(ra, orc, seed):
 def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc):
     """A whole-axis ClimateUDEB run over more than 65 536 members (one wavefront per SIMD) is issued as two halves of the members on two
     streams in chunks of model steps (rscm_ens_last_run_plan: 2 x 8 for 750 steps; each chunk reloads and stores the ocean columns and
-    the scalars like any resumed run).  The same axis in three pieces of fewer than 288 steps takes the single-launch path: same bits,
+    the scalars like any resumed run).  The same axis in five pieces of 150 steps (fewer than three chunks) takes the single-launch path: same bits,
     also the internal state at the end; members on both sides of the cut against the oracle."""
     n = 70_001
     years = np.arange(1750.0, 2501.0)
@@ -389,8 +389,8 @@ def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc):
 
     cut_rows, cut_sample, plans, st_cut, ck_cut = run(())
     assert plans == [(2, 8)], plans
-    one_rows, one_sample, plans, st_one, ck_one = run((250, 500))
-    assert plans == [(1, 1)] * 3, plans
+    one_rows, one_sample, plans, st_one, ck_one = run((150, 300, 450, 600))
+    assert plans == [(1, 1)] * 5, plans
     assert np.array_equal(st_cut, st_one) and not st_cut.any()
     for k in NAMES:
         assert np.array_equal(cut_rows[k], one_rows[k], equal_nan=True), k
