@@ -1,4 +1,8 @@
-for chunk in 32 48 64 96 128 192; do for first in 65536 49152 57344 73728; do
-  v=$(RSCM_SPLIT_CHUNK=$chunk RSCM_SPLIT_FIRST=$first python bench.py --no-extra --no-cpu-baseline --steps 40 --warmup 10 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4))")
-  echo "chunk $chunk first $first: $v ms"
+#!/bin/bash
+# the member split's two knobs (rscm_gpu.cpp, plan_member_split) against the headline: RSCM_SPLIT_CHUNK (model steps per launch) and
+# RSCM_SPLIT_FIRST (members of the first block); MODE=fast for the FAST arithmetic
+MODE="${MODE:-exact}"
+for chunk in ${CHUNKS:-32 48 64 96 128 192}; do for first in ${FIRSTS:-65536 57344}; do
+  v=$(RSCM_SPLIT_CHUNK=$chunk RSCM_SPLIT_FIRST=$first python bench.py --mode $MODE --no-extra --no-cpu-baseline --steps 40 --warmup 10 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4))")
+  echo "mode $MODE chunk $chunk first $first: $v ms"
 done; done
