@@ -1,4 +1,5 @@
 #!/bin/bash
+# (a record of round 3: the whole-graph launch -- fusion mode 4 -- and the four-wavefront ClimateUDEB kernel -- variant 4 -- it exercises were removed in round 4)
 # round 3, session a: the two-wavefront ClimateUDEB kernel against the one-thread kernel (parity tests + timing per variant)
 set -o pipefail
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (a record of round 3: the whole-graph launch -- fusion mode 4 -- and the four-wavefront ClimateUDEB kernel -- variant 4 -- it exercises were removed in round 4)
 # round 3, session b: where the whole-graph launch spends its time (configs[3] share, 600 monthly steps)
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (a record of round 3: the whole-graph launch -- fusion mode 4 -- and the four-wavefront ClimateUDEB kernel -- variant 4 -- it exercises were removed in round 4)
 # round 3, session g: scalar- and instruction-cache behaviour of the whole-graph launch (fusion mode 4), configs[3] at 125 000 members
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
