@@ -1369,10 +1369,19 @@ static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begi
     h->last_chunks = (step_end - step_begin + m.chunk - 1) / m.chunk;
     HIPCHK(hipEventRecord(h->split_fork, h->stream));
     HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
-    for (int32_t b = step_begin; b < step_end; b += m.chunk) {
-        const int32_t e = std::min(step_end, b + m.chunk);
-        HIPCHK(issue(b, e, (int64_t)0, m.first, h->stream));
-        HIPCHK(issue(b, e, m.first, h->N - m.first, h->split_stream));
+    // (experiments: RSCM_SPLIT_CHUNK2 gives the second block its own chunk length; the block that is behind is issued next)
+    static const int32_t chunk2_env = [] { const char* e = getenv("RSCM_SPLIT_CHUNK2"); return e ? atoi(e) : 0; }();
+    const int32_t c0 = m.chunk, c1 = chunk2_env > 0 ? chunk2_env : m.chunk;
+    for (int32_t b0 = step_begin, b1 = step_begin; b0 < step_end || b1 < step_end;) {
+        if (b0 < step_end && (b0 <= b1 || b1 >= step_end)) {
+            const int32_t e = std::min(step_end, b0 + c0);
+            HIPCHK(issue(b0, e, (int64_t)0, m.first, h->stream));
+            b0 = e;
+        } else {
+            const int32_t e = std::min(step_end, b1 + c1);
+            HIPCHK(issue(b1, e, m.first, h->N - m.first, h->split_stream));
+            b1 = e;
+        }
     }
     HIPCHK(hipEventRecord(h->split_join, h->split_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, h->split_join, 0));
