@@ -1372,19 +1372,22 @@ static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begi
     // (experiments: RSCM_SPLIT_CHUNK2 gives the second block its own chunk length; the block that is behind is issued next)
     static const int32_t chunk2_env = [] { const char* e = getenv("RSCM_SPLIT_CHUNK2"); return e ? atoi(e) : 0; }();
     const int32_t c0 = m.chunk, c1 = chunk2_env > 0 ? chunk2_env : m.chunk;
-    for (int32_t b0 = step_begin, b1 = step_begin; b0 < step_end || b1 < step_end;) {
+    hipError_t err = hipSuccess;
+    for (int32_t b0 = step_begin, b1 = step_begin; err == hipSuccess && (b0 < step_end || b1 < step_end);) {
         if (b0 < step_end && (b0 <= b1 || b1 >= step_end)) {
             const int32_t e = std::min(step_end, b0 + c0);
-            HIPCHK(issue(b0, e, (int64_t)0, m.first, h->stream));
+            err = issue(b0, e, (int64_t)0, m.first, h->stream);
             b0 = e;
         } else {
             const int32_t e = std::min(step_end, b1 + c1);
-            HIPCHK(issue(b1, e, m.first, h->N - m.first, h->split_stream));
+            err = issue(b1, e, m.first, h->N - m.first, h->split_stream);
             b1 = e;
         }
     }
+    // the join is made whatever happened: the caller's stream never runs ahead of what was issued on the helper stream
     HIPCHK(hipEventRecord(h->split_join, h->split_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, h->split_join, 0));
+    HIPCHK(err);
     return RSCM_OK;
 }
 
