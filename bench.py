@@ -43,15 +43,22 @@ ALG_BYTES_PER_MEMBER_YEAR = 16.0   # store Ts, Td
 ALG_OPS_PER_MEMBER_YEAR = 700.0    # 620 add/mul + 80 div, exact mode
 
 
-def measured_traffic(kind, members, mode):
-    """HBM bytes per launch of (kind, members, mode) from the committed rocprofv3 PMC summaries
-    (profiles/traffic.json); (None, None) where no profile of that configuration exists."""
+def profile_entry(kind, members, mode):
+    """The committed rocprofv3 PMC summary of (kind, members, mode) as profiles/traffic.json records it: HBM bytes per launch, and --
+    where scripts/update_traffic.py found them in the summary -- the shader clock the chip held under that kernel, the measured VALU
+    issue utilisation and the executed vector instructions per wavefront-year.  {} where no profile of that configuration exists."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             table = json.load(f)
     except (OSError, ValueError):
-        return None, None
-    e = table.get(f"{kind}|{members}|{mode}")
+        return {}
+    return table.get(f"{kind}|{members}|{mode}") or {}
+
+
+def measured_traffic(kind, members, mode):
+    """HBM bytes per launch of (kind, members, mode) from the committed rocprofv3 PMC summaries
+    (profiles/traffic.json); (None, None) where no profile of that configuration exists."""
+    e = profile_entry(kind, members, mode)
     return (e["bytes"], e["source"]) if e else (None, None)
 
 
@@ -61,8 +68,12 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
     my = members * years
     gbs = bytes_per_member_year * my / (kernel_ms * 1e-3) / 1e9
     traffic, source = measured_traffic(kind, members, mode)
+    prof = profile_entry(kind, members, mode)
     hbm = {"bound": "hbm", "binding": "fp64_valu", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+           # the clock the chip held under this kernel when the PMC passes were taken (GRBM_GUI_ACTIVE / 8 XCDs / dispatch time):
+           # fractions of the FP64 issue peak below are of the NOMINAL 2.4 GHz; the measured issue utilisation is at this clock
+           "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
            "peak_measured_store_stream": HBM_STORE_STREAM_GBS, "frac_of_measured": gbs / HBM_STORE_STREAM_GBS,
            "traffic_source": (f"{source}: separate rocprofv3 --pmc passes of this launch (FETCH_SIZE x2 + WRITE_SIZE, KiB), "
                               "read from profiles/traffic.json; not re-measured inside bench.py") if source else None,
@@ -87,7 +98,11 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
         note = ("algorithmic 620 add/mul + 80 div per member-year (unfused, div counted as 1)" if mode == "exact" else
                 "300 fused f64 instructions per member-year (10 RK4 steps x 30)")
     tins = ops * my / (kernel_ms * 1e-3) / 1e12
-    valu = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR, "note": note}
+    valu = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR, "note": note,
+            "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
+            "measured_valu_issue_utilisation_at_effective_clock": prof.get("valu_issue_utilisation"),
+            "valu_instructions_per_wavefront_year_executed": prof.get("valu_per_wavefront_year"),
+            "counters_source": prof.get("source")}
     return hbm, valu
 
 
@@ -175,9 +190,9 @@ def make_ghg_ensemble(members, device, method, stream=None):
     return ens
 
 
-def calibration_extra(device, walkers=100_000, iterations=20):
+def calibration_sampler(device):
     """two-layer, 6 parameters, Surface Temperature observations 1850..2020 step 10
-    (sigma 0.1 K) from the default-parameter run; one iteration = two half-ensemble evaluations."""
+    (sigma 0.1 K) from the default-parameter run; (runner, device sampler)."""
     from rscm_amd import calibrate as cal
     from rscm_amd import core
     from rscm_amd.two_layer import TwoLayerBuilder
@@ -198,7 +213,13 @@ def calibration_extra(device, walkers=100_000, iterations=20):
     params = cal.ParameterSet()
     for k, lo, hi in zip(names, TL_LOW, TL_HIGH):
         params.add(k, cal.Uniform(float(lo), float(hi)))
-    sampler = cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+    return runner, cal.DeviceEnsembleSampler(params, runner, cal.GaussianLikelihood(), target)
+
+
+def calibration_extra(device, walkers=100_000, iterations=20):
+    """One iteration = two half-ensemble evaluations (stretch move, fused run + likelihood, accept step on the device)."""
+    from rscm_amd import calibrate as cal
+    runner, sampler = calibration_sampler(device)
     rng = np.random.default_rng(SEED)
     sampler.run(2, cal.WalkerInit.from_prior(), n_walkers=walkers, rng=rng, seed=1)  # warm-up
     t0 = time.perf_counter()
@@ -255,6 +276,265 @@ def graph_calibration_extra(device, walkers=100_000, iterations=10, mode=0):
             "note": "four linked ensembles as the sampler's evaluator; proposals, lock-step run, likelihood and accept step on the device"}
 
 
+def _in_group(dist):
+    return dist.is_available() and dist.is_initialized()
+
+
+def _gather_obj(dist, obj):
+    """Every rank's `obj`, in rank order (a list of one without a process group)."""
+    if not _in_group(dist):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def scale_measure(rank, world, torch, dist, prepare, body, sync, cleanup, reps=None, min_seconds=0.4, solo=True, after=None):
+    """One side measurement taken on ALL ranks at once -- the N > 1 counterpart of `side` -- with the headline's procedure: untimed
+    warm-up, then `reps` units of work between a barrier + synchronize on both sides, the wall time = max over ranks, every rank's
+    own time beside it.  With more than one rank, rank 0 first runs the same `reps` units ALONE (the other ranks wait at a
+    barrier): `weak_efficiency` = that time / the all-ranks wall time, an in-job estimate of the N = 1 figure of the same extra on
+    the same card minutes apart (the driver computes its own from its N = 1 run).
+
+    prepare() -> state; body(state, alone, k) issues unit k of a timed region; sync(state) waits for it; cleanup(state); after(state) -> dict
+    of per-rank facts gathered into `per_rank`.  No collective is entered inside prepare / body / after; a rank whose prepare fails
+    tells the others so before any barrier, and a body that raises still reaches the closing barrier -- a failing extra is
+    reported in its place and never hangs the job."""
+    group = _in_group(dist)
+    state, err = None, None
+    try:
+        state = prepare()
+    except Exception as exc:  # noqa: BLE001 -- reported, not hidden
+        err = f"{type(exc).__name__}: {exc}"[:300]
+    errs = _gather_obj(dist, err)
+    if any(errs):
+        if state is not None:
+            cleanup(state)
+        return {"error": "prepare failed on rank(s) " + ", ".join(f"{r}: {e}" for r, e in enumerate(errs) if e)}
+
+    def barrier():
+        if group:
+            dist.barrier()
+
+    def device_sync():
+        if torch.cuda.is_available():   # (--rendezvous-only exercises this procedure on the CPU)
+            torch.cuda.synchronize()
+
+    def run_units(n, alone):
+        device_sync()
+        t0 = time.perf_counter()
+        for k in range(n):
+            body(state, alone, k)
+        sync(state)
+        device_sync()
+        return time.perf_counter() - t0
+
+    result = {}
+    try:
+        try:
+            warm = run_units(1, False)          # untimed in the result: first-touch of the series, code objects, communicators
+        except Exception as exc:  # noqa: BLE001
+            warm, err = None, f"{type(exc).__name__}: {exc}"[:300]
+        warms = _gather_obj(dist, (warm, err))
+        if any(e for _, e in warms):
+            return {"error": "warm-up failed on rank(s) " + ", ".join(f"{r}: {e}" for r, (_, e) in enumerate(warms) if e)}
+        if reps is None:
+            reps = int(min(200, max(1, -(-min_seconds // max(1e-4, min(w for w, _ in warms))))))
+        alone_s = None
+        if group and solo and world > 1:
+            barrier()
+            if rank == 0:
+                try:
+                    alone_s = run_units(reps, True)
+                except Exception as exc:  # noqa: BLE001
+                    err = f"{type(exc).__name__}: {exc}"[:300]
+            barrier()
+        barrier()
+        t0 = time.perf_counter()
+        mine = None
+        try:
+            mine = run_units(reps, False)
+        except Exception as exc:  # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"[:300]
+        finally:
+            barrier()
+        wall = time.perf_counter() - t0
+        facts = None
+        if err is None and after is not None:
+            try:
+                facts = after(state)
+            except Exception as exc:  # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"[:300]
+        rows = _gather_obj(dist, {"wall_s": wall, "own_s": mine, "alone_s": alone_s, "error": err, "facts": facts})
+        if any(r["error"] for r in rows):
+            return {"error": "failed on rank(s) " + ", ".join(f"{k}: {r['error']}" for k, r in enumerate(rows) if r["error"])}
+        wall = max(r["wall_s"] for r in rows)
+        result = {"ranks": len(rows), "units_per_rank": reps, "warmup_units": 1, "wall_s": wall,
+                  "wall_s_per_unit": wall / reps,
+                  "per_rank": {"own_s": [r["own_s"] for r in rows], "facts": [r["facts"] for r in rows]},
+                  "timing": "barrier + synchronize | units | synchronize + barrier; wall_s = max over ranks of that; own_s = each rank's "
+                            "time from its opening barrier to its own synchronize"}
+        alone = rows[0]["alone_s"]
+        if alone is not None:
+            result["rank0_alone_s"] = alone
+            result["weak_efficiency"] = alone / wall
+            result["weak_efficiency_note"] = ("rank 0 running the same units alone in this job (the other ranks waiting at a barrier) / "
+                                              "the all-ranks wall time")
+        else:
+            result["weak_efficiency"] = 1.0 if len(rows) == 1 else None
+        return result
+    finally:
+        cleanup(state)
+
+
+def scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, years, extra):
+    """The configs that are DEFINED on more than one GPU, measured on every rank at once (and, under the same keys, on the one rank
+    of an N = 1 run, so that the per-N lines compare): the north-star's weak-scaling point (1e6 members per GPU, two-layer EXACT
+    and the coupled chain FAST), each rank's configs[3] share, and configs[4]'s sampler sharded over the process group."""
+
+    def both(label, fn):
+        try:
+            out = fn()
+        except Exception as exc:  # noqa: BLE001 -- a rank that raises outside scale_measure's own guards
+            out = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if rank == 0:
+            extra[label] = out
+            if "error" in out:
+                print(f"bench.py: extra {label} failed: {out['error']}", file=sys.stderr)
+
+    def resident(members, mode, coupled):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        box = {}
+
+        def prepare():
+            return make_ensemble(members, local_rank, rank, world, mode, stream, coupled=coupled)
+
+        def body(ens, alone, k):
+            if k == 0:   # first unit of a timed region: restart the HIP-event bracket (the last region is the all-ranks one)
+                box["n"] = 0
+                ev[0].record(tstream)
+            one_pass(ens)
+            box["n"] += 1
+            ev[1].record(tstream)
+
+        def after(ens):
+            return {"kernel_ms": ev[0].elapsed_time(ev[1]) / max(1, box["n"]), "run_plan": list(ens.last_run_plan()),
+                    "failed_members": int(ens.status().sum())}
+
+        out = scale_measure(rank, world, torch, dist, prepare, body, lambda e: e.sync(), lambda e: e.close(),
+                            min_seconds=0.4, after=after)
+        if "error" in out:
+            return out
+        n = out["units_per_rank"]
+        out["member_years_per_s"] = float(out["ranks"]) * members * years * n / out["wall_s"]
+        out["members_per_gpu"] = members
+        kms = [f["kernel_ms"] for f in out["per_rank"]["facts"]]
+        out["per_rank"]["kernel_ms"] = kms
+        bpy = 56.0 if coupled else ALG_BYTES_PER_MEMBER_YEAR
+        hbm, valu = two_layer_rooflines(members, years, max(kms), "fast" if mode else "exact", "coupled" if coupled else "two_layer", bpy)
+        describe_run_plan(hbm, out["per_rank"]["facts"][0]["run_plan"])
+        hbm["note"] = "slowest rank's launch duration; " + hbm["note"]
+        out["roofline"], out["roofline_fp64_valu"] = hbm, valu
+        return out
+
+    m6 = args.scale_members
+    both("scale_exact_1e6", lambda: resident(m6, 0, False))
+    both("scale_coupled_fast_1e6", lambda: resident(m6, 1, True))
+
+    def share():
+        from scripts import run_configs3_share as prog
+        members, yrs = args.share_members, args.share_years
+
+        def prepare():
+            from rscm_amd import _lib as L
+            free0, total = L.mem_info(local_rank)
+            t0 = time.perf_counter()
+            model = prog.build(members, yrs, False, 96, device=local_rank, member_offset=rank * members, members_total=world * members)
+            return {"model": model, "build_s": time.perf_counter() - t0, "hbm_gib": (free0 - L.mem_info(local_rank)[0]) / 2**30}
+
+        def body(st, alone, k):
+            st["model"].rewind()
+            st["model"].run()
+
+        def after(st):
+            model = st["model"]
+            rows = {n: model.get_series(n, t_stride=12)[:, :64] for n in prog.NAMES}
+            small = prog.first_64(members, yrs, False, 96, device=local_rank, member_offset=rank * members, members_total=world * members)
+            same = all(bool(np.array_equal(rows[n].view(np.uint64), small[n].view(np.uint64)) or np.array_equal(rows[n], small[n], equal_nan=True))
+                       for n in prog.NAMES)
+            warm = model.ensembles["Transform:Surface Temperature"].summary(1, yrs * 12)
+            return {"build_s": st["build_s"], "hbm_allocated_gib": st["hbm_gib"], "first_64_members_equal_a_64_member_run": same,
+                    "failed_members": int(model.ensembles["ClimateUDEB"].status().sum()), "warming_end_K_mean": warm["mean"]}
+
+        out = scale_measure(rank, world, torch, dist, prepare, body, lambda st: None, lambda st: st["model"].close(), reps=1, after=after)
+        if "error" in out:
+            return out
+        facts = out["per_rank"]["facts"]
+        out["workload"] = (f"BASELINE configs[3], every rank its own share: MAGICC graph, {members} members x {yrs * 12} monthly steps, "
+                           f"window 96 rows + annual outputs, mode FAST; the members of rank r are the block r of one draw of {world * members}")
+        out["run_s"] = out["wall_s"]
+        out["per_rank"]["run_s"] = out["per_rank"]["own_s"]
+        out["member_years_per_s"] = float(out["ranks"]) * members * yrs / out["wall_s"]
+        out["parity_anchor_all_ranks"] = all(f["first_64_members_equal_a_64_member_run"] for f in facts)
+        out["failed_members"] = sum(f["failed_members"] for f in facts)
+        if not out["parity_anchor_all_ranks"] or out["failed_members"]:
+            out["error"] = "parity anchor or member status failed on a rank (per_rank.facts)"
+        return out
+
+    both("scale_configs3_share", share)
+
+    def sampler(per_gpu):
+        """configs[4]: `walkers` walkers per iteration in all (per_gpu False: the config as BASELINE.json names it, the evaluations
+        of an iteration split over the ranks -- strong scaling), or per GPU (weak scaling: walkers x ranks in all)."""
+        from rscm_amd import calibrate as cal
+        total = args.scale_walkers * (world if per_gpu else 1)
+        iters = args.scale_sweeps
+
+        def prepare():
+            runner, smp = calibration_sampler(local_rank)
+            return {"runner": runner, "sampler": smp, "ms": {}, "x": {}}
+
+        def body(st, alone, k):
+            smp = st["sampler"]
+            w = args.scale_walkers if alone else total     # alone: one GPU's worth of this extra, unsharded
+            smp.run(iters, cal.WalkerInit.from_prior(), thin=iters, n_walkers=w, rng=np.random.default_rng(SEED), seed=2,
+                    shard=False if alone else None)
+            st["ms"][alone], st["x"][alone] = smp.device_ms, smp.exchange_ms
+
+        def after(st):
+            smp = st["sampler"]
+            return {"device_ms_per_iteration": st["ms"][False] / iters, "exchange_ms_per_iteration": st["x"][False] / iters,
+                    "exchange_bytes_per_half_step": smp.exchange_bytes_per_half_step, "acceptance_rate": smp.acceptance_rate(),
+                    "alone_device_ms_per_iteration": (st["ms"][True] / iters) if True in st["ms"] else None}
+
+        out = scale_measure(rank, world, torch, dist, prepare, body, lambda st: None, lambda st: st["runner"].close(), reps=1, after=after)
+        if "error" in out:
+            return out
+        facts = out["per_rank"]["facts"]
+        dm = max(f["device_ms_per_iteration"] for f in facts)
+        xm = max(f["exchange_ms_per_iteration"] for f in facts)
+        out.update({"walkers": total, "walkers_per_gpu": total // out["ranks"], "iterations": iters, "scaling": "weak" if per_gpu else "strong",
+                    "device_ms_per_iteration": dm, "exchange_ms_per_iteration": xm, "exchange_share_of_iteration": xm / dm if dm else None,
+                    "model_evaluations_per_s": total / (dm * 1e-3),
+                    "note": "rscm_sampler_create_sharded: every rank holds a replica of the walkers and updates its block of each half; per half-step "
+                            "the blocks are all-gathered (RCCL with the nccl backend, device to device); device_ms_per_iteration is the slowest "
+                            "rank's host-clock time of the sweeps incl. the exchanges; exchange_ms: from this rank's block packed to every "
+                            "rank's block landed (the all-gather and the wait for the slowest rank)"})
+        if out["ranks"] > 1 and facts[0]["alone_device_ms_per_iteration"]:
+            a = facts[0]["alone_device_ms_per_iteration"]   # device-event time of the unsharded loop on rank 0: one GPU's worth
+            out["rank0_alone_device_ms_per_iteration"] = a
+            if per_gpu:
+                out["weak_efficiency"] = a / dm
+            else:
+                out["speedup"] = a / dm
+                out["strong_efficiency"] = a / dm / out["ranks"]
+                out["weak_efficiency"] = None
+        return out
+
+    both("scale_calibrate_sharded_1e5", lambda: sampler(False))
+    both("scale_calibrate_sharded_1e5_per_gpu", lambda: sampler(True))
+
+
 def one_pass(ens):
     ens.rewind()
     ens.run(sync=False)
@@ -264,10 +544,13 @@ def _coll_device(torch, dist):
     return "cuda" if dist.get_backend() == "nccl" else "cpu"
 
 
-def timed_passes(ens, steps, warmup, torch, dist, world, tstream):
+def timed_passes(ens, steps, warmup, torch, dist, world, tstream, collective=None):
     # world > 1, or a one-rank process group created for rehearsal (RSCM_BENCH_FORCE_DIST=1): the
-    # barrier / max-over-ranks path of the contract runs either way
-    world = 2 if (world == 1 and dist.is_available() and dist.is_initialized()) else world
+    # barrier / max-over-ranks path of the contract runs either way.  collective=False: this rank times alone
+    # (the side measurements of rank 0 at N = 1) whatever process group exists.
+    if collective is None:
+        collective = world > 1 or (dist.is_available() and dist.is_initialized())
+    world = 2 if collective else 1
     for _ in range(warmup):
         one_pass(ens)
     ens.sync()
@@ -370,12 +653,23 @@ def host_description():
     return info
 
 
+def baseline_threads(host):
+    """One thread per core this process is actually GRANTED: the cores it may run on, capped by the cgroup's CPU quota when one
+    is set (a leased box shows all of the host's cores and throttles to its share: more threads than the quota only take turns)."""
+    import math
+    quota = host.get("cgroup_cpu_quota_cores")
+    n = host["affinity_cores"]
+    if quota:
+        n = min(n, max(1, math.ceil(quota)))
+    return max(1, n)
+
+
 def cpu_baseline(threads=None, target_seconds=12.0):
     """The CPU oracle (a port of the reference algorithm) on a bounded sample of the same
-    workload, on ALL of this host's cores (one thread per core this process may run on)."""
+    workload, on the cores this process is granted (baseline_threads: affinity capped by the cgroup quota)."""
     from oracle import cbind
     host = host_description()
-    threads = threads or host["affinity_cores"]
+    threads = threads or baseline_threads(host)
     t = np.arange(T0, T1 + 1, dtype=np.float64)
     b = cbind.bounds_from_values(t)
     F = f_syn(t)
@@ -408,7 +702,8 @@ def cpu_baseline(threads=None, target_seconds=12.0):
             "cgroup_cpu_quota_cores": host["cgroup_cpu_quota_cores"], "cpu_model": host["cpu_model"],
             "kind": "port", "single_thread_value": n1 * (T1 - T0) / dt1,
             "sample": f"{reps} pass(es) over {n} members x {T1 - T0} years, oracle/rscm_oracle.c two_layer_run "
-                      f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads (one per core this process may run on; "
+                      f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads (one per core this process is granted: "
+                      f"min(affinity {host['affinity_cores']}, ceil(cgroup quota {host['cgroup_cpu_quota_cores']})); "
                       f"the host has {host['host_cores']})"}
 
 
@@ -603,10 +898,30 @@ def rendezvous_only(args, rank, world, torch, dist):
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     collective, per_rank = rank_report(10.0 * (rank + 1), wall, 1, torch, dist)
+    # the all-ranks side-measurement procedure (scale_measure) with sleeps for work: a healthy one, one whose prepare fails on
+    # one rank, one whose timed body raises on one rank -- each must come back on every rank, the failures as reports
+    bad = int(os.environ.get("RSCM_BENCH_SELFTEST_BAD_RANK", "1"))
+
+    def selftest(fail_prepare=False, fail_body=False):
+        def prepare():
+            if fail_prepare and rank == bad:
+                raise RuntimeError("prepare refused (self-test)")
+            return {"units": 0}
+
+        def body(st, alone, k):
+            if fail_body and rank == bad and st["units"] >= 1:
+                raise RuntimeError("body raised (self-test)")
+            st["units"] += 1
+            time.sleep(0.005 * (rank + 1))
+
+        return scale_measure(rank, world, torch, dist, prepare, body, lambda st: None, lambda st: None, reps=3,
+                             after=lambda st: {"units": st["units"]})
+
+    tests = {"healthy": selftest(), "prepare_fails": selftest(fail_prepare=True), "body_fails": selftest(fail_body=True)}
     if rank == 0:
         print(json.dumps({"metric": "ensemble-member-years/sec, two-layer 1750-2500 f64", "value": None, "unit": "member-years/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rendezvous_only": True,
-                          "collective": collective, "per_rank": per_rank, "wall_s": wall}))
+                          "collective": collective, "per_rank": per_rank, "wall_s": wall, "scale_selftest": tests}))
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     return 0
@@ -621,6 +936,14 @@ def main():
     ap.add_argument("--mode", choices=["exact", "fast"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary 1e6-member / fast-mode lines")
+    ap.add_argument("--scale-members", type=int, default=1_000_000,
+                    help="members per GPU of scale_exact_1e6 / scale_coupled_fast_1e6 (the north-star's weak-scaling point; tests pass less)")
+    ap.add_argument("--share-members", type=int, default=125_000, help="members per GPU of scale_configs3_share (configs[3]: 1e6 / 8)")
+    ap.add_argument("--share-years", type=int, default=750, help="years (x 12 monthly steps) of scale_configs3_share")
+    ap.add_argument("--scale-walkers", type=int, default=100_000, help="walkers per iteration of scale_calibrate_sharded_1e5 (configs[4])")
+    ap.add_argument("--scale-sweeps", type=int, default=200, help="timed sweeps of scale_calibrate_sharded_1e5")
+    ap.add_argument("--scale-only", action="store_true", help="of the extras, only the scale_* ones (tests)")
+    ap.add_argument("--no-scale", action="store_true", help="skip the scale_* extras (the configs defined on more than one GPU)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: the ranks meet over gloo, run the contract's barrier / max-over-ranks / rank report and rank 0 "
                          "prints a line with value null (tests/test_distributed_cpu.py checks the launcher and the N > 1 plumbing with it)")
@@ -659,11 +982,24 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # librccl prints its version banner on stdout when the communicator is created: the contract is ONE JSON line there, so
+        # stdout points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     # a real (non-null) HIP stream shared by torch's events and the library's launches
     tstream = torch.cuda.Stream()
     stream = tstream.cuda_stream
@@ -673,6 +1009,7 @@ def main():
     ens = make_ensemble(args.members, local_rank, rank, world, mode, stream)
     wall, kernel_ms = timed_passes(ens, args.steps, args.warmup, torch, dist, world, tstream)
     n_fail = int(ens.status().sum())
+    fails = _gather_obj(dist, n_fail)
     run_plan = ens.last_run_plan()
     s_mid = ens.summary("Surface Temperature", 270)  # year 2020
     gather = loss_gather_report(ens, args.members, world, dist)
@@ -696,7 +1033,12 @@ def main():
             extra[label] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             print(f"bench.py: extra {label} failed: {exc}", file=sys.stderr)
 
-    if rank == 0 and world == 1 and not args.no_extra:
+    # Every config that is defined on more than one GPU, on ALL ranks (and under the same keys at N = 1): scale_exact_1e6,
+    # scale_coupled_fast_1e6, scale_configs3_share, scale_calibrate_sharded_1e5[_per_gpu].  After the headline, which is unchanged.
+    if not args.no_extra and not args.no_scale:
+        scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, years, extra)
+
+    if rank == 0 and world == 1 and not args.no_extra and not args.scale_only:
         def two_layer_case(members, m, cp):
             e2 = make_ensemble(members, local_rank, 0, 1, m, stream, coupled=cp)
             k = max(3, args.steps // 4)
@@ -832,6 +1174,10 @@ def main():
                 "parameters": "device Latin hypercube over typical ranges, seed 20260327",
                 "outputs": "Ts,Td every year to HBM (16 B/member-year)",
                 "sharding": f"contiguous member blocks, {world} rank(s), no data-path collective",
+                # part of the draw, not a fault: over these ranges a few per cent of the Latin hypercube's members have
+                # lambda0 - a*Ts turn negative and run away to inf; they are stepped and stored like the others and flagged
+                "failed_members": int(sum(fails)), "failed_members_per_rank": fails,
+                "failed_members_fraction": sum(fails) / float(world * args.members),
             },
             "roofline": roofline_hbm,
             "roofline_fp64_valu": roofline_valu,

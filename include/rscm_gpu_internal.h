@@ -37,8 +37,11 @@ RSCM_API int rscm_gpu_lockstep_stats(int64_t* launches, int64_t* component_steps
 RSCM_API int rscm_gpu_lockstep_split_launches(int64_t* out);
 
 /* Which ClimateUDEB kernel the calling thread's launches take (csrc/udeb.hip): 0 one thread per member, 2 a hemisphere per
- * wavefront; -1 (default): chosen by ensemble size.  The two carry the same bits.  (Layer counts other than 20 / 30 / 40 / 50
- * always take the any-count kernel.)  The setting is per calling THREAD: launches issued from another thread do not see it. */
+ * wavefront; -1 (default): chosen by ensemble size.  The two carry the same bits, at every layer count up to 64 (20 / 30 / 40 / 50
+ * with the count compiled in, the others with the count at run time in the next capacity's instance).  3: the columns-in-HBM
+ * kernel that serves more than 64 layers, for a count it would not otherwise serve -- the yardstick the runtime-count kernels
+ * are held to, bit for bit (not available at 20 / 30 / 40 / 50: its work arrays are not allocated there, the launch fails).
+ * The setting is per calling THREAD: launches issued from another thread do not see it. */
 RSCM_API int rscm_gpu_set_udeb_variant(int32_t variant);
 
 /* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an

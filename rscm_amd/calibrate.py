@@ -916,6 +916,8 @@ class DeviceEnsembleSampler:
         self.n_accepted = None
         self.n_proposed = None
         self.device_ms = 0.0
+        self.exchange_ms = 0.0
+        self.exchange_bytes_per_half_step = 0
         kinds, pa, pb, plo, phi = [], [], [], [], []
         for d in params.distributions():
             lo, hi = -math.inf, math.inf
@@ -952,6 +954,7 @@ class DeviceEnsembleSampler:
         ``shard``: split the walkers over the ranks of the initialised ``torch.distributed`` group
         (default: whenever there is one); the chain is the same for any number of ranks."""
         import ctypes as C
+        self.exchange_ms, self.exchange_bytes_per_half_step = 0.0, 0
         n_walkers = n_walkers or self.default_n_walkers * n_groups
         if n_walkers < 2:
             raise ValueError("Must have at least 2 walkers")
@@ -1072,9 +1075,13 @@ class DeviceEnsembleSampler:
             h_send, h_recv = np.empty(per), np.empty(per * world)
             t_send, t_recv = torch.from_numpy(h_send), torch.from_numpy(h_recv)
 
+        self.exchange_ms = 0.0   # host clock from "this rank's block is packed" to "every rank's block has landed here": the
+        #                          all-gather itself plus the wait for the slowest rank's half-step
+
         def half_step(half: int, identity: int) -> None:
             L.check(lib.rscm_sampler_half_step(h, half, identity))
             L.check(lib.rscm_sampler_sync(h))        # the packed block is complete before the collective reads it
+            t_x = time.perf_counter()
             if not on_device:
                 L.check(lib.rscm_gpu_copy_to_host(ens.device, h_send.ctypes.data_as(C.c_void_p), send, h_send.nbytes))
             dist.all_gather_into_tensor(t_recv, t_send)
@@ -1082,11 +1089,14 @@ class DeviceEnsembleSampler:
                 torch.cuda.current_stream().synchronize()   # the gathered blocks have landed before the unpack launch
             else:
                 L.check(lib.rscm_gpu_copy_to_device(ens.device, recv, h_recv.ctypes.data_as(C.c_void_p), h_recv.nbytes))
+            self.exchange_ms += (time.perf_counter() - t_x) * 1e3
             L.check(lib.rscm_sampler_apply_exchange(h, half))
 
         L.check(lib.rscm_sampler_set_positions(h, L.dptr(pos)))
         for half in (0, 1):
             half_step(half, 1)
+        self.exchange_ms = 0.0   # the identity half-steps above scored the initial positions: not part of the sweeps
+        self.exchange_bytes_per_half_step = per * 8 * world
         chain = Chain(self.params.param_names, thin)
         logp = np.empty(n_walkers)
         t0 = time.perf_counter()

@@ -41,7 +41,7 @@ int rscm_gpu_lockstep_split_launches(int64_t* out)
 
 int rscm_gpu_set_udeb_variant(int32_t variant)
 {
-    if (variant != -1 && variant != 0 && variant != 2) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0 or 2");
+    if (variant != -1 && variant != 0 && variant != 2 && variant != 3) return fail(RSCM_ERR_INVALID, "ClimateUDEB kernel variant must be -1, 0, 2 or 3");
     rscm::set_udeb_variant(variant);
     return RSCM_OK;
 }

@@ -377,6 +377,7 @@ struct CoupledArgs {
 constexpr int kUdebBlock = 64;  // one wavefront per workgroup: ~250 VGPRs per lane
 constexpr int kUdebNParams = 37;
 constexpr int kUdebScalars = 11;
+constexpr int kUdebMaxOnChipLayers = 64;   // up to this many ocean layers a member's columns stay in registers + LDS (csrc/udeb.hip)
 
 struct UdebArgs {
     int64_t n_members;
@@ -394,12 +395,12 @@ struct UdebArgs {
     const double* bounds;   // [T+1] (device)
     const int32_t* win_kfull;  // [T] first history entry that enters the cumulative-T window whole
     const double* win_partw;   // [T] weight of entry win_kfull-1 (0: not in the window)
-    // rows [NL][6] = {af_top, af_bot, af_diff, 1 - rel_depth, G_nh, G_sh}, NL = n_layers <= 50 (udeb_tables.hpp): passed BY
-    // VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
-    double tables[6 * 50];
+    // rows [NL][6] = {af_top, af_bot, af_diff, 1 - rel_depth, G_nh, G_sh}, NL = n_layers <= 64 (udeb_tables.hpp), zero rows after
+    // them: passed BY VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
+    double tables[6 * kUdebMaxOnChipLayers];
     const double* derived;     // [kDerivedRows][N] member constants: the base LAMCALC solve (launch_udeb_derive; udeb_body.hpp)
     int32_t derived_uniform;   // every parameter row it is formed from is uniform: element 0 serves all members
-    const double* tables_dev;  // the same rows in device memory, any NL: the any-layer-count kernel (udeb_any_body.hpp); else nullptr
+    const double* tables_dev;  // the same rows in device memory, any NL: the columns-in-HBM kernel (udeb_any_body.hpp); else nullptr
     double* work;              // [NL][N] the Thomas sweep's c' array of that kernel; else nullptr
     double* ocean;          // [2][NL][N] layer temperatures
     double* scal;           // [10][N] upwelling, land, ground, alpha_eff, hemi exchange (x2 hemispheres)
@@ -647,7 +648,8 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
-bool udeb_layers_unrolled(int32_t n_layers);  // the layer counts the register-resident column kernels are instantiated for
+bool udeb_layers_unrolled(int32_t n_layers);  // the layer counts whose columns stay on chip (2 .. kUdebMaxOnChipLayers)
+bool udeb_layers_fixed(int32_t n_layers);     // ... with the count compiled into the instance (20 / 30 / 40 / 50)
 void set_udeb_variant(int variant);            // which ClimateUDEB kernel the calling thread's launches take (udeb.hip; -1: by size)
 hipError_t launch_ghg(const GhgArgs& a, hipStream_t s);
 // Member constants: what a light component's body formed from its parameters alone at the top of EVERY one-step launch (GhgForcing:

@@ -358,8 +358,9 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             if (row(j, i) != row(j, 0))
                 return fail(RSCM_ERR_INVALID, "ClimateUDEB parameter row %d must be the same for every member", j);
     const double nl = row(RSCM_UD_P_N_LAYERS, 0), steps = row(RSCM_UD_P_STEPS_PER_YEAR, 0);
-    // mod.rs:162-165: "invalid n_layers: must be >= 2".  20 / 30 / 40 / 50 layers have a register-resident, unrolled column solve;
-    // every other count runs the any-count kernel (columns in HBM; csrc/udeb_any_body.hpp).  The upper bound is this library's.
+    // mod.rs:162-165: "invalid n_layers: must be >= 2".  Up to 64 layers a member's columns stay in registers + LDS (20 / 30 / 40 / 50
+    // with the count compiled in, the others in the next capacity's runtime-count instance); more run the columns-in-HBM kernel
+    // (csrc/udeb_any_body.hpp).  The upper bound is this library's.
     if (nl != std::floor(nl) || nl < 2.0) return fail(RSCM_ERR_INVALID, "invalid n_layers: must be >= 2, got %g", nl);
     if (nl > 4096.0) return fail(RSCM_ERR_INVALID, "n_layers = %g: the device path takes at most 4096 ocean layers", nl);
     if (h->udeb_ready && (int32_t)nl != h->udeb_n_layers && h->time_index > 0)
@@ -406,7 +407,7 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     {   // the columns: room for 50 layers at least (any of the unrolled kernels), more if asked for
-        const int32_t want = std::max(50, h->udeb_n_layers);
+        const int32_t want = std::max(rscm::kUdebMaxOnChipLayers, h->udeb_n_layers);
         if (want > h->udeb_ocean_layers) {
             (void)hipFree(h->d_ocean);
             h->d_ocean = nullptr;
@@ -418,7 +419,8 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             h->udeb_ocean_layers = want;
         }
     }
-    if (!rscm::udeb_layers_unrolled(h->udeb_n_layers)) {   // the any-count kernel: its c' array and its table live in device memory
+    if (!rscm::udeb_layers_fixed(h->udeb_n_layers)) {   // the columns-in-HBM kernel (more than 64 layers; up to 64 only on request, as the
+        // yardstick of the runtime-count kernels -- rscm_gpu_set_udeb_variant(3)): its c' array and its table live in device memory
         if (h->udeb_n_layers > h->udeb_work_layers) {
             (void)hipFree(h->d_udeb_work);
             (void)hipFree(h->d_udeb_tables);
@@ -1667,9 +1669,9 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         a.win_kfull = h->d_win_kfull;
         a.win_partw = h->d_win_partw;
         if (h->udeb_tables.size() != (size_t)6 * h->udeb_n_layers) return fail(RSCM_ERR_STATE, "ClimateUDEB tables not built");
-        if (rscm::udeb_layers_unrolled(h->udeb_n_layers)) {   // by value, in the kernel-argument segment
+        if (rscm::udeb_layers_unrolled(h->udeb_n_layers))   // by value, in the kernel-argument segment (rows past n_layers stay zero)
             memcpy(a.tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double));
-        } else {
+        if (!rscm::udeb_layers_fixed(h->udeb_n_layers)) {
             if (!h->d_udeb_tables || !h->d_udeb_work || h->udeb_work_layers < h->udeb_n_layers)
                 return fail(RSCM_ERR_STATE, "ClimateUDEB work arrays for %d layers not allocated", h->udeb_n_layers);
             a.tables_dev = h->d_udeb_tables;

@@ -44,14 +44,15 @@ namespace {
 
 using namespace udeb;
 
-// One thread per member (udeb_body.hpp: Udeb1): the launch of large ensembles.
-template <int NL, bool FAST>
+// One thread per member (udeb_body.hpp: Udeb1): the launch of large ensembles.  DYN: NL is the capacity of the register-resident
+// column, the layer count is a.n_layers <= NL (every count the fixed instances do not cover, up to kUdebMaxOnChipLayers).
+template <int NL, bool FAST, bool DYN = false>
 __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 {
     __shared__ double park[NL][kUdebBlock];
     const int64_t i = (int64_t)blockIdx.x * kUdebBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    Udeb1<NL> m(park);
+    Udeb1<NL, DYN> m(park);
     m.begin(a, i);
     if (m.status != 0) {  // the reference refuses to build this component: every output NaN
         for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<true, FAST>(a, n);
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 }
 
 // Two wavefronts per 64 members, one hemisphere each (udeb_body.hpp), one wavefront per SIMD.
-template <int NL, bool FAST>
+template <int NL, bool FAST, bool DYN = false>
 __global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
 {
     __shared__ Udeb2Lds lds;
-    Udeb2<NL> m(lds);
+    Udeb2<NL, DYN> m(lds);
     m.begin(a);
     for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<FAST>(a, n);
     m.end(a);
@@ -115,27 +116,35 @@ hipError_t launch_udeb_derive(const double* params, uint64_t uniform_rows, int64
     return hipGetLastError();
 }
 
-// 0: one thread per member, 2: a hemisphere per wavefront; -1: by ensemble size
+// 0: one thread per member, 2: a hemisphere per wavefront, 3: the columns-in-HBM kernel whatever the count (A/B runs and the
+// bit-for-bit test of the runtime-count kernels against it); -1: by ensemble size
 static thread_local int t_udeb_variant = -1;
 void set_udeb_variant(int variant) { t_udeb_variant = variant; }
 
-template <int NL>
+template <int NL, bool DYN>
 static void launch_udeb_nl(const UdebArgs& a, int variant, hipStream_t s)
 {
     const bool two_waves = variant == 2;
     if (two_waves) {
         const dim3 grid((unsigned)((a.n_members + 63) / 64));
-        if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true>), grid, dim3(kUdeb2Block), 0, s, a);
-        else hipLaunchKernelGGL((udeb2_kernel<NL, false>), grid, dim3(kUdeb2Block), 0, s, a);
+        if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true, DYN>), grid, dim3(kUdeb2Block), 0, s, a);
+        else hipLaunchKernelGGL((udeb2_kernel<NL, false, DYN>), grid, dim3(kUdeb2Block), 0, s, a);
     } else {
         const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
-        if (a.fast) hipLaunchKernelGGL((udeb_kernel<NL, true>), grid, dim3(kUdebBlock), 0, s, a);
-        else hipLaunchKernelGGL((udeb_kernel<NL, false>), grid, dim3(kUdebBlock), 0, s, a);
+        if (a.fast) hipLaunchKernelGGL((udeb_kernel<NL, true, DYN>), grid, dim3(kUdebBlock), 0, s, a);
+        else hipLaunchKernelGGL((udeb_kernel<NL, false, DYN>), grid, dim3(kUdebBlock), 0, s, a);
     }
 }
 
-// the layer counts with an unrolled, register-resident column solve; every other count >= 2 runs the any-count kernel
+// The layer counts whose columns stay on chip (registers + LDS) for a whole launch: 20 / 30 / 40 / 50 with the count compiled
+// in, every other count up to kUdebMaxOnChipLayers in the next capacity's runtime-count instance (same statements per row).
 bool udeb_layers_unrolled(int32_t n_layers)
+{
+    return n_layers >= 2 && n_layers <= kUdebMaxOnChipLayers;
+}
+
+// ... with the layer count a compile-time constant of the instance
+bool udeb_layers_fixed(int32_t n_layers)
 {
     return n_layers == 20 || n_layers == 30 || n_layers == 40 || n_layers == 50;
 }
@@ -154,18 +163,26 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     // RSCM_UDEB_VARIANT = 0 / 2 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
     int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;
+    const bool in_hbm = variant == 3 || !udeb_layers_unrolled(a.n_layers);
     if (variant != 0 && variant != 2) variant = a.n_members <= 32768 ? 2 : 0;
-    switch (a.n_layers) {   // the column loops are unrolled, the column lives in registers: one instance per supported layer count
-        case 20: launch_udeb_nl<20>(a, variant, s); break;
-        case 30: launch_udeb_nl<30>(a, variant, s); break;
-        case 40: launch_udeb_nl<40>(a, variant, s); break;
-        case 50: launch_udeb_nl<50>(a, variant, s); break;
-        default: {   // every other count the reference accepts (>= 2): the completeness path
-            if (a.n_layers < 2 || !a.tables_dev || !a.work) return hipErrorInvalidValue;
-            const dim3 grid((unsigned)((a.n_members + 255) / 256));
-            if (a.fast) hipLaunchKernelGGL(udeb_any_kernel<true>, grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(udeb_any_kernel<false>, grid, dim3(256), 0, s, a);
-        }
+    if (in_hbm) {   // more layers than the registers hold (or asked for): columns in HBM, plain loops
+        if (a.n_layers < 2 || !a.tables_dev || !a.work) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)((a.n_members + 255) / 256));
+        if (a.fast) hipLaunchKernelGGL(udeb_any_kernel<true>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(udeb_any_kernel<false>, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    switch (a.n_layers) {   // the column loops are unrolled, the column lives in registers
+        case 20: launch_udeb_nl<20, false>(a, variant, s); break;
+        case 30: launch_udeb_nl<30, false>(a, variant, s); break;
+        case 40: launch_udeb_nl<40, false>(a, variant, s); break;
+        case 50: launch_udeb_nl<50, false>(a, variant, s); break;
+        default:   // any other count: the smallest capacity that holds it, the count at run time
+            if (a.n_layers < 20) launch_udeb_nl<20, true>(a, variant, s);
+            else if (a.n_layers < 30) launch_udeb_nl<30, true>(a, variant, s);
+            else if (a.n_layers < 40) launch_udeb_nl<40, true>(a, variant, s);
+            else if (a.n_layers < 50) launch_udeb_nl<50, true>(a, variant, s);
+            else launch_udeb_nl<kUdebMaxOnChipLayers, true>(a, variant, s);
     }
     return hipGetLastError();
 }

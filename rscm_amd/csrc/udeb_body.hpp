@@ -315,18 +315,28 @@ struct YearGeom {
 // awaited, then the next chunk's rows are requested, then the chunk's arithmetic runs under those loads.  An opaque zero offset
 // per solve keeps the loads from being hoisted out of the sub-step and year loops (hundreds of scalar registers, spilled into
 // vector lanes), and a scheduling barrier per chunk keeps each request where it is written.
+//
+// DYN (a runtime layer count in a column of CAPACITY NL): the reference takes every n_layers >= 2 at the same cost per layer
+// (parameters/climate_udeb.rs:41, mod.rs:162-165).  The column still lives in the registers of dp[NL] and the sweep is still
+// unrolled over NL rows, but the rows that exist are [0, nl), nl = n_layers <= NL, wave-uniform: every row starts with a scalar
+// compare-and-branch on nl -- interior row, bottom row, or past the end -- and the statements of a live row are the ones of
+// the fixed-count kernel, so a count runs the same arithmetic whichever capacity holds it.  The table's rows [nl, NL) are zero
+// (never used, but requested with their chunk).  The bottom temperature, dp[nl - 1], has no static register index: the caller
+// carries it in *bottom across the solves (set here from the clamped bottom row).
 constexpr int kRowsAhead = 3;
 constexpr int kTabCols = 6;
 
-template <int NL, bool FAST>
+template <int NL, bool FAST, bool DYN = false>
 __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom& y,
                                                   const double* tables, int32_t land_hc,
                                                   double (&dp)[NL], int hemi,
                                                   double forcing, double hemi_hx, double ground_temp,
-                                                  double land_temp, double alpha_eff, double w)
+                                                  double land_temp, double alpha_eff, double w,
+                                                  int32_t nl_rt = NL, double* bottom = nullptr)
 {
     constexpr int R = kRowsAhead;
     constexpr int NCH = (NL + R - 1) / R;
+    const int32_t nl = DYN ? nl_rt : NL;
     int32_t opaque = 0;
     asm volatile("" : "+s"(opaque));
     const double* __restrict__ tab = tables + opaque;
@@ -347,10 +357,13 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
     request(cur, tab, 0);
 
     const double t_top = dp[0];
-    const double kslope = y.kdC * (t_top - dp[NL - 1]);
+    double t_bot;
+    if constexpr (DYN) t_bot = *bottom;
+    else t_bot = dp[NL - 1];
+    const double kslope = y.kdC * (t_top - t_bot);
     // kappa_l * dt/dz^2 with the (positive) factor folded into the three constants: one multiply
     // less per interior row, the same value to rounding
-    const double kslope2 = y.kdC2 * (t_top - dp[NL - 1]);
+    const double kslope2 = y.kdC2 * (t_top - t_bot);
     const double delta_w = w - p.w0;
     // |delta_w| <= 1e-15: the reference skips the profile-advection terms; adding exact zeros is
     // the same thing without a branch per row
@@ -361,8 +374,10 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
 
     double ncp[NL];  // -c'
     double tdu = 0.0;
+    double x_bot = 0.0;   // DYN: the bottom row's solution, where the back substitution starts
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        if (DYN && c * R >= nl) continue;   // (not an early exit: the unroller wants one way out of the loop)
         await(cur);
         if (c + 1 < NCH) request(nxt, tab, (c + 1) * R);
         // Nothing crosses: the request stays above the chunk it runs under (left alone the scheduler sinks it to where its values are
@@ -374,6 +389,7 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
         for (int r = 0; r < R; ++r) {
             const int i = c * R + r;
             if (i >= NL) break;
+            if (DYN && i >= nl) continue;
             const double af_top = cur[r][0], af_bot = cur[r][1], af_diff = cur[r][2], omr = cur[r][3], G = sh ? cur[r][5] : cur[r][4];
             if (i == 0) {   // ---- row 0 (mixed layer)
                 const double kap0 = fmax(__builtin_fma(omr, kslope, y.kC), y.kminC);
@@ -389,13 +405,14 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
                 const double rr = refined_rcp(b0);
                 ncp[0] = nc0 * rr;
                 dp[0] = d0 * rr;
-                tdu = kap0 * y.dt_dzdz1;  // row 1: dz_up = dz/2
+                // row 1 as an interior row: dz_up = dz/2; as the BOTTOM row (two layers) the reference takes dz for it (ocean_column.rs:191)
+                tdu = kap0 * ((DYN && nl == 2) ? y.dt_dz2 : y.dt_dzdz1);
                 continue;
             }
             // ---- interior rows and the bottom row: forward sweep
             const double t_i = dp[i];
             const double tdu_aft = tdu * af_top;
-            if (i < NL - 1) {
+            if (i < nl - 1) {
                 const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
                 const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
                 const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
@@ -415,7 +432,14 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
                 const double bi = __builtin_fma(tdu + tul, af_top, 1.0);
                 const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_top, t_i));
                 const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
-                dp[i] = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
+                const double xb = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
+                if constexpr (DYN) {
+                    x_bot = xb;
+                    dp[i] = fmin(xb, p.max_temp);
+                    *bottom = dp[i];
+                } else {
+                    dp[i] = xb;
+                }
             }
         }
 #pragma unroll
@@ -425,10 +449,16 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
     }
     // ---- back substitution, clamp.  thomas_solve returns the unclamped vector; the state keeps
     // min(x, max_temp)
-    double x = dp[NL - 1];
-    dp[NL - 1] = fmin(x, p.max_temp);
+    double x;
+    if constexpr (DYN) {
+        x = x_bot;   // (its row was clamped where it was solved)
+    } else {
+        x = dp[NL - 1];
+        dp[NL - 1] = fmin(x, p.max_temp);
+    }
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) {
+        if (DYN && i >= nl - 1) continue;
         x = __builtin_fma(ncp[i], x, dp[i]);
         dp[i] = fmin(x, p.max_temp);
     }
@@ -442,10 +472,13 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
 // the solver's d' array), the other one is parked in this lane's LDS slots (park[layer][lane]: 8 NL bytes per lane,
 // each lane touches only its own slots -- no barriers, no bank conflicts) and the two are exchanged after every
 // column solve.  HBM sees the columns once in begin() (resume) and once in end(): ocean[hemi][layer][N].
-template <int NL>
+// DYN: NL is the capacity, the column has nl = a.n_layers <= NL rows (step_hemisphere); HBM keeps [2][nl][N].
+template <int NL, bool DYN = false>
 struct Udeb1 {
     double (*park)[kUdebBlock];
     int lane;
+    int32_t nl;                 // rows of a column (wave-uniform; NL when not DYN)
+    double bot_cur, bot_park;   // DYN: the bottom-row temperature of the column in col[] / of the parked one
     int64_t N, i;
     UdebP p;
     int32_t status;
@@ -466,6 +499,8 @@ struct Udeb1 {
     {
         lane = threadIdx.x;
         i = member;
+        nl = DYN ? a.n_layers : NL;
+        bot_cur = bot_park = 0.0;
         N = a.row_stride;   // the stride of every [..][N] array (the caller has checked `member` against a.n_members)
         auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
         p.dz_mix = P(1); p.dz = P(2); p.kappa = P(3); p.kappa_min = P(4); p.kappa_dkdt = P(5);
@@ -500,7 +535,7 @@ struct Udeb1 {
         if (status != 0) return;  // the reference refuses to build this component: step() writes NaN rows
         // ---- internal state (ClimateUDEBState::new) or resume
         double* T_nh = a.ocean + i;
-        double* T_sh = a.ocean + (size_t)NL * N + i;
+        double* T_sh = a.ocean + (size_t)nl * N + i;
         if (a.step_begin == 0) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) park[l][lane] = 0.0;
@@ -516,13 +551,23 @@ struct Udeb1 {
             // The southern column first, all NL loads at once into the registers of col[], from there to its LDS
             // slots; then the northern one (two round trips to HBM; interleaved with the LDS writes, a layer at a
             // time, the compiler waited for every pair: 25 round trips per launch).
+            if constexpr (DYN) {   // (rows past the end stay zero)
+                bot_park = T_sh[(size_t)(nl - 1) * N];
+                bot_cur = T_nh[(size_t)(nl - 1) * N];
+            }
 #pragma unroll
-            for (int l = 0; l < NL; ++l) col[l] = T_sh[(size_t)l * N];
+            for (int l = 0; l < NL; ++l) {
+                if (DYN && l >= nl) continue;
+                col[l] = T_sh[(size_t)l * N];
+            }
 #pragma unroll
             for (int l = 0; l < NL; ++l) park[l][lane] = col[l];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int l = 0; l < NL; ++l) col[l] = T_nh[(size_t)l * N];
+            for (int l = 0; l < NL; ++l) {
+                if (DYN && l >= nl) continue;
+                col[l] = T_nh[(size_t)l * N];
+            }
         }
         const int32_t scen = a.scen ? a.scen[i] : 0;
         F = a.link ? a.link + i : a.erf + (size_t)scen * a.n_times;   // a linked forcing is another ensemble's [T][N] series
@@ -653,10 +698,10 @@ struct Udeb1 {
 #pragma unroll
             for (int hemi = 0; hemi < 2; ++hemi) {
                 const bool sh = hemi != 0;
-                sst_pair[hemi] = step_hemisphere<NL, FAST>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
-                                                           sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
-                                                           sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
-                                                           sh ? up_sh : up_nh);
+                sst_pair[hemi] = step_hemisphere<NL, FAST, DYN>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
+                                                                sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
+                                                                sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
+                                                                sh ? up_sh : up_nh, nl, &bot_cur);
                 // exchange the solved column with the parked hemisphere.  (Tried: both columns in registers and the c' array of the solve
                 // in progress in the LDS slots instead -- as many LDS instructions, none of them between two solves: the register
                 // allocator answers with 505 spilled VGPRs and 652 spilled SGPRs.  Tried: the exchange layer by layer inside the back
@@ -664,9 +709,15 @@ struct Udeb1 {
                 // starts to spill, and 65 536 members x 750 years take 58.8 ms instead of 54.8.)
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
+                    if (DYN && l >= nl) continue;
                     const double other = park[l][lane];
                     park[l][lane] = col[l];
                     col[l] = other;
+                }
+                if constexpr (DYN) {
+                    const double other = bot_park;
+                    bot_park = bot_cur;
+                    bot_cur = other;
                 }
             }
             const double sst_nh = sst_pair[0], sst_sh = sst_pair[1];
@@ -709,10 +760,16 @@ struct Udeb1 {
             double total = 0.0;
             total += rho_c * p.dz_mix * sst_nh;
 #pragma unroll
-            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
+            for (int l = 1; l < NL; ++l) {
+                if (DYN && l >= nl) continue;
+                total += rho_c * p.dz * col[l];
+            }
             total += rho_c * p.dz_mix * sst_sh;
 #pragma unroll 7
-            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * park[l][lane];
+            for (int l = 1; l < NL; ++l) {
+                if (DYN && l >= nl) continue;
+                total += rho_c * p.dz * park[l][lane];
+            }
             a.ohc[r1] = total / 2.0;
         }
         a.st0[r1] = air_nh;
@@ -732,14 +789,20 @@ struct Udeb1 {
         s[8 * N] = hx_nh; s[9 * N] = hx_sh;
         s[10 * N] = win_sum;
         double* T_nh = a.ocean + i;
-        double* T_sh = a.ocean + (size_t)NL * N + i;
+        double* T_sh = a.ocean + (size_t)nl * N + i;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) T_nh[(size_t)l * N] = col[l];
+        for (int l = 0; l < NL; ++l) {
+            if (DYN && l >= nl) continue;
+            T_nh[(size_t)l * N] = col[l];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int l = 0; l < NL; ++l) col[l] = park[l][lane];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) T_sh[(size_t)l * N] = col[l];
+        for (int l = 0; l < NL; ++l) {
+            if (DYN && l >= nl) continue;
+            T_sh[(size_t)l * N] = col[l];
+        }
     }
 };
 
@@ -767,10 +830,12 @@ struct Udeb2Lds {
 // or resume), step(n) for consecutive n, end() (internal state back to HBM).  Every thread of the workgroup
 // must make the same calls: step() and begin() hold workgroup barriers.  Lanes past the end of the ensemble
 // compute on a copy of the last member and store nothing.
-template <int NL>
+template <int NL, bool DYN = false>
 struct Udeb2 {
     Udeb2Lds& lds;
     int tid, lane;
+    int32_t nl;      // rows of the column (wave-uniform; NL when not DYN)
+    double bot;      // DYN: the column's bottom-row temperature
     int hemi;        // 0: northern column, 1: southern (wave-uniform)
     int64_t N, i;
     bool live;       // this lane stands for a member of the ensemble
@@ -801,6 +866,8 @@ struct Udeb2 {
         tid = threadIdx.x;
         lane = tid & 63;
         hemi = __builtin_amdgcn_readfirstlane(tid >> 6);
+        nl = DYN ? a.n_layers : NL;
+        bot = 0.0;
         N = a.row_stride;   // the stride of every [..][N] array; a.n_members: the members this launch covers
         const int64_t i_raw = (int64_t)blockIdx.x * 64 + lane;
         live = i_raw < a.n_members;
@@ -832,7 +899,7 @@ struct Udeb2 {
         hist_last = 0.0;
         win_lo = 0;
         n_sub = 0;
-        double* T_own = a.ocean + (size_t)hemi * NL * N + i;
+        double* T_own = a.ocean + (size_t)hemi * nl * N + i;
         if (a.step_begin == 0) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) col[l] = 0.0;
@@ -846,9 +913,13 @@ struct Udeb2 {
             win_sum = a.scal[(size_t)10 * N + i];
             win_lo = a.step_begin > 1 ? a.win_kfull[a.step_begin - 1] : 0;
             hist_last = a.hist[(size_t)(a.step_begin - 1) * N + i];
-            top_o = a.ocean[(size_t)(1 - hemi) * NL * N + i];
+            top_o = a.ocean[(size_t)(1 - hemi) * nl * N + i];
+            if constexpr (DYN) bot = T_own[(size_t)(nl - 1) * N];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) col[l] = T_own[(size_t)l * N];
+            for (int l = 0; l < NL; ++l) {
+                if (DYN && l >= nl) { col[l] = 0.0; continue; }
+                col[l] = T_own[(size_t)l * N];
+            }
         }
         const int32_t scen = a.scen ? a.scen[i] : 0;
         F = a.link ? a.link + i : a.erf + (size_t)scen * a.n_times;   // a linked forcing is another ensemble's [T][N] series
@@ -960,7 +1031,7 @@ struct Udeb2 {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f_ocean = adj * q_o, f_land = adj * q_l;
             if (a.land_hc) gr = __builtin_fma(land - gr, gfac, gr);
-            const double sst = step_hemisphere<NL, FAST>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up);   // the same function as the one-thread kernel: the same bits
+            const double sst = step_hemisphere<NL, FAST, DYN>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up, nl, &bot);   // the same function as the one-thread kernel: the same bits
             t_air = sst_to_air(airmap, sst);
             land = land_temperature(ka, p.max_temp, t_air, f_land, fg_l, r_land);
             // what the other hemisphere needs of this one: air and land temperature
@@ -987,7 +1058,10 @@ struct Udeb2 {
             double total = 0.0;
             total += rho_c * p.dz_mix * sst;
 #pragma unroll
-            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
+            for (int l = 1; l < NL; ++l) {
+                if (DYN && l >= nl) continue;
+                total += rho_c * p.dz * col[l];
+            }
             lds.xy[ypar][0][2][lane] = total;
         }
         lds.xy[ypar][hemi][0][lane] = sst;
@@ -1025,7 +1099,10 @@ struct Udeb2 {
             double total = lds.xy[ypar][0][2][lane];
             total += rho_c * p.dz_mix * sst;
 #pragma unroll
-            for (int l = 1; l < NL; ++l) total += rho_c * p.dz * col[l];
+            for (int l = 1; l < NL; ++l) {
+                if (DYN && l >= nl) continue;
+                total += rho_c * p.dz * col[l];
+            }
             if (live) {
                 a.ohc[r1] = dead ? nan : total / 2.0;
                 a.st2[r1] = dead ? nan : air;
@@ -1041,9 +1118,12 @@ struct Udeb2 {
         double* s = a.scal + (size_t)hemi * N + i;
         s[0 * N] = up; s[2 * N] = land; s[4 * N] = gr; s[6 * N] = ae; s[8 * N] = hx;
         if (hemi == 0) a.scal[(size_t)10 * N + i] = win_sum;
-        double* T_own = a.ocean + (size_t)hemi * NL * N + i;
+        double* T_own = a.ocean + (size_t)hemi * nl * N + i;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) T_own[(size_t)l * N] = col[l];
+        for (int l = 0; l < NL; ++l) {
+            if (DYN && l >= nl) continue;
+            T_own[(size_t)l * N] = col[l];
+        }
     }
 };
 

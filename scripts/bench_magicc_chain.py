@@ -49,8 +49,11 @@ def chain_components():
             B.OceanCarbonBuilder.from_parameters({}).build(), B.CO2BudgetBuilder.from_parameters({}).build()]
 
 
-def build_chain(members: int, years: int = 750, order: str = "topological", steps_per_year: int = 1, **build_kwargs):
-    """The emissions-driven graph for `members` members; returns the GraphModel, ready to run."""
+def build_chain(members: int, years: int = 750, order: str = "topological", steps_per_year: int = 1, device: int = 0,
+                member_offset: int = 0, members_total: int = None, **build_kwargs):
+    """The emissions-driven graph for `members` members; returns the GraphModel, ready to run.  `member_offset` / `members_total`:
+    these members are the block [member_offset, member_offset + members) of one seeded draw of `members_total` members (one rank's
+    share of a sharded ensemble; default: the whole draw)."""
     t, exo, init, contributors = chain_inputs(years, steps_per_year)
     schema = core.VariableSchema()
     for n in list(exo) + [k for k in init if k not in ("Surface Temperature", "Effective Radiative Forcing")] + contributors + [
@@ -61,7 +64,7 @@ def build_chain(members: int, years: int = 750, order: str = "topological", step
     schema.add_aggregate("Effective Radiative Forcing", "W/m^2", "Sum", contributors)
     comps = chain_components()
     axis = core.TimeAxis.from_values(t)
-    bld = core.ModelBuilder().with_time_axis(axis).with_schema(schema).with_initial_values(init)
+    bld = core.ModelBuilder().with_device(device).with_time_axis(axis).with_schema(schema).with_initial_values(init)
     for c in comps:
         bld.with_rust_component(c)
     for name, vals in exo.items():
@@ -69,14 +72,18 @@ def build_chain(members: int, years: int = 750, order: str = "topological", step
     model = bld.build(n_members=members, execution_order=order, **build_kwargs)
     model._chain_components = comps
     rng = np.random.default_rng(20260327)
+    total = members if members_total is None else members_total
+    if not (0 <= member_offset and member_offset + members <= total):
+        raise ValueError("member block outside the draw")
+    block = slice(member_offset, member_offset + members)
     ud = model.ensembles["ClimateUDEB"]
     P = ud.get_params()
-    P[L.UD_PARAM_NAMES.index("ecs")] = rng.uniform(2.0, 4.5, members)
-    P[L.UD_PARAM_NAMES.index("kappa")] = rng.uniform(0.5, 1.2, members)
+    P[L.UD_PARAM_NAMES.index("ecs")] = rng.uniform(2.0, 4.5, total)[block]
+    P[L.UD_PARAM_NAMES.index("kappa")] = rng.uniform(0.5, 1.2, total)[block]
     ud.set_params(P)
     tc = model.ensembles["TerrestrialCarbon"]
     P = tc.get_params()
-    P[L.TC_PARAM_NAMES.index("beta")] = P[L.TC_PARAM_NAMES.index("beta")] * rng.uniform(0.7, 1.3, members)
+    P[L.TC_PARAM_NAMES.index("beta")] = P[L.TC_PARAM_NAMES.index("beta")] * rng.uniform(0.7, 1.3, total)[block]
     tc.set_params(P)
     return model
 

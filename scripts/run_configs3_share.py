@@ -26,14 +26,24 @@ NAMES = ["Sea Surface Temperature", "Atmospheric Concentration|CO2", "Effective 
          "Carbon Flux|Ocean"]
 
 
-def run(members, years, exact, window=16):
-    free0, total = L.mem_info(0)
+def build(members, years, exact, window=16, device=0, member_offset=0, members_total=None):
+    """The share's graph, built and in its arithmetic mode, ready to run (bench.py's N > 1 leg times `model.run()` itself)."""
+    model = build_chain(members, years, "topological", steps_per_year=12, device=device, member_offset=member_offset,
+                        members_total=members_total, series_window=window, output_stride=12)
+    if not exact:
+        model.set_mode(L.MODE_FAST)
+    return model
+
+
+def run(members, years, exact, window=16, device=0, member_offset=0, members_total=None):
+    free0, total = L.mem_info(device)
     t0 = time.perf_counter()
-    model = build_chain(members, years, "topological", steps_per_year=12, series_window=window, output_stride=12)
+    model = build_chain(members, years, "topological", steps_per_year=12, device=device, member_offset=member_offset,
+                        members_total=members_total, series_window=window, output_stride=12)
     if not exact:
         model.set_mode(L.MODE_FAST)
     build_s = time.perf_counter() - t0
-    free1, _ = L.mem_info(0)
+    free1, _ = L.mem_info(device)
     L.check(L.load().rscm_gpu_lockstep_stats(None, None))
     t0 = time.perf_counter()
     model.run()
@@ -50,25 +60,27 @@ def run(members, years, exact, window=16):
                 component_steps=int(ns.value), warm=warm, co2=co2, failed=status), rows
 
 
-def first_64(members, years, exact, window=16):
+def first_64(members, years, exact, window=16, device=0, member_offset=0, members_total=None):
     """Parity anchor at this size: a 64-member ensemble that is GIVEN the first 64 members' parameters of the
     `members`-member one (build_chain draws whole vectors from one seeded generator: replayed here for the big
     ensemble's draws).  Returns the kept (annual) rows of NAMES."""
     import scripts.bench_magicc_chain as mod
-    small = build_chain(64, years, "topological", steps_per_year=12, series_window=window, output_stride=12)
+    small = build_chain(64, years, "topological", steps_per_year=12, device=device, series_window=window, output_stride=12)
     rng = np.random.default_rng(20260327)
-    ecs = rng.uniform(2.0, 4.5, members)
-    kappa = rng.uniform(0.5, 1.2, members)
-    beta_f = rng.uniform(0.7, 1.3, members)
+    total = members if members_total is None else members_total
+    first = slice(member_offset, member_offset + 64)
+    ecs = rng.uniform(2.0, 4.5, total)
+    kappa = rng.uniform(0.5, 1.2, total)
+    beta_f = rng.uniform(0.7, 1.3, total)
     ud = small.ensembles["ClimateUDEB"]
     P = ud.get_params()
-    P[L.UD_PARAM_NAMES.index("ecs")] = ecs[:64]
-    P[L.UD_PARAM_NAMES.index("kappa")] = kappa[:64]
+    P[L.UD_PARAM_NAMES.index("ecs")] = ecs[first]
+    P[L.UD_PARAM_NAMES.index("kappa")] = kappa[first]
     ud.set_params(P)
     tc = small.ensembles["TerrestrialCarbon"]
     Q = tc.get_params()
     base_beta = mod.chain_components()[7].param_vector()[L.TC_PARAM_NAMES.index("beta")]
-    Q[L.TC_PARAM_NAMES.index("beta")] = base_beta * beta_f[:64]
+    Q[L.TC_PARAM_NAMES.index("beta")] = base_beta * beta_f[first]
     tc.set_params(Q)
     if not exact:
         small.set_mode(L.MODE_FAST)

@@ -46,6 +46,17 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert line["per_rank"]["kernel_ms"] == [10.0, 20.0]            # every rank's own figure reached rank 0, in rank order
     eff = line["per_rank"]["weak_efficiency"]
     assert len(eff) == 2 and eff[0] < eff[1] <= 1.0 + 1e-9          # the rank that waited shows
+    # the all-ranks side measurements' procedure (bench.py scale_measure, sleeps for work): barrier to barrier, the slowest rank
+    # sets the wall time, rank 0's time alone beside it; a rank that fails -- before the barriers or inside the timed region --
+    # turns the extra into a report on every rank instead of hanging the job
+    t = line["scale_selftest"]
+    h = t["healthy"]
+    assert h["ranks"] == 2 and h["units_per_rank"] == 3 and len(h["per_rank"]["own_s"]) == 2
+    assert h["per_rank"]["own_s"][0] < h["per_rank"]["own_s"][1] <= h["wall_s"] + 1e-3
+    assert 0.2 < h["weak_efficiency"] < 0.9 and h["rank0_alone_s"] < h["wall_s"]     # rank 0 sleeps 5 ms per unit, rank 1 10 ms
+    assert [f["units"] for f in h["per_rank"]["facts"]] == [1 + 3 + 3, 1 + 3]        # warm-up + alone (rank 0 only) + timed
+    assert "prepare failed on rank(s) 1" in t["prepare_fails"]["error"] and "self-test" in t["prepare_fails"]["error"]
+    assert "rank(s) 1" in t["body_fails"]["error"] and "body raised" in t["body_fails"]["error"]
 
 
 def test_bench_under_a_launcher_keeps_the_launchers_ranks():

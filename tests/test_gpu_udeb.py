@@ -110,13 +110,22 @@ def test_udeb_gpu_other_layer_counts(ra, orc, n_layers, n_members):
     _assert_close({k: v[:, pick] for k, v in got.items()}, want, f"{n_layers} layers")
 
 
-@pytest.mark.parametrize("n_layers", [2, 3, 7, 25, 64])
+def _variant(ra, v):
+    from rscm_amd import _lib as L
+    L.check(L.load().rscm_gpu_set_udeb_variant(v))
+
+
+@pytest.mark.parametrize("n_layers", [2, 3, 7, 19, 21, 25, 49, 51, 64, 65, 80])
 def test_udeb_gpu_any_layer_count(ra, orc, n_layers):
     """Every n_layers >= 2 the reference accepts (parameters/climate_udeb.rs:41; from_parameters refuses < 2, mod.rs:162-165) runs on
-    the device: counts without an unrolled kernel take the any-count kernel (csrc/udeb_any_body.hpp: columns in HBM, plain loops over
-    the layers, the same row arithmetic).  Same 1e-9 bar against the oracle; both arithmetic modes; launch boundaries (resume from
-    the stored columns and scalars) change nothing; a member the reference refuses to build is flagged and NaN; more than 50 layers
-    means the initial profile's last value below layer 50, as in the oracle."""
+    the device.  Up to 64 layers a member's columns stay in registers + LDS: counts other than 20 / 30 / 40 / 50 take the next
+    capacity's instance of the unrolled kernels with the count at run time (csrc/udeb_body.hpp, DYN: a scalar branch per row, the
+    statements of a live row unchanged); beyond 64 the columns-in-HBM kernel (csrc/udeb_any_body.hpp: plain loops over the layers,
+    the same row arithmetic).  Same 1e-9 bar against the oracle (which takes any count; the reference's MAGICC7 files pin 50
+    layers only: parity at other counts is against the restatement); both arithmetic modes; launch boundaries (resume from the
+    stored columns and scalars) change nothing; a member the reference refuses to build is flagged and NaN; more than 50 layers
+    means the initial profile's last value below layer 50, as in the oracle.  Up to 64 layers the three kernels -- a hemisphere per
+    wavefront, one thread per member, columns in HBM -- carry the same bits."""
     years = np.arange(1850.0, 1931.0)
     b = np.append(years, 1931.0)
     n = 300   # a ragged last workgroup of the 256-thread kernel
@@ -134,6 +143,41 @@ def test_udeb_gpu_any_layer_count(ra, orc, n_layers):
         assert np.array_equal(again[k], got[k], equal_nan=True), k
     fast, _ = _gpu(ra, b, P, F, scen=scen, mode=ra.MODE_FAST)
     _assert_close(fast, want, f"{n_layers} layers, FAST")
+    if n_layers <= 64:
+        try:
+            for mode, ref in ((None, got), (ra.MODE_FAST, fast)):
+                for v in (0, 2, 3):   # one thread per member; a hemisphere per wavefront; columns in HBM
+                    _variant(ra, v)
+                    other, st_v = _gpu(ra, b, P, F, scen=scen, chunks=(17,), mode=mode)
+                    assert (st_v == st).all()
+                    for k in NAMES:
+                        assert np.array_equal(other[k], ref[k], equal_nan=True), (v, mode, k)
+        finally:
+            _variant(ra, -1)
+
+
+@pytest.mark.parametrize("n_layers", [21, 49, 51, 64])
+def test_udeb_gpu_runtime_layer_count_one_thread_kernel(ra, orc, n_layers):
+    """The one-thread-per-member kernel (the default beyond 32 768 members) with the layer count at run time, at a size that
+    takes it by default: against the oracle on a sample of members, and bit for bit against the two-wavefront kernel."""
+    years = np.arange(1850.0, 1911.0)
+    b = np.append(years, 1911.0)
+    n = 33_000
+    P = _ensemble_params(orc, n, seed=200 + n_layers, n_layers=float(n_layers))
+    F = np.stack([np.where(years >= 1851, 3.71, 0.0), 3.71 * np.log(np.where(years > 1850, 1.01 ** (years - 1850), 1.0)) / np.log(2.0)])
+    scen = (np.arange(n) % 2).astype(np.int32)
+    pick = np.random.default_rng(2).choice(n, 192, replace=False)
+    want, wst = orc.udeb_run(b, P[:, pick].copy(), F, scen=scen[pick].copy(), threads=8)
+    got, st = _gpu(ra, b, P, F, scen=scen, chunks=(1, 29))
+    assert not st.any() and not wst.any()
+    _assert_close({k: v[:, pick] for k, v in got.items()}, want, f"{n_layers} layers")
+    try:
+        _variant(ra, 2)
+        two, _ = _gpu(ra, b, P, F, scen=scen)
+    finally:
+        _variant(ra, -1)
+    for k in NAMES:
+        assert np.array_equal(two[k], got[k], equal_nan=True), k
 
 
 def test_udeb_gpu_layer_count_errors(ra, orc):

@@ -103,3 +103,56 @@ def test_bench_two_ranks_with_and_without_a_launcher():
         g = two["collective"]["loss_gather"]   # configs[4]'s exchange: per-member losses scored on the device, all-gathered over the ranks
         assert "error" not in g and g["members_gathered"] == 40000 and g["finite"] > 0.9 * 40000 and g["ms"] > 0
         assert two["check"]["failed_members_rank0"] < 0.1 * 20000
+        assert len(two["config"]["failed_members_per_rank"]) == 2 and two["config"]["failed_members"] == sum(two["config"]["failed_members_per_rank"])
+
+
+SCALE_KEYS = ("scale_exact_1e6", "scale_coupled_fast_1e6", "scale_configs3_share", "scale_calibrate_sharded_1e5",
+              "scale_calibrate_sharded_1e5_per_gpu")
+SCALE_SMALL = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--scale-members", "30000",
+               "--share-members", "1024", "--share-years", "2", "--scale-walkers", "4096", "--scale-sweeps", "3"]
+
+
+def _check_scale_extras(line, ranks):
+    extra = line["extra"]
+    for key in SCALE_KEYS:
+        assert key in extra, sorted(extra)
+        e = extra[key]
+        assert "error" not in e, (key, e)
+        assert e["ranks"] == ranks and e["wall_s"] > 0
+        assert len(e["per_rank"]["own_s"]) == ranks and min(e["per_rank"]["own_s"]) > 0
+        if ranks > 1:
+            assert e["rank0_alone_s"] > 0
+    for key in ("scale_exact_1e6", "scale_coupled_fast_1e6"):
+        e = extra[key]
+        assert e["member_years_per_s"] > 0 and len(e["per_rank"]["kernel_ms"]) == ranks and min(e["per_rank"]["kernel_ms"]) > 0
+        assert e["roofline"]["frac"] > 0 and e["members_per_gpu"] == 30000
+        if ranks > 1:
+            assert 0 < e["weak_efficiency"] < 1.5    # both ranks on one card: about a half
+    share = extra["scale_configs3_share"]
+    assert share["parity_anchor_all_ranks"] and share["failed_members"] == 0 and len(share["per_rank"]["run_s"]) == ranks
+    # the ranks hold different blocks of one draw: their ensemble means differ
+    if ranks > 1:
+        means = [f["warming_end_K_mean"] for f in share["per_rank"]["facts"]]
+        assert means[0] != means[1]
+    for key, scaling in (("scale_calibrate_sharded_1e5", "strong"), ("scale_calibrate_sharded_1e5_per_gpu", "weak")):
+        c = extra[key]
+        assert c["scaling"] == scaling and c["device_ms_per_iteration"] > 0 and 0.05 < c["per_rank"]["facts"][0]["acceptance_rate"] < 0.95
+        assert c["walkers"] == 4096 * (ranks if scaling == "weak" else 1)
+        if ranks > 1:
+            assert c["exchange_ms_per_iteration"] > 0 and 0 < c["exchange_share_of_iteration"] < 1
+            assert c["per_rank"]["facts"][0]["exchange_bytes_per_half_step"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
+def test_bench_two_ranks_measures_every_multi_gpu_config():
+    """`bench.py --gpus 2` runs the configs that are defined on more than one GPU on BOTH ranks, barrier to barrier with the
+    max-over-ranks wall time and every rank's own time: 1e6-per-GPU two-layer and coupled FAST (here 30 000), each rank's configs[3]
+    share (its own block of one draw, parity anchor on every rank), and the device sampler sharded over the process group (walkers
+    split over the ranks, and per GPU) with the exchange's share of an iteration -- and the same keys exist at N = 1."""
+    knobs = {"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"}
+    two = _bench_line(["--gpus", "2", *SCALE_SMALL], knobs)
+    assert two["n_gpus"] == 2 and two["value"] > 0
+    _check_scale_extras(two, 2)
+    one = _bench_line(["--gpus", "1", *SCALE_SMALL, "--scale-only"], {})
+    _check_scale_extras(one, 1)
