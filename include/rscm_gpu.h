@@ -55,8 +55,13 @@ extern "C" {
 /* Bumped whenever an entry point is added or a mode changes what a kind computes while the major version stays:
  *   1  rscm_sampler_create_graph; four hooks moved to rscm_gpu_internal.h; RSCM_MODE_FAST acts on ClimateUDEB
  *   2  RSCM_MODE_FAST acts on the coupled chain and on CarbonCycle; rscm_gpu_abi_minor itself
- *   3  rscm_ens_last_run_plan                                                                                  */
-#define RSCM_GPU_ABI_MINOR 3
+ *   3  rscm_ens_last_run_plan.  In the internal header (rscm_gpu_internal.h, not part of this ABI) the same release REMOVED
+ *      rscm_gpu_graph_stamps, made rscm_gpu_set_udeb_variant(4) an error (the four-wavefront kernel is gone) and re-used
+ *      rscm_gpu_set_lockstep_fusion mode 4 (was: the whole-graph launch; now: mode 1 without the two-wavefront op split): a
+ *      host built against the round-3 internal header does not link, or gets the new meaning of mode 4
+ *   4  ClimateUDEB keeps its columns on chip at EVERY n_layers <= 64 (no entry point changed: same results, the counts
+ *      other than 20 / 30 / 40 / 50 are ~15x faster); internal header: rscm_gpu_fail_chunk_launch, rscm_gpu_set_udeb_variant(3) */
+#define RSCM_GPU_ABI_MINOR 4
 
 #if defined(__GNUC__)
 #define RSCM_API __attribute__((visibility("default")))
@@ -284,8 +289,13 @@ extern "C" {
 /* UDEB parameter rows (P = 37): ClimateUDEBParameters field order
  * (crates/rscm-magicc/src/parameters/climate_udeb.rs), booleans/enums/integers as doubles.
  * Rows marked [u] are structural and must be equal for every member.  n_layers: any count >= 2 as in the reference
- * (climate/udeb/mod.rs:162-165; at most 4096 here) -- 20, 30, 40 and 50 layers run the register-resident, unrolled column
- * solve, every other count a slower kernel with the columns in HBM (same arithmetic, same parity bar);
+ * (climate/udeb/mod.rs:162-165; at most 4096 here).  Up to 64 layers a member's two columns stay in registers + LDS for a
+ * whole launch (20, 30, 40, 50 with the count compiled in; every other count in the next capacity's instance of the same
+ * unrolled solve with the count at run time); more than 64 layers run a slower kernel with the columns in HBM (same
+ * arithmetic, same parity bar).  Device memory per handle besides the series: 2 x max(64, n_layers) x N x 8 B of columns,
+ * 11 x N x 8 B of scalars, T x N x 8 B of temperature history, and -- for counts other than 20 / 30 / 40 / 50 --
+ * n_layers x N x 8 B of work array (e.g. n_layers = 4096, N = 1e5: 9.8 GB; n_layers = 49: 90 MB).  The reference's MAGICC7
+ * files pin the 50-layer configuration only: at every other count parity is against the CPU restatement kept with the tests.
  * ocean_temp_profile = 2 (CMIP5) only. */
 #define RSCM_UD_NPARAMS 37
 #define RSCM_UD_P_N_LAYERS 0              /* [u] */
@@ -524,8 +534,11 @@ RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);
  * members than the chip holds wavefronts at one per SIMD, and over at least ~190 model steps, is issued as TWO member blocks on two
  * streams (the caller's and one of the handle's own, forked and joined with events), each in chunks of ~64 model steps: the same
  * kernels on the same operands -- the same bits -- and the wavefronts even out over the SIMDs (1e5 members x 750 years: 2.7 -> 2.3 ms).
+ * An unlinked whole-axis ClimateUDEB run over more than 65 536 members is cut the same way (two HALVES, chunks of ~96 steps; each
+ * chunk reloads and stores the block's ocean columns and scalars, which is how rscm_ens_run in pieces resumes anyway; both halves
+ * take the kernel variant chosen for the whole ensemble's size, so one run is one kernel).
  * member_blocks x step_chunks launches in all; 1 x 1 otherwise.  To the caller the run is one asynchronous operation on its stream
- * either way.  Environment RSCM_SPLIT_RUNS=0 turns the cut off. */
+ * either way: the helper stream and the fork / join events are the handle's own.  Environment RSCM_SPLIT_RUNS=0 turns the cut off. */
 RSCM_API int rscm_ens_last_run_plan(rscm_ens* h, int32_t* member_blocks, int32_t* step_chunks);
 
 /* ---- outputs ------------------------------------------------------------------------------ */

@@ -44,6 +44,14 @@ RSCM_API int rscm_gpu_lockstep_split_launches(int64_t* out);
  * The setting is per calling THREAD: launches issued from another thread do not see it. */
 RSCM_API int rscm_gpu_set_udeb_variant(int32_t variant);
 
+/* Fault injection for the cut runs (rscm_ens_last_run_plan: member blocks x step chunks on two streams): the k-th chunk launch
+ * (1-based, counted over both blocks in issue order) of the calling THREAD's next cut run is not issued and reports
+ * hipErrorLaunchFailure instead; the hook then turns itself off.  0 turns it off.  What must hold afterwards
+ * (tests/test_gpu_parity.py): rscm_ens_run returns RSCM_ERR_DEVICE, the caller's stream has been joined with the helper stream
+ * (nothing issued there is still running once the caller's stream is synchronised), the time index has not moved, and a fresh
+ * whole run gives the uncut path's bits. */
+RSCM_API int rscm_gpu_fail_chunk_launch(int32_t k);
+
 /* OceanCarbon in RSCM_MODE_FAST replaces the O(T^2) history convolution of carbon/ocean.rs:151-190 by an
  * O(T) recurrence: lags below `near_lags` months explicitly, the rest through decaying modes fitted to the
  * scaled impulse response (parameters/ocean_carbon.rs:85-216) by the host.  This runs that fit alone (no

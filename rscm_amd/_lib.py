@@ -265,6 +265,7 @@ SIGNATURES = {
     # not reach lock-step runs or ClimateUDEB launches issued from another, and the launch counters are the calling thread's own.
     "rscm_gpu_set_lockstep_fusion": (C.c_int, [C.c_int32]),
     "rscm_gpu_set_udeb_variant": (C.c_int, [C.c_int32]),
+    "rscm_gpu_fail_chunk_launch": (C.c_int, [C.c_int32]),
     "rscm_gpu_lockstep_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_gpu_lockstep_split_launches": (C.c_int, [C.POINTER(C.c_int64)]),
     "rscm_ens_sync": (C.c_int, [_h]),

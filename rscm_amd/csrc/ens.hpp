@@ -88,6 +88,7 @@ struct rscm_ens {
     double* d_derived = nullptr;
     bool derived_dirty = true;
     bool params_exposed = false; // rscm_ens_params_devptr handed the block out: uniform_rows stays 0 for the life of the handle
+    bool derived_hold = false;   // inside one rscm_ens_run_lockstep call: the member constants were formed at its start and serve all its steps
     double* d_series = nullptr;  // [(V-1)][T][N], variable v at slot v-1
     double* d_forcing = nullptr; // [S][n_inputs][T]
     int32_t n_inputs = 1;        // rows per scenario of the shared input block
@@ -254,8 +255,9 @@ inline int set_device(const rscm_ens* h)
 // One launch range of one handle, in pieces (rscm_gpu.cpp); rscm_ens_run_lockstep (lockstep.cpp) fuses the
 // launches of several handles out of the same pieces.
 extern "C" {
-int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end);
-int ensure_derived(rscm_ens* h);   // (called by step_check: every run starts with current member constants)
+int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end, bool derive = true);
+void set_fail_chunk_launch(int32_t k);   // test hook: the k-th chunk launch of the calling thread's next cut run fails (0: off)
+int ensure_derived(rscm_ens* h);   // (every run starts with current member constants: run_range after its first event, rscm_ens_run_lockstep once per call)
 int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out);
 // op_out: nothing is launched, the arguments go into a fused launch's table (kind -1: this handle cannot be fused)

@@ -46,6 +46,13 @@ int rscm_gpu_set_udeb_variant(int32_t variant)
     return RSCM_OK;
 }
 
+int rscm_gpu_fail_chunk_launch(int32_t k)
+{
+    if (k < 0) return fail(RSCM_ERR_INVALID, "chunk launch number %d (1-based; 0 turns the hook off)", k);
+    set_fail_chunk_launch(k);
+    return RSCM_OK;
+}
+
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
     if (enabled < 0 || enabled > 4) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..4)", enabled);
@@ -372,8 +379,15 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
     struct DeferGuard {
         rscm_ens* const* hs; int32_t n;
         DeferGuard(rscm_ens* const* h, int32_t k, WindowDeferral* d) : hs(h), n(k) { for (int32_t i = 0; i < n; ++i) hs[i]->defer = d; }
-        ~DeferGuard() { for (int32_t i = 0; i < n; ++i) hs[i]->defer = nullptr; }
+        ~DeferGuard() { for (int32_t i = 0; i < n; ++i) { hs[i]->defer = nullptr; hs[i]->derived_hold = false; } }
     } guard(handles, n_handles, t_ls.fuse ? &deferral : nullptr);
+    // The member constants of every handle once per call, also where the caller holds the parameter block's device pointer (such a
+    // block is re-derived before every run: here "run" is this call, not each of its one-step launches).
+    for (int32_t k = 0; k < n_handles; ++k) {
+        if (handles[k]->params_set)
+            if (int rc = ensure_derived(handles[k])) return rc;
+        handles[k]->derived_hold = true;
+    }
     if (segments.size() == 1 && segments[0].second > 1) {
         // The whole graph is one fused segment: many model steps per launch.  A chunk ends where a windowed
         // handle runs out of rows (its window slides between launches).

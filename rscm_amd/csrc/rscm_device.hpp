@@ -382,6 +382,8 @@ constexpr int kUdebMaxOnChipLayers = 64;   // up to this many ocean layers a mem
 struct UdebArgs {
     int64_t n_members;
     int64_t row_stride;     // as in TwoLayerArgs: the stride of every [..][N] array when a block of members is launched
+    int64_t n_total;        // members of the whole ensemble (0: n_members): the kernel variant is chosen by this, so that the member
+                            // blocks of one cut run take one kernel
     int32_t n_times;
     int32_t step_begin, step_end;
     int32_t n_scen;

@@ -1210,6 +1210,10 @@ int ensure_derived(rscm_ens* h)
 {
     if (!has_derived(h) || !h->params_set) return RSCM_OK;
     if (!h->derived_dirty && !h->params_exposed && h->d_derived) return RSCM_OK;
+    // a block the caller may write directly is re-derived before every run -- once per API call: the steps of one
+    // rscm_ens_run_lockstep call share the constants formed at its start (a one-step launch per model step used to pay the
+    // derive kernel, ClimateUDEB's secant solve, every step)
+    if (h->derived_hold && !h->derived_dirty && h->d_derived) return RSCM_OK;
     if (int rc = set_device(h)) return rc;
     if (!h->d_derived) {
         const hipError_t e = hipMalloc(&h->d_derived, (size_t)rscm::kDerivedRows * h->N * sizeof(double));
@@ -1223,7 +1227,7 @@ int ensure_derived(rscm_ens* h)
     return RSCM_OK;
 }
 
-int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
+int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end, bool derive)
 {
     NEED(h);
     if (step_begin < 0 || step_end > h->T - 1 || step_begin > step_end)
@@ -1252,7 +1256,7 @@ int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end)
     for (int32_t v = 1; v < h->V; ++v)
         if (h->is_state(v) && !h->initial_set[v])  // builder.rs:704-717 MissingInitialValue
             return fail(RSCM_ERR_STATE, "state variable %d has no initial value (MissingInitialValue)", v);
-    return ensure_derived(h);
+    return derive ? ensure_derived(h) : RSCM_OK;
 }
 
 // (2) schedule tables and the handle's own window: room for the rows this range writes
@@ -1349,7 +1353,11 @@ static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t st
     const int64_t per_round = (int64_t)cus * 4 * 64;   // one wavefront on every SIMD: 65 536 members on an MI355X
     if (h->N <= per_round) return m;                   // every wavefront has a SIMD to itself already
     m.first = halves ? (h->N / 2 + 63) / 64 * 64 : std::max(per_round, (h->N / 2) / per_round * per_round);
-    if (first_env > 0 && first_env < h->N) m.first = (first_env + 63) / 64 * 64;
+    if (first_env > 0) {   // (experiment knob) rounded up to whole wavefronts; ignored unless both blocks keep members
+        const int64_t want = (first_env + 63) / 64 * 64;
+        if (want > 0 && want < h->N) m.first = want;
+    }
+    if (!(m.first > 0 && m.first < h->N)) return m;   // never a block that reaches past the ensemble
     const int32_t n_chunks = (len + kChunk - 1) / kChunk;
     m.chunk = (len + n_chunks - 1) / n_chunks;
     m.on = true;
@@ -1362,6 +1370,11 @@ static int member_split_streams(rscm_ens* h)
     if (!h->split_join) HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
     return RSCM_OK;
 }
+// Test hook (include/rscm_gpu_internal.h, rscm_gpu_fail_chunk_launch): the k-th chunk launch of the calling thread's next cut run
+// reports a launch failure instead of being issued -- the only way to execute the join-after-failure path below.
+static thread_local int32_t t_fail_chunk = 0;
+void set_fail_chunk_launch(int32_t k) { t_fail_chunk = k; }
+
 // issue(begin, end, first_member, count, stream) launches one chunk of one block; the fork and the join around all of them
 static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begin, int32_t step_end,
                             const std::function<hipError_t(int32_t, int32_t, int64_t, int64_t, hipStream_t)>& issue)
@@ -1375,14 +1388,18 @@ static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begi
     static const int32_t chunk2_env = [] { const char* e = getenv("RSCM_SPLIT_CHUNK2"); return e ? atoi(e) : 0; }();
     const int32_t c0 = m.chunk, c1 = chunk2_env > 0 ? chunk2_env : m.chunk;
     hipError_t err = hipSuccess;
+    auto guarded = [&](int32_t b, int32_t e, int64_t m0, int64_t cnt, hipStream_t st) -> hipError_t {
+        if (t_fail_chunk > 0 && --t_fail_chunk == 0) return hipErrorLaunchFailure;   // (test hook)
+        return issue(b, e, m0, cnt, st);
+    };
     for (int32_t b0 = step_begin, b1 = step_begin; err == hipSuccess && (b0 < step_end || b1 < step_end);) {
         if (b0 < step_end && (b0 <= b1 || b1 >= step_end)) {
             const int32_t e = std::min(step_end, b0 + c0);
-            err = issue(b0, e, (int64_t)0, m.first, h->stream);
+            err = guarded(b0, e, (int64_t)0, m.first, h->stream);
             b0 = e;
         } else {
             const int32_t e = std::min(step_end, b1 + c1);
-            err = issue(b1, e, m.first, h->N - m.first, h->split_stream);
+            err = guarded(b1, e, m.first, h->N - m.first, h->split_stream);
             b1 = e;
         }
     }
@@ -1649,6 +1666,7 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         rscm::UdebArgs a{};
         a.n_members = h->N;
         a.row_stride = h->N;
+        a.n_total = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
         a.step_end = step_end;
@@ -1787,12 +1805,13 @@ int step_finish(rscm_ens* h, int32_t step_begin, int32_t step_end)
 int run_range(rscm_ens* h, int32_t step_begin, int32_t step_end, bool timed)
 {
     NEED(h);
-    if (int rc = step_check(h, step_begin, step_end)) return rc;
+    if (int rc = step_check(h, step_begin, step_end, false)) return rc;
     if (int rc = step_window_pre(h, step_begin, step_end)) return rc;
     rscm::InputLinks links{};
     int32_t linked = 0;
     if (int rc = step_links(h, step_begin, step_end, links, linked)) return rc;
     if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (int rc = ensure_derived(h)) return rc;   // (after the first event: rscm_ens_last_run_ms includes the derive launch)
     if (int rc = step_launch(h, step_begin, step_end, links, linked, nullptr)) return rc;
     if (int rc = step_finish(h, step_begin, step_end)) return rc;
     if (timed) {

@@ -46,13 +46,13 @@ using namespace udeb;
 
 // One thread per member (udeb_body.hpp: Udeb1): the launch of large ensembles.  DYN: NL is the capacity of the register-resident
 // column, the layer count is a.n_layers <= NL (every count the fixed instances do not cover, up to kUdebMaxOnChipLayers).
-template <int NL, bool FAST, bool DYN = false>
+template <int NL, bool FAST, bool DYN = false, int LOW = NL>
 __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 {
     __shared__ double park[NL][kUdebBlock];
     const int64_t i = (int64_t)blockIdx.x * kUdebBlock + threadIdx.x;
     if (i >= a.n_members) return;
-    Udeb1<NL, DYN> m(park);
+    Udeb1<NL, DYN, LOW> m(park);
     m.begin(a, i);
     if (m.status != 0) {  // the reference refuses to build this component: every output NaN
         for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<true, FAST>(a, n);
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(kUdebBlock) void udeb_kernel(UdebArgs a)
 }
 
 // Two wavefronts per 64 members, one hemisphere each (udeb_body.hpp), one wavefront per SIMD.
-template <int NL, bool FAST, bool DYN = false>
+template <int NL, bool FAST, bool DYN = false, int LOW = NL>
 __global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
 {
     __shared__ Udeb2Lds lds;
-    Udeb2<NL, DYN> m(lds);
+    Udeb2<NL, DYN, LOW> m(lds);
     m.begin(a);
     for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<FAST>(a, n);
     m.end(a);
@@ -121,18 +121,19 @@ hipError_t launch_udeb_derive(const double* params, uint64_t uniform_rows, int64
 static thread_local int t_udeb_variant = -1;
 void set_udeb_variant(int variant) { t_udeb_variant = variant; }
 
-template <int NL, bool DYN>
+// LOW: the smallest layer count a runtime-count instance serves (the previous capacity + 1)
+template <int NL, bool DYN, int LOW = NL>
 static void launch_udeb_nl(const UdebArgs& a, int variant, hipStream_t s)
 {
     const bool two_waves = variant == 2;
     if (two_waves) {
         const dim3 grid((unsigned)((a.n_members + 63) / 64));
-        if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true, DYN>), grid, dim3(kUdeb2Block), 0, s, a);
-        else hipLaunchKernelGGL((udeb2_kernel<NL, false, DYN>), grid, dim3(kUdeb2Block), 0, s, a);
+        if (a.fast) hipLaunchKernelGGL((udeb2_kernel<NL, true, DYN, LOW>), grid, dim3(kUdeb2Block), 0, s, a);
+        else hipLaunchKernelGGL((udeb2_kernel<NL, false, DYN, LOW>), grid, dim3(kUdeb2Block), 0, s, a);
     } else {
         const dim3 grid((unsigned)((a.n_members + kUdebBlock - 1) / kUdebBlock));
-        if (a.fast) hipLaunchKernelGGL((udeb_kernel<NL, true, DYN>), grid, dim3(kUdebBlock), 0, s, a);
-        else hipLaunchKernelGGL((udeb_kernel<NL, false, DYN>), grid, dim3(kUdebBlock), 0, s, a);
+        if (a.fast) hipLaunchKernelGGL((udeb_kernel<NL, true, DYN, LOW>), grid, dim3(kUdebBlock), 0, s, a);
+        else hipLaunchKernelGGL((udeb_kernel<NL, false, DYN, LOW>), grid, dim3(kUdebBlock), 0, s, a);
     }
 }
 
@@ -164,7 +165,7 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
     int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;
     const bool in_hbm = variant == 3 || !udeb_layers_unrolled(a.n_layers);
-    if (variant != 0 && variant != 2) variant = a.n_members <= 32768 ? 2 : 0;
+    if (variant != 0 && variant != 2) variant = (a.n_total > 0 ? a.n_total : a.n_members) <= 32768 ? 2 : 0;
     if (in_hbm) {   // more layers than the registers hold (or asked for): columns in HBM, plain loops
         if (a.n_layers < 2 || !a.tables_dev || !a.work) return hipErrorInvalidValue;
         const dim3 grid((unsigned)((a.n_members + 255) / 256));
@@ -178,11 +179,11 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
         case 40: launch_udeb_nl<40, false>(a, variant, s); break;
         case 50: launch_udeb_nl<50, false>(a, variant, s); break;
         default:   // any other count: the smallest capacity that holds it, the count at run time
-            if (a.n_layers < 20) launch_udeb_nl<20, true>(a, variant, s);
-            else if (a.n_layers < 30) launch_udeb_nl<30, true>(a, variant, s);
-            else if (a.n_layers < 40) launch_udeb_nl<40, true>(a, variant, s);
-            else if (a.n_layers < 50) launch_udeb_nl<50, true>(a, variant, s);
-            else launch_udeb_nl<kUdebMaxOnChipLayers, true>(a, variant, s);
+            if (a.n_layers < 20) launch_udeb_nl<20, true, 2>(a, variant, s);
+            else if (a.n_layers < 30) launch_udeb_nl<30, true, 21>(a, variant, s);
+            else if (a.n_layers < 40) launch_udeb_nl<40, true, 31>(a, variant, s);
+            else if (a.n_layers < 50) launch_udeb_nl<50, true, 41>(a, variant, s);
+            else launch_udeb_nl<kUdebMaxOnChipLayers, true, 51>(a, variant, s);
     }
     return hipGetLastError();
 }

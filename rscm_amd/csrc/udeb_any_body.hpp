@@ -70,27 +70,22 @@ __device__ __forceinline__ double step_hemisphere_any(const UdebP& p, const Year
 #pragma unroll
             for (int k = 0; k < kTabCols; ++k) r_ahead[k] = nxt[k];
         }
+        // one formula for every row below the mixed layer: the bottom row's table entries say af_bot = 0, af_diff = af_top
+        // (udeb_tables.hpp), as in the unrolled kernels -- the same bits
         const double tdu_aft = tdu * af_top;
-        if (i < NL - 1) {
-            const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
-            const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
-            const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
-            const double denom = __builtin_fma(-tdu_aft, ncp_prev, bi);
-            const double r0 = __builtin_amdgcn_rcp(denom);
-            const double e = __builtin_fma(-denom, r0, 1.0);
-            const double u = FAST ? e : __builtin_fma(e, e, e);
-            const double t = (tdd + tul) * af_bot * r0;
-            ncp_prev = __builtin_fma(t, u, t);
-            const double sdp = __builtin_fma(tdu_aft, dp_prev, di) * r0;
-            dp_prev = __builtin_fma(sdp, u, sdp);
-            ncp[(size_t)i * N] = ncp_prev;
-            tdu = tdd;
-        } else {
-            const double bi = __builtin_fma(tdu + tul, af_top, 1.0);
-            const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_top, t_i));
-            const double denom = __builtin_fma(-tdu_aft, ncp_prev, bi);
-            dp_prev = __builtin_fma(tdu_aft, dp_prev, di) * refined_rcp(denom);
-        }
+        const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
+        const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
+        const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
+        const double denom = __builtin_fma(-tdu_aft, ncp_prev, bi);
+        const double r0 = __builtin_amdgcn_rcp(denom);
+        const double e = __builtin_fma(-denom, r0, 1.0);
+        const double u = FAST ? e : __builtin_fma(e, e, e);
+        const double t = (tdd + tul) * af_bot * r0;
+        ncp_prev = __builtin_fma(t, u, t);
+        const double sdp = __builtin_fma(tdu_aft, dp_prev, di) * r0;
+        dp_prev = __builtin_fma(sdp, u, sdp);
+        ncp[(size_t)i * N] = ncp_prev;
+        tdu = tdd;
         T[(size_t)i * N] = dp_prev;
     }
     // ---- back substitution, clamp (thomas_solve returns the unclamped vector; the state keeps min(x, max_temp))

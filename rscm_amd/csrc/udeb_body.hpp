@@ -304,7 +304,9 @@ struct YearGeom {
 //   b_i        = 1 + (tdu + tul)*af_top[i] + tdd*af_bot[i]
 //   d_i        = T_i + (pi*tul*T0)*af_diff[i] + (dt/dz*dw)*G[i]
 //   G[i]       = init[i+1]*af_bot[i] - init[i]*af_top[i] + T_polar*af_diff[i]   (host table)
-// and the Thomas recurrences with one refined reciprocal per row; c' is kept negated.
+// and the Thomas recurrences with one reciprocal per row, refined by its series; c' is kept negated.  The bottom row is an
+// interior row whose table entries say af_bot = 0, af_diff = af_top (udeb_tables.hpp): one formula for every row below the
+// mixed layer.
 // FAST (RSCM_MODE_FAST): one refinement term of the row reciprocals instead of two (relative error 2^-46 instead of 2^-69 per row).
 //
 // The geometry tables are rows of six values per layer, [NL][6] = {af_top, af_bot, af_diff, 1 - relative depth, G_nh, G_sh}
@@ -317,16 +319,20 @@ struct YearGeom {
 // vector lanes), and a scheduling barrier per chunk keeps each request where it is written.
 //
 // DYN (a runtime layer count in a column of CAPACITY NL): the reference takes every n_layers >= 2 at the same cost per layer
-// (parameters/climate_udeb.rs:41, mod.rs:162-165).  The column still lives in the registers of dp[NL] and the sweep is still
-// unrolled over NL rows, but the rows that exist are [0, nl), nl = n_layers <= NL, wave-uniform: every row starts with a scalar
-// compare-and-branch on nl -- interior row, bottom row, or past the end -- and the statements of a live row are the ones of
-// the fixed-count kernel, so a count runs the same arithmetic whichever capacity holds it.  The table's rows [nl, NL) are zero
-// (never used, but requested with their chunk).  The bottom temperature, dp[nl - 1], has no static register index: the caller
-// carries it in *bottom across the solves (set here from the clamped bottom row).
+// (parameters/climate_udeb.rs:41, mod.rs:162-165).  The sweep stays one straight line of NL rows -- a first attempt that skipped
+// the rows past the end with a scalar branch per row ran 3.4x slower than the fixed-count kernel (182 against 53 ms at 49 / 50
+// layers, 65 536 members x 750 years): each row became its own basic block and nothing of the next row's arithmetic ran under
+// the latency of this row's reciprocal.  Instead the rows [nl, NL) are DATA: their table rows are zero, so b = 1, c' = 0 and
+// d = the row's own (zero) temperature; the forward sweep leaves them zero, the back substitution passes through them with
+// x = fma(0, x, 0), and the live bottom row, whose c' is 0 as well, gets fma(0, 0, d') = d' exactly.  The statements of a live
+// row are those of the fixed-count kernel: a count carries the same bits whichever kernel holds it.  What needs the count at
+// run time: the bottom temperature dp[nl - 1] (no static register index: the caller carries it in *bottom; it is picked up
+// from the clamped solution with a select on the rows [LOW - 1, NL) this instance can end at), and the two-layer case of the
+// reference's dz_up rule.
 constexpr int kRowsAhead = 3;
 constexpr int kTabCols = 6;
 
-template <int NL, bool FAST, bool DYN = false>
+template <int NL, bool FAST, bool DYN = false, int LOW = NL>
 __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom& y,
                                                   const double* tables, int32_t land_hc,
                                                   double (&dp)[NL], int hemi,
@@ -374,10 +380,8 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
 
     double ncp[NL];  // -c'
     double tdu = 0.0;
-    double x_bot = 0.0;   // DYN: the bottom row's solution, where the back substitution starts
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (DYN && c * R >= nl) continue;   // (not an early exit: the unroller wants one way out of the loop)
         await(cur);
         if (c + 1 < NCH) request(nxt, tab, (c + 1) * R);
         // Nothing crosses: the request stays above the chunk it runs under (left alone the scheduler sinks it to where its values are
@@ -389,7 +393,6 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
         for (int r = 0; r < R; ++r) {
             const int i = c * R + r;
             if (i >= NL) break;
-            if (DYN && i >= nl) continue;
             const double af_top = cur[r][0], af_bot = cur[r][1], af_diff = cur[r][2], omr = cur[r][3], G = sh ? cur[r][5] : cur[r][4];
             if (i == 0) {   // ---- row 0 (mixed layer)
                 const double kap0 = fmax(__builtin_fma(omr, kslope, y.kC), y.kminC);
@@ -409,38 +412,24 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
                 tdu = kap0 * ((DYN && nl == 2) ? y.dt_dz2 : y.dt_dzdz1);
                 continue;
             }
-            // ---- interior rows and the bottom row: forward sweep
+            // ---- every row below the mixed layer (the bottom row by its table entries; rows past the end of a DYN column: no-ops)
             const double t_i = dp[i];
             const double tdu_aft = tdu * af_top;
-            if (i < nl - 1) {
-                const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
-                const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
-                const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
-                const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
-                // 1/denom = r0 (1 + e + e^2 + ...), e = 1 - denom*r0: the hardware estimate is good
-                // to ~2^-23, so the series cut after e^2 is exact to rounding, and the c' chain that
-                // feeds the next row's denominator is five dependent operations instead of seven
-                const double r0 = __builtin_amdgcn_rcp(denom);
-                const double e = __builtin_fma(-denom, r0, 1.0);
-                const double u = FAST ? e : __builtin_fma(e, e, e);
-                const double t = (tdd + tul) * af_bot * r0;
-                ncp[i] = __builtin_fma(t, u, t);
-                const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
-                dp[i] = __builtin_fma(sdp, u, sdp);
-                tdu = tdd;
-            } else {
-                const double bi = __builtin_fma(tdu + tul, af_top, 1.0);
-                const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_top, t_i));
-                const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
-                const double xb = __builtin_fma(tdu_aft, dp[i - 1], di) * refined_rcp(denom);
-                if constexpr (DYN) {
-                    x_bot = xb;
-                    dp[i] = fmin(xb, p.max_temp);
-                    *bottom = dp[i];
-                } else {
-                    dp[i] = xb;
-                }
-            }
+            const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
+            const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
+            const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
+            const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
+            // 1/denom = r0 (1 + e + e^2 + ...), e = 1 - denom*r0: the hardware estimate is good
+            // to ~2^-23, so the series cut after e^2 is exact to rounding, and the c' chain that
+            // feeds the next row's denominator is five dependent operations instead of seven
+            const double r0 = __builtin_amdgcn_rcp(denom);
+            const double e = __builtin_fma(-denom, r0, 1.0);
+            const double u = FAST ? e : __builtin_fma(e, e, e);
+            const double t = (tdd + tul) * af_bot * r0;
+            ncp[i] = __builtin_fma(t, u, t);
+            const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
+            dp[i] = __builtin_fma(sdp, u, sdp);
+            tdu = tdd;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -448,20 +437,21 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
             for (int k = 0; k < kTabCols; ++k) cur[r][k] = nxt[r][k];
     }
     // ---- back substitution, clamp.  thomas_solve returns the unclamped vector; the state keeps
-    // min(x, max_temp)
-    double x;
-    if constexpr (DYN) {
-        x = x_bot;   // (its row was clamped where it was solved)
-    } else {
-        x = dp[NL - 1];
-        dp[NL - 1] = fmin(x, p.max_temp);
-    }
+    // min(x, max_temp).  (The last row's c' is 0 -- the bottom row's by its table entries, a dead row's because all of its are.)
+    double bot = 0.0;
+    auto pick_bottom = [&](int i) {   // DYN: the clamped solution of the row that is this column's last
+        if constexpr (DYN) bot = (i == nl - 1) ? dp[i] : bot;
+    };
+    double x = dp[NL - 1];
+    dp[NL - 1] = fmin(x, p.max_temp);
+    pick_bottom(NL - 1);
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) {
-        if (DYN && i >= nl - 1) continue;
         x = __builtin_fma(ncp[i], x, dp[i]);
         dp[i] = fmin(x, p.max_temp);
+        if (i >= LOW - 1) pick_bottom(i);
     }
+    if constexpr (DYN) *bottom = bot;
     return dp[0];
 }
 
@@ -472,8 +462,9 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
 // the solver's d' array), the other one is parked in this lane's LDS slots (park[layer][lane]: 8 NL bytes per lane,
 // each lane touches only its own slots -- no barriers, no bank conflicts) and the two are exchanged after every
 // column solve.  HBM sees the columns once in begin() (resume) and once in end(): ocean[hemi][layer][N].
-// DYN: NL is the capacity, the column has nl = a.n_layers <= NL rows (step_hemisphere); HBM keeps [2][nl][N].
-template <int NL, bool DYN = false>
+// DYN: NL is the capacity, the column has nl = a.n_layers rows, LOW <= nl <= NL (step_hemisphere); HBM keeps [2][nl][N]; the
+// rows past the end are zero in registers and in LDS and are carried along.
+template <int NL, bool DYN = false, int LOW = NL>
 struct Udeb1 {
     double (*park)[kUdebBlock];
     int lane;
@@ -698,7 +689,7 @@ struct Udeb1 {
 #pragma unroll
             for (int hemi = 0; hemi < 2; ++hemi) {
                 const bool sh = hemi != 0;
-                sst_pair[hemi] = step_hemisphere<NL, FAST, DYN>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
+                sst_pair[hemi] = step_hemisphere<NL, FAST, DYN, LOW>(p, y, tables, a.land_hc, col, hemi, sh ? f2 : f0,
                                                                 sh ? hx_sh : hx_nh, sh ? gr_sh : gr_nh,
                                                                 sh ? land_sh : land_nh, sh ? ae_sh_y : ae_nh_y,
                                                                 sh ? up_sh : up_nh, nl, &bot_cur);
@@ -709,7 +700,6 @@ struct Udeb1 {
                 // starts to spill, and 65 536 members x 750 years take 58.8 ms instead of 54.8.)
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
-                    if (DYN && l >= nl) continue;
                     const double other = park[l][lane];
                     park[l][lane] = col[l];
                     col[l] = other;
@@ -830,7 +820,7 @@ struct Udeb2Lds {
 // or resume), step(n) for consecutive n, end() (internal state back to HBM).  Every thread of the workgroup
 // must make the same calls: step() and begin() hold workgroup barriers.  Lanes past the end of the ensemble
 // compute on a copy of the last member and store nothing.
-template <int NL, bool DYN = false>
+template <int NL, bool DYN = false, int LOW = NL>
 struct Udeb2 {
     Udeb2Lds& lds;
     int tid, lane;
@@ -1031,7 +1021,7 @@ struct Udeb2 {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f_ocean = adj * q_o, f_land = adj * q_l;
             if (a.land_hc) gr = __builtin_fma(land - gr, gfac, gr);
-            const double sst = step_hemisphere<NL, FAST, DYN>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up, nl, &bot);   // the same function as the one-thread kernel: the same bits
+            const double sst = step_hemisphere<NL, FAST, DYN, LOW>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up, nl, &bot);   // the same function as the one-thread kernel: the same bits
             t_air = sst_to_air(airmap, sst);
             land = land_temperature(ka, p.max_temp, t_air, f_land, fg_l, r_land);
             // what the other hemisphere needs of this one: air and land temperature

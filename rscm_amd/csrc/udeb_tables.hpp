@@ -59,6 +59,12 @@ inline double ocean_area_at_depth(double depth_m, double depth_dependent_area)
 //   G[0]     = (init[1] - T_polar) * af_bot[0]
 //   G[l]     = init[l+1]*af_bot[l] - init[l]*af_top[l] + T_polar*af_diff[l]      0 < l < n-1
 //   G[n-1]   = (T_polar - init[n-1]) * af_top[n-1]
+// The BOTTOM row's af_bot is stored as 0 and its af_diff as af_top[n-1]: the last row of the tridiagonal system has no lower
+// neighbour (ocean_column.rs:188-198: b = 1 + (diff_up + upwell) af_top, no c, entrainment weighted by af_top instead of
+// af_diff), which is exactly what an interior row's formulas give with those two values -- 1 + tdd*0 is 1, c' is 0 -- so the
+// kernels run ONE row formula for every row below the mixed layer and never ask which row is the last.  That is what lets the
+// layer count be a run-time value in an unrolled sweep (udeb_body.hpp): rows past the end read all-zero table rows and stay
+// exact no-ops (b = 1, c' = 0, d = the row's own zero).
 constexpr int kUdebTableCols = 6;
 inline std::vector<double> udeb_tables(int n, double dz_mix, double dz, double depth_dependent_area)
 {
@@ -94,6 +100,8 @@ inline std::vector<double> udeb_tables(int n, double dz_mix, double dz, double d
         for (int l = 1; l < n - 1; ++l) G(l) = init(l + 1) * afb[l] - init(l) * aft[l] + t_polar * afd[l];
         G(n - 1) = (t_polar - init(n - 1)) * aft[n - 1];
     }
+    t[(size_t)(n - 1) * kUdebTableCols + 1] = 0.0;            // (after G, which is built from the true area factors)
+    t[(size_t)(n - 1) * kUdebTableCols + 2] = aft[n - 1];
     return t;
 }
 

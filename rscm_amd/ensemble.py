@@ -234,7 +234,9 @@ class Ensemble:
 
     def last_run_plan(self):
         """(member blocks, step chunks) the most recent run was cut into: (2, k) when a whole-axis run of the two-layer or the
-        coupled kind was issued as two member blocks on two streams in k chunks of model steps (rscm_ens_last_run_plan), else (1, 1)."""
+        coupled kind -- or an unlinked ClimateUDEB run over more than 65 536 members (two halves, each chunk reloading and storing
+        the block's columns) -- was issued as two member blocks on two streams in k chunks of model steps
+        (rscm_ens_last_run_plan), else (1, 1)."""
         mb, sc = C.c_int32(), C.c_int32()
         L.check(self._lib.rscm_ens_last_run_plan(self._h, C.byref(mb), C.byref(sc)))
         return mb.value, sc.value

@@ -32,12 +32,65 @@ def test_header_and_binding_table_agree():
     assert decl == set(_lib.SIGNATURES)
 
 
+_C_BASE = {"int": "i4", "int32_t": "i4", "uint32_t": "u4", "int64_t": "i8", "uint64_t": "u8", "double": "f8", "float": "f4",
+           "uint8_t": "u1", "char": "i1", "void": "void", "rscm_ens": "void", "rscm_sampler": "void"}   # opaque handles travel as void*
+
+
+def _c_type(text):
+    """Canonical form of one C parameter or return type as the header writes it: base type by kind and width, one "p:" per level of
+    indirection (`double out[4]` is a pointer; `const` does not change the ABI); the parameter's name, if any, is dropped."""
+    text = text.replace("const", " ").strip()
+    depth = text.count("*") + text.count("[")
+    words = re.findall(r"[A-Za-z_]\w*", re.sub(r"\[.*?\]", " ", text))
+    assert words and words[0] in _C_BASE, text
+    return "p:" * depth + _C_BASE[words[0]]
+
+
+def _prototypes(headers=("rscm_gpu.h", "rscm_gpu_internal.h")):
+    out = {}
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for ret, name, args in re.findall(r"RSCM_API\s+([\w\s\*]+?)\b(rscm_\w+)\s*\(([^)]*)\)\s*;", text):
+            args = [a for a in (x.strip() for x in args.split(",")) if a and a != "void"]
+            out[name] = (_c_type(ret), [_c_type(a) for a in args])
+    return out
+
+
+def _ctypes_type(t):
+    import ctypes as C
+    if t is None:
+        return "void"
+    if t is C.c_void_p:
+        return "p:void"
+    if t is C.c_char_p:
+        return "p:i1"
+    if hasattr(t, "_type_") and not isinstance(t._type_, str):   # POINTER(X)
+        return "p:" + _ctypes_type(t._type_)
+    kind = {"i": "i", "l": "i", "q": "i", "I": "u", "L": "u", "Q": "u", "B": "u", "b": "i", "d": "f", "f": "f", "P": "p:void", "z": "p:i1"}[t._type_]
+    return kind if kind.startswith("p:") else f"{kind}{C.sizeof(t)}"
+
+
+def test_binding_table_agrees_with_the_header_by_type():
+    """Every entry of the ctypes table against the C prototype in the headers, argument by argument: kind (signed / unsigned / float
+    / pointer), width and level of indirection -- the compiler checks the header against the implementation, this checks the
+    Python table against the header (an int64 passed as int32, a missing argument or a double taken for a pointer would corrupt a
+    call silently)."""
+    protos = _prototypes()
+    assert set(protos) == set(_lib.SIGNATURES)
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        want_ret, want_args = protos[name]
+        assert _ctypes_type(restype) == want_ret, (name, "return", _ctypes_type(restype), want_ret)
+        got = [_ctypes_type(a) for a in argtypes]
+        assert got == want_args, (name, got, want_args)
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # binds each symbol; AttributeError if one is missing
     for name in _declared():
         assert hasattr(lib, name)
     assert lib.rscm_gpu_abi_version() == 1
-    assert lib.rscm_gpu_abi_minor() >= 3
+    assert lib.rscm_gpu_abi_minor() >= 4
     assert lib.rscm_gpu_last_error() is not None
 
 

@@ -1,0 +1,82 @@
+"""A compiled, non-Python caller of the boundary: tests/c_abi/caller.c (strict C11, includes only include/rscm_gpu.h, links
+rscm_amd/librscm_gpu.so) does ModelRunner::run_batch's job for the two-layer model
+(crates/rscm-calibrate/src/model_runner.rs:161-266) the way a Rust / cgo / JNI host would: through the C prototypes, not through
+ctypes.  CPU tier: it compiles and links with -Wall -Wextra -Werror -pedantic and fails loudly without a GPU.  GPU tier: its output
+equals the oracle's bit for bit on every member and kept row."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOW = np.array([0.8, 0.0, 1.0, 0.5, 5.0, 50.0])
+HIGH = np.array([1.5, 0.1, 1.8, 1.0, 15.0, 200.0])
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "caller")
+    libdir = os.path.join(ROOT, "rscm_amd")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "caller.c"), "-o", exe, "-L", libdir, "-lrscm_gpu", f"-Wl,-rpath,{libdir}",
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_c_caller_builds_against_the_header_alone(tmp_path):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 64 and "usage" in r.stderr
+    if _gpus() == 0:   # no CPU fallback behind the C-ABI either: the first device call reports, the caller exits non-zero
+        r = subprocess.run([exe, str(tmp_path / "out.bin"), "8"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "rscm_gpu_device_count failed" in r.stderr and not (tmp_path / "out.bin").exists()
+
+
+def caller_inputs(n):
+    """The caller's inputs re-formed with the same integer and IEEE operations (no libm on either side)."""
+    i = np.arange(n, dtype=np.uint64)[:, None]
+    j = np.arange(6, dtype=np.uint64)[None, :]
+    hashed = (i * np.uint64(2654435761) + j * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    u = hashed.astype(np.float64) / 4294967296.0
+    params = LOW[None, :] + (HIGH - LOW)[None, :] * u          # [N][P]
+    t = np.arange(1750, 2501, dtype=np.float64)
+    x = (t - 1750.0) / 120.0
+    return params, 4.0 * x / (1.0 + x), np.append(t, 2501.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
+@pytest.mark.parametrize("n", [1000, 70_000])   # one launch; a run cut into two member blocks on two streams
+def test_c_caller_matches_the_oracle_bit_for_bit(tmp_path, n):
+    from oracle import cbind
+    exe = _build(tmp_path)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([exe, str(out), str(n)], capture_output=True, text=True, timeout=600)   # a child process, never an exec
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    raw = out.read_bytes()
+    n_file, kept = np.frombuffer(raw, dtype=np.int64, count=2)
+    rows = np.frombuffer(raw, dtype=np.int32, count=int(kept), offset=16)
+    off = 16 + 4 * int(kept)
+    ts = np.frombuffer(raw, dtype=np.float64, count=int(kept) * n, offset=off).reshape(int(kept), n)
+    td = np.frombuffer(raw, dtype=np.float64, count=int(kept) * n, offset=off + 8 * int(kept) * n).reshape(int(kept), n)
+    status = np.frombuffer(raw, dtype=np.uint8, count=n, offset=off + 16 * int(kept) * n)
+    assert n_file == n and list(rows) == list(range(0, 751, 50)) and len(raw) == off + 16 * int(kept) * n + n
+    params, forcing, bounds = caller_inputs(n)
+    want_ts, want_td = cbind.two_layer_run(bounds, np.ascontiguousarray(params.T), forcing, 0.0, 0.0, threads=8)
+    assert np.array_equal(ts.view(np.uint64), want_ts[rows].view(np.uint64))
+    assert np.array_equal(td.view(np.uint64), want_td[rows].view(np.uint64))
+    bad = ~(np.isfinite(want_ts[-1]) & np.isfinite(want_td[-1]))
+    assert np.array_equal(status != 0, bad)
+    assert line["members"] == n and line["time_index"] == 750 and line["failed_members"] == int(bad.sum())
+    assert (line["member_blocks"], line["step_chunks"] > 1) == ((2, True) if n > 65536 else (1, False))
+    fin = np.isfinite(want_ts[270])
+    assert line["ts_2020_count"] == fin.sum() and abs(line["ts_2020_mean"] - want_ts[270][fin].mean()) < 1e-9
