@@ -106,11 +106,69 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
     return hbm, valu
 
 
+CONFIGS3_SERIES = 36                     # stored variables of the MAGICC graph (scripts/bench_magicc_chain.py)
+
+
+def configs3_roofline(members, steps, run_s, ranks=1):
+    """`roofline` of a configs[3] share: algorithmic bytes = every stored variable's new row, 36 x 8 B per member and monthly step
+    (what the reference's stepper writes into its collection, runtime.rs:480), over the run's wall time.  The run is 4 launches per
+    step in a dependency chain, two thirds of it ClimateUDEB's 12 column solves: FP64 issue and launch latency bind, not HBM."""
+    alg = CONFIGS3_SERIES * 8.0 * members * steps * ranks
+    gbs = alg / run_s / 1e9
+    return {"bound": "hbm", "binding": "fp64_valu (ClimateUDEB, ~2/3 of a step) + the dependency chain of 4 launches per step",
+            "achieved": gbs, "peak": HBM_PEAK_GBS * ranks, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * ranks), "traffic": None,
+            "algorithmic_bytes": alg, "algorithmic_bytes_per_member_step": CONFIGS3_SERIES * 8.0,
+            "traffic_note": "no PMC pass of this run; by its layout a step also moves ClimateUDEB's two 50-layer columns in and out "
+                            "(1600 B per member) and reads each linked row back once (~300 B): ~2.2 KB per member-step, 7.6x the algorithmic bytes",
+            "note": "36 series x 8 B x members x monthly steps / run wall time"}
+
+
+UDEB_ALG_BYTES_PER_MEMBER_YEAR = 72.0   # 7 output rows + the history row written, ~1 history entry read back (the columns stay on chip)
+
+
+def udeb_rooflines(members, years, kernel_ms, plan=(1, 1)):
+    """`roofline` (HBM, algorithmic 72 B per member-year) and the binding FP64-issue figure of a ClimateUDEB launch.  The executed
+    instruction count, the issue utilisation and the clock come from this round's PMC summary of the 50-layer kernel at 65 536
+    members (profiles/traffic.json -> profiles/r5_udeb_65536.txt), not from constants in this file."""
+    prof = profile_entry("udeb", 65536, "exact")
+    my = members * years
+    gbs = UDEB_ALG_BYTES_PER_MEMBER_YEAR * my / (kernel_ms * 1e-3) / 1e9
+    traffic = prof.get("bytes") * members / 65536.0 if prof.get("bytes") else None   # measured at 65 536 members, linear in the members
+    hbm = {"bound": "hbm", "binding": "fp64_valu", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": (f"{prof.get('source')}: measured at 65 536 members, scaled by the member count"
+                                                  if traffic else None),
+           "kernel": "udeb2_kernel" if members <= 32768 else "udeb_kernel", "kernel_ms": kernel_ms,
+           "algorithmic_bytes": UDEB_ALG_BYTES_PER_MEMBER_YEAR * my, "launches_per_pass": plan[0] * plan[1],
+           "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
+           "note": "7 output rows + the history row per member-year; the two 50-layer columns stay in registers + LDS for the launch"}
+    out = {"hbm_frac": gbs / HBM_PEAK_GBS, "roofline": hbm}
+    per_wy = prof.get("valu_per_wavefront_year")
+    if per_wy:   # vector instructions per wavefront-year as EXECUTED (SQ_INSTS_VALU / waves / years; ~12 % are not f64 arithmetic:
+        # moves between register files, compares, selects) x 64 lanes against 39.3 T f64 lane-ops/s at the nominal clock
+        tins = per_wy * my / (kernel_ms * 1e-3) / 1e12
+        out["roofline_fp64_valu"] = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR,
+                                     "valu_instructions_per_wavefront_year_executed": per_wy,
+                                     "measured_valu_issue_utilisation_at_65536": prof.get("valu_issue_utilisation"),
+                                     "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
+                                     "counters_source": prof.get("source"),
+                                     "note": "one wavefront per SIMD (256 VGPR + 209 AGPR): nothing hides a dependent instruction's latency but the "
+                                             "other hemisphere's independent rows; utilisation is of the 4-cycle issue limit at the measured clock"}
+        out["fp64_valu_frac"] = tins / FP64_VALU_PEAK_TINSTR
+    return out
+
+
 def describe_run_plan(roofline, plan):
     """How one pass was issued (rscm_ens_last_run_plan): `kernel_ms` is the HIP-event time of a whole pass on the launch stream, which
     forks into and joins the library's second stream -- with a cut it covers blocks x chunks overlapping launches of the kernel."""
-    blocks, chunks = plan
+    blocks, chunks = plan[0], plan[1]
+    tasks, task_steps = (plan[2], plan[3]) if len(plan) > 2 else (0, 0)
     roofline["launches_per_pass"] = blocks * chunks
+    if tasks:
+        roofline["kernel"] = "two_layer_queue_kernel"
+        roofline["tasks_per_pass"] = tasks
+        roofline["run_plan"] = (f"ONE persistent launch: a work queue of {tasks} tasks = (64-member block, chunk of {task_steps} model steps) claimed by "
+                                "resident wavefronts in chunk-major order, a block's chunk waiting only for the same block's previous chunk "
+                                "(csrc/two_layer.hip, rscm_ens_last_run_tasks): the same body on the same operands, the SIMDs evenly loaded to the end")
     if blocks * chunks > 1:
         roofline["run_plan"] = (f"{blocks} member blocks on two streams x {chunks} chunks of model steps, issued in turn: the same kernel on the same "
                                 "operands, the wavefronts evened out over the SIMDs (include/rscm_gpu.h, rscm_ens_last_run_plan); kernel_ms = "
@@ -418,7 +476,7 @@ def scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, ye
             ev[1].record(tstream)
 
         def after(ens):
-            return {"kernel_ms": ev[0].elapsed_time(ev[1]) / max(1, box["n"]), "run_plan": list(ens.last_run_plan()),
+            return {"kernel_ms": ev[0].elapsed_time(ev[1]) / max(1, box["n"]), "run_plan": list(ens.last_run_plan() + ens.last_run_tasks()),
                     "failed_members": int(ens.status().sum())}
 
         out = scale_measure(rank, world, torch, dist, prepare, body, lambda e: e.sync(), lambda e: e.close(),
@@ -475,6 +533,7 @@ def scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, ye
         out["run_s"] = out["wall_s"]
         out["per_rank"]["run_s"] = out["per_rank"]["own_s"]
         out["member_years_per_s"] = float(out["ranks"]) * members * yrs / out["wall_s"]
+        out["roofline"] = configs3_roofline(members, yrs * 12, out["wall_s"], out["ranks"])
         out["parity_anchor_all_ranks"] = all(f["first_64_members_equal_a_64_member_run"] for f in facts)
         out["failed_members"] = sum(f["failed_members"] for f in facts)
         if not out["parity_anchor_all_ranks"] or out["failed_members"]:
@@ -1010,7 +1069,7 @@ def main():
     wall, kernel_ms = timed_passes(ens, args.steps, args.warmup, torch, dist, world, tstream)
     n_fail = int(ens.status().sum())
     fails = _gather_obj(dist, n_fail)
-    run_plan = ens.last_run_plan()
+    run_plan = ens.last_run_plan() + ens.last_run_tasks()
     s_mid = ens.summary("Surface Temperature", 270)  # year 2020
     gather = loss_gather_report(ens, args.members, world, dist)
     ens.close()
@@ -1043,7 +1102,7 @@ def main():
             e2 = make_ensemble(members, local_rank, 0, 1, m, stream, coupled=cp)
             k = max(3, args.steps // 4)
             w2, k2 = timed_passes(e2, k, 1, torch, dist, 1, tstream)
-            plan2 = e2.last_run_plan()
+            plan2 = e2.last_run_plan() + e2.last_run_tasks()
             e2.close()
             bpy = 56.0 if cp else ALG_BYTES_PER_MEMBER_YEAR
             out = {"member_years_per_s": members * years * k / w2, "kernel_ms": k2,
@@ -1067,17 +1126,9 @@ def main():
             # SIMD, exactly one round; 1e5: 1563 wavefronts on 1024 SIMDs, two rounds; 32 768: the two-wavefront kernel)
             e3 = make_udeb_ensemble(members, local_rank, stream)
             w3, k3 = timed_passes(e3, 2, 1, torch, dist, 1, tstream)
+            plan3 = e3.last_run_plan()
             e3.close()
-            return {"member_years_per_s": members * years * 2 / w3, "kernel_ms": k3,
-                    # 7 output rows + the history row written, ~1 history entry read back;
-                    # the ocean columns stay in registers/LDS for the whole launch
-                    "hbm_frac": 72.0 * members * years / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    # 28.7e3 vector instructions per wavefront-year as EXECUTED (SQ_INSTS_VALU of profiles/r3_udeb_65536.txt; 12 % of them are
-                    # not f64 arithmetic: moves between register files, compares, selects) against 39.3 T f64 lane-ops/s; the
-                    # same profile's measured issue utilisation is beside it (0.67 at 65 536 members: one wavefront per SIMD)
-                    "fp64_valu_frac": 28.7e3 * members * years / (k3 * 1e-3) / 39.3e12,
-                    "valu_instructions_per_member_year": 28.7e3, "valu_count_source": "profiles/r3_udeb_65536.txt (SQ_INSTS_VALU / waves / years)",
-                    "measured_valu_issue_utilisation_at_65536": 0.67}
+            return dict({"member_years_per_s": members * years * 2 / w3, "kernel_ms": k3}, **udeb_rooflines(members, years, k3, plan3))
 
         side("udeb_1e5", lambda: udeb_case(100_000))
         side("udeb_65536", lambda: udeb_case(65_536))
@@ -1123,6 +1174,7 @@ def main():
                 sys.argv = argv
             out = json.loads(buf.getvalue().strip().splitlines()[-1])
             out["exit_code"] = code
+            out["roofline"] = configs3_roofline(125_000, 9000, out["run_s"])
             if code not in (0, None):  # the parity anchor (first 64 members == a 64-member run) or a member failed
                 raise RuntimeError(f"run_configs3_share exited with {code}: {json.dumps(out)[:400]}")
             return out

@@ -266,6 +266,7 @@ SIGNATURES = {
     "rscm_gpu_set_lockstep_fusion": (C.c_int, [C.c_int32]),
     "rscm_gpu_set_udeb_variant": (C.c_int, [C.c_int32]),
     "rscm_gpu_fail_chunk_launch": (C.c_int, [C.c_int32]),
+    "rscm_gpu_set_run_plan": (C.c_int, [C.c_int32]),
     "rscm_gpu_lockstep_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_gpu_lockstep_split_launches": (C.c_int, [C.POINTER(C.c_int64)]),
     "rscm_ens_sync": (C.c_int, [_h]),
@@ -278,6 +279,7 @@ SIGNATURES = {
     "rscm_ens_rewind": (C.c_int, [_h]),
     "rscm_ens_last_run_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "rscm_ens_last_run_plan": (C.c_int, [_h, _ip, _ip]),
+    "rscm_ens_last_run_tasks": (C.c_int, [_h, C.POINTER(C.c_int64), _ip]),
     "rscm_ens_get_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                       C.c_int64, _dp]),
     "rscm_ens_series_devptr": (C.c_int, [_h, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -46,6 +46,13 @@ int rscm_gpu_set_udeb_variant(int32_t variant)
     return RSCM_OK;
 }
 
+int rscm_gpu_set_run_plan(int32_t mode)
+{
+    if (mode < -1 || mode > 2) return fail(RSCM_ERR_INVALID, "run plan %d (-1 default, 0 one launch, 1 two-stream cut, 2 work queue)", mode);
+    set_run_plan(mode);
+    return RSCM_OK;
+}
+
 int rscm_gpu_fail_chunk_launch(int32_t k)
 {
     if (k < 0) return fail(RSCM_ERR_INVALID, "chunk launch number %d (1-based; 0 turns the hook off)", k);

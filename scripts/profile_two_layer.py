@@ -28,6 +28,9 @@ if kind == 2:  # ClimateUDEB: defaults, ECS / kappa / RLO / k_lo varied
     for name, (a_, b_) in dict(ecs=(2.0, 5.0), kappa=(0.5, 1.5), rlo=(1.2, 1.45), k_lo=(1.0, 2.0)).items():
         j = _lib.UD_PARAM_NAMES.index(name)
         lo[j], hi[j] = a_, b_
+    if os.environ.get("UDEB_LAYERS"):  # any count >= 2 (<= 64: columns on chip; 20/30/40/50 with the count compiled in)
+        j = _lib.UD_PARAM_NAMES.index("n_layers")
+        lo[j] = hi[j] = float(os.environ["UDEB_LAYERS"])
     if os.environ.get("UDEB_NOFB"):  # constant ECS: no LAMCALC re-solve per year
         for name in ("feedback_q_sensitivity", "feedback_cumt_sensitivity"):
             j = _lib.UD_PARAM_NAMES.index(name)

@@ -124,7 +124,7 @@ int main(int argc, char** argv)
     for (int64_t i = 0; i < n; ++i) failed += status[i] != 0;
     printf("{\"members\": %lld, \"time_index\": %d, \"member_blocks\": %d, \"step_chunks\": %d, \"run_ms\": %.3f, "
            "\"failed_members\": %lld, \"ts_2020_count\": %.0f, \"ts_2020_mean\": %.17g}\n",
-           (long long)n, tidx, blocks, chunks, (double)ms, (long long)failed, summary[0], summary[1]);
+           (long long)n, tidx, blocks, chunks, (double)ms, (long long)failed, summary[0], summary[0] > 0.0 ? summary[1] / summary[0] : 0.0);   /* count, sum, min, max */
     free(ts); free(td); free(status); free(params); free(forcing); free(bounds);
     return 0;
 }

@@ -77,6 +77,66 @@ def test_c_caller_matches_the_oracle_bit_for_bit(tmp_path, n):
     bad = ~(np.isfinite(want_ts[-1]) & np.isfinite(want_td[-1]))
     assert np.array_equal(status != 0, bad)
     assert line["members"] == n and line["time_index"] == 750 and line["failed_members"] == int(bad.sum())
-    assert (line["member_blocks"], line["step_chunks"] > 1) == ((2, True) if n > 65536 else (1, False))
+    # (more than 65 536 members: one persistent launch with a work queue, or -- RSCM_QUEUE_RUNS=0 -- two member blocks on two streams)
+    assert (line["member_blocks"], line["step_chunks"]) in ([(1, 1), (2, 12)] if n > 65536 else [(1, 1)])
     fin = np.isfinite(want_ts[270])
     assert line["ts_2020_count"] == fin.sum() and abs(line["ts_2020_mean"] - want_ts[270][fin].mean()) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# One process, one thread + one handle per device: tests/c_abi/two_devices.c
+
+
+def _build_two_devices(tmp_path):
+    exe = str(tmp_path / "two_devices")
+    libdir = os.path.join(ROOT, "rscm_amd")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "two_devices.c"), "-o", exe, "-L", libdir, "-lrscm_gpu",
+           "-L", "/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_threaded_multi_device_caller_builds(tmp_path):
+    exe = _build_two_devices(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 64 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
+@pytest.mark.parametrize("n_total,threads", [(100_001, 2), (70_000, 3)])
+def test_one_process_one_thread_per_handle_equals_one_handle(tmp_path, n_total, threads):
+    """The host the north-star names is one (Rust) process driving the GPUs of a node: one thread and one handle per device, member
+    blocks of one global Latin hypercube drawn where they run, the per-member losses gathered from the library's device pointers --
+    ncclAllGather when every thread has a device of its own, and on a one-GPU box (RCCL takes one rank per device) host copies plus
+    a one-rank ncclAllGather of the same pointer.  Whatever the number of threads, the gathered vector is the one a single handle of
+    all the members computes, bit for bit; handles driven from different threads of one process do not disturb each other."""
+    import rscm_amd
+    exe = _build_two_devices(tmp_path)
+    out = tmp_path / "out.bin"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, str(out), str(n_total), str(threads)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["members"] == n_total and line["threads"] == threads and len(line["run_ms"]) == threads and min(line["run_ms"]) > 0
+    if line["devices"] < threads:
+        assert line["gather"] == "rscm_gpu_copy_to_host" and line["one_rank_rccl_ok"] is True
+    else:
+        assert line["gather"] == "ncclAllGather"
+    raw = out.read_bytes()
+    got = np.frombuffer(raw, dtype=np.float64, count=n_total)
+    status = np.frombuffer(raw, dtype=np.uint8, count=n_total, offset=8 * n_total)
+    _, forcing, bounds = caller_inputs(1)
+    with rscm_amd.Ensemble(rscm_amd.KIND_TWO_LAYER, n_total, bounds) as e:
+        e.sample_lhs(20260327, LOW, HIGH)
+        e.set_forcing(forcing)
+        e.set_initial("Surface Temperature", 0.0)
+        e.set_initial("Deep Ocean Temperature", 0.0)
+        e.run()
+        tidx = 100 + 10 * np.arange(18)
+        want = e.loglik(["Surface Temperature"] * 18, tidx, 1.0 + 0.004 * tidx, np.full(18, 0.1))
+        assert np.array_equal(status, e.status())
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.isfinite(got).sum() > 0.9 * n_total
