@@ -161,14 +161,7 @@ def describe_run_plan(roofline, plan):
     """How one pass was issued (rscm_ens_last_run_plan): `kernel_ms` is the HIP-event time of a whole pass on the launch stream, which
     forks into and joins the library's second stream -- with a cut it covers blocks x chunks overlapping launches of the kernel."""
     blocks, chunks = plan[0], plan[1]
-    tasks, task_steps = (plan[2], plan[3]) if len(plan) > 2 else (0, 0)
     roofline["launches_per_pass"] = blocks * chunks
-    if tasks:
-        roofline["kernel"] = "two_layer_queue_kernel"
-        roofline["tasks_per_pass"] = tasks
-        roofline["run_plan"] = (f"ONE persistent launch: a work queue of {tasks} tasks = (64-member block, chunk of {task_steps} model steps) claimed by "
-                                "resident wavefronts in chunk-major order, a block's chunk waiting only for the same block's previous chunk "
-                                "(csrc/two_layer.hip, rscm_ens_last_run_tasks): the same body on the same operands, the SIMDs evenly loaded to the end")
     if blocks * chunks > 1:
         roofline["run_plan"] = (f"{blocks} member blocks on two streams x {chunks} chunks of model steps, issued in turn: the same kernel on the same "
                                 "operands, the wavefronts evened out over the SIMDs (include/rscm_gpu.h, rscm_ens_last_run_plan); kernel_ms = "
@@ -476,7 +469,7 @@ def scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, ye
             ev[1].record(tstream)
 
         def after(ens):
-            return {"kernel_ms": ev[0].elapsed_time(ev[1]) / max(1, box["n"]), "run_plan": list(ens.last_run_plan() + ens.last_run_tasks()),
+            return {"kernel_ms": ev[0].elapsed_time(ev[1]) / max(1, box["n"]), "run_plan": list(ens.last_run_plan()),
                     "failed_members": int(ens.status().sum())}
 
         out = scale_measure(rank, world, torch, dist, prepare, body, lambda e: e.sync(), lambda e: e.close(),
@@ -1069,7 +1062,7 @@ def main():
     wall, kernel_ms = timed_passes(ens, args.steps, args.warmup, torch, dist, world, tstream)
     n_fail = int(ens.status().sum())
     fails = _gather_obj(dist, n_fail)
-    run_plan = ens.last_run_plan() + ens.last_run_tasks()
+    run_plan = ens.last_run_plan()
     s_mid = ens.summary("Surface Temperature", 270)  # year 2020
     gather = loss_gather_report(ens, args.members, world, dist)
     ens.close()
@@ -1102,7 +1095,7 @@ def main():
             e2 = make_ensemble(members, local_rank, 0, 1, m, stream, coupled=cp)
             k = max(3, args.steps // 4)
             w2, k2 = timed_passes(e2, k, 1, torch, dist, 1, tstream)
-            plan2 = e2.last_run_plan() + e2.last_run_tasks()
+            plan2 = e2.last_run_plan()
             e2.close()
             bpy = 56.0 if cp else ALG_BYTES_PER_MEMBER_YEAR
             out = {"member_years_per_s": members * years * k / w2, "kernel_ms": k2,

@@ -60,7 +60,8 @@ extern "C" {
  *      rscm_gpu_set_lockstep_fusion mode 4 (was: the whole-graph launch; now: mode 1 without the two-wavefront op split): a
  *      host built against the round-3 internal header does not link, or gets the new meaning of mode 4
  *   4  ClimateUDEB keeps its columns on chip at EVERY n_layers <= 64 (no entry point changed: same results, the counts
- *      other than 20 / 30 / 40 / 50 are ~15x faster); internal header: rscm_gpu_fail_chunk_launch, rscm_gpu_set_udeb_variant(3) */
+ *      other than 20 / 30 / 40 / 50 are ~15x faster); internal header: rscm_gpu_fail_chunk_launch, rscm_gpu_set_run_plan,
+ *      rscm_gpu_set_udeb_variant(3) */
 #define RSCM_GPU_ABI_MINOR 4
 
 #if defined(__GNUC__)
@@ -540,15 +541,6 @@ RSCM_API int rscm_ens_last_run_ms(rscm_ens* h, float* out_ms);
  * member_blocks x step_chunks launches in all; 1 x 1 otherwise.  To the caller the run is one asynchronous operation on its stream
  * either way: the helper stream and the fork / join events are the handle's own.  Environment RSCM_SPLIT_RUNS=0 turns the cut off. */
 RSCM_API int rscm_ens_last_run_plan(rscm_ens* h, int32_t* member_blocks, int32_t* step_chunks);
-/* (ABI minor 4) A whole-axis run of the two-layer kind over more than 65 536 members goes out as ONE persistent launch instead: a work
- * queue of tasks = (64-member block, chunk of ~25 model steps) claimed by resident wavefronts in chunk-major order, a block's chunk
- * waiting only for the SAME block's previous chunk (flag + two handed-over state values, release / acquire at device scope) -- the
- * same body on the same operands, the same bits, and the SIMDs stay evenly loaded to the end of the run (1e5 members x 750 years:
- * 2.30 -> see DESIGN.md section 4.1).  rscm_ens_last_run_plan then reports 1 x 1 (one launch) and this call the number of tasks and
- * the model steps per task; 0 / 0 for a run that did not go through the queue.  Environment RSCM_QUEUE_RUNS=0 turns the queue off
- * (the two-stream cut above then applies).  If a wavefront ever gave up waiting for a predecessor (bounded wait; never observed),
- * the next rscm_ens_sync / rscm_ens_run returns RSCM_ERR_DEVICE. */
-RSCM_API int rscm_ens_last_run_tasks(rscm_ens* h, int64_t* tasks, int32_t* steps_per_task);
 
 /* ---- outputs ------------------------------------------------------------------------------ */
 /* Copy series[var][t][m] for t in {t_begin, t_begin+t_stride, ...} < t_end and

@@ -45,9 +45,8 @@ RSCM_API int rscm_gpu_lockstep_split_launches(int64_t* out);
 RSCM_API int rscm_gpu_set_udeb_variant(int32_t variant);
 
 /* How the calling THREAD's whole-axis runs over more members than the chip holds at one wavefront per SIMD go out: -1 (default) by
- * the environment (RSCM_QUEUE_RUNS, RSCM_SPLIT_RUNS) and the sizes -- the work queue for the two-layer kind, the two-stream cut for
- * the coupled kind and ClimateUDEB; 0 always one plain launch; 1 the two-stream cut where it applies (also for the two-layer kind);
- * 2 the work queue where it applies, nothing else cut.  All of them carry the same bits (tests/test_gpu_parity.py). */
+ * the environment (RSCM_SPLIT_RUNS) and the sizes -- the two-stream cut where it applies; 0 always one plain launch (the yardstick of
+ * the parity tests); 1 the two-stream cut where it applies whatever the environment says.  The same bits either way. */
 RSCM_API int rscm_gpu_set_run_plan(int32_t mode);
 
 /* Fault injection for the cut runs (rscm_ens_last_run_plan: member blocks x step chunks on two streams): the k-th chunk launch

@@ -279,7 +279,6 @@ SIGNATURES = {
     "rscm_ens_rewind": (C.c_int, [_h]),
     "rscm_ens_last_run_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "rscm_ens_last_run_plan": (C.c_int, [_h, _ip, _ip]),
-    "rscm_ens_last_run_tasks": (C.c_int, [_h, C.POINTER(C.c_int64), _ip]),
     "rscm_ens_get_series": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                       C.c_int64, _dp]),
     "rscm_ens_series_devptr": (C.c_int, [_h, C.c_int32, C.POINTER(C.c_void_p)]),

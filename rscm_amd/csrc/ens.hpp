@@ -83,14 +83,6 @@ struct rscm_ens {
     // whole-axis runs as two member blocks on two streams in chunks of model steps (rscm_gpu.cpp, plan_member_split): the second stream
     // and the fork / join events, created with the first such run
     int32_t last_blocks = 1, last_chunks = 1;   // how the last run was cut (rscm_ens_last_run_plan)
-    // the work queue of the persistent two-layer launch (csrc/two_layer.hip): counter + per-block flags, hand-over values, error word
-    int32_t* d_queue_ctl = nullptr;      // [1 + queue_blocks]
-    int64_t queue_blocks = 0;
-    double* d_queue_hand = nullptr;      // [2][N]
-    int32_t* queue_error_host = nullptr; // host-mapped
-    int32_t* queue_error_dev = nullptr;
-    int64_t last_tasks = 0;              // tasks of the most recent run if it went through the queue, else 0
-    int32_t last_task_steps = 0;
     hipStream_t split_stream = nullptr;
     hipEvent_t split_fork = nullptr, split_join = nullptr;
     double* d_derived = nullptr;
@@ -264,7 +256,7 @@ inline int set_device(const rscm_ens* h)
 // launches of several handles out of the same pieces.
 extern "C" {
 int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end, bool derive = true);
-void set_run_plan(int32_t mode);          // A/B hook: -1 default, 0 one launch, 1 two-stream cut, 2 work queue (calling thread)
+void set_run_plan(int32_t mode);          // A/B hook: -1 default, 0 one plain launch, 1 the two-stream cut where it applies (calling thread)
 void set_fail_chunk_launch(int32_t k);   // test hook: the k-th chunk launch of the calling thread's next cut run fails (0: off)
 int ensure_derived(rscm_ens* h);   // (every run starts with current member constants: run_range after its first event, rscm_ens_run_lockstep once per call)
 int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end);

@@ -48,7 +48,7 @@ int rscm_gpu_set_udeb_variant(int32_t variant)
 
 int rscm_gpu_set_run_plan(int32_t mode)
 {
-    if (mode < -1 || mode > 2) return fail(RSCM_ERR_INVALID, "run plan %d (-1 default, 0 one launch, 1 two-stream cut, 2 work queue)", mode);
+    if (mode < -1 || mode > 1) return fail(RSCM_ERR_INVALID, "run plan %d (-1 default, 0 one plain launch, 1 the two-stream cut)", mode);
     set_run_plan(mode);
     return RSCM_OK;
 }

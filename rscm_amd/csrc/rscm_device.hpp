@@ -353,17 +353,6 @@ struct TwoLayerArgs {
     double* loglik;               // [N]
 };
 
-// The work queue of two_layer_queue_kernel (csrc/two_layer.hip): tasks = (64-member block, chunk of model steps), claimed in
-// chunk-major order by resident wavefronts; a block's chunk c waits for its chunk c - 1.
-struct TlQueue {
-    int32_t* next;          // [1] the next task to hand out (zeroed before the launch)
-    int32_t* done;          // [n_blocks] chunks completed per block (zeroed before the launch)
-    int32_t* error;         // [1] host-mapped: a wavefront gave up waiting (never seen in practice; the exit every wait has)
-    double* hand;           // [2][row_stride] Ts, Td at the end of a block's last completed chunk
-    int32_t n_blocks, n_chunks, chunk;
-    int32_t spin_limit;     // polls of a predecessor's flag before giving up
-};
-
 // Coupled chain CarbonCycle -> CO2ERF -> Sum -> TwoLayer over steps [step_begin, step_end).
 struct CoupledArgs {
     int64_t n_members;
@@ -661,7 +650,6 @@ hipError_t launch_two_layer(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_two_layer_loglik(const TwoLayerArgs& a, int mode, hipStream_t s);
 hipError_t launch_coupled(const CoupledArgs& a, int mode, hipStream_t s);
 hipError_t launch_udeb(const UdebArgs& a, hipStream_t s);
-hipError_t launch_two_layer_queue(const TwoLayerArgs& a, const TlQueue& q, int mode, int waves_per_simd, int n_cus, hipStream_t s);
 bool udeb_layers_unrolled(int32_t n_layers);  // the layer counts whose columns stay on chip (2 .. kUdebMaxOnChipLayers)
 bool udeb_layers_fixed(int32_t n_layers);     // ... with the count compiled into the instance (20 / 30 / 40 / 50)
 void set_udeb_variant(int variant);            // which ClimateUDEB kernel the calling thread's launches take (udeb.hip; -1: by size)

@@ -749,9 +749,6 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipFree(h->d_udeb_work);
     (void)hipFree(h->d_udeb_tables);
     (void)hipFree(h->d_derived);
-    (void)hipFree(h->d_queue_ctl);
-    (void)hipFree(h->d_queue_hand);
-    if (h->queue_error_host) (void)hipHostFree(h->queue_error_host);
     if (h->split_stream) (void)hipStreamDestroy(h->split_stream);
     if (h->split_fork) (void)hipEventDestroy(h->split_fork);
     if (h->split_join) (void)hipEventDestroy(h->split_join);
@@ -1335,7 +1332,7 @@ int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLin
 // operands: the same bits.  The caller's stream forks into the helper stream and joins it again with events: to the caller this is one
 // asynchronous run on its stream, as before.  RSCM_SPLIT_RUNS=0 turns it off (A/B).
 // A/B and test hook (include/rscm_gpu_internal.h, rscm_gpu_set_run_plan): how the calling thread's whole-axis runs go out --
-// -1 by the environment and the sizes (default), 0 always one plain launch, 1 the two-stream cut where it applies, 2 the work queue.
+// -1 by the environment and the sizes (default), 0 always one plain launch, 1 the two-stream cut where it applies.
 static thread_local int32_t t_run_plan = -1;
 void set_run_plan(int32_t mode) { t_run_plan = mode; }
 
@@ -1418,66 +1415,12 @@ static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begi
     return RSCM_OK;
 }
 
-// A whole-axis two-layer run over more members than the chip holds wavefronts at one per SIMD as ONE persistent launch with a work
-// queue of (64-member block, chunk of steps) tasks (csrc/two_layer.hip): the dependency between a block's chunks is per block, not
-// per kernel, so the SIMDs stay evenly loaded to the end.  RSCM_QUEUE_RUNS=0 turns it off (the two-stream cut then applies).
-struct QueuePlan {
-    bool on = false;
-    int32_t chunk = 0, n_chunks = 0, waves = 0, cus = 0;
-    int64_t n_blocks = 0;
-};
-static QueuePlan plan_queue(rscm_ens* h, int32_t step_begin, int32_t step_end, bool linked, size_t lds_bytes)
-{
-    static const bool enabled = [] { const char* e = getenv("RSCM_QUEUE_RUNS"); return !e || atoi(e) != 0; }();
-    // (tuning knobs for experiments: model steps per task, resident wavefronts per SIMD)
-    static const int32_t chunk_env = [] { const char* e = getenv("RSCM_QUEUE_CHUNK"); return e ? atoi(e) : 0; }();
-    static const int32_t waves_env = [] { const char* e = getenv("RSCM_QUEUE_WAVES"); return e ? atoi(e) : 0; }();
-    QueuePlan q;
-    const int32_t kChunk = chunk_env > 0 ? chunk_env : 25;
-    const int32_t len = step_end - step_begin;
-    if ((t_run_plan >= 0 ? t_run_plan != 2 : !enabled) || linked || h->windowed || h->rows != h->T || len < 3 * kChunk) return q;
-    if (lds_bytes > (size_t)rscm::kMaxLds / 4) return q;   // the whole launch's forcing, several workgroups per CU
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) return q;
-    if (h->N <= (int64_t)cus * 4 * 64) return q;          // every wavefront has a SIMD to itself already
-    q.cus = cus;
-    q.waves = waves_env > 0 ? std::min(waves_env, 8) : 2;
-    q.n_blocks = (h->N + 63) / 64;
-    q.n_chunks = (len + kChunk - 1) / kChunk;
-    q.chunk = (len + q.n_chunks - 1) / q.n_chunks;
-    q.n_chunks = (len + q.chunk - 1) / q.chunk;
-    if (q.n_blocks * q.n_chunks > (int64_t)1 << 30) return q;
-    q.on = true;
-    return q;
-}
-static int queue_buffers(rscm_ens* h, const QueuePlan& q)
-{
-    if (h->queue_blocks < q.n_blocks) {
-        (void)hipFree(h->d_queue_ctl);
-        h->d_queue_ctl = nullptr;
-        h->queue_blocks = 0;
-        HIPCHK(hipMalloc(&h->d_queue_ctl, (size_t)(1 + q.n_blocks) * sizeof(int32_t)));
-        h->queue_blocks = q.n_blocks;
-    }
-    if (!h->d_queue_hand) HIPCHK(hipMalloc(&h->d_queue_hand, (size_t)2 * h->N * sizeof(double)));
-    if (!h->queue_error_host) {
-        HIPCHK(hipHostMalloc((void**)&h->queue_error_host, sizeof(int32_t), hipHostMallocMapped));
-        *h->queue_error_host = 0;
-        HIPCHK(hipHostGetDevicePointer((void**)&h->queue_error_dev, h->queue_error_host, 0));
-    }
-    return RSCM_OK;
-}
-
 int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::InputLinks& links, int32_t linked,
                 rscm::GroupOp* op_out)
 {
     const int32_t len = step_end - step_begin;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
-    if (!op_out) {
-        h->last_blocks = h->last_chunks = 1;
-        h->last_tasks = 0;
-        h->last_task_steps = 0;
-    }
+    if (!op_out) h->last_blocks = h->last_chunks = 1;
     if (h->kind == RSCM_KIND_TWO_LAYER) {
         rscm::TwoLayerArgs a{};
         a.n_members = h->N;
@@ -1512,25 +1455,8 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
             op_out->u.tl = a;
             return RSCM_OK;
         }
-        const QueuePlan qp = plan_queue(h, step_begin, step_end, linked != 0, lds_bytes);
-        const MemberSplit ms = qp.on ? MemberSplit() : plan_member_split(h, step_begin, step_end, linked != 0);
-        if (qp.on) {
-            if (int rc = queue_buffers(h, qp)) return rc;
-            rscm::TlQueue q{};
-            q.next = h->d_queue_ctl;
-            q.done = h->d_queue_ctl + 1;
-            q.error = h->queue_error_dev;
-            q.hand = h->d_queue_hand;
-            q.n_blocks = (int32_t)qp.n_blocks;
-            q.n_chunks = qp.n_chunks;
-            q.chunk = qp.chunk;
-            q.spin_limit = 1 << 20;   // ~2 s of polling a flag that is set within microseconds
-            a.lds_forcing = 1;
-            HIPCHK(hipMemsetAsync(h->d_queue_ctl, 0, (size_t)(1 + qp.n_blocks) * sizeof(int32_t), h->stream));
-            HIPCHK(rscm::launch_two_layer_queue(a, q, h->mode, qp.waves, qp.cus, h->stream));
-            h->last_tasks = qp.n_blocks * qp.n_chunks;
-            h->last_task_steps = qp.chunk;
-        } else if (ms.on) {
+        const MemberSplit ms = plan_member_split(h, step_begin, step_end, linked != 0);
+        if (ms.on) {
             const int32_t mode = h->mode;
             if (int rc = run_member_split(h, ms, step_begin, step_end, [&](int32_t b, int32_t e, int64_t m0, int64_t cnt, hipStream_t st) {
                     rscm::TwoLayerArgs c = a;
@@ -1950,11 +1876,6 @@ int rscm_ens_sync(rscm_ens* h)
     NEED(h);
     if (int rc = set_device(h)) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->queue_error_host && *h->queue_error_host != 0) {   // a wavefront of the work-queue launch gave up waiting for its predecessor
-        *h->queue_error_host = 0;
-        return fail(RSCM_ERR_DEVICE, "the work-queue launch of the two-layer run did not complete (a task's predecessor was never published); "
-                                     "the series of this run are incomplete: rewind and run again, RSCM_QUEUE_RUNS=0 selects the cut runs");
-    }
     return RSCM_OK;
     GUARD_END
 }
@@ -1970,14 +1891,6 @@ int rscm_ens_last_run_plan(rscm_ens* h, int32_t* member_blocks, int32_t* step_ch
     NEED(h);
     if (member_blocks) *member_blocks = h->last_blocks;
     if (step_chunks) *step_chunks = h->last_chunks;
-    return RSCM_OK;
-}
-
-int rscm_ens_last_run_tasks(rscm_ens* h, int64_t* tasks, int32_t* steps_per_task)
-{
-    NEED(h);
-    if (tasks) *tasks = h->last_tasks;
-    if (steps_per_task) *steps_per_task = h->last_task_steps;
     return RSCM_OK;
 }
 

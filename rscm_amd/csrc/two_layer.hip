@@ -58,128 +58,15 @@ __global__ __launch_bounds__(kBlock) void two_layer_kernel(TwoLayerArgs a)
     tl::two_layer_body<MODE, LDS, STORE>(a, lds_forcing, i, a.step_begin, a.step_end);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// One persistent launch with a dependency-ordered work queue.
-//
-// 1e5 members are 1563 wavefront-sized blocks on 1024 SIMDs: as one launch the SIMDs that got two blocks take twice as long as
-// those that got one (2.72 ms per 750 years; the chip's full rate would be 2.11).  Cutting the run into member blocks x chunks of
-// steps on two streams lets the hardware dispatcher even the load out at chunk granularity (2.30 ms), but a chunk is a kernel:
-// a block's next chunk cannot start before EVERY block of its half has finished the previous one.  Here the unit of work is a
-// task = (64-member block, chunk of model steps) and the dependency is per block.  A fixed number of wavefronts (a few per
-// SIMD) stay resident; each claims the next task with one atomic add, in chunk-major order (all blocks' chunk 0, then all
-// blocks' chunk 1, ...), waits -- almost never: its predecessor was claimed a whole round of the chip earlier -- until the same
-// block's previous chunk has been published, resumes from the two state values that chunk handed over, steps the chunk with the
-// SAME body on the same operands (the same bits), stores the rows as always, hands its final state over and publishes.  The
-// forcing of the whole launch is staged in LDS once per workgroup.
-//
-// Progress: tasks are claimed in increasing order and a task only ever waits for a LOWER-numbered one, which has been claimed by a
-// wavefront that is resident and running (it was running when it claimed) -- the lowest unfinished task never waits, so the queue
-// drains whatever the placement of the workgroups; a workgroup that starts late finds fewer tasks or none.  Every wait is
-// bounded all the same (spin_limit polls, then the error flag and out), and every wavefront leaves when the counter passes the
-// last task.
-//
-// Visibility across the 8 XCDs (their L2s are not coherent with each other): the two hand-over values and the flag are all
-// device-scope (agent) relaxed atomic accesses -- stores that write through the L2, loads that do not trust its lines -- and the
-// flag is stored after the wavefront has waited for its hand-over stores (s_waitcnt vmcnt(0)), read before the hand-over loads
-// are issued (the branch on its value).  Nothing else is shared: the series rows are not read back inside the launch.  (The
-// by-the-book form -- plain hand-over accesses around a RELEASE store / ACQUIRE load of the flag -- costs an L2 write-back and an
-// L2 invalidate per task: 28 us per task measured, 3.3 ms per pass at 1e5 members against 2.3 for the cut runs.)
-// a double through an agent-scope (device-coherent, L2 write-through / bypass) relaxed atomic access
-__device__ __forceinline__ double load_agent(const double* p)
-{
-    const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __longlong_as_double((long long)bits);
-}
-__device__ __forceinline__ void store_agent(double* p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-struct QueueCache : NoCache {
-    const double* hand;   // this member's Ts (Td at hand + stride) from the previous chunk, or nullptr: read the stored row
-    size_t stride;
-    double* out;          // out[0], out[1]: the state after the last step of this chunk
-    bool last;
-    __device__ __forceinline__ double state(int k, const double* row) const { return hand ? load_agent(hand + (size_t)k * stride) : *row; }
-    __device__ __forceinline__ void put(int k, double v) const { out[k] = v; }
-    __device__ __forceinline__ bool last_step() const { return last; }
-};
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void two_layer_queue_kernel(TwoLayerArgs a, TlQueue q)
-{
-    extern __shared__ double lds_forcing[];
-    const int32_t len = a.step_end - a.step_begin;
-    for (int32_t idx = threadIdx.x; idx < a.n_scen * len; idx += kBlock) {
-        const int32_t s = idx / len, k = idx - s * len;
-        lds_forcing[idx] = a.forcing[(size_t)s * a.n_times + a.step_begin + a.src_off + k];
-    }
-    __syncthreads();   // the only workgroup barrier: from here on every wavefront is on its own
-    const int lane = threadIdx.x & 63;
-    const int32_t n_tasks = q.n_blocks * q.n_chunks;
-    for (;;) {
-        int32_t task = 0;
-        if (lane == 0) task = __hip_atomic_fetch_add(q.next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        task = __builtin_amdgcn_readfirstlane(task);
-        if (task >= n_tasks) break;
-        const int32_t chunk = task / q.n_blocks, block = task - chunk * q.n_blocks;
-        if (chunk > 0) {   // the same block's previous chunk must have been published
-            int32_t polls = 0;
-            bool ok = true;
-            while (__hip_atomic_load(q.done + block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
-                __builtin_amdgcn_s_sleep(16);
-                ++polls;   // (the error flag lives in host memory: looked at once in a while)
-                if (polls > q.spin_limit || ((polls & 255) == 0 && __hip_atomic_load(q.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
-                    ok = false;
-                    break;
-                }
-            }
-            if (!ok) {   // never seen; the way out every wait must have
-                if (lane == 0) __hip_atomic_store(q.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-        const int64_t i = (int64_t)block * 64 + lane;
-        const int32_t b = a.step_begin + chunk * q.chunk;
-        const int32_t e = b + q.chunk < a.step_end ? b + q.chunk : a.step_end;
-        double fin[2] = {0.0, 0.0};
-        if (i < a.n_members) {
-            QueueCache cache;
-            cache.hand = chunk > 0 ? q.hand + i : nullptr;
-            cache.stride = (size_t)a.row_stride;
-            cache.out = fin;
-            cache.last = e == a.step_end;
-            tl::two_layer_body<MODE, true, true, QueueCache>(a, lds_forcing, i, b, e, cache, len, a.step_begin);
-            if (e < a.step_end) {
-                store_agent(q.hand + i, fin[0]);
-                store_agent(q.hand + (size_t)a.row_stride + i, fin[1]);
-            }
-        }
-        if (e < a.step_end) {   // every lane's hand-over stores have been performed at device scope before lane 0 publishes
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(q.done + block, chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 }  // namespace
 
-hipError_t launch_two_layer_queue(const TwoLayerArgs& a, const TlQueue& q, int mode, int waves_per_simd, int n_cus, hipStream_t s)
-{
-    if (a.n_members <= 0 || a.step_end <= a.step_begin) return hipSuccess;
-    const size_t lds = (size_t)a.n_scen * (a.step_end - a.step_begin) * sizeof(double);
-    void (*kern)(TwoLayerArgs, TlQueue) = mode == 0 ? two_layer_queue_kernel<0> : two_layer_queue_kernel<1>;
-    if (lds > (size_t)kMaxStaticLds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    // a workgroup is one wavefront per SIMD of a CU; no more workgroups than there are blocks to start with
-    int64_t groups = (int64_t)n_cus * waves_per_simd;
-    const int64_t useful = (q.n_blocks + 3) / 4;
-    if (groups > useful) groups = useful;
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(kBlock), lds, s, a, q);
-    return hipGetLastError();
-}
+// (Round 5 built ONE persistent launch with a dependency-ordered work queue here -- tasks = (64-member block, chunk of steps) claimed by
+// resident wavefronts, a block's chunk waiting only for the same block's previous chunk, the state handed over through device-scope
+// accesses -- bit-identical to the plain launch, and removed it again: it never beat the two-stream cut of rscm_gpu.cpp.  The premise
+// was wrong: 1e5 members are 1563 independent chains for 1024 SIMDs, a SIMD needs two to be saturated, and ONE wavefront alone runs at
+// 0.93 of a saturated SIMD's rate (65 536 members: 1.505 ms; 131 072: 2.807) -- the configuration's own bound is 2.21 ms per pass, the
+// cut runs take 2.31, the queue 2.45 with one wavefront per SIMD and worse with more (fewer blocks than wavefronts: every task waits for
+// its predecessor).  DESIGN.md section 4.1, profiles/r5_queue_experiment.txt, commit history of this file.)
 
 template <bool STORE>
 static hipError_t launch_impl(const TwoLayerArgs& a, int mode, hipStream_t s)

@@ -141,11 +141,9 @@ __device__ __forceinline__ void lik_consume(const TwoLayerArgs& a, LikAcc& L, in
 // lds_forcing ([n_scen][len]); otherwise read through L2 (table or linked series).
 // Cache: NoCache for the stand-alone kernels; the fused multi-step launch (group.hip) keeps parameters, the
 // state and the linked forcing of the current step in LDS between its steps (rscm_device.hpp, LdsCache).
-// lds_len >= 0: lds_forcing holds [n_scen][lds_len] rows starting at model step lds_begin (the work-queue kernel stages the whole
-// launch once and steps it a chunk at a time); otherwise exactly this call's range.
 template <int MODE, bool LDS, bool STORE, class Cache = NoCache>
 __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const double* lds_forcing, int64_t i, int32_t step_begin,
-                                               int32_t step_end, const Cache& cache = Cache(), int32_t lds_len = -1, int32_t lds_begin = 0)
+                                               int32_t step_end, const Cache& cache = Cache())
 {
     const int32_t len = step_end - step_begin;
     const int64_t N = a.row_stride;   // the rows' stride (the caller has checked i against a.n_members)
@@ -161,7 +159,7 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
     // [T][N] series: coalesced, one stride of N per year
     const double* fglob = a.link ? a.link + (size_t)a.src_off * N + i : a.forcing + (size_t)scen * a.n_times + a.src_off;
     const size_t fstride = a.link ? (size_t)N : (size_t)1;
-    const int32_t fl0 = lds_len >= 0 ? scen * lds_len - lds_begin : scen * len - step_begin;  // lds_forcing[fl0 + n], n >= step_begin
+    const int32_t fl0 = scen * len - step_begin;  // lds_forcing[fl0 + n], n >= step_begin
     auto forcing_at = [&](int32_t n) -> double {
         if constexpr (LDS) return lds_forcing[fl0 + n];
         else return fglob[(size_t)n * fstride];

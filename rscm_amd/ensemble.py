@@ -241,14 +241,6 @@ class Ensemble:
         L.check(self._lib.rscm_ens_last_run_plan(self._h, C.byref(mb), C.byref(sc)))
         return mb.value, sc.value
 
-    def last_run_tasks(self):
-        """(tasks, model steps per task) of the most recent run if it went out as one persistent launch with a work queue of
-        (64-member block, chunk of steps) tasks (rscm_ens_last_run_tasks: whole-axis two-layer runs over more than 65 536 members),
-        else (0, 0)."""
-        n, k = C.c_int64(), C.c_int32()
-        L.check(self._lib.rscm_ens_last_run_tasks(self._h, C.byref(n), C.byref(k)))
-        return n.value, k.value
-
     # -- checkpoint / resume ------------------------------------------------------------------
     def state_vars(self) -> Dict[str, int]:
         """The State variables of the kind (what the stepper reads back at the next step)."""

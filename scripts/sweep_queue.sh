@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5 experiment: RSCM_QUEUE_RUNS / RSCM_QUEUE_WAVES / RSCM_QUEUE_CHUNK drove the work-queue launch, which was removed again -- the
+# queue lines below now measure the default plan; results of the experiment: profiles/r5_queue_experiment.txt)
 # The work-queue launch of the two-layer kind against the two-stream cut and the plain launch: ms per pass of the default bench
 # (1e5 members x 750 years, EXACT) over task lengths and resident wavefronts per SIMD, then other sizes.
 set -o pipefail

@@ -77,8 +77,7 @@ def test_c_caller_matches_the_oracle_bit_for_bit(tmp_path, n):
     bad = ~(np.isfinite(want_ts[-1]) & np.isfinite(want_td[-1]))
     assert np.array_equal(status != 0, bad)
     assert line["members"] == n and line["time_index"] == 750 and line["failed_members"] == int(bad.sum())
-    # (more than 65 536 members: one persistent launch with a work queue, or -- RSCM_QUEUE_RUNS=0 -- two member blocks on two streams)
-    assert (line["member_blocks"], line["step_chunks"]) in ([(1, 1), (2, 12)] if n > 65536 else [(1, 1)])
+    assert (line["member_blocks"], line["step_chunks"]) == ((2, 12) if n > 65536 else (1, 1))   # a cut run above 65 536 members
     fin = np.isfinite(want_ts[270])
     assert line["ts_2020_count"] == fin.sum() and abs(line["ts_2020_mean"] - want_ts[270][fin].mean()) < 1e-9
 

@@ -1030,16 +1030,13 @@ def _run_plan(mode):
     L.check(L.load().rscm_gpu_set_run_plan(mode))
 
 
-@pytest.mark.parametrize("kind,plan", [("two_layer", "queue"), ("two_layer", "cut"), ("coupled", "cut")])
+@pytest.mark.parametrize("kind", ["two_layer", "coupled"])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mode, plan):
-    """A whole-axis run over more members than the chip holds wavefronts at one per SIMD does not go out as one plain launch.  The
-    two-layer kind: ONE persistent launch with a work queue of (64-member block, chunk of 25 steps) tasks, a block's chunk waiting for
-    the same block's previous chunk (rscm_ens_last_run_tasks: 1563 blocks x 30 chunks; rscm_ens_last_run_plan 1 x 1).  The coupled kind
-    -- and the two-layer kind when asked (rscm_gpu_set_run_plan(1), RSCM_QUEUE_RUNS=0) --: two member blocks on two streams in chunks
-    of model steps (rscm_ens_last_run_plan: 2 x 12 for 750 steps).  Runs of fewer than 192 steps are neither: the same axis in five
-    pieces is the single-launch path, and must give the same bits -- with a scenario map (its pointer moves with the block), a
-    ragged member count, and against the oracle on a sample of members from both blocks."""
+def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mode):
+    """A whole-axis run over more members than the chip holds wavefronts at one per SIMD is issued as two member blocks on two streams in
+    chunks of model steps (rscm_ens_last_run_plan: 2 x 12 for 750 steps).  The yardstick is the same axis as plain launches
+    (rscm_gpu_set_run_plan(0)), in five pieces: the same bits -- with a scenario map (its pointer moves with the block), a ragged
+    member count, and against the oracle on a sample of members from both blocks."""
     n = 100_001
     t = axis_values()
     b = np.append(t, t[-1] + 1.0)
@@ -1073,26 +1070,22 @@ def test_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, kind, mod
             plans = []
             for c in pieces:
                 e.run(c)
-                plans.append(e.last_run_plan() + e.last_run_tasks())
+                plans.append(e.last_run_plan())
             e.run()
-            plans.append(e.last_run_plan() + e.last_run_tasks())
+            plans.append(e.last_run_plan())
             assert e.finished() and e.last_run_ms() > 0
             rows = {name: e.get_series(name, 0, 751, 150) for name in names}      # rows 0, 150, ..., 750 of every member
             sample = {name: e.get_series(name, 0, 751, 1, 65_500, 65_600) for name in names}   # members on both sides of the cut
             return rows, sample, plans, e.status()
 
-    try:
-        _run_plan({"queue": 2, "cut": 1}[plan])
-        cut_rows, cut_sample, plans, st_cut = run(())
-    finally:
-        _run_plan(-1)
-    assert plans == ([(1, 1, 1563 * 30, 25)] if plan == "queue" else [(2, 12, 0, 0)]), plans
+    cut_rows, cut_sample, plans, st_cut = run(())
+    assert plans == [(2, 12)], plans
     try:
         _run_plan(0)      # the yardstick: plain launches, one per piece
         one_rows, one_sample, plans, st_one = run((150, 300, 450, 600))
     finally:
         _run_plan(-1)
-    assert plans == [(1, 1, 0, 0)] * 5, plans
+    assert plans == [(1, 1)] * 5, plans
     assert np.array_equal(st_cut, st_one)
     for name in names:
         assert_bit_equal(cut_rows[name], one_rows[name], f"{kind} mode {mode}: {name}, every member at six rows")
@@ -1133,7 +1126,6 @@ def test_a_failed_chunk_launch_joins_the_streams_and_leaves_the_run_undone(ra, o
         e.set_forcing(F)
         e.set_initial("Surface Temperature", 0.0)
         e.set_initial("Deep Ocean Temperature", 0.0)
-        L.check(L.load().rscm_gpu_set_run_plan(1))          # the two-stream cut (the two-layer kind's default is the work queue)
         L.check(L.load().rscm_gpu_fail_chunk_launch(fail_at))
         try:
             with pytest.raises(ra.RscmGpuError) as err:
@@ -1145,7 +1137,6 @@ def test_a_failed_chunk_launch_joins_the_streams_and_leaves_the_run_undone(ra, o
             assert e.last_run_plan() == (2, 12) and e.finished()
         finally:
             L.check(L.load().rscm_gpu_fail_chunk_launch(0))
-            L.check(L.load().rscm_gpu_set_run_plan(-1))
         cut = {name: e.get_series(name, 0, 751, 75) for name in ("Surface Temperature", "Deep Ocean Temperature")}
         st_cut = e.status()
     with ra.Ensemble(ra.KIND_TWO_LAYER, n, b) as e:
