@@ -99,6 +99,7 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
                 "300 fused f64 instructions per member-year (10 RK4 steps x 30)")
     tins = ops * my / (kernel_ms * 1e-3) / 1e12
     valu = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR, "note": note,
+            "parallelism_bound": two_layer_parallelism_bound(members, years, kernel_ms) if (kind == "two_layer" and mode == "exact") else None,
             "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
             "measured_valu_issue_utilisation_at_effective_clock": prof.get("valu_issue_utilisation"),
             "valu_instructions_per_wavefront_year_executed": prof.get("valu_per_wavefront_year"),
@@ -155,6 +156,30 @@ def udeb_rooflines(members, years, kernel_ms, plan=(1, 1)):
                                              "other hemisphere's independent rows; utilisation is of the 4-cycle issue limit at the measured clock"}
         out["fp64_valu_frac"] = tins / FP64_VALU_PEAK_TINSTR
     return out
+
+
+# What ONE wavefront alone on a SIMD does, and two sharing one (plain launches at sizes that put exactly one / two on every SIMD,
+# EXACT, 750 years; profiles/r5_queue_experiment.txt section 3): the alone one runs at 0.93 of a saturated SIMD's rate.
+TL_EXACT_MS_ONE_WAVE_PER_SIMD = 1.505
+TL_EXACT_MS_TWO_WAVES_PER_SIMD = 2.807
+
+
+def two_layer_parallelism_bound(members, years, kernel_ms):
+    """The EXACT two-layer configuration's own bound when it has fewer than two wavefront-sized member blocks per SIMD: the blocks are
+    independent chains that cannot be cut in members or overlapped in time, a SIMD needs two of them to be saturated, so with
+    1024 < blocks < 2048 the best any schedule can do is keep (blocks - 1024) SIMDs at the two-chain rate and the others at the
+    one-chain rate to the end.  None where the configuration fills the chip (>= 2 blocks per SIMD) or fits in one round."""
+    simds = 1024
+    blocks = -(-members // 64)
+    if not (simds < blocks < 2 * simds):
+        return None
+    paired = blocks - simds
+    rate = paired * 2.0 / TL_EXACT_MS_TWO_WAVES_PER_SIMD + (simds - paired) * 1.0 / TL_EXACT_MS_ONE_WAVE_PER_SIMD   # blocks x 750 years per ms
+    bound_ms = blocks / rate * years / 750.0
+    return {"ms": bound_ms, "achieved_frac": bound_ms / kernel_ms, "blocks": blocks, "simds": simds,
+            "ms_one_wavefront_per_simd": TL_EXACT_MS_ONE_WAVE_PER_SIMD, "ms_two_wavefronts_per_simd": TL_EXACT_MS_TWO_WAVES_PER_SIMD,
+            "note": f"{blocks} independent 64-member chains on {simds} SIMDs: {paired} SIMDs can hold two (saturated), {simds - paired} hold one "
+                    "(0.93 of the saturated rate); measured rates from profiles/r5_queue_experiment.txt"}
 
 
 def describe_run_plan(roofline, plan):
