@@ -49,6 +49,12 @@ RSCM_API int rscm_gpu_set_udeb_variant(int32_t variant);
  * the parity tests); 1 the two-stream cut where it applies whatever the environment says.  The same bits either way. */
 RSCM_API int rscm_gpu_set_run_plan(int32_t mode);
 
+/* Member-constant ("derive") kernels launched by the calling THREAD since its last call of this function (GhgForcing, TerrestrialCarbon,
+ * ClimateUDEB: what their bodies need of the parameters alone, formed once per parameter set); resets the counter.  A handle whose
+ * parameter block the caller holds a device pointer to (rscm_ens_params_devptr) is re-derived before every RUN -- once per
+ * rscm_ens_run* / rscm_ens_run_lockstep call, not once per model step of it (tests/test_gpu_links.py). */
+RSCM_API int rscm_gpu_derive_launches(int64_t* out);
+
 /* Fault injection for the cut runs (rscm_ens_last_run_plan: member blocks x step chunks on two streams): the k-th chunk launch
  * (1-based, counted over both blocks in issue order) of the calling THREAD's next cut run is not issued and reports
  * hipErrorLaunchFailure instead; the hook then turns itself off.  0 turns it off.  What must hold afterwards

@@ -258,6 +258,7 @@ extern "C" {
 int step_check(rscm_ens* h, int32_t step_begin, int32_t step_end, bool derive = true);
 void set_run_plan(int32_t mode);          // A/B hook: -1 default, 0 one plain launch, 1 the two-stream cut where it applies (calling thread)
 void set_fail_chunk_launch(int32_t k);   // test hook: the k-th chunk launch of the calling thread's next cut run fails (0: off)
+int64_t take_derive_launches();           // test hook: member-constant kernels launched by the calling thread since the last call
 int ensure_derived(rscm_ens* h);   // (every run starts with current member constants: run_range after its first event, rscm_ens_run_lockstep once per call)
 int step_window_pre(rscm_ens* h, int32_t step_begin, int32_t step_end);
 int step_links(rscm_ens* h, int32_t step_begin, int32_t step_end, rscm::InputLinks& links, int32_t& linked_out);

@@ -53,6 +53,13 @@ int rscm_gpu_set_run_plan(int32_t mode)
     return RSCM_OK;
 }
 
+int rscm_gpu_derive_launches(int64_t* out)
+{
+    const int64_t n = take_derive_launches();
+    if (out) *out = n;
+    return RSCM_OK;
+}
+
 int rscm_gpu_fail_chunk_launch(int32_t k)
 {
     if (k < 0) return fail(RSCM_ERR_INVALID, "chunk launch number %d (1-based; 0 turns the hook off)", k);

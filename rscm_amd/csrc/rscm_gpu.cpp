@@ -1206,6 +1206,15 @@ static bool has_derived(const rscm_ens* h)
     return h->kind == RSCM_KIND_GHG_FORCING || h->kind == RSCM_KIND_TERRESTRIAL_CARBON || h->kind == RSCM_KIND_UDEB;
 }
 
+// (test hook: derive launches issued by the calling thread, rscm_gpu_derive_launches)
+static thread_local int64_t t_derive_launches = 0;
+int64_t take_derive_launches()
+{
+    const int64_t n = t_derive_launches;
+    t_derive_launches = 0;
+    return n;
+}
+
 int ensure_derived(rscm_ens* h)
 {
     if (!has_derived(h) || !h->params_set) return RSCM_OK;
@@ -1223,6 +1232,7 @@ int ensure_derived(rscm_ens* h)
     if (h->kind == RSCM_KIND_GHG_FORCING) HIPCHK(rscm::launch_ghg_derive(h->d_params, h->uniform_rows, h->ghg_method, h->N, h->d_derived, h->stream));
     else if (h->kind == RSCM_KIND_UDEB) HIPCHK(rscm::launch_udeb_derive(h->d_params, h->uniform_rows, h->N, h->d_derived, h->stream));
     else HIPCHK(rscm::launch_terrestrial_derive(h->d_params, h->uniform_rows, h->N, h->d_derived, h->stream));
+    ++t_derive_launches;
     h->derived_dirty = false;
     return RSCM_OK;
 }

@@ -53,6 +53,9 @@ if kind == 11:  # OceanCarbon (3D-GFDL preset): gas exchange, temperature sensit
         j = _lib.OC_PARAM_NAMES.index(name)
         lo[j], hi[j] = a_, b_
 P = {0: 6, 1: 10, 2: 37, 3: 21, 11: 24}[kind]
+if not os.environ.get("PROFILE_CUT"):   # one launch = the whole axis: a summary describes ONE kernel launch (the cut runs' launches are chunks)
+    from rscm_amd import _lib as _L
+    _L.check(_L.load().rscm_gpu_set_run_plan(0))
 with rscm_amd.Ensemble(kind, members, b) as e:
     if kind != 3:
         e.set_mode(mode)

@@ -139,3 +139,15 @@ def test_one_process_one_thread_per_handle_equals_one_handle(tmp_path, n_total, 
         assert np.array_equal(status, e.status())
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     assert np.isfinite(got).sum() > 0.9 * n_total
+
+
+@pytest.mark.parametrize("header", ["rscm_gpu.h", "rscm_gpu_internal.h"])
+def test_headers_compile_alone_as_strict_c11_and_as_cxx(tmp_path, header):
+    """The boundary's headers are self-contained C (what a bindgen / cgo / JNI generator reads) and valid C++ (extern "C" guards)."""
+    src = tmp_path / "use.c"
+    src.write_text(f'#include "{header}"\nint main(void) {{ return RSCM_GPU_ABI_VERSION == 1 ? 0 : 1; }}\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                ["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)]):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, " ".join(cmd) + "\n" + r.stderr[-2000:]

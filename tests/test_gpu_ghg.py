@@ -264,3 +264,34 @@ def test_member_constants_follow_every_way_of_writing_the_parameters(ra, orc, me
             Pc = np.ascontiguousarray(P)
             L.check(e._lib.rscm_gpu_copy_to_device(0, ptr, Pc.ctypes.data_as(C.c_void_p), Pc.nbytes))
             check(P, "written through the device pointer")
+
+
+def test_member_constants_are_formed_once_per_call_not_once_per_step(ra, orc):
+    """A handle whose parameter block the caller holds a device pointer to is re-derived before every RUN.  A lock-step run of many
+    one-step launches is one run: the member constants are formed once at its start (advisor, round 4: they were formed before
+    every step, and outside the timed region) -- counted through rscm_gpu_derive_launches -- and the results are the oracle's."""
+    import ctypes as C
+    from rscm_amd import _lib as L
+    from rscm_amd.ensemble import run_lockstep
+    T, n = 120, 257
+    yr = np.arange(T)
+    conc = np.stack([278.0 * 1.006 ** yr, 722.0 + 6.0 * yr, 270.0 + 0.4 * yr])[None]
+    b = np.arange(T + 1, dtype=float) + 1750.0
+    P1 = _ensemble(orc, n, "Ipcctar", seed=21)
+    P2 = np.ascontiguousarray(_ensemble(orc, n, "Ipcctar", seed=22))
+    count = C.c_int64()
+    with ra.Ensemble(ra.KIND_GHG_FORCING, n, b) as e:
+        e.set_forcing(conc)
+        e.set_params(P1)
+        ptr = C.c_void_p()
+        L.check(e._lib.rscm_ens_params_devptr(e._h, C.byref(ptr)))
+        L.check(e._lib.rscm_gpu_copy_to_device(0, ptr, P2.ctypes.data_as(C.c_void_p), P2.nbytes))
+        L.check(e._lib.rscm_gpu_derive_launches(C.byref(count)))      # reset
+        run_lockstep((e,), 40)                                          # 40 one-step launches, one call
+        L.check(e._lib.rscm_gpu_derive_launches(C.byref(count)))
+        assert count.value == 1, count.value
+        e.run()                                                         # the rest of the axis: another run, another derive
+        L.check(e._lib.rscm_gpu_derive_launches(C.byref(count)))
+        assert count.value == 1 and e.last_run_ms() > 0
+        got = {k: e.get_series(v) for k, v in NAMES.items()}
+        _assert_close(got, orc.ghg_run(T, P2, conc), "parameters written through the device pointer, stepped in lock-step")

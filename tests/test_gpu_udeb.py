@@ -403,7 +403,8 @@ def test_udeb_fuzz(ra, orc, seed):
     _assert_close(got, want, f"fuzz seed {seed} ({fixed}, T={T}, n={n}, cuts={cuts})")
 
 
-def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc):
+@pytest.mark.parametrize("n_layers", [50, 49])   # the count compiled in; the count at run time (capacity 50)
+def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, n_layers):
     """A whole-axis ClimateUDEB run over more than 65 536 members (one wavefront per SIMD) is issued as two halves of the members on two
     streams in chunks of model steps (rscm_ens_last_run_plan: 2 x 8 for 750 steps; each chunk reloads and stores the ocean columns and
     the scalars like any resumed run).  The same axis in five pieces of 150 steps (fewer than three chunks) takes the single-launch path: same bits,
@@ -411,7 +412,7 @@ def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc):
     n = 70_001
     years = np.arange(1750.0, 2501.0)
     b = np.append(years, 2501.0)
-    P = _ensemble_params(orc, n, seed=21)
+    P = _ensemble_params(orc, n, seed=21, n_layers=float(n_layers))
     F = np.stack([3.71 * np.minimum((years - 1750.0) / 200.0, 1.0), 1.5 * np.sin((years - 1750.0) / 40.0)])
     scen = (np.arange(n) % 2).astype(np.int32)
 
