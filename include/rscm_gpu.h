@@ -292,8 +292,9 @@ extern "C" {
  * Rows marked [u] are structural and must be equal for every member.  n_layers: any count >= 2 as in the reference
  * (climate/udeb/mod.rs:162-165; at most 4096 here).  Up to 64 layers a member's two columns stay in registers + LDS for a
  * whole launch (20, 30, 40, 50 with the count compiled in; every other count in the next capacity's instance of the same
- * unrolled solve with the count at run time); more than 64 layers run a slower kernel with the columns in HBM (same
- * arithmetic, same parity bar).  Device memory per handle besides the series: 2 x max(64, n_layers) x N x 8 B of columns,
+ * unrolled solve with the count at run time); 65 to 128 layers keep the column in registers and the solve's work array in LDS
+ * (about 6x the per-layer cost of the counts up to 64), more than 128 run a slower kernel with the columns in HBM (same
+ * arithmetic, same parity bar throughout).  Device memory per handle besides the series: 2 x max(64, n_layers) x N x 8 B of columns,
  * 11 x N x 8 B of scalars, T x N x 8 B of temperature history, and -- for counts other than 20 / 30 / 40 / 50 --
  * n_layers x N x 8 B of work array (e.g. n_layers = 4096, N = 1e5: 9.8 GB; n_layers = 49: 90 MB).  The reference's MAGICC7
  * files pin the 50-layer configuration only: at every other count parity is against the CPU restatement kept with the tests.

@@ -25,7 +25,7 @@
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
-#define NL_MAX 128
+#define NL_MAX 256
 
 /* parameters/climate_udeb.rs constants */
 static const double DIFFUSIVITY_CM2S_TO_M2YR = 3155.76;

@@ -378,6 +378,7 @@ constexpr int kUdebBlock = 64;  // one wavefront per workgroup: ~250 VGPRs per l
 constexpr int kUdebNParams = 37;
 constexpr int kUdebScalars = 11;
 constexpr int kUdebMaxOnChipLayers = 64;   // up to this many ocean layers a member's columns stay in registers + LDS (csrc/udeb.hip)
+constexpr int kUdebMaxLdsLayers = 128;     // ... and up to this many with the Thomas sweep's c' array in LDS (a hemisphere per wavefront)
 
 struct UdebArgs {
     int64_t n_members;

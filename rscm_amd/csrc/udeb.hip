@@ -73,6 +73,22 @@ __global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
     m.end(a);
 }
 
+// 65 .. kUdebMaxLdsLayers layers: a hemisphere per wavefront as above, the column in registers (it fills them) and the sweep's c' array
+// in LDS (2 x 128 rows x 512 B = 128 KB per workgroup: one workgroup per CU, i.e. two of a CU's four SIMDs busy -- half the on-chip
+// kernels' rate per layer, six times the columns-in-HBM kernel's).  The geometry table comes from device memory (6 KB: past the
+// kernel-argument segment), through the scalar cache all the same.
+template <bool FAST>
+__global__ __launch_bounds__(kUdeb2Block) void udeb2_lds_kernel(UdebArgs a)
+{
+    __shared__ Udeb2Lds lds;
+    extern __shared__ double ncp_slots[];   // [2][kUdebMaxLdsLayers][64]
+    Udeb2<kUdebMaxLdsLayers, true, kUdebMaxOnChipLayers + 1, true> m(lds);
+    m.ncp_lds = ncp_slots + (size_t)(threadIdx.x >> 6) * kUdebMaxLdsLayers * 64 + (threadIdx.x & 63);
+    m.begin(a);
+    for (int32_t n = a.step_begin; n < a.step_end; ++n) m.template step<FAST>(a, n);
+    m.end(a);
+}
+
 // Any other layer count (>= 2): columns in HBM, plain loops (udeb_any_body.hpp).  256 threads: nothing lives in registers across rows.
 template <bool FAST>
 __global__ __launch_bounds__(256) void udeb_any_kernel(UdebArgs a)
@@ -164,7 +180,20 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     // RSCM_UDEB_VARIANT = 0 / 2 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
     static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
     int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;
-    const bool in_hbm = variant == 3 || !udeb_layers_unrolled(a.n_layers);
+    const bool in_hbm = variant == 3 || a.n_layers > kUdebMaxLdsLayers;
+    if (!in_hbm && a.n_layers > kUdebMaxOnChipLayers) {   // c' in LDS, the two-wavefront shape at every ensemble size
+        if (!a.tables_dev) return hipErrorInvalidValue;
+        const size_t lds = (size_t)2 * kUdebMaxLdsLayers * 64 * sizeof(double);
+        void (*kern)(UdebArgs) = a.fast ? udeb2_lds_kernel<true> : udeb2_lds_kernel<false>;
+        static bool raised[2] = {false, false};   // (idempotent: a race sets it twice)
+        if (!raised[a.fast ? 1 : 0]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised[a.fast ? 1 : 0] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_members + 63) / 64)), dim3(kUdeb2Block), lds, s, a);
+        return hipGetLastError();
+    }
     if (variant != 0 && variant != 2) variant = (a.n_total > 0 ? a.n_total : a.n_members) <= 32768 ? 2 : 0;
     if (in_hbm) {   // more layers than the registers hold (or asked for): columns in HBM, plain loops
         if (a.n_layers < 2 || !a.tables_dev || !a.work) return hipErrorInvalidValue;

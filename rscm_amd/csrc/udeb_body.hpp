@@ -332,13 +332,18 @@ struct YearGeom {
 constexpr int kRowsAhead = 3;
 constexpr int kTabCols = 6;
 
-template <int NL, bool FAST, bool DYN = false, int LOW = NL>
+//
+// NCP_LDS (capacities above 64 rows): the column alone fills the vector registers, so the sweep's c' array lives in this lane's LDS
+// slots (ncp_lds[row * 64]; the caller's pointer is already at the lane) -- written in the forward sweep, read back in the back
+// substitution; the forward recurrence itself takes the previous row's c' from a register, as before, so its dependent chain does
+// not grow by an LDS round trip.  The same statements on the same values: the same bits as with c' in registers.
+template <int NL, bool FAST, bool DYN = false, int LOW = NL, bool NCP_LDS = false>
 __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom& y,
                                                   const double* tables, int32_t land_hc,
                                                   double (&dp)[NL], int hemi,
                                                   double forcing, double hemi_hx, double ground_temp,
                                                   double land_temp, double alpha_eff, double w,
-                                                  int32_t nl_rt = NL, double* bottom = nullptr)
+                                                  int32_t nl_rt = NL, double* bottom = nullptr, double* ncp_lds = nullptr)
 {
     constexpr int R = kRowsAhead;
     constexpr int NCH = (NL + R - 1) / R;
@@ -378,7 +383,8 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
     const double s_afd = p.pi_ratio * tul * t_top;
     const double dwq = y.dt_dz * dwv;
 
-    double ncp[NL];  // -c'
+    double ncp[NCP_LDS ? 1 : NL];  // -c'
+    double ncp_prev = 0.0;         // (NCP_LDS: the previous row's, for the recurrence)
     double tdu = 0.0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -406,7 +412,12 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
                 if (land_hc) d0 = __builtin_fma(-(land_temp - ground_temp) * (sh ? y.lhc[1] : y.lhc[0]), af_top, d0);
                 d0 = __builtin_fma(y.dt_dzmix * dwv, G, d0);
                 const double rr = refined_rcp(b0);
-                ncp[0] = nc0 * rr;
+                if constexpr (NCP_LDS) {
+                    ncp_prev = nc0 * rr;
+                    ncp_lds[0] = ncp_prev;
+                } else {
+                    ncp[0] = nc0 * rr;
+                }
                 dp[0] = d0 * rr;
                 // row 1 as an interior row: dz_up = dz/2; as the BOTTOM row (two layers) the reference takes dz for it (ocean_column.rs:191)
                 tdu = kap0 * ((DYN && nl == 2) ? y.dt_dz2 : y.dt_dzdz1);
@@ -418,7 +429,10 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
             const double tdd = fmax(__builtin_fma(omr, kslope2, y.kC2), y.kminC2);
             const double bi = __builtin_fma(tdu + tul, af_top, __builtin_fma(tdd, af_bot, 1.0));
             const double di = __builtin_fma(dwq, G, __builtin_fma(s_afd, af_diff, t_i));
-            const double denom = __builtin_fma(-tdu_aft, ncp[i - 1], bi);
+            double c_up;
+            if constexpr (NCP_LDS) c_up = ncp_prev;
+            else c_up = ncp[i - 1];
+            const double denom = __builtin_fma(-tdu_aft, c_up, bi);
             // 1/denom = r0 (1 + e + e^2 + ...), e = 1 - denom*r0: the hardware estimate is good
             // to ~2^-23, so the series cut after e^2 is exact to rounding, and the c' chain that
             // feeds the next row's denominator is five dependent operations instead of seven
@@ -426,7 +440,12 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
             const double e = __builtin_fma(-denom, r0, 1.0);
             const double u = FAST ? e : __builtin_fma(e, e, e);
             const double t = (tdd + tul) * af_bot * r0;
-            ncp[i] = __builtin_fma(t, u, t);
+            if constexpr (NCP_LDS) {
+                ncp_prev = __builtin_fma(t, u, t);
+                ncp_lds[(size_t)i * 64] = ncp_prev;
+            } else {
+                ncp[i] = __builtin_fma(t, u, t);
+            }
             const double sdp = __builtin_fma(tdu_aft, dp[i - 1], di) * r0;
             dp[i] = __builtin_fma(sdp, u, sdp);
             tdu = tdd;
@@ -447,7 +466,10 @@ __device__ __forceinline__ double step_hemisphere(const UdebP& p, const YearGeom
     pick_bottom(NL - 1);
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) {
-        x = __builtin_fma(ncp[i], x, dp[i]);
+        double c_i;
+        if constexpr (NCP_LDS) c_i = ncp_lds[(size_t)i * 64];
+        else c_i = ncp[i];
+        x = __builtin_fma(c_i, x, dp[i]);
         dp[i] = fmin(x, p.max_temp);
         if (i >= LOW - 1) pick_bottom(i);
     }
@@ -820,9 +842,10 @@ struct Udeb2Lds {
 // or resume), step(n) for consecutive n, end() (internal state back to HBM).  Every thread of the workgroup
 // must make the same calls: step() and begin() hold workgroup barriers.  Lanes past the end of the ensemble
 // compute on a copy of the last member and store nothing.
-template <int NL, bool DYN = false, int LOW = NL>
+template <int NL, bool DYN = false, int LOW = NL, bool NCP_LDS = false>
 struct Udeb2 {
     Udeb2Lds& lds;
+    double* ncp_lds = nullptr;   // NCP_LDS: this lane's column of c' slots ([NL][64] doubles per wavefront; the kernel sets it)
     int tid, lane;
     int32_t nl;      // rows of the column (wave-uniform; NL when not DYN)
     double bot;      // DYN: the column's bottom-row temperature
@@ -933,7 +956,8 @@ struct Udeb2 {
     __device__ __forceinline__ void step(const UdebArgs& a, int32_t n)
     {
         const bool sh = hemi != 0;
-        const double* tables = a.tables;  // kernarg segment
+        // kernarg segment; above 64 rows the table does not fit there (6 KB at 128 rows): the same rows in device memory, still wave-uniform
+        const double* tables = NCP_LDS ? a.tables_dev : a.tables;
         const double nan = __builtin_nan("");
         const bool dead = status != 0;    // the reference refuses to build this component: every output NaN
         const double erf_start = F[(size_t)n * f_stride], erf_end = F[(size_t)(n + 1) * f_stride];
@@ -1021,7 +1045,7 @@ struct Udeb2 {
             const double adj = substep_forcing(erf_start, erf_end, step_idx, inv_steps, eff_scale);
             const double f_ocean = adj * q_o, f_land = adj * q_l;
             if (a.land_hc) gr = __builtin_fma(land - gr, gfac, gr);
-            const double sst = step_hemisphere<NL, FAST, DYN, LOW>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up, nl, &bot);   // the same function as the one-thread kernel: the same bits
+            const double sst = step_hemisphere<NL, FAST, DYN, LOW, NCP_LDS>(p, y, tables, a.land_hc, col, hemi, f_ocean, hx, gr, land, ae_y, up, nl, &bot, ncp_lds);   // the same function as the one-thread kernel: the same bits
             t_air = sst_to_air(airmap, sst);
             land = land_temperature(ka, p.max_temp, t_air, f_land, fg_l, r_land);
             // what the other hemisphere needs of this one: air and land temperature

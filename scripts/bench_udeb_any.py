@@ -11,7 +11,7 @@ from rscm_amd import _lib  # noqa: E402
 members = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 t = np.arange(1750.0, 2501.0)
 F = 4.0 * (1.0 - np.exp(-(t - 1750.0) / 120.0))
-counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (50, 49, 51, 64, 40, 41, 30, 25, 21, 20, 19, 2, 65, 100)
+counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (50, 49, 51, 64, 65, 80, 100, 128, 129, 200, 40, 41, 30, 25, 21, 20, 19, 2)
 for nl in counts:
     lo = np.array(_lib.UD_DEFAULTS, dtype=float)
     lo[_lib.UD_PARAM_NAMES.index("n_layers")] = nl
@@ -30,6 +30,6 @@ for nl in counts:
         t0 = time.perf_counter()
         e.run()
         dt = time.perf_counter() - t0
-        kind = "register-resident, count compiled in" if nl in (20, 30, 40, 50) else "register-resident, count at run time" if nl <= 64 else "columns in HBM"
+        kind = "register-resident, count compiled in" if nl in (20, 30, 40, 50) else "register-resident, count at run time" if nl <= 64 else "column in registers, c' in LDS" if nl <= 128 else "columns in HBM"
         print(f"ClimateUDEB n_layers={nl:3d} members={members}: {dt * 1e3:8.1f} ms per 750 years ({kind} kernel), "
               f"failed members {int(e.status().astype(bool).sum())}", flush=True)

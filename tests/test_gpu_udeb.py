@@ -115,17 +115,17 @@ def _variant(ra, v):
     L.check(L.load().rscm_gpu_set_udeb_variant(v))
 
 
-@pytest.mark.parametrize("n_layers", [2, 3, 7, 19, 21, 25, 49, 51, 64, 65, 80])
+@pytest.mark.parametrize("n_layers", [2, 3, 7, 19, 21, 25, 49, 51, 64, 65, 80, 100, 128, 129])
 def test_udeb_gpu_any_layer_count(ra, orc, n_layers):
     """Every n_layers >= 2 the reference accepts (parameters/climate_udeb.rs:41; from_parameters refuses < 2, mod.rs:162-165) runs on
     the device.  Up to 64 layers a member's columns stay in registers + LDS: counts other than 20 / 30 / 40 / 50 take the next
     capacity's instance of the unrolled kernels with the count at run time (csrc/udeb_body.hpp, DYN: a scalar branch per row, the
-    statements of a live row unchanged); beyond 64 the columns-in-HBM kernel (csrc/udeb_any_body.hpp: plain loops over the layers,
-    the same row arithmetic).  Same 1e-9 bar against the oracle (which takes any count; the reference's MAGICC7 files pin 50
+    statements of a live row unchanged); 65 to 128 layers a hemisphere per wavefront with the column in registers and the sweep's c' array
+    in LDS; beyond 128 the columns-in-HBM kernel (csrc/udeb_any_body.hpp: plain loops over the layers, the same row arithmetic).  Same 1e-9 bar against the oracle (which takes any count; the reference's MAGICC7 files pin 50
     layers only: parity at other counts is against the restatement); both arithmetic modes; launch boundaries (resume from the
     stored columns and scalars) change nothing; a member the reference refuses to build is flagged and NaN; more than 50 layers
     means the initial profile's last value below layer 50, as in the oracle.  Up to 64 layers the three kernels -- a hemisphere per
-    wavefront, one thread per member, columns in HBM -- carry the same bits."""
+    wavefront, one thread per member, columns in HBM -- carry the same bits; from 65 to 128 the LDS kernel and the HBM kernel do."""
     years = np.arange(1850.0, 1931.0)
     b = np.append(years, 1931.0)
     n = 300   # a ragged last workgroup of the 256-thread kernel
@@ -143,10 +143,10 @@ def test_udeb_gpu_any_layer_count(ra, orc, n_layers):
         assert np.array_equal(again[k], got[k], equal_nan=True), k
     fast, _ = _gpu(ra, b, P, F, scen=scen, mode=ra.MODE_FAST)
     _assert_close(fast, want, f"{n_layers} layers, FAST")
-    if n_layers <= 64:
+    if n_layers <= 128:
         try:
             for mode, ref in ((None, got), (ra.MODE_FAST, fast)):
-                for v in (0, 2, 3):   # one thread per member; a hemisphere per wavefront; columns in HBM
+                for v in ((0, 2, 3) if n_layers <= 64 else (3,)):   # one thread per member; a hemisphere per wavefront; columns in HBM
                     _variant(ra, v)
                     other, st_v = _gpu(ra, b, P, F, scen=scen, chunks=(17,), mode=mode)
                     assert (st_v == st).all()
