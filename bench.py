@@ -1038,6 +1038,9 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # a leased box shows all of the host's cores and grants a share of them: torch's (and gloo's) CPU-side work with one thread per
+    # VISIBLE core only takes turns (the two-rank gloo rehearsal of the sharded sampler: 226 ms per exchange with 256 threads)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), baseline_threads(host_description()))))
     if args.rendezvous_only:
         raise SystemExit(rendezvous_only(args, rank, world, torch, dist))
     from rscm_amd import _lib
