@@ -1020,6 +1020,9 @@ def main():
     ap.add_argument("--scale-walkers", type=int, default=100_000, help="walkers per iteration of scale_calibrate_sharded_1e5 (configs[4])")
     ap.add_argument("--scale-sweeps", type=int, default=200, help="timed sweeps of scale_calibrate_sharded_1e5")
     ap.add_argument("--scale-only", action="store_true", help="of the extras, only the scale_* ones (tests)")
+    ap.add_argument("--extras-budget", type=float, default=540.0,
+                    help="seconds after the headline at which a watchdog prints the line as it stands and ends the process, should a side "
+                         "measurement hang (default 540; the whole default run takes about a minute)")
     ap.add_argument("--no-scale", action="store_true", help="skip the scale_* extras (the configs defined on more than one GPU)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: the ranks meet over gloo, run the contract's barrier / max-over-ranks / rank report and rank 0 "
@@ -1104,6 +1107,79 @@ def main():
     describe_run_plan(roofline_hbm, run_plan)
 
     extra = {}
+    # The line is complete from here on: the headline stands, the side measurements and the CPU baseline fill `extra` /
+    # `cpu_baseline` in place.  Should any of them hang (a collective that never returns on some rank, a kernel that never ends),
+    # the watchdog prints the line as it is after --extras-budget seconds and ends the process: a side measurement never costs the
+    # headline, not even by not coming back.
+    out = {
+        "metric": "ensemble-member-years/sec, two-layer 1750-2500 f64",
+        "value": value,
+        "unit": "member-years/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"two-layer energy balance, {args.members} members/GPU x 751 points "
+                        f"(1750-2500 annual, 750 steps, RK4 h=0.1), BASELINE.json configs[1]",
+            "members_per_gpu": args.members,
+            "years": years,
+            "arithmetic_mode": args.mode,
+            "forcing": "F_syn (SURVEY 8d), exogenous, 1 scenario in LDS",
+            "parameters": "device Latin hypercube over typical ranges, seed 20260327",
+            "outputs": "Ts,Td every year to HBM (16 B/member-year)",
+            "sharding": f"contiguous member blocks, {world} rank(s), no data-path collective",
+            # part of the draw, not a fault: over these ranges a few per cent of the Latin hypercube's members have
+            # lambda0 - a*Ts turn negative and run away to inf; they are stepped and stored like the others and flagged
+            "failed_members": int(sum(fails)), "failed_members_per_rank": fails,
+            "failed_members_fraction": sum(fails) / float(world * args.members),
+        },
+        "roofline": roofline_hbm,
+        "roofline_fp64_valu": roofline_valu,
+        "collective": collective,
+        "per_rank": per_rank,
+        "cpu_baseline": None,
+        "check": {"failed_members_rank0": n_fail, "Ts_2020_mean_rank0": s_mid["mean"],
+                  "finite_members_2020_rank0": s_mid["count"]},
+        "extra": extra,
+    }
+
+    import threading
+    printed = threading.Lock()
+
+    def emit(note=None):
+        if not printed.acquire(blocking=False):
+            return False
+        if rank == 0:
+            if note:
+                out["watchdog"] = note
+            text = None
+            for _ in range(5):   # (the watchdog serialises while the main thread may be adding an extra)
+                try:
+                    text = json.dumps(dict(out, extra=dict(extra)))
+                    break
+                except RuntimeError:
+                    time.sleep(0.01)
+            sys.stdout.write((text or json.dumps(dict(out, extra={}))) + "\n")
+            sys.stdout.flush()
+        return True
+
+    def watchdog():
+        time.sleep(max(1.0, args.extras_budget))
+        fired = emit(f"the side measurements did not finish within {args.extras_budget:g} s: the line was printed without the missing ones "
+                     f"(present: {sorted(extra)})")
+        if not fired:
+            time.sleep(30.0)   # the line is out already: only a teardown that never returns is left to end
+        sys.stderr.write(f"bench.py: rank {rank}: watchdog ends the process {'(line printed by it)' if fired else '(after the line)'}\n")
+        sys.stderr.flush()
+        os._exit(0)   # (no exec, no collective: the other ranks' watchdogs end them the same way)
+
+    threading.Thread(target=watchdog, daemon=True).start()
 
     def side(label, fn):
         """A side measurement never costs the headline line: a failure is reported in its place."""
@@ -1223,45 +1299,8 @@ def main():
             cpu = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             print(f"bench.py: cpu_baseline failed: {exc}", file=sys.stderr)
 
-    if rank == 0:
-        out = {
-            "metric": "ensemble-member-years/sec, two-layer 1750-2500 f64",
-            "value": value,
-            "unit": "member-years/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"two-layer energy balance, {args.members} members/GPU x 751 points "
-                            f"(1750-2500 annual, 750 steps, RK4 h=0.1), BASELINE.json configs[1]",
-                "members_per_gpu": args.members,
-                "years": years,
-                "arithmetic_mode": args.mode,
-                "forcing": "F_syn (SURVEY 8d), exogenous, 1 scenario in LDS",
-                "parameters": "device Latin hypercube over typical ranges, seed 20260327",
-                "outputs": "Ts,Td every year to HBM (16 B/member-year)",
-                "sharding": f"contiguous member blocks, {world} rank(s), no data-path collective",
-                # part of the draw, not a fault: over these ranges a few per cent of the Latin hypercube's members have
-                # lambda0 - a*Ts turn negative and run away to inf; they are stepped and stored like the others and flagged
-                "failed_members": int(sum(fails)), "failed_members_per_rank": fails,
-                "failed_members_fraction": sum(fails) / float(world * args.members),
-            },
-            "roofline": roofline_hbm,
-            "roofline_fp64_valu": roofline_valu,
-            "collective": collective,
-            "per_rank": per_rank,
-            "cpu_baseline": cpu,
-            "check": {"failed_members_rank0": n_fail, "Ts_2020_mean_rank0": s_mid["mean"],
-                      "finite_members_2020_rank0": s_mid["count"]},
-            "extra": extra,
-        }
-        print(json.dumps(out))
+    out["cpu_baseline"] = cpu
+    emit()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 

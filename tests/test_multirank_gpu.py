@@ -156,3 +156,17 @@ def test_bench_two_ranks_measures_every_multi_gpu_config():
     _check_scale_extras(two, 2)
     one = _bench_line(["--gpus", "1", *SCALE_SMALL, "--scale-only"], {})
     _check_scale_extras(one, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
+def test_bench_watchdog_keeps_the_headline_when_side_measurements_do_not_finish():
+    """Once the headline is measured the line is complete; should a side measurement not come back (a collective that hangs on an
+    8-GPU node would otherwise take the headline with it), the watchdog prints the line as it stands and ends the process with exit
+    code 0.  Here the budget is simply too short for the extras."""
+    line = _bench_line(["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--extras-budget", "1.5"], {})
+    assert line["value"] > 0 and line["n_gpus"] == 1 and "watchdog" in line and "did not finish" in line["watchdog"]
+    assert isinstance(line["extra"], dict) and "calibrate_graph_device_1e5_fast" not in line["extra"]
+    two = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--extras-budget", "1.5"],
+                      {"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"})
+    assert two["value"] > 0 and two["n_gpus"] == 2 and "watchdog" in two
