@@ -185,11 +185,9 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
         if (!a.tables_dev) return hipErrorInvalidValue;
         const size_t lds = (size_t)2 * kUdebMaxLdsLayers * 64 * sizeof(double);
         void (*kern)(UdebArgs) = a.fast ? udeb2_lds_kernel<true> : udeb2_lds_kernel<false>;
-        static bool raised[2] = {false, false};   // (idempotent: a race sets it twice)
-        if (!raised[a.fast ? 1 : 0]) {
+        {   // (every launch: the attribute belongs to the function ON THE CURRENT DEVICE, and a host may drive several)
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            raised[a.fast ? 1 : 0] = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_members + 63) / 64)), dim3(kUdeb2Block), lds, s, a);
         return hipGetLastError();
