@@ -448,3 +448,30 @@ def test_udeb_runs_cut_into_member_blocks_and_chunks_keep_the_bits(ra, orc, n_la
     want, wst = orc.udeb_run(b, P[:, pick].copy(), F, scen=scen[pick].copy(), threads=8)
     assert not wst.any()
     _assert_close(cut_sample, want, "members across the cut")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_udeb_fuzz_over_layer_counts(ra, orc, seed):
+    """The fuzz of test_udeb_fuzz with the LAYER COUNT drawn too -- 2 to 128, i.e. every instance of the column solve: the count
+    compiled in, the count at run time in each capacity, the c' array in LDS -- together with layer thickness, mixed-layer depth and the
+    depth-dependent area (which shape the geometry table the rows past the end of a column read as zeros), random launch chunking
+    (resume through the stored columns) and ensemble sizes on both sides of a wavefront."""
+    rng = np.random.default_rng(900 + seed)
+    T = int(rng.integers(3, 60))
+    n = int(rng.choice([1, 64, 65, 200]))
+    nl = int(rng.choice([2, 5, 11, 20, 23, 30, 37, 40, 46, 50, 57, 64, 65, 90, 128]))
+    b = np.concatenate([[1850.0], 1850.0 + np.cumsum(rng.choice([0.5, 1.0, 1.0, 2.0], T))])
+    fixed = dict(n_layers=float(nl), layer_thickness=float(rng.choice([40.0, 100.0, 250.0])), mixed_layer_depth=float(rng.choice([50.0, 60.0, 90.0])),
+                 land_heat_capacity_enabled=float(rng.integers(0, 2)), efficacy_apply=float(rng.integers(0, 3)),
+                 steps_per_year=float(rng.choice([1, 4, 12])), depth_dependent_area=float(rng.choice([0.0, 0.5, 1.0])),
+                 feedback_cumt_period=float(rng.choice([3.0, 17.5, 300.0])))
+    P = _ensemble_params(orc, n, seed=seed, **fixed)
+    S = int(rng.choice([1, 3]))
+    F = np.cumsum(rng.normal(0.05, 0.3, (S, T)), axis=1)
+    scen = rng.integers(0, S, n).astype(np.int32) if S > 1 else None
+    want, wst = orc.udeb_run(b, P, F, scen=scen, threads=8)
+    cuts = tuple(sorted(set(int(x) for x in rng.integers(1, T, int(rng.integers(0, 3))))))
+    for mode in (None, ra.MODE_FAST):
+        got, st = _gpu(ra, b, P, F, scen=scen, chunks=cuts, mode=mode)
+        assert (st == wst).all()
+        _assert_close(got, want, f"fuzz seed {seed} ({fixed}, T={T}, n={n}, cuts={cuts}, mode={mode})")
