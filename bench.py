@@ -523,7 +523,7 @@ def scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, ye
 
         def prepare():
             from rscm_amd import _lib as L
-            free0, total = L.mem_info(local_rank)
+            free0 = L.mem_info(local_rank)[0]
             t0 = time.perf_counter()
             model = prog.build(members, yrs, False, 96, device=local_rank, member_offset=rank * members, members_total=world * members)
             return {"model": model, "build_s": time.perf_counter() - t0, "hbm_gib": (free0 - L.mem_info(local_rank)[0]) / 2**30}
