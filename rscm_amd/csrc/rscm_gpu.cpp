@@ -430,9 +430,12 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             if (e != hipSuccess)
                 return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "work array of %d layers x %lld members: %s",
                             h->udeb_n_layers, (long long)h->N, hipGetErrorString(e));
-            HIPCHK(hipMalloc(&h->d_udeb_tables, (size_t)6 * h->udeb_n_layers * sizeof(double)));
+            // (room for the largest on-chip capacity: the unrolled sweeps request the table rows of their whole capacity, and the rows past
+            // the layer count must read as zeros -- they are what makes those rows of the column exact no-ops)
+            HIPCHK(hipMalloc(&h->d_udeb_tables, (size_t)6 * std::max(h->udeb_n_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double)));
             h->udeb_work_layers = h->udeb_n_layers;
         }
+        HIPCHK(hipMemsetAsync(h->d_udeb_tables, 0, (size_t)6 * std::max(h->udeb_work_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double), h->stream));
         HIPCHK(hipMemcpyAsync(h->d_udeb_tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
