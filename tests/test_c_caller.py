@@ -151,3 +151,61 @@ def test_headers_compile_alone_as_strict_c11_and_as_cxx(tmp_path, header):
                 ["g++", "-std=c++17", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)]):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, " ".join(cmd) + "\n" + r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The component-graph API from C: tests/c_abi/caller_graph.c
+
+
+def _build_graph_caller(tmp_path):
+    exe = str(tmp_path / "caller_graph")
+    libdir = os.path.join(ROOT, "rscm_amd")
+    cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "caller_graph.c"), "-o", exe, "-L", libdir, "-lrscm_gpu", f"-Wl,-rpath,{libdir}",
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_graph_caller_builds_against_the_header_alone(tmp_path):
+    exe = _build_graph_caller(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 64 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
+def test_c_graph_caller_links_steps_and_scores(tmp_path):
+    """The reference's coupled model (docs/notebooks/coupled_model.py: CarbonCycle -> CO2ERF -> Sum -> TwoLayer with the lagged
+    temperature feedback) assembled FROM C as four linked ensembles with each consumer's VariableSource, stepped in lock-step on the
+    caller's stream, equals the fused kind bit for bit on every series and in the per-member log-likelihood (checked inside the C
+    program), refuses to destroy a source that is still linked, and matches the oracle within the coupled kind's 1e-11."""
+    from oracle import cbind
+    n = 3000
+    exe = _build_graph_caller(tmp_path)
+    out = tmp_path / "graph.bin"
+    r = subprocess.run([exe, str(out), str(n)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"members": n, "steps": 200, "linked_equals_fused": True, "destroy_of_a_linked_source_refused": True}
+    raw = out.read_bytes()
+    n_file, T = (int(x) for x in np.frombuffer(raw, dtype=np.int64, count=2))
+    assert (n_file, T) == (n, 201)
+    ts = np.frombuffer(raw, dtype=np.float64, count=T * n, offset=16).reshape(T, n)
+    co2 = np.frombuffer(raw, dtype=np.float64, count=T * n, offset=16 + 8 * T * n).reshape(T, n)
+    ll = np.frombuffer(raw, dtype=np.float64, count=n, offset=16 + 16 * T * n)
+    lo = np.array([0.9, 0.0, 1.0, 0.5, 5.0, 50.0, 15.0, 278.0, 0.0, 3.7])
+    hi = np.array([1.5, 0.05, 1.8, 1.0, 15.0, 200.0, 40.0, 278.0, 0.1, 3.7])
+    i = np.arange(n, dtype=np.uint64)[None, :]
+    j = np.arange(10, dtype=np.uint64)[:, None]
+    hashed = (i * np.uint64(2246822519) + j * np.uint64(374761393) + np.uint64(7)) & np.uint64(0xFFFFFFFF)
+    P = lo[:, None] + (hi - lo)[:, None] * (hashed.astype(np.float64) / 4294967296.0)
+    t = np.arange(1750.0, 1951.0)
+    want = cbind.coupled_run(np.append(t, 1951.0), np.ascontiguousarray(P), 0.02 * np.arange(201.0),
+                             dict(ts=0.0, td=0.0, conc=278.0, cum_uptake=0.0, cum_emis=0.0), threads=8)
+    close = lambda a, b: np.abs(a - b) <= 1e-11 * np.maximum(1.0, np.abs(b))   # noqa: E731
+    assert close(ts, want["ts"]).all() and close(co2, want["conc"]).all()
+    tidx = 30 * np.arange(1, 7)
+    expect = (-0.5 * ((0.004 * tidx[:, None] - want["ts"][tidx]) ** 2 / 0.2 ** 2)).sum(axis=0)
+    assert np.allclose(ll, expect, rtol=1e-9, atol=1e-9) and np.isfinite(ll).all()
