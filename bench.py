@@ -1192,7 +1192,10 @@ def main():
     # Every config that is defined on more than one GPU, on ALL ranks (and under the same keys at N = 1): scale_exact_1e6,
     # scale_coupled_fast_1e6, scale_configs3_share, scale_calibrate_sharded_1e5[_per_gpu].  After the headline, which is unchanged.
     if not args.no_extra and not args.no_scale:
-        scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, years, extra)
+        try:
+            scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, years, extra)
+        except Exception as exc:  # noqa: BLE001 -- e.g. a collective that fails because a peer's watchdog has ended it: the headline stands
+            print(f"bench.py: rank {rank}: the scale extras stopped: {type(exc).__name__}: {exc}", file=sys.stderr)
 
     if rank == 0 and world == 1 and not args.no_extra and not args.scale_only:
         def two_layer_case(members, m, cp):
@@ -1302,7 +1305,10 @@ def main():
     out["cpu_baseline"] = cpu
     emit()
     if dist.is_available() and dist.is_initialized():
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001 -- the line is out; a peer that has already gone must not turn this rank's exit code
+            print(f"bench.py: rank {rank}: destroy_process_group: {type(exc).__name__}: {exc}", file=sys.stderr)
 
 
 if __name__ == "__main__":
