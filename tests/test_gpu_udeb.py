@@ -475,3 +475,25 @@ def test_udeb_fuzz_over_layer_counts(ra, orc, seed):
         got, st = _gpu(ra, b, P, F, scen=scen, chunks=cuts, mode=mode)
         assert (st == wst).all()
         _assert_close(got, want, f"fuzz seed {seed} ({fixed}, T={T}, n={n}, cuts={cuts}, mode={mode})")
+
+
+@pytest.mark.parametrize("n_layers,n", [(49, 200), (21, 40_000), (100, 130)])
+def test_udeb_runtime_layer_count_one_step_per_launch(ra, orc, n_layers, n):
+    """What a lock-step graph does to ClimateUDEB -- one model step per launch, the columns and scalars out to HBM and back every
+    step -- with the layer count at run time (two-wavefront and one-thread kernels, c' in LDS): the same bits as the whole axis in one
+    launch."""
+    years = np.arange(1850.0, 1886.0)
+    b = np.append(years, 1886.0)
+    P = _ensemble_params(orc, n, seed=300 + n_layers, n_layers=float(n_layers))
+    F = 3.71 * np.minimum((years - 1850.0) / 20.0, 1.0)
+    whole, st = _gpu(ra, b, P, F)
+    assert not st.any()
+    with ra.Ensemble(ra.KIND_UDEB, n, b) as e:
+        e.set_params(P)
+        e.set_forcing(F)
+        for k in range(1, 5):
+            e.set_initial(k, 0.0)
+        while not e.finished():
+            e.step()
+        for k, v in NAMES.items():
+            assert np.array_equal(e.get_series(v), whole[k], equal_nan=True), k
