@@ -17,13 +17,13 @@
 #include <new>
 #include <cstdlib>
 
-// Debug aid (RSCM_POISON_ALLOC=1 in the environment): every device allocation of the host layer is filled with 0xFF bytes -- NaN as a
+// Every device allocation of the host layer goes through dev_malloc.  Debug aid (RSCM_POISON_ALLOC=1 in the environment): it is filled with 0xFF bytes -- NaN as a
 // double, -1 as an integer, 255 as a status byte -- so that a kernel or a copy that reads memory nobody wrote shows up as a wrong
 // result in the parity tests instead of passing on whatever a fresh allocation happens to hold (usually zeros).  Off by default: one
 // fill per allocation.  The GPU tier is run once per round with it on.
 namespace rscm {
 template <class T>
-inline hipError_t poisoned_malloc(T** p, size_t n)
+inline hipError_t dev_malloc(T** p, size_t n)
 {
     static const bool poison = [] { const char* e = getenv("RSCM_POISON_ALLOC"); return e && atoi(e) != 0; }();
     const hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n);
@@ -32,7 +32,6 @@ inline hipError_t poisoned_malloc(T** p, size_t n)
     return f == hipSuccess ? hipDeviceSynchronize() : f;
 }
 }  // namespace rscm
-#define hipMalloc(p, n) rscm::poisoned_malloc((p), (n))
 #include <string>
 #include <vector>
 

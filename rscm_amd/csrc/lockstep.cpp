@@ -383,7 +383,7 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
             plan->cached.assign((size_t)n_handles, rscm::GroupOp());
             plan->valid.assign((size_t)n_handles, 0);
             plan->ring_pos = 0;
-            HIPCHK(hipMalloc(&plan->d_ops, (size_t)n_handles * sizeof(rscm::GroupOp)));
+            HIPCHK(rscm::dev_malloc(&plan->d_ops, (size_t)n_handles * sizeof(rscm::GroupOp)));
             if (!plan->staging) HIPCHK(hipHostMalloc((void**)&plan->staging, LockstepPlan::kRing * sizeof(rscm::GroupOp), hipHostMallocDefault));
         }
     }

@@ -289,7 +289,7 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(h->d_ocean_irf));
     h->d_ocean_irf = nullptr;
-    HIPCHK(hipMalloc(&h->d_ocean_irf, tab.size() * sizeof(double)));
+    HIPCHK(rscm::dev_malloc(&h->d_ocean_irf, tab.size() * sizeof(double)));
     HIPCHK(hipMemcpy(h->d_ocean_irf, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     // The flux history is a ring: the convolution reads at most max_history_months pulses back, a tile writes
     // up to 48 new ones before it is done reading (ocean.hip), the O(T) recurrence reads the pulse that leaves
@@ -306,7 +306,7 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
                         (long long)rows, h->time_index);
         HIPCHK(hipFree(h->d_ocean_hist));
         h->d_ocean_hist = nullptr;
-        const hipError_t e = hipMalloc(&h->d_ocean_hist, (size_t)rows * h->N * sizeof(double));
+        const hipError_t e = rscm::dev_malloc(&h->d_ocean_hist, (size_t)rows * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE,
                         "flux history of %lld members x %lld months: %s", (long long)h->N, (long long)rows, hipGetErrorString(e));
@@ -314,7 +314,7 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
         h->ocean_hist_rows = rows;
     }
     if (!h->d_ocean_partial) {
-        const hipError_t e = hipMalloc(&h->d_ocean_partial, (size_t)(rscm::kOceanSplitYears - 1) * 12 * h->N * sizeof(double));
+        const hipError_t e = rscm::dev_malloc(&h->d_ocean_partial, (size_t)(rscm::kOceanSplitYears - 1) * 12 * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "split-tile sums of %lld members: %s",
                         (long long)h->N, hipGetErrorString(e));
@@ -326,12 +326,12 @@ int configure_ocean(rscm_ens* h, int64_t n_check, Row row)
     h->ocean_fit_error = ocean_fit_modes(tab, (int)model, row(RSCM_OC_P_IRF_SWITCH_TIME, 0), (int64_t)max_hist, &h->ocean_near, &h->ocean_modes);
     h->ocean_recur_ok = h->ocean_fit_error >= 0.0 && h->ocean_fit_error <= kOceanFitTolerance;
     if (h->ocean_recur_ok && !h->d_ocean_mode_state) {
-        const hipError_t e = hipMalloc(&h->d_ocean_mode_state, (size_t)rscm::kOceanModes * h->N * sizeof(double));
+        const hipError_t e = rscm::dev_malloc(&h->d_ocean_mode_state, (size_t)rscm::kOceanModes * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "mode sums of %lld members: %s", (long long)h->N, hipGetErrorString(e));
     }
     if (h->ocean_recur_ok) {
-        if (!h->d_ocean_mode_table) HIPCHK(hipMalloc(&h->d_ocean_mode_table, (size_t)3 * rscm::kOceanModes * sizeof(double)));
+        if (!h->d_ocean_mode_table) HIPCHK(rscm::dev_malloc(&h->d_ocean_mode_table, (size_t)3 * rscm::kOceanModes * sizeof(double)));
         double t3[3 * rscm::kOceanModes];
         for (int q = 0; q < rscm::kOceanModes; ++q) {
             t3[q] = h->ocean_modes.d[q];
@@ -400,8 +400,8 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             kfull[n] = kf;
             partw[n] = pw;
         }
-        if (!h->d_win_kfull) HIPCHK(hipMalloc(&h->d_win_kfull, (size_t)h->T * sizeof(int32_t)));
-        if (!h->d_win_partw) HIPCHK(hipMalloc(&h->d_win_partw, (size_t)h->T * sizeof(double)));
+        if (!h->d_win_kfull) HIPCHK(rscm::dev_malloc(&h->d_win_kfull, (size_t)h->T * sizeof(int32_t)));
+        if (!h->d_win_partw) HIPCHK(rscm::dev_malloc(&h->d_win_partw, (size_t)h->T * sizeof(double)));
         HIPCHK(hipMemcpyAsync(h->d_win_kfull, kfull.data(), kfull.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_win_partw, partw.data(), partw.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -412,7 +412,7 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             (void)hipFree(h->d_ocean);
             h->d_ocean = nullptr;
             h->udeb_ocean_layers = 0;
-            const hipError_t e = hipMalloc(&h->d_ocean, (size_t)2 * want * h->N * sizeof(double));
+            const hipError_t e = rscm::dev_malloc(&h->d_ocean, (size_t)2 * want * h->N * sizeof(double));
             if (e != hipSuccess)
                 return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "ocean columns of %d layers x %lld members: %s", want,
                             (long long)h->N, hipGetErrorString(e));
@@ -426,13 +426,13 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
             (void)hipFree(h->d_udeb_tables);
             h->d_udeb_work = h->d_udeb_tables = nullptr;
             h->udeb_work_layers = 0;
-            const hipError_t e = hipMalloc(&h->d_udeb_work, (size_t)h->udeb_n_layers * h->N * sizeof(double));
+            const hipError_t e = rscm::dev_malloc(&h->d_udeb_work, (size_t)h->udeb_n_layers * h->N * sizeof(double));
             if (e != hipSuccess)
                 return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "work array of %d layers x %lld members: %s",
                             h->udeb_n_layers, (long long)h->N, hipGetErrorString(e));
             // (room for the largest on-chip capacity: the unrolled sweeps request the table rows of their whole capacity, and the rows past
             // the layer count must read as zeros -- they are what makes those rows of the column exact no-ops)
-            HIPCHK(hipMalloc(&h->d_udeb_tables, (size_t)6 * std::max(h->udeb_n_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double)));
+            HIPCHK(rscm::dev_malloc(&h->d_udeb_tables, (size_t)6 * std::max(h->udeb_n_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double)));
             h->udeb_work_layers = h->udeb_n_layers;
         }
         HIPCHK(hipMemsetAsync(h->d_udeb_tables, 0, (size_t)6 * std::max(h->udeb_work_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double), h->stream));
@@ -679,35 +679,35 @@ int rscm_ens_create_windowed(int32_t kind, int64_t n_members, int32_t n_times, c
     CK(hipEventCreate(&h->ev0));
     CK(hipEventCreate(&h->ev1));
     const size_t series_elems = (size_t)(h->V - 1) * (size_t)h->rows * (size_t)h->N;
-    CK(hipMalloc(&h->d_params, (size_t)h->P * h->N * sizeof(double)));
-    CK(hipMalloc(&h->d_series, series_elems * sizeof(double)));
-    CK(hipMalloc(&h->d_status, (size_t)h->N));
+    CK(rscm::dev_malloc(&h->d_params, (size_t)h->P * h->N * sizeof(double)));
+    CK(rscm::dev_malloc(&h->d_series, series_elems * sizeof(double)));
+    CK(rscm::dev_malloc(&h->d_status, (size_t)h->N));
     if (h->windowed) {
-        CK(hipMalloc(&h->d_row0, (size_t)(h->V - 1) * h->N * sizeof(double)));
+        CK(rscm::dev_malloc(&h->d_row0, (size_t)(h->V - 1) * h->N * sizeof(double)));
         if (h->n_out > 0) {
             const size_t out_elems = (size_t)h->n_out * h->out_rows * h->N;
-            CK(hipMalloc(&h->d_out, out_elems * sizeof(double)));
-            CK(hipMalloc(&h->d_out_vars, (size_t)h->n_out * sizeof(int32_t)));
+            CK(rscm::dev_malloc(&h->d_out, out_elems * sizeof(double)));
+            CK(rscm::dev_malloc(&h->d_out_vars, (size_t)h->n_out * sizeof(int32_t)));
             CK(hipMemcpy(h->d_out_vars, h->out_vars.data(), (size_t)h->n_out * sizeof(int32_t), hipMemcpyHostToDevice));
             CK(rscm::launch_fill(h->d_out, (int64_t)out_elems, std::numeric_limits<double>::quiet_NaN(), h->stream));
         }
     }
-    CK(hipMalloc(&h->d_nsub_tl, (size_t)(h->T - 1) * sizeof(int32_t)));
-    CK(hipMalloc(&h->d_nsub_cc, (size_t)(h->T - 1) * sizeof(int32_t)));
-    CK(hipMalloc(&h->d_partial, 4 * 1024 * sizeof(double)));
-    CK(hipMalloc(&h->d_out4, 4 * sizeof(double)));
+    CK(rscm::dev_malloc(&h->d_nsub_tl, (size_t)(h->T - 1) * sizeof(int32_t)));
+    CK(rscm::dev_malloc(&h->d_nsub_cc, (size_t)(h->T - 1) * sizeof(int32_t)));
+    CK(rscm::dev_malloc(&h->d_partial, 4 * 1024 * sizeof(double)));
+    CK(rscm::dev_malloc(&h->d_out4, 4 * sizeof(double)));
     if (kind == RSCM_KIND_UDEB) {
-        CK(hipMalloc(&h->d_scal, (size_t)rscm::kUdebScalars * h->N * sizeof(double)));
-        CK(hipMalloc(&h->d_hist, (size_t)h->T * h->N * sizeof(double)));
+        CK(rscm::dev_malloc(&h->d_scal, (size_t)rscm::kUdebScalars * h->N * sizeof(double)));
+        CK(rscm::dev_malloc(&h->d_hist, (size_t)h->T * h->N * sizeof(double)));
     }
     if (kind == RSCM_KIND_UDEB || kind == RSCM_KIND_N2O_CHEMISTRY || kind == RSCM_KIND_CO2_BUDGET ||
         kind == RSCM_KIND_TERRESTRIAL_CARBON || kind == RSCM_KIND_OCEAN_CARBON ||
         kind == RSCM_KIND_HALOCARBON) {  // kinds that use the step length
-        CK(hipMalloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
+        CK(rscm::dev_malloc(&h->d_bounds, (size_t)(h->T + 1) * sizeof(double)));
         CK(hipMemcpyAsync(h->d_bounds, h->bounds.data(), (size_t)(h->T + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     if (kind == RSCM_KIND_AGGREGATE) {  // contributors that are neither linked nor set stay NaN = skipped
-        CK(hipMalloc(&h->d_forcing, (size_t)h->n_inputs * h->T * sizeof(double)));
+        CK(rscm::dev_malloc(&h->d_forcing, (size_t)h->n_inputs * h->T * sizeof(double)));
         CK(rscm::launch_fill(h->d_forcing, (int64_t)h->n_inputs * h->T, std::numeric_limits<double>::quiet_NaN(), h->stream));
         h->n_scen = 1;
         h->forcing_set = true;
@@ -942,11 +942,11 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
     if (n_scen != h->n_scen || !h->d_forcing) {
         HIPCHK(hipFree(h->d_forcing));
         h->d_forcing = nullptr;
-        HIPCHK(hipMalloc(&h->d_forcing, (size_t)n_scen * h->n_inputs * h->T * sizeof(double)));
+        HIPCHK(rscm::dev_malloc(&h->d_forcing, (size_t)n_scen * h->n_inputs * h->T * sizeof(double)));
         if (h->kind == RSCM_KIND_GHG_FORCING) {
             HIPCHK(hipFree(h->d_ghg_tables));
             h->d_ghg_tables = nullptr;
-            HIPCHK(hipMalloc(&h->d_ghg_tables, (size_t)n_scen * rscm::kGhgRows * h->T * sizeof(double)));
+            HIPCHK(rscm::dev_malloc(&h->d_ghg_tables, (size_t)n_scen * rscm::kGhgRows * h->T * sizeof(double)));
         }
     }
     HIPCHK(hipMemcpyAsync(h->d_forcing, series, (size_t)n_scen * h->n_inputs * h->T * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -956,7 +956,7 @@ int rscm_ens_set_forcing(rscm_ens* h, int32_t var_id, int32_t n_scen, const doub
         HIPCHK(hipMemcpyAsync(h->d_ghg_tables, ghg_tab.data(), ghg_tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     if (scenario_of_member) {
-        if (!h->d_scen) HIPCHK(hipMalloc(&h->d_scen, (size_t)h->N * sizeof(int32_t)));
+        if (!h->d_scen) HIPCHK(rscm::dev_malloc(&h->d_scen, (size_t)h->N * sizeof(int32_t)));
         HIPCHK(hipMemcpyAsync(h->d_scen, scenario_of_member, (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     } else if (h->d_scen) {
         HIPCHK(hipFree(h->d_scen));
@@ -1228,7 +1228,7 @@ int ensure_derived(rscm_ens* h)
     if (h->derived_hold && !h->derived_dirty && h->d_derived) return RSCM_OK;
     if (int rc = set_device(h)) return rc;
     if (!h->d_derived) {
-        const hipError_t e = hipMalloc(&h->d_derived, (size_t)rscm::kDerivedRows * h->N * sizeof(double));
+        const hipError_t e = rscm::dev_malloc(&h->d_derived, (size_t)rscm::kDerivedRows * h->N * sizeof(double));
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, "member constants of %lld members: %s", (long long)h->N, hipGetErrorString(e));
     }
@@ -2021,7 +2021,7 @@ static int loglik_on_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, 
                     return fail(RSCM_ERR_INVALID, "observations must be grouped by variable");
     }
     if (int rc = set_device(h)) return rc;
-    if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+    if (!h->d_loglik) HIPCHK(rscm::dev_malloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
     if (uncomputed) {
         HIPCHK(rscm::launch_fill(h->d_loglik, h->N, -std::numeric_limits<double>::infinity(), h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -2045,7 +2045,7 @@ static int loglik_on_device(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, 
         memcpy(blob.data() + off_sig, obs_sigma, sz_d);
         memcpy(blob.data() + off_grp, obs_var, sz_i);
     }
-    HIPCHK(hipMalloc(&d_blob, blob.size()));
+    HIPCHK(rscm::dev_malloc(&d_blob, blob.size()));
     hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, h->stream);
     rscm::LoglikArgs a{};
     a.n_members = h->N;
@@ -2140,7 +2140,7 @@ int prepare_obs(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_
         HIPCHK(hipFree(h->d_obs));
         h->d_obs = nullptr;
         h->obs_capacity = 0;
-        HIPCHK(hipMalloc(&h->d_obs, blob.size()));
+        HIPCHK(rscm::dev_malloc(&h->d_obs, blob.size()));
         h->obs_capacity = blob.size();
     }
     HIPCHK(hipMemcpy(h->d_obs, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -2149,7 +2149,7 @@ int prepare_obs(rscm_ens* h, int32_t n_obs, const int32_t* obs_var, const int32_
     for (int32_t j = 0; j < n_obs; ++j) h->obs_last_tidx = std::max(h->obs_last_tidx, obs_tidx[j]);
     h->obs_normalize = normalize ? 1 : 0;
     h->obs_first_is_deep = first_var == RSCM_TL_VAR_TD ? 1 : 0;
-    if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+    if (!h->d_loglik) HIPCHK(rscm::dev_malloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
     return RSCM_OK;
 }
 
@@ -2277,8 +2277,8 @@ int rscm_ens_summary_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32_
     const int32_t nb = rscm::summary_blocks(h->N);
     double* d_partial = nullptr;
     double* d_out = nullptr;
-    HIPCHK(hipMalloc(&d_partial, (size_t)computed * nb * 4 * sizeof(double)));
-    hipError_t e = hipMalloc(&d_out, (size_t)computed * 4 * sizeof(double));
+    HIPCHK(rscm::dev_malloc(&d_partial, (size_t)computed * nb * 4 * sizeof(double)));
+    hipError_t e = rscm::dev_malloc(&d_out, (size_t)computed * 4 * sizeof(double));
     if (e == hipSuccess)
         e = rscm::launch_summary_rows(h->series(var_id) + (size_t)t_begin * h->N, h->N, computed, d_partial, nb, d_out, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)computed * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -2311,8 +2311,8 @@ int rscm_ens_quantile_series(rscm_ens* h, int32_t var_id, int32_t t_begin, int32
     double* d_q = nullptr;
     double* d_out = nullptr;
     std::vector<double> host((size_t)computed * (n_q + 1));
-    HIPCHK(hipMalloc(&d_q, (size_t)n_q * sizeof(double)));
-    hipError_t e = hipMalloc(&d_out, host.size() * sizeof(double));
+    HIPCHK(rscm::dev_malloc(&d_q, (size_t)n_q * sizeof(double)));
+    hipError_t e = rscm::dev_malloc(&d_out, host.size() * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_q, q, (size_t)n_q * sizeof(double), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = rscm::launch_quantile_rows(h->series(var_id) + (size_t)t_begin * h->N, h->N, computed, d_q, n_q, d_out, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -2378,7 +2378,7 @@ int rscm_ens_sample_lhs(rscm_ens* h, uint64_t seed, const double* low, const dou
         h->ghg_method = (int32_t)m;
     }
     double* d_lh = nullptr;
-    HIPCHK(hipMalloc(&d_lh, 2 * (size_t)h->P * sizeof(double)));
+    HIPCHK(rscm::dev_malloc(&d_lh, 2 * (size_t)h->P * sizeof(double)));
     hipError_t e = hipMemcpyAsync(d_lh, low, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_lh + h->P, high, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = rscm::launch_lhs(h->d_params, h->P, h->N, seed, d_lh, d_lh + h->P, member_offset, n_total, h->stream);
@@ -2473,8 +2473,8 @@ int rscm_gpu_selftest_div(int32_t device_id, int64_t n, const double* num, const
     HIPCHK(hipSetDevice(device_id));
     double* d = nullptr;
     uint8_t* du = nullptr;
-    HIPCHK(hipMalloc(&d, 4 * (size_t)n * sizeof(double)));
-    hipError_t e = hipMalloc(&du, (size_t)n);
+    HIPCHK(rscm::dev_malloc(&d, 4 * (size_t)n * sizeof(double)));
+    hipError_t e = rscm::dev_malloc(&du, (size_t)n);
     if (e == hipSuccess) e = hipMemcpy(d, num, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + n, den, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = rscm::launch_divtest(d, d + n, d + 2 * n, d + 3 * n, du, n, nullptr);

@@ -207,7 +207,7 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
                     if (obs_var[k] == obs_var[j]) return fail(RSCM_ERR_INVALID, "observations must be grouped by variable");
         }
         if (int rc = set_device(h)) return rc;
-        if (!h->d_loglik) HIPCHK(hipMalloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
+        if (!h->d_loglik) HIPCHK(rscm::dev_malloc(&h->d_loglik, (size_t)h->N * sizeof(double)));
     }
     rscm_sampler* s = new rscm_sampler();
     s->ev = h;
@@ -232,22 +232,22 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
             return cleanup(fail(e2_ == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, \
                                 "%s failed: %s", #expr, hipGetErrorString(e2_)));              \
     } while (0)
-    CK(hipMalloc(&s->d_rows, D * sizeof(int32_t)));
-    CK(hipMalloc(&s->d_kind, D * sizeof(int32_t)));
-    CK(hipMalloc(&s->d_base, (size_t)h->P * sizeof(double)));
-    CK(hipMalloc(&s->d_pa, D * sizeof(double)));
-    CK(hipMalloc(&s->d_pb, D * sizeof(double)));
-    CK(hipMalloc(&s->d_plo, D * sizeof(double)));
-    CK(hipMalloc(&s->d_phi, D * sizeof(double)));
-    CK(hipMalloc(&s->d_pos, D * W * sizeof(double)));
-    CK(hipMalloc(&s->d_logp, W * sizeof(double)));
-    CK(hipMalloc(&s->d_prop, D * H * sizeof(double)));
-    CK(hipMalloc(&s->d_z, H * sizeof(double)));
-    CK(hipMalloc(&s->d_lp, H * sizeof(double)));
-    CK(hipMalloc(&s->d_send, (D + 1) * H * sizeof(double)));   // 2 x (D + 1) x H doubles: also for one rank (the exchange of
-    CK(hipMalloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));   // a one-rank group is a copy)
-    CK(hipMalloc(&s->d_nacc, W * sizeof(int64_t)));
-    CK(hipMalloc(&s->d_nprop, W * sizeof(int64_t)));
+    CK(rscm::dev_malloc(&s->d_rows, D * sizeof(int32_t)));
+    CK(rscm::dev_malloc(&s->d_kind, D * sizeof(int32_t)));
+    CK(rscm::dev_malloc(&s->d_base, (size_t)h->P * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_pa, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_pb, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_plo, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_phi, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_pos, D * W * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_logp, W * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_prop, D * H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_z, H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_lp, H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_send, (D + 1) * H * sizeof(double)));   // 2 x (D + 1) x H doubles: also for one rank (the exchange of
+    CK(rscm::dev_malloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));   // a one-rank group is a copy)
+    CK(rscm::dev_malloc(&s->d_nacc, W * sizeof(int64_t)));
+    CK(rscm::dev_malloc(&s->d_nprop, W * sizeof(int64_t)));
     CK(hipMemcpy(s->d_rows, param_rows, D * sizeof(int32_t), hipMemcpyHostToDevice));
     CK(hipMemcpy(s->d_kind, prior_kind, D * sizeof(int32_t), hipMemcpyHostToDevice));
     CK(hipMemcpy(s->d_base, base_params, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice));
@@ -277,7 +277,7 @@ int rscm_sampler_create_sharded(rscm_ens* evaluator, int32_t n_walkers, int32_t 
             memcpy(blob.data() + off_sig, obs_sigma, sz_d);
             memcpy(blob.data() + off_grp, obs_var, sz_i);
         }
-        CK(hipMalloc(&s->d_sobs, blob.size()));
+        CK(rscm::dev_malloc(&s->d_sobs, blob.size()));
         CK(hipMemcpy(s->d_sobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
         s->lik.n_members = h->N;
         s->lik.n_obs = n_obs;
@@ -356,7 +356,7 @@ int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32
                     return fail(RSCM_ERR_INVALID, "observation %d: the observations of (handle %d, variable %d) must be contiguous", j, obs_owner[j], obs_var[j]);
     }
     if (int rc = set_device(lead)) return rc;
-    if (!lead->d_loglik) HIPCHK(hipMalloc(&lead->d_loglik, (size_t)lead->N * sizeof(double)));
+    if (!lead->d_loglik) HIPCHK(rscm::dev_malloc(&lead->d_loglik, (size_t)lead->N * sizeof(double)));
     rscm_sampler* s = new rscm_sampler();
     s->ev = lead;
     s->fused = false;
@@ -384,21 +384,21 @@ int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32
             return cleanup(fail(e2_ == hipErrorOutOfMemory ? RSCM_ERR_NOMEM : RSCM_ERR_DEVICE, \
                                 "%s failed: %s", #expr, hipGetErrorString(e2_)));              \
     } while (0)
-    CK(hipMalloc(&s->d_kind, D * sizeof(int32_t)));
-    CK(hipMalloc(&s->d_pa, D * sizeof(double)));
-    CK(hipMalloc(&s->d_pb, D * sizeof(double)));
-    CK(hipMalloc(&s->d_plo, D * sizeof(double)));
-    CK(hipMalloc(&s->d_phi, D * sizeof(double)));
-    CK(hipMalloc(&s->d_pos, D * W * sizeof(double)));
-    CK(hipMalloc(&s->d_logp, W * sizeof(double)));
-    CK(hipMalloc(&s->d_prop, D * H * sizeof(double)));
-    CK(hipMalloc(&s->d_z, H * sizeof(double)));
-    CK(hipMalloc(&s->d_lp, H * sizeof(double)));
-    CK(hipMalloc(&s->d_send, (D + 1) * H * sizeof(double)));
-    CK(hipMalloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));
-    CK(hipMalloc(&s->d_nacc, W * sizeof(int64_t)));
-    CK(hipMalloc(&s->d_nprop, W * sizeof(int64_t)));
-    CK(hipMalloc((void**)&s->d_param_ptr, D * sizeof(double*)));
+    CK(rscm::dev_malloc(&s->d_kind, D * sizeof(int32_t)));
+    CK(rscm::dev_malloc(&s->d_pa, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_pb, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_plo, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_phi, D * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_pos, D * W * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_logp, W * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_prop, D * H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_z, H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_lp, H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_send, (D + 1) * H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_recv, (size_t)n_ranks * (D + 1) * H * sizeof(double)));
+    CK(rscm::dev_malloc(&s->d_nacc, W * sizeof(int64_t)));
+    CK(rscm::dev_malloc(&s->d_nprop, W * sizeof(int64_t)));
+    CK(rscm::dev_malloc((void**)&s->d_param_ptr, D * sizeof(double*)));
     {
         std::vector<double*> ptrs(D);
         for (size_t d = 0; d < D; ++d) ptrs[d] = handles[param_owner[d]]->d_params + (size_t)param_rows[d] * H;
@@ -436,7 +436,7 @@ int rscm_sampler_create_graph(rscm_ens* const* handles, int32_t n_handles, int32
             memcpy(blob.data() + off_sig, obs_sigma, sz_d);
             memcpy(blob.data() + off_grp, grp.data(), sz_i);
         }
-        CK(hipMalloc(&s->d_sobs, blob.size()));
+        CK(rscm::dev_malloc(&s->d_sobs, blob.size()));
         CK(hipMemcpy(s->d_sobs, blob.data(), blob.size(), hipMemcpyHostToDevice));
         s->lik.n_members = lead->N;
         s->lik.n_obs = n_obs;
