@@ -36,6 +36,7 @@ T0, T1 = 1750, 2500
 TL_LOW = np.array([0.8, 0.0, 1.0, 0.5, 5.0, 50.0])
 TL_HIGH = np.array([1.5, 0.1, 1.8, 1.0, 15.0, 200.0])
 SEED = 20260327
+WATCHDOG_EXIT = 3              # the watchdog ended the process: the line on stdout is valid, an extra or the teardown did not return
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 HBM_STORE_STREAM_GBS = 5460.0  # what a store-only streaming kernel reaches on the card (tools/hbm_stream.hip, profiles/r2_hbm_stream.txt)
 FP64_VALU_PEAK_TINSTR = 39.3   # 256 CU x 4 SIMD x 16 f64 lanes x 2.4 GHz (FMA would count 2 flops)
@@ -75,6 +76,7 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
            # fractions of the FP64 issue peak below are of the NOMINAL 2.4 GHz; the measured issue utilisation is at this clock
            "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
            "peak_measured_store_stream": HBM_STORE_STREAM_GBS, "frac_of_measured": gbs / HBM_STORE_STREAM_GBS,
+           "traffic_from": "profiles/traffic.json" if source else None,   # a committed PMC figure of this launch, not re-measured in this run
            "traffic_source": (f"{source}: separate rocprofv3 --pmc passes of this launch (FETCH_SIZE x2 + WRITE_SIZE, KiB), "
                               "read from profiles/traffic.json; not re-measured inside bench.py") if source else None,
            "kernel": ("coupled_fast_kernel" if mode == "fast" else "coupled_kernel") if kind == "coupled" else "two_layer_kernel",
@@ -191,6 +193,175 @@ def describe_run_plan(roofline, plan):
         roofline["run_plan"] = (f"{blocks} member blocks on two streams x {chunks} chunks of model steps, issued in turn: the same kernel on the same "
                                 "operands, the wavefronts evened out over the SIMDs (include/rscm_gpu.h, rscm_ens_last_run_plan); kernel_ms = "
                                 "HIP events around the whole pass / passes, the launches overlap")
+
+
+# ---- the line the driver parses ------------------------------------------------------------------------------------------
+# bench.py measures into a FULL record (every roofline object with its notes and sources, per-rank facts, run plans, ensemble
+# statistics).  That record goes to a side file (--details, default ./bench_details.json) and to stderr; stdout carries ONE compact
+# line built from it by `compact_line`: the contract's keys, numbers rounded to 6 significant digits, `extra` numbers only.
+# The driver keeps 8 KB of stdout: LINE_LIMIT_BYTES is asserted in tests/test_bench_line.py at N = 1 and on an 8-rank record.
+LINE_LIMIT_BYTES = 6000
+LINE_LIMIT_BYTES_8_RANKS = 8000
+_EXTRA_RATE_KEYS = ("member_years_per_s", "model_evaluations_per_s")
+_EXTRA_MS_KEYS = ("kernel_ms", "ms", "device_ms_per_iteration")
+
+
+def _num(x, sig=6):
+    """A JSON-safe number: bools and ints as they are, floats rounded to `sig` significant digits, NaN / inf -> None."""
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{sig}g}")
+    return None
+
+
+def _pick(obj, keys):
+    out = {}
+    for k in keys:
+        v = (obj or {}).get(k)
+        if isinstance(v, str):
+            out[k] = v if len(v) <= 120 else v[:117] + "..."
+        elif isinstance(v, (list, tuple)):
+            out[k] = [_num(e) for e in v]
+        elif isinstance(v, dict):
+            continue
+        else:
+            out[k] = _num(v)
+    return out
+
+
+def _short_binding(text):
+    """`binding` names a roof, not a paragraph: the part before the first parenthesis."""
+    return text.split(" (")[0].strip() if isinstance(text, str) else text
+
+
+def compact_extra(e):
+    """One extra as numbers only: rate (member-years/s or model evaluations/s), ms (its launch / pass / iteration time; seconds-long
+    runs as s), frac (of the HBM roof, algorithmic bytes), fp64_frac (of the FP64 issue roof, where the record has it), traffic (HBM
+    bytes per launch from the committed PMC passes, where the record has it), weak_efficiency, failed (members flagged); a failed
+    extra as {"error": "..."} (the full text is in the details)."""
+    if not isinstance(e, dict):
+        return None
+    if "error" in e:
+        return {"error": str(e["error"])[:80]}
+    out = {}
+    for k in _EXTRA_RATE_KEYS:
+        if e.get(k) is not None:
+            out["rate"] = _num(e[k])
+            break
+    rank_ms = (e.get("per_rank") or {}).get("kernel_ms")
+    for k in _EXTRA_MS_KEYS:
+        if e.get(k) is not None:
+            out["ms"] = _num(e[k])
+            break
+    else:
+        if rank_ms:   # an all-ranks extra of resident launches: the slowest rank's launch duration
+            out["ms"] = _num(max(rank_ms))
+    if "ms" not in out:
+        for k in ("run_s", "wall_s"):
+            if e.get(k) is not None:
+                out["s"] = _num(e[k])
+                break
+    roof = e.get("roofline") or {}
+    frac = roof.get("frac", e.get("hbm_frac"))
+    if frac is not None:
+        out["frac"] = _num(frac)
+    valu = e.get("roofline_fp64_valu") or {}
+    if valu.get("frac") is not None:
+        out["fp64_frac"] = _num(valu["frac"])
+    if roof.get("traffic") is not None:
+        out["traffic"] = _num(roof["traffic"])
+    if e.get("weak_efficiency") is not None and e.get("ranks", 1) > 1:
+        out["weak_efficiency"] = _num(e["weak_efficiency"])
+    for k in ("speedup", "exchange_share_of_iteration"):
+        if e.get(k) is not None:
+            out[k] = _num(e[k])
+    if e.get("failed_members"):
+        out["failed"] = _num(e["failed_members"])
+    return out
+
+
+def compact_line(full, details_path=None):
+    """The ONE stdout line from the full record: exactly the contract's keys (see the module docstring of tests/test_bench_line.py),
+    strict JSON (no NaN / Infinity), no prose beyond `config.workload`, `cpu_baseline.sample` and the kernel / backend names."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    if full.get("rendezvous_only"):
+        line["rendezvous_only"] = True
+    line["config"] = _pick(full.get("config"), ("workload", "members_per_gpu", "years", "arithmetic_mode", "failed_members"))
+    roof = full.get("roofline")
+    if roof is not None:
+        r = _pick(roof, ("bound", "binding", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "algorithmic_bytes", "kernel",
+                         "kernel_ms", "launches_per_pass", "effective_clock_ghz"))
+        r["binding"] = _short_binding(r.get("binding"))
+        line["roofline"] = r
+    valu = full.get("roofline_fp64_valu")
+    if valu is not None:
+        v = _pick(valu, ("frac", "achieved", "peak", "unit"))
+        v["issue_utilisation"] = _num(valu.get("measured_valu_issue_utilisation_at_effective_clock"))
+        pb = valu.get("parallelism_bound")
+        v["parallelism_bound"] = _pick(pb, ("ms", "achieved_frac")) if pb else None
+        line["roofline_fp64_valu"] = v
+    cpu = full.get("cpu_baseline")
+    if cpu is None or "error" in cpu:
+        line["cpu_baseline"] = cpu if cpu is None else {"error": str(cpu["error"])[:120]}
+    else:
+        line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "threads_used", "single_thread_value", "kind", "sample"))
+    line["collective"] = _pick(full.get("collective"), ("backend", "world", "rccl_ranks_seen", "ranks_seen"))
+    gather = (full.get("collective") or {}).get("loss_gather")
+    if gather:
+        line["collective"]["loss_gather_ms"] = _num(gather.get("ms")) if "error" not in gather else None
+    line["per_rank"] = _pick(full.get("per_rank"), ("kernel_ms", "weak_efficiency"))
+    line["extra"] = {k: compact_extra(v) for k, v in (full.get("extra") or {}).items()}
+    if full.get("watchdog"):
+        line["watchdog"] = str(full["watchdog"])[:160]
+    if details_path:
+        line["details"] = details_path
+    return line
+
+
+def dumps_line(line):
+    """Strict JSON on one line, no spaces after the separators."""
+    return json.dumps(line, allow_nan=False, separators=(",", ":"))
+
+
+def _jsonable(x):
+    """The full record with NaN / inf as None and numpy scalars as Python ones (the details file is strict JSON too)."""
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        return None if (x != x or x in (float("inf"), float("-inf"))) else x
+    return x
+
+
+def write_details(full, path):
+    """The full record -> `path` (best effort: a read-only cwd must not cost the line) and, always, stderr."""
+    text = json.dumps(_jsonable(full), allow_nan=False)
+    written = None
+    if path:
+        try:
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                f.write(text + "\n")
+            os.replace(tmp, path)
+            written = path
+        except OSError as exc:
+            sys.stderr.write(f"bench.py: could not write {path}: {exc}\n")
+    sys.stderr.write("bench.py details: " + text + "\n")
+    sys.stderr.flush()
+    return written
 
 
 def f_syn(t):
@@ -778,7 +949,8 @@ def cpu_baseline(threads=None, target_seconds=12.0):
             "host_cores": host["host_cores"], "threads_used": threads, "affinity_cores": host["affinity_cores"],
             "cgroup_cpu_quota_cores": host["cgroup_cpu_quota_cores"], "cpu_model": host["cpu_model"],
             "kind": "port", "single_thread_value": n1 * (T1 - T0) / dt1,
-            "sample": f"{reps} pass(es) over {n} members x {T1 - T0} years, oracle/rscm_oracle.c two_layer_run "
+            "sample": f"{reps} pass(es) x {n} members x {T1 - T0} years, oracle/rscm_oracle.c, {dt:.1f} s on {threads} threads",
+            "sample_note": f"{reps} pass(es) over {n} members x {T1 - T0} years, oracle/rscm_oracle.c two_layer_run "
                       f"(-O2 -ffp-contract=off), {dt:.1f} s on {threads} threads (one per core this process is granted: "
                       f"min(affinity {host['affinity_cores']}, ceil(cgroup quota {host['cgroup_cpu_quota_cores']})); "
                       f"the host has {host['host_cores']})"}
@@ -921,22 +1093,27 @@ def launch_ranks(n, argv):
     for th in threads:
         th.start()
     failed = None
+    hung_since = None      # a rank's watchdog ended it (WATCHDOG_EXIT): the other ranks' watchdogs end them within ~30 s of their own line
     while any(th.is_alive() for th in threads):
         for r, pr in enumerate(procs):
             code = pr.poll()
-            if code not in (None, 0) and failed is None:
+            if code == WATCHDOG_EXIT:
+                hung_since = hung_since or time.monotonic()
+            elif code not in (None, 0) and failed is None:
                 failed = (r, code)
-                for other in procs:   # one rank down: the others would wait in a collective until its timeout
-                    if other.poll() is None:
-                        other.terminate()
+        if failed is not None or (hung_since is not None and time.monotonic() - hung_since > 60.0):
+            for other in procs:   # one rank down: the others would wait in a collective until its timeout
+                if other.poll() is None:
+                    other.terminate()
         for th in threads:
             th.join(timeout=0.2)
     for r, pr in enumerate(procs):
-        if pr.returncode != 0 and failed is None:
+        if pr.returncode not in (0, WATCHDOG_EXIT) and failed is None and hung_since is None:
             failed = (r, pr.returncode)
+    hung = [r for r, pr in enumerate(procs) if pr.returncode == WATCHDOG_EXIT]
     for r in range(1, n):
         so, se = outs[r] or ("", "")
-        if (so or se) and (failed is not None):
+        if (so or se) and (failed is not None or hung):
             sys.stderr.write(f"---- rank {r} (exit {procs[r].returncode})\n{(so or '')[-2000:]}{(se or '')[-4000:]}\n")
     line = (outs[0] or ("", None))[0] or ""
     if failed is not None:
@@ -953,7 +1130,31 @@ def launch_ranks(n, argv):
         return 1
     sys.stdout.write(result + "\n")
     sys.stdout.flush()
+    if hung:   # line valid, extras (or the teardown) hung on these ranks: the line is relayed, the exit code says so
+        sys.stderr.write(f"bench.py: watchdog ended rank(s) {hung}: the headline line above is valid, a side measurement or the "
+                         f"teardown did not return (see the ranks' stderr)\n")
+        return WATCHDOG_EXIT
     return 0
+
+
+def start_watchdog(budget_s, emit, rank, present, grace_s=30.0):
+    """After `budget_s` seconds: print the line as it stands (emit(note) -> True if this call printed it) and end the process with
+    WATCHDOG_EXIT -- non-zero and distinct: the headline line is valid, a side measurement (or, when the line was already out, the
+    teardown) did not return.  launch_ranks relays the line and passes the code on.  No exec, no collective: the other ranks'
+    watchdogs end them the same way."""
+    import threading
+
+    def watchdog():
+        time.sleep(max(1.0, budget_s))
+        fired = emit(f"side measurements unfinished after {budget_s:g} s; present: {len(present)}")
+        if not fired:
+            time.sleep(grace_s)   # the line is out already: only a teardown that never returns is left to end
+        sys.stderr.write(f"bench.py: rank {rank}: watchdog ends the process {'(line printed by it)' if fired else '(after the line)'}"
+                         f" with exit code {WATCHDOG_EXIT}; extras present: {sorted(present)}\n")
+        sys.stderr.flush()
+        os._exit(WATCHDOG_EXIT)
+
+    threading.Thread(target=watchdog, daemon=True).start()
 
 
 def rendezvous_only(args, rank, world, torch, dist):
@@ -995,10 +1196,27 @@ def rendezvous_only(args, rank, world, torch, dist):
                              after=lambda st: {"units": st["units"]})
 
     tests = {"healthy": selftest(), "prepare_fails": selftest(fail_prepare=True), "body_fails": selftest(fail_body=True)}
+    record = {"metric": "ensemble-member-years/sec, two-layer 1750-2500 f64", "value": None, "unit": "member-years/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rendezvous_only": True,
+              "collective": collective, "per_rank": per_rank, "wall_s": wall, "scale_selftest": tests}
+    if os.environ.get("RSCM_BENCH_SELFTEST_HANG") == "1":
+        # self-test of the watchdog's exit path: a "side measurement" that never returns on any rank.  Rank 0's watchdog prints the
+        # line, every rank ends with WATCHDOG_EXIT, the launcher relays the line and returns that code.
+        import threading
+        once = threading.Lock()
+
+        def emit(note=None):
+            if not once.acquire(blocking=False):
+                return False
+            if rank == 0:
+                sys.stdout.write(json.dumps(dict(record, watchdog=note)) + "\n")
+                sys.stdout.flush()
+            return True
+
+        start_watchdog(args.extras_budget, emit, rank, {})
+        time.sleep(3600.0)
     if rank == 0:
-        print(json.dumps({"metric": "ensemble-member-years/sec, two-layer 1750-2500 f64", "value": None, "unit": "member-years/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rendezvous_only": True,
-                          "collective": collective, "per_rank": per_rank, "wall_s": wall, "scale_selftest": tests}))
+        print(json.dumps(record))
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     return 0
@@ -1023,6 +1241,9 @@ def main():
     ap.add_argument("--extras-budget", type=float, default=540.0,
                     help="seconds after the headline at which a watchdog prints the line as it stands and ends the process, should a side "
                          "measurement hang (default 540; the whole default run takes about a minute)")
+    ap.add_argument("--details", default="bench_details.json",
+                    help="where rank 0 writes the FULL record (every roofline object with its notes, per-rank facts, run plans); stdout "
+                         "carries only the compact line built from it.  Empty string: stderr only")
     ap.add_argument("--no-scale", action="store_true", help="skip the scale_* extras (the configs defined on more than one GPU)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="no GPU work: the ranks meet over gloo, run the contract's barrier / max-over-ranks / rank report and rank 0 "
@@ -1107,10 +1328,10 @@ def main():
     describe_run_plan(roofline_hbm, run_plan)
 
     extra = {}
-    # The line is complete from here on: the headline stands, the side measurements and the CPU baseline fill `extra` /
-    # `cpu_baseline` in place.  Should any of them hang (a collective that never returns on some rank, a kernel that never ends),
-    # the watchdog prints the line as it is after --extras-budget seconds and ends the process: a side measurement never costs the
-    # headline, not even by not coming back.
+    # The record is complete from here on: the headline stands, the CPU baseline is taken next, the side measurements fill `extra`
+    # in place.  Should one of them hang (a collective that never returns on some rank, a kernel that never ends), the watchdog
+    # prints the line as it is after --extras-budget seconds and ends the process with WATCHDOG_EXIT: a side measurement never
+    # costs the headline, not even by not coming back, and a hang is never reported as a clean run.
     out = {
         "metric": "ensemble-member-years/sec, two-layer 1750-2500 f64",
         "value": value,
@@ -1125,8 +1346,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"two-layer energy balance, {args.members} members/GPU x 751 points "
-                        f"(1750-2500 annual, 750 steps, RK4 h=0.1), BASELINE.json configs[1]",
+            "workload": f"two-layer energy balance, {args.members} members/GPU x 750 annual steps 1750-2500, RK4 h=0.1, BASELINE configs[1]",
             "members_per_gpu": args.members,
             "years": years,
             "arithmetic_mode": args.mode,
@@ -1149,6 +1369,15 @@ def main():
         "extra": extra,
     }
 
+    # The CPU leg comes right after the headline and before any extra: whatever happens later (a watchdog print included), the line
+    # carries `cpu_baseline`.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as exc:  # noqa: BLE001 -- the GPU figure must not be lost to the CPU leg
+            out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            print(f"bench.py: cpu_baseline failed: {exc}", file=sys.stderr)
+
     import threading
     printed = threading.Lock()
 
@@ -1158,28 +1387,23 @@ def main():
         if rank == 0:
             if note:
                 out["watchdog"] = note
-            text = None
+            full = None
             for _ in range(5):   # (the watchdog serialises while the main thread may be adding an extra)
                 try:
-                    text = json.dumps(dict(out, extra=dict(extra)))
+                    full = dict(out, extra=dict(extra))
+                    details = write_details(full, args.details)
+                    text = dumps_line(compact_line(full, details))
                     break
                 except RuntimeError:
+                    full = None
                     time.sleep(0.01)
-            sys.stdout.write((text or json.dumps(dict(out, extra={}))) + "\n")
+            if full is None:
+                text = dumps_line(compact_line(dict(out, extra={})))
+            sys.stdout.write(text + "\n")
             sys.stdout.flush()
         return True
 
-    def watchdog():
-        time.sleep(max(1.0, args.extras_budget))
-        fired = emit(f"the side measurements did not finish within {args.extras_budget:g} s: the line was printed without the missing ones "
-                     f"(present: {sorted(extra)})")
-        if not fired:
-            time.sleep(30.0)   # the line is out already: only a teardown that never returns is left to end
-        sys.stderr.write(f"bench.py: rank {rank}: watchdog ends the process {'(line printed by it)' if fired else '(after the line)'}\n")
-        sys.stderr.flush()
-        os._exit(0)   # (no exec, no collective: the other ranks' watchdogs end them the same way)
-
-    threading.Thread(target=watchdog, daemon=True).start()
+    start_watchdog(args.extras_budget, emit, rank, extra)
 
     def side(label, fn):
         """A side measurement never costs the headline line: a failure is reported in its place."""
@@ -1294,15 +1518,6 @@ def main():
         side("calibrate_graph_device_1e5", lambda: graph_calibration_extra(local_rank))
         side("calibrate_graph_device_1e5_fast", lambda: graph_calibration_extra(local_rank, mode=1))
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline()
-        except Exception as exc:  # noqa: BLE001 -- the GPU figure must not be lost to the CPU leg
-            cpu = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            print(f"bench.py: cpu_baseline failed: {exc}", file=sys.stderr)
-
-    out["cpu_baseline"] = cpu
     emit()
     if dist.is_available() and dist.is_initialized():
         try:

@@ -14,7 +14,7 @@ import csv
 import glob
 import sys
 
-HOT = ("two_layer_kernel", "coupled_kernel", "coupled_fast_kernel", "udeb_kernel", "udeb2_kernel", "udeb_any_kernel", "ghg_kernel", "ocean_kernel", "ocean_recur_kernel",
+HOT = ("two_layer_kernel", "coupled_kernel", "coupled_fast_kernel", "udeb_kernel", "udeb2_kernel", "udeb2_lds_kernel", "udeb_any_kernel", "ghg_kernel", "ocean_kernel", "ocean_recur_kernel",
        "group_kernel", "group_seq_kernel")
 
 

@@ -1,12 +1,13 @@
 """The N > 1 path with REAL ensembles: several ranks share the one GPU of the box, collectives over gloo.
 
-Two of these tests are in the driver's tier (`-m gpu`): sharded ensemble == single process with real kernels on two ranks,
-and bench.py started as `python bench.py --gpus 2` (its own launcher) printing a valid line.  They start their ranks as
+These are in the driver's tier (`-m gpu`): sharded ensemble == single process with real kernels on two ranks, the sharded
+sampler (plain and with a graph as the evaluator) == the single-rank chain bit for bit on two ranks, and bench.py started as
+`python bench.py --gpus 2` (its own launcher) printing a valid, compact line.  They start their ranks as
 CHILD processes (subprocess), exactly as tests/test_gpu_parity.py::test_external_stream_and_async_run starts its child
 from the same pytest process -- what the pool forbids is replacing a GPU process by exec, not starting children -- and they
 keep the number of processes on the card at three (pytest + two ranks; the pool allows six).
 
-The wider rehearsals (four ranks, the sharded samplers) stay under their own marker and their own pytest process:
+The wider rehearsal (four ranks) stays under its own marker and its own pytest process:
 
     python -m pytest tests/test_multirank_gpu.py -m gpu_ranks -q
 
@@ -46,16 +47,20 @@ def test_sharded_ensemble_equals_single_process(tmp_path):
         assert c["lhs_params_bit_equal"] and c["status_bit_equal"] and c["loglik_bit_equal"] and c["calibrate_batch_bit_equal"]
 
 
-@pytest.mark.gpu_ranks
 @pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
-@pytest.mark.parametrize("ranks", [2, 4])
+@pytest.mark.parametrize("ranks", [pytest.param(2, marks=[pytest.mark.gpu, pytest.mark.gpu_ranks]), pytest.param(4, marks=pytest.mark.gpu_ranks)])
 def test_sharded_sampler_reproduces_the_single_rank_chain(tmp_path, ranks):
+    """rscm_sampler_create_sharded: the walkers split over the ranks, each half-step's blocks all-gathered -- the single-rank chain,
+    bit for bit (positions, log-probabilities, acceptance counters).  The 2-rank case is in the driver's tier (pytest + two ranks =
+    three processes on the card); 4 ranks stay under `gpu_ranks` only.  Reference: crates/rscm-calibrate/src/sampler/ensemble.rs:143-177,
+    496-547 (the half-ensemble evaluation the ranks split)."""
     for res in _launch("rehearse_sharded_sampler.py", ranks, 29543 + ranks, tmp_path, ["--walkers", "4096", "20000", "--sweeps", "3"]):
         assert res["world"] == ranks and res["ok"], res
         for case in res["cases"]:
             assert case["positions_bit_equal"] and case["log_probs_bit_equal"] and case["counters_equal"]
 
 
+@pytest.mark.gpu
 @pytest.mark.gpu_ranks
 @pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
 def test_sharded_graph_sampler_reproduces_the_single_rank_chain(tmp_path):
@@ -67,18 +72,29 @@ def test_sharded_graph_sampler_reproduces_the_single_rank_chain(tmp_path):
             assert case["positions_bit_equal"] and case["log_probs_bit_equal"] and case["counters_equal"]
 
 
-def _bench_line(argv, env_extra, launcher=False):
+def _bench_line(argv, env_extra, launcher=False, expect_code=0):
+    """(line, details): the ONE compact line bench.py prints -- under 8000 bytes, the driver keeps 8 KB of stdout -- and the full
+    record it wrote to --details."""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable]
     if launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29561"]
-    cmd += [os.path.join(ROOT, "bench.py"), *argv]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    rows = [x for x in r.stdout.splitlines() if x.lstrip().startswith("{")]
-    assert len(rows) == 1, r.stdout[-3000:]
-    return json.loads(rows[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "bench_details.json")
+        cmd += [os.path.join(ROOT, "bench.py"), *argv, "--details", path]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == expect_code, r.stdout[-3000:] + r.stderr[-3000:]
+        rows = [x for x in r.stdout.splitlines() if x.lstrip().startswith("{")]
+        assert len(rows) == 1, r.stdout[-3000:]
+        assert len(rows[0].encode()) < 8000, len(rows[0])
+        line = json.loads(rows[0])
+        assert line["details"] == path
+        with open(path) as f:
+            details = json.load(f)
+    assert details["value"] == pytest.approx(line["value"], rel=1e-5) and set(details["extra"]) == set(line["extra"])
+    return line, details
 
 
 @pytest.mark.gpu
@@ -89,17 +105,19 @@ def test_bench_two_ranks_with_and_without_a_launcher():
     one rank's share of it (both ranks on this box's one GPU: they take turns on the card), and every rank's own kernel time is in
     the line.  Collectives over gloo here; on the driver's 8-GPU node the same code path runs RCCL."""
     small = ["--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--members", "20000"]
-    one = _bench_line(["--gpus", "1", *small], {})
+    one, full = _bench_line(["--gpus", "1", *small], {})
     assert one["n_gpus"] == 1 and one["value"] > 0 and one["per_rank"]["kernel_ms"][0] > 0
+    assert one["roofline"]["frac"] > 0 and one["roofline"]["kernel_ms"] > 0 and one["cpu_baseline"] is None
     # (a few per cent of the Latin hypercube's members run away -- lambda0 - a Ts < 0 -- and are flagged: part of the workload)
-    assert one["collective"]["world"] == 1 and one["check"]["failed_members_rank0"] < 0.1 * 20000
+    assert one["collective"]["world"] == 1 and full["check"]["failed_members_rank0"] < 0.1 * 20000
     knobs = {"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"}
     for launcher in (False, True):
-        two = _bench_line(["--gpus", "2", *small], knobs, launcher=launcher)
+        two, full = _bench_line(["--gpus", "2", *small], knobs, launcher=launcher)
         assert two["n_gpus"] == 2 and two["value"] > 0 and two["scaling"] == "weak"
-        assert two["collective"]["world"] == 2 and two["collective"]["ranks_seen"] == 2
+        assert two["collective"]["world"] == 2 and two["collective"]["ranks_seen"] == 2 and two["collective"]["loss_gather_ms"] > 0
         assert len(two["per_rank"]["kernel_ms"]) == 2 and min(two["per_rank"]["kernel_ms"]) > 0
-        assert two["config"]["members_per_gpu"] == 20000
+        assert two["config"]["members_per_gpu"] == 20000 and two["config"]["failed_members"] == full["config"]["failed_members"]
+        two = full   # the facts below live in the details
         g = two["collective"]["loss_gather"]   # configs[4]'s exchange: per-member losses scored on the device, all-gathered over the ranks
         assert "error" not in g and g["members_gathered"] == 40000 and g["finite"] > 0.9 * 40000 and g["ms"] > 0
         assert two["check"]["failed_members_rank0"] < 0.1 * 20000
@@ -112,8 +130,14 @@ SCALE_SMALL = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members"
                "--share-members", "1024", "--share-years", "2", "--scale-walkers", "4096", "--scale-sweeps", "3"]
 
 
-def _check_scale_extras(line, ranks):
-    extra = line["extra"]
+def _check_scale_extras(line, details, ranks):
+    for key in SCALE_KEYS:   # the line: numbers only
+        e = line["extra"][key]
+        assert "error" not in e and e["rate"] > 0 and (e.get("ms") or e.get("s")) > 0, (key, e)
+        assert all(isinstance(v, (int, float)) for v in e.values()), (key, e)
+        if ranks > 1 and key != "scale_calibrate_sharded_1e5":
+            assert 0 < e["weak_efficiency"] < 1.5, (key, e)
+    extra = details["extra"]
     for key in SCALE_KEYS:
         assert key in extra, sorted(extra)
         e = extra[key]
@@ -151,22 +175,24 @@ def test_bench_two_ranks_measures_every_multi_gpu_config():
     share (its own block of one draw, parity anchor on every rank), and the device sampler sharded over the process group (walkers
     split over the ranks, and per GPU) with the exchange's share of an iteration -- and the same keys exist at N = 1."""
     knobs = {"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"}
-    two = _bench_line(["--gpus", "2", *SCALE_SMALL], knobs)
+    two, full2 = _bench_line(["--gpus", "2", *SCALE_SMALL], knobs)
     assert two["n_gpus"] == 2 and two["value"] > 0
-    _check_scale_extras(two, 2)
-    one = _bench_line(["--gpus", "1", *SCALE_SMALL, "--scale-only"], {})
-    _check_scale_extras(one, 1)
+    _check_scale_extras(two, full2, 2)
+    one, full1 = _bench_line(["--gpus", "1", *SCALE_SMALL, "--scale-only"], {})
+    _check_scale_extras(one, full1, 1)
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(_gpus() < 1, reason="needs a GPU")
 def test_bench_watchdog_keeps_the_headline_when_side_measurements_do_not_finish():
     """Once the headline is measured the line is complete; should a side measurement not come back (a collective that hangs on an
-    8-GPU node would otherwise take the headline with it), the watchdog prints the line as it stands and ends the process with exit
-    code 0.  Here the budget is simply too short for the extras."""
-    line = _bench_line(["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--extras-budget", "1.5"], {})
-    assert line["value"] > 0 and line["n_gpus"] == 1 and "watchdog" in line and "did not finish" in line["watchdog"]
+    8-GPU node would otherwise take the headline with it), the watchdog prints the line as it stands and ends the process with
+    exit code 3 (bench.WATCHDOG_EXIT: line valid, extras unfinished -- never a clean 0).  Here the budget is simply too short for
+    the extras."""
+    line, _ = _bench_line(["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--extras-budget", "1.5"], {},
+                          expect_code=3)
+    assert line["value"] > 0 and line["n_gpus"] == 1 and "watchdog" in line and "unfinished" in line["watchdog"]
     assert isinstance(line["extra"], dict) and "calibrate_graph_device_1e5_fast" not in line["extra"]
-    two = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--extras-budget", "1.5"],
-                      {"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"})
+    two, _ = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--members", "20000", "--extras-budget", "1.5"],
+                         {"RSCM_BENCH_BACKEND": "gloo", "RSCM_BENCH_DEVICE": "0"}, expect_code=3)
     assert two["value"] > 0 and two["n_gpus"] == 2 and "watchdog" in two
