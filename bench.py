@@ -112,18 +112,35 @@ def two_layer_rooflines(members, years, kernel_ms, mode, kind="two_layer", bytes
 CONFIGS3_SERIES = 36                     # stored variables of the MAGICC graph (scripts/bench_magicc_chain.py)
 
 
-def configs3_roofline(members, steps, run_s, ranks=1):
+def configs3_roofline(members, steps, run_s, ranks=1, mode="fast"):
     """`roofline` of a configs[3] share: algorithmic bytes = every stored variable's new row, 36 x 8 B per member and monthly step
-    (what the reference's stepper writes into its collection, runtime.rs:480), over the run's wall time.  The run is 4 launches per
-    step in a dependency chain, two thirds of it ClimateUDEB's 12 column solves: FP64 issue and launch latency bind, not HBM."""
+    (what the reference's stepper writes into its collection, runtime.rs:480), over the run's wall time.  `traffic` = the HBM bytes
+    the step's four kernels move per member-step (separate FETCH_SIZE / WRITE_SIZE passes of scripts/run_configs3_share.py at 125 000
+    members, profiles/traffic.json -> profiles/r6_configs3_share_pmc*.txt) x members x steps: ClimateUDEB's two 50-layer columns in and
+    out every step and OceanCarbon's recurrence state are what it moves beyond the 288 algorithmic bytes.  The run is 4 launches per
+    step in a dependency chain, two thirds of it ClimateUDEB's 12 column solves: FP64 issue and the chain's latency bind, not HBM."""
     alg = CONFIGS3_SERIES * 8.0 * members * steps * ranks
     gbs = alg / run_s / 1e9
-    return {"bound": "hbm", "binding": "fp64_valu (ClimateUDEB, ~2/3 of a step) + the dependency chain of 4 launches per step",
-            "achieved": gbs, "peak": HBM_PEAK_GBS * ranks, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * ranks), "traffic": None,
-            "algorithmic_bytes": alg, "algorithmic_bytes_per_member_step": CONFIGS3_SERIES * 8.0,
-            "traffic_note": "no PMC pass of this run; by its layout a step also moves ClimateUDEB's two 50-layer columns in and out "
-                            "(1600 B per member) and reads each linked row back once (~300 B): ~2.2 KB per member-step, 7.6x the algorithmic bytes",
-            "note": "36 series x 8 B x members x monthly steps / run wall time"}
+    prof = profile_entry("configs3_share", 125000, mode)
+    per = prof.get("bytes_per_member_step")
+    out = {"bound": "hbm", "binding": "fp64_valu (ClimateUDEB, ~2/3 of a step) + the dependency chain of 4 launches per step",
+           "achieved": gbs, "peak": HBM_PEAK_GBS * ranks, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * ranks),
+           "traffic": per * members * steps * ranks if per else None,
+           "traffic_from": "profiles/traffic.json" if per else None,
+           "traffic_source": (f"{prof.get('source')}: {per:.0f} B per member-step measured at {prof.get('members')} members "
+                              f"(read {prof.get('read_per_member_step'):.0f} + written {prof.get('written_per_member_step'):.0f}), x members x steps") if per else None,
+           "traffic_over_algorithmic": per / (CONFIGS3_SERIES * 8.0) if per else None,
+           "hbm_frac_of_measured_traffic": (per * members * steps * ranks / run_s / 1e9) / (HBM_PEAK_GBS * ranks) if per else None,
+           "algorithmic_bytes": alg, "algorithmic_bytes_per_member_step": CONFIGS3_SERIES * 8.0,
+           "kernel": "udeb_kernel + ocean kernel + group_split_kernel + group_kernel_args (one of each per step)",
+           "kernel_us_per_step_profiled": prof.get("kernel_us_per_step"),
+           "note": "36 series x 8 B x members x monthly steps / run wall time"}
+    valu = None
+    if prof.get("valu_issue_utilisation") is not None:
+        valu = {"frac": prof["valu_issue_utilisation"], "unit": "of the 4-cycle f64 issue limit, whole step, measured",
+                "counters_source": prof.get("source"),
+                "note": "4 x sum(SQ_INSTS_VALU) / 1024 SIMDs / sum(kernel cycles) over the step's four kernels at 125 000 members"}
+    return out, valu
 
 
 UDEB_ALG_BYTES_PER_MEMBER_YEAR = 72.0   # 7 output rows + the history row written, ~1 history entry read back (the columns stay on chip)
@@ -131,27 +148,33 @@ UDEB_ALG_BYTES_PER_MEMBER_YEAR = 72.0   # 7 output rows + the history row writte
 
 def udeb_rooflines(members, years, kernel_ms, plan=(1, 1)):
     """`roofline` (HBM, algorithmic 72 B per member-year) and the binding FP64-issue figure of a ClimateUDEB launch.  The executed
-    instruction count, the issue utilisation and the clock come from this round's PMC summary of the 50-layer kernel at 65 536
-    members (profiles/traffic.json -> profiles/r5_udeb_65536.txt), not from constants in this file."""
-    prof = profile_entry("udeb", 65536, "exact")
+    instruction count, the issue utilisation, the clock and the traffic come from the PMC summary of THE KERNEL THAT RUNS at this
+    size (profiles/traffic.json): up to 32 768 members the two-wavefront udeb2_kernel (profiles/r6_udeb2_32768.txt), beyond that
+    the one-thread udeb_kernel (profiles/r5_udeb_65536.txt; its traffic is linear in the members: parameters in, rows out)."""
+    two_wave = members <= 32768
+    at = 32768 if two_wave else 65536
+    prof = profile_entry("udeb2" if two_wave else "udeb", at, "exact")
     my = members * years
     gbs = UDEB_ALG_BYTES_PER_MEMBER_YEAR * my / (kernel_ms * 1e-3) / 1e9
-    traffic = prof.get("bytes") * members / 65536.0 if prof.get("bytes") else None   # measured at 65 536 members, linear in the members
+    traffic = prof.get("bytes") * members / float(at) if prof.get("bytes") else None
     hbm = {"bound": "hbm", "binding": "fp64_valu", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_source": (f"{prof.get('source')}: measured at 65 536 members, scaled by the member count"
-                                                  if traffic else None),
-           "kernel": "udeb2_kernel" if members <= 32768 else "udeb_kernel", "kernel_ms": kernel_ms,
+           "traffic": traffic, "traffic_from": "profiles/traffic.json" if traffic else None,
+           "traffic_source": (f"{prof.get('source')}: this kernel measured at {at} members"
+                              + ("" if members == at else ", x members / that (same kernel)")) if traffic else None,
+           "kernel": "udeb2_kernel" if two_wave else "udeb_kernel", "kernel_ms": kernel_ms,
            "algorithmic_bytes": UDEB_ALG_BYTES_PER_MEMBER_YEAR * my, "launches_per_pass": plan[0] * plan[1],
            "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
            "note": "7 output rows + the history row per member-year; the two 50-layer columns stay in registers + LDS for the launch"}
     out = {"hbm_frac": gbs / HBM_PEAK_GBS, "roofline": hbm}
     per_wy = prof.get("valu_per_wavefront_year")
     if per_wy:   # vector instructions per wavefront-year as EXECUTED (SQ_INSTS_VALU / waves / years; ~12 % are not f64 arithmetic:
-        # moves between register files, compares, selects) x 64 lanes against 39.3 T f64 lane-ops/s at the nominal clock
-        tins = per_wy * my / (kernel_ms * 1e-3) / 1e12
+        # moves between register files, compares, selects) x 64 lanes against 39.3 T f64 lane-ops/s at the nominal clock; the
+        # two-wavefront kernel has two wavefronts per 64 members, each executing about half a member's instructions
+        waves_per_64 = 2.0 if two_wave else 1.0
+        tins = per_wy * waves_per_64 * my / (kernel_ms * 1e-3) / 1e12
         out["roofline_fp64_valu"] = {"achieved": tins, "peak": FP64_VALU_PEAK_TINSTR, "unit": "T f64-instr/s", "frac": tins / FP64_VALU_PEAK_TINSTR,
-                                     "valu_instructions_per_wavefront_year_executed": per_wy,
-                                     "measured_valu_issue_utilisation_at_65536": prof.get("valu_issue_utilisation"),
+                                     "valu_instructions_per_wavefront_year_executed": per_wy, "wavefronts_per_64_members": waves_per_64,
+                                     "measured_valu_issue_utilisation": prof.get("valu_issue_utilisation"), "measured_at_members": at,
                                      "effective_clock_ghz": prof.get("clock_ghz"), "nominal_clock_ghz": 2.4,
                                      "counters_source": prof.get("source"),
                                      "note": "one wavefront per SIMD (256 VGPR + 209 AGPR): nothing hides a dependent instruction's latency but the "
@@ -722,7 +745,7 @@ def scale_extras(args, rank, local_rank, world, torch, dist, tstream, stream, ye
         out["run_s"] = out["wall_s"]
         out["per_rank"]["run_s"] = out["per_rank"]["own_s"]
         out["member_years_per_s"] = float(out["ranks"]) * members * yrs / out["wall_s"]
-        out["roofline"] = configs3_roofline(members, yrs * 12, out["wall_s"], out["ranks"])
+        out["roofline"], out["roofline_fp64_valu"] = configs3_roofline(members, yrs * 12, out["wall_s"], out["ranks"])
         out["parity_anchor_all_ranks"] = all(f["first_64_members_equal_a_64_member_run"] for f in facts)
         out["failed_members"] = sum(f["failed_members"] for f in facts)
         if not out["parity_anchor_all_ranks"] or out["failed_members"]:
@@ -1498,7 +1521,7 @@ def main():
                 sys.argv = argv
             out = json.loads(buf.getvalue().strip().splitlines()[-1])
             out["exit_code"] = code
-            out["roofline"] = configs3_roofline(125_000, 9000, out["run_s"])
+            out["roofline"], out["roofline_fp64_valu"] = configs3_roofline(125_000, 9000, out["run_s"], mode="exact" if "--exact" in flags else "fast")
             if code not in (0, None):  # the parity anchor (first 64 members == a 64-member run) or a member failed
                 raise RuntimeError(f"run_configs3_share exited with {code}: {json.dumps(out)[:400]}")
             return out

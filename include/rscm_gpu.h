@@ -37,6 +37,15 @@
  *                               entries are NaN, builder.rs:772-780)
  *   forcing  [S][T]      f64   shared scenarios, staged in LDS by the kernels
  *
+ * Environment: the library reads exactly two variables, both once per process, neither changes a result.
+ *   RSCM_SPLIT_RUNS=0     whole-axis runs over more members than one wavefront per SIMD are issued as ONE plain launch
+ *                         instead of two member blocks on two streams in chunks of model steps (rscm_ens_last_run_plan);
+ *                         same kernels on the same operands, the same bits -- an A/B and debugging switch.  Default: on.
+ *   RSCM_POISON_ALLOC=1   debug aid: every device allocation starts as 0xFF bytes (NaN as a double, 255 as a status byte) so
+ *                         that a read of memory nobody wrote shows in the results.  Default: off (one fill per allocation).
+ * Nothing else in the environment reaches a launch plan: the sweep knobs of earlier rounds exist only in the experiments
+ * build (csrc/experiment_env.hpp, `make EXPERIMENTS=1`), which rscm_gpu_experiments_build() of the internal header identifies.
+ *
  * Threading: a handle is not thread-safe; use one handle per device per thread
  * (the reference calls run_batch from one thread at a time, sampler/ensemble.rs:145).
  * Ownership: the caller owns every input buffer (copied/uploaded before the call returns);
@@ -61,8 +70,11 @@ extern "C" {
  *      host built against the round-3 internal header does not link, or gets the new meaning of mode 4
  *   4  ClimateUDEB keeps its columns on chip at EVERY n_layers <= 64 (no entry point changed: same results, the counts
  *      other than 20 / 30 / 40 / 50 are ~15x faster); internal header: rscm_gpu_fail_chunk_launch, rscm_gpu_set_run_plan,
- *      rscm_gpu_set_udeb_variant(3) */
-#define RSCM_GPU_ABI_MINOR 4
+ *      rscm_gpu_set_udeb_variant(3)
+ *   5  no entry point changed.  The shipped library no longer reads RSCM_SPLIT_CHUNK / _CHUNK2 / _FIRST, RSCM_LOCKSTEP_SPLIT or
+ *      RSCM_UDEB_VARIANT (section "Environment" above); internal header: rscm_gpu_experiments_build, and
+ *      rscm_gpu_fail_chunk_launch is consumed by the next cut run whether or not k is reached */
+#define RSCM_GPU_ABI_MINOR 5
 
 #if defined(__GNUC__)
 #define RSCM_API __attribute__((visibility("default")))

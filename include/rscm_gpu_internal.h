@@ -49,6 +49,12 @@ RSCM_API int rscm_gpu_set_udeb_variant(int32_t variant);
  * the parity tests); 1 the two-stream cut where it applies whatever the environment says.  The same bits either way. */
 RSCM_API int rscm_gpu_set_run_plan(int32_t mode);
 
+/* 1 if this library was built with -DRSCM_EXPERIMENTS (`make -C rscm_amd/csrc EXPERIMENTS=1`): the environment-variable experiment
+ * knobs of csrc/experiment_env.hpp (RSCM_SPLIT_CHUNK / _CHUNK2 / _FIRST, RSCM_LOCKSTEP_SPLIT, RSCM_UDEB_VARIANT) are compiled in.
+ * 0 for the shipped library, whose launch plans read only the two variables documented in rscm_gpu.h ("Environment").
+ * __graft_entry__.build() and tests/test_abi_symbols.py refuse an experiments build left in place. */
+RSCM_API int rscm_gpu_experiments_build(void);
+
 /* Member-constant ("derive") kernels launched by the calling THREAD since its last call of this function (GhgForcing, TerrestrialCarbon,
  * ClimateUDEB: what their bodies need of the parameters alone, formed once per parameter set); resets the counter.  A handle whose
  * parameter block the caller holds a device pointer to (rscm_ens_params_devptr) is re-derived before every RUN -- once per
@@ -57,7 +63,9 @@ RSCM_API int rscm_gpu_derive_launches(int64_t* out);
 
 /* Fault injection for the cut runs (rscm_ens_last_run_plan: member blocks x step chunks on two streams): the k-th chunk launch
  * (1-based, counted over both blocks in issue order) of the calling THREAD's next cut run is not issued and reports
- * hipErrorLaunchFailure instead; the hook then turns itself off.  0 turns it off.  What must hold afterwards
+ * hipErrorLaunchFailure instead.  The next cut run consumes the hook whether or not it issues as many as k launches (a k beyond the
+ * run's launches fails nothing and is gone afterwards); a run that is NOT cut (one plain launch) does not consume it -- it stays
+ * armed for the thread's next cut run.  0 turns it off.  What must hold afterwards
  * (tests/test_gpu_parity.py): rscm_ens_run returns RSCM_ERR_DEVICE, the caller's stream has been joined with the helper stream
  * (nothing issued there is still running once the caller's stream is synchronised), the time index has not moved, and a fresh
  * whole run gives the uncut path's bits. */

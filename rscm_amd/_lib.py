@@ -267,6 +267,7 @@ SIGNATURES = {
     "rscm_gpu_set_udeb_variant": (C.c_int, [C.c_int32]),
     "rscm_gpu_fail_chunk_launch": (C.c_int, [C.c_int32]),
     "rscm_gpu_set_run_plan": (C.c_int, [C.c_int32]),
+    "rscm_gpu_experiments_build": (C.c_int, []),
     "rscm_gpu_derive_launches": (C.c_int, [C.POINTER(C.c_int64)]),
     "rscm_gpu_lockstep_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_gpu_lockstep_split_launches": (C.c_int, [C.POINTER(C.c_int64)]),

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "ens.hpp"
+#include "experiment_env.hpp"
 
 extern "C" {
 
@@ -58,6 +59,15 @@ int rscm_gpu_derive_launches(int64_t* out)
     const int64_t n = take_derive_launches();
     if (out) *out = n;
     return RSCM_OK;
+}
+
+int rscm_gpu_experiments_build(void)
+{
+#ifdef RSCM_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int rscm_gpu_fail_chunk_launch(int32_t k)
@@ -189,7 +199,7 @@ static int32_t op_cost(int32_t kind)
 }
 static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, SplitPlan* out)
 {
-    static const bool enabled = [] { const char* e = getenv("RSCM_LOCKSTEP_SPLIT"); return !e || atoi(e) != 0; }();   // 0: A/B runs without it
+    static const bool enabled = rscm::experiment_env("RSCM_LOCKSTEP_SPLIT", 1) != 0;   // (experiments build only: 0 = A/B runs without it)
     if (!enabled || !t_ls.split || count < 3 || count > rscm::kGroupTableOps) return false;
     bool tie[rscm::kGroupTableOps][rscm::kGroupTableOps] = {};
     int32_t cost[rscm::kGroupTableOps], serial = 0;

@@ -379,6 +379,13 @@ constexpr int kUdebNParams = 37;
 constexpr int kUdebScalars = 11;
 constexpr int kUdebMaxOnChipLayers = 64;   // up to this many ocean layers a member's columns stay in registers + LDS (csrc/udeb.hip)
 constexpr int kUdebMaxLdsLayers = 128;     // ... and up to this many with the Thomas sweep's c' array in LDS (a hemisphere per wavefront)
+// The geometry table has two homes, and the unrolled sweeps read BOTH by their compiled CAPACITY, not by the layer count (rows past
+// the count are zero rows: exact no-ops).  So each home must hold, zero-padded, as many rows as the largest capacity that reads it:
+//   UdebArgs::tables (by value, kernarg)  <- every on-chip instance,        capacity <= kUdebArgTableRows
+//   rscm_ens::d_udeb_tables (device)      <- the c'-in-LDS instance,        capacity <= kUdebDevTableRows
+// udeb_body.hpp static_asserts each instantiation against its home; rscm_gpu.cpp allocates and zero-fills by these constants.
+constexpr int kUdebArgTableRows = kUdebMaxOnChipLayers;
+constexpr int kUdebDevTableRows = kUdebMaxLdsLayers;
 
 struct UdebArgs {
     int64_t n_members;
@@ -400,7 +407,7 @@ struct UdebArgs {
     const double* win_partw;   // [T] weight of entry win_kfull-1 (0: not in the window)
     // rows [NL][6] = {af_top, af_bot, af_diff, 1 - rel_depth, G_nh, G_sh}, NL = n_layers <= 64 (udeb_tables.hpp), zero rows after
     // them: passed BY VALUE so the kernel reads them from the kernarg segment with scalar loads (no VGPRs, no vmcnt)
-    double tables[6 * kUdebMaxOnChipLayers];
+    double tables[6 * kUdebArgTableRows];
     const double* derived;     // [kDerivedRows][N] member constants: the base LAMCALC solve (launch_udeb_derive; udeb_body.hpp)
     int32_t derived_uniform;   // every parameter row it is formed from is uniform: element 0 serves all members
     const double* tables_dev;  // the same rows in device memory, any NL: the columns-in-HBM kernel (udeb_any_body.hpp); else nullptr

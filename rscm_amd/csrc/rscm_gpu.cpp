@@ -7,6 +7,7 @@
 // state the bounds; GhgForcing's linked-input path evaluates the same factors with the device
 // library and is compared with the table path in tests/test_gpu_links.py).
 #include "ens.hpp"
+#include "experiment_env.hpp"
 #include <functional>
 
 #include "udeb_tables.hpp"
@@ -432,10 +433,10 @@ int configure_udeb(rscm_ens* h, int64_t n_check, Row row)
                             h->udeb_n_layers, (long long)h->N, hipGetErrorString(e));
             // (room for the largest on-chip capacity: the unrolled sweeps request the table rows of their whole capacity, and the rows past
             // the layer count must read as zeros -- they are what makes those rows of the column exact no-ops)
-            HIPCHK(rscm::dev_malloc(&h->d_udeb_tables, (size_t)6 * std::max(h->udeb_n_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double)));
+            HIPCHK(rscm::dev_malloc(&h->d_udeb_tables, (size_t)6 * std::max(h->udeb_n_layers, (int32_t)rscm::kUdebDevTableRows) * sizeof(double)));
             h->udeb_work_layers = h->udeb_n_layers;
         }
-        HIPCHK(hipMemsetAsync(h->d_udeb_tables, 0, (size_t)6 * std::max(h->udeb_work_layers, (int32_t)rscm::kUdebMaxLdsLayers) * sizeof(double), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_udeb_tables, 0, (size_t)6 * std::max(h->udeb_work_layers, (int32_t)rscm::kUdebDevTableRows) * sizeof(double), h->stream));
         HIPCHK(hipMemcpyAsync(h->d_udeb_tables, h->udeb_tables.data(), h->udeb_tables.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -1357,9 +1358,9 @@ struct MemberSplit {
 static MemberSplit plan_member_split(rscm_ens* h, int32_t step_begin, int32_t step_end, bool linked, bool halves = false)
 {
     static const bool enabled = [] { const char* e = getenv("RSCM_SPLIT_RUNS"); return !e || atoi(e) != 0; }();
-    // (tuning knobs for experiments: model steps per chunk, members of the first block)
-    static const int32_t chunk_env = [] { const char* e = getenv("RSCM_SPLIT_CHUNK"); return e ? atoi(e) : 0; }();
-    static const int64_t first_env = [] { const char* e = getenv("RSCM_SPLIT_FIRST"); return e ? atoll(e) : 0ll; }();
+    // (tuning knobs of the experiments build only, experiment_env.hpp: model steps per chunk, members of the first block)
+    static const int32_t chunk_env = (int32_t)rscm::experiment_env("RSCM_SPLIT_CHUNK", 0);
+    static const int64_t first_env = (int64_t)rscm::experiment_env("RSCM_SPLIT_FIRST", 0);
     MemberSplit m;
     // two-layer / coupled: 32-64 steps per chunk 2.30 ms at 1e5 members, 96: 2.32, 192: 2.37 (scripts/sweep_split.sh); ClimateUDEB reloads
     // and stores its columns with every chunk: 96 (88 ms at 1e5 members against 90 with 64)
@@ -1403,7 +1404,7 @@ static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begi
     HIPCHK(hipEventRecord(h->split_fork, h->stream));
     HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
     // (experiments: RSCM_SPLIT_CHUNK2 gives the second block its own chunk length; the block that is behind is issued next)
-    static const int32_t chunk2_env = [] { const char* e = getenv("RSCM_SPLIT_CHUNK2"); return e ? atoi(e) : 0; }();
+    static const int32_t chunk2_env = (int32_t)rscm::experiment_env("RSCM_SPLIT_CHUNK2", 0);
     const int32_t c0 = m.chunk, c1 = chunk2_env > 0 ? chunk2_env : m.chunk;
     hipError_t err = hipSuccess;
     auto guarded = [&](int32_t b, int32_t e, int64_t m0, int64_t cnt, hipStream_t st) -> hipError_t {
@@ -1421,6 +1422,7 @@ static int run_member_split(rscm_ens* h, const MemberSplit& m, int32_t step_begi
             b1 = e;
         }
     }
+    t_fail_chunk = 0;   // (test hook) a cut run consumes it, whether k was reached or not: it never outlives the run it was set for
     // the join is made whatever happened: the caller's stream never runs ahead of what was issued on the helper stream
     HIPCHK(hipEventRecord(h->split_join, h->split_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, h->split_join, 0));

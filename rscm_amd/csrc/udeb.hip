@@ -37,6 +37,7 @@
 #include <cstdlib>
 
 #include "udeb_any_body.hpp"
+#include "experiment_env.hpp"
 
 namespace rscm {
 
@@ -177,8 +178,9 @@ hipError_t launch_udeb(const UdebArgs& a, hipStream_t s)
     // in round 3 and removed in round 4: 71 ms against 54 ms at 65 536 members x 750 years, ahead only below ~4096 members, and its
     // twisted factorisation agrees with these two to rounding, not to the bit -- selecting it by ensemble size would have made a
     // member's bits depend on how many members run beside it.  profiles/r3_udeb4_65536.txt, DESIGN.md section 8, commit 03abd7b.)
-    // RSCM_UDEB_VARIANT = 0 / 2 forces one kernel for the process (A/B runs), rscm_gpu_set_udeb_variant for the calling thread.
-    static const int forced = [] { const char* e = getenv("RSCM_UDEB_VARIANT"); return e ? atoi(e) : -1; }();
+    // rscm_gpu_set_udeb_variant (include/rscm_gpu_internal.h) forces one kernel for the calling thread (A/B runs, tests); the
+    // experiments build also reads RSCM_UDEB_VARIANT = 0 / 2 / 3 for the whole process (experiment_env.hpp).
+    static const int forced = (int)rscm::experiment_env("RSCM_UDEB_VARIANT", -1);
     int variant = t_udeb_variant >= 0 ? t_udeb_variant : forced;
     const bool in_hbm = variant == 3 || a.n_layers > kUdebMaxLdsLayers;
     if (!in_hbm && a.n_layers > kUdebMaxOnChipLayers) {   // c' in LDS, the two-wavefront shape at every ensemble size

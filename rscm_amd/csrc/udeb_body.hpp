@@ -957,6 +957,9 @@ struct Udeb2 {
     {
         const bool sh = hemi != 0;
         // kernarg segment; above 64 rows the table does not fit there (6 KB at 128 rows): the same rows in device memory, still wave-uniform
+        // (read by CAPACITY: both homes are zero-padded to the largest capacity that reads them, rscm_device.hpp)
+        static_assert(NCP_LDS ? NL <= kUdebDevTableRows : NL <= kUdebArgTableRows,
+                      "this instance reads NL rows of a geometry table that holds fewer: raise kUdebDevTableRows / kUdebArgTableRows with the capacity");
         const double* tables = NCP_LDS ? a.tables_dev : a.tables;
         const double nan = __builtin_nan("");
         const bool dead = status != 0;    // the reference refuses to build this component: every output NaN

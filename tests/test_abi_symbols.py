@@ -90,7 +90,8 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name)
     assert lib.rscm_gpu_abi_version() == 1
-    assert lib.rscm_gpu_abi_minor() >= 4
+    assert lib.rscm_gpu_abi_minor() >= 5
+    assert lib.rscm_gpu_experiments_build() == 0     # the shipped library reads no experiment knob from the environment
     assert lib.rscm_gpu_last_error() is not None
 
 
@@ -124,3 +125,90 @@ def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
     (tmp_path / "librscm_gpu.so").write_bytes(b"not an ELF file")
     with pytest.raises(RscmGpuUnavailable, match="cannot load"):
         _lib.load()
+
+
+# ---- the Rust binding text of INTEGRATION.md ------------------------------------------------------------------------------------
+# north_star puts the host in Rust; this image has no rustc, so the `extern "C"` blocks a maintainer would paste into
+# crates/rscm-calibrate/src/model_runner.rs:38-85 (`impl ModelRunner`) and crates/rscm-core/src/component.rs:350-437 (`impl Component`)
+# are checked the way the ctypes table is: declaration by declaration against the prototypes of include/rscm_gpu.h.
+
+_RUST_BASE = {"i32": "i4", "i64": "i8", "u8": "u1", "u32": "u4", "u64": "u8", "f64": "f8", "f32": "f4", "c_int": "i4", "c_char": "i1",
+              "c_void": "void", "RscmEns": "void", "RscmSampler": "void"}
+
+
+def _rust_type(text):
+    """`*mut *mut RscmEns` -> p:p:void, `*const f64` -> p:f8, `c_int` -> i4; anything this table does not know fails the test."""
+    words = text.split()
+    depth = 0
+    while words and words[0] == "*":
+        assert len(words) >= 3 and words[1] in ("const", "mut"), text
+        depth += 1
+        words = words[2:]
+    assert len(words) == 1 and words[0] in _RUST_BASE, f"unknown Rust type {text!r}"
+    return "p:" * depth + _RUST_BASE[words[0]]
+
+
+def _rust_externs(path=os.path.join(ROOT, "INTEGRATION.md")):
+    """{name: [(ret, [arg types]), ...]} over every `extern "C" { ... }` block inside a ```rust fence of INTEGRATION.md."""
+    text = open(path).read()
+    out = {}
+    for fence in re.findall(r"```rust\n(.*?)```", text, flags=re.S):
+        for block in re.findall(r'extern\s+"C"\s*\{(.*?)\n\}', fence, flags=re.S):
+            block = re.sub(r"/\*.*?\*/", " ", block, flags=re.S)
+            block = re.sub(r"//[^\n]*", " ", block)
+            for name, args, ret in re.findall(r"\bfn\s+(\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+?))?\s*;", block, flags=re.S):
+                parsed = []
+                for a in (x.strip() for x in args.split(",")):
+                    if not a:
+                        continue
+                    assert ":" in a, (name, a)
+                    parsed.append(_rust_type(a.split(":", 1)[1].replace("*", " * ")))
+                out.setdefault(name, []).append((_rust_type(ret.replace("*", " * ")) if ret else "void", parsed))
+            # nothing in a block may be left undeclared-looking: an elided argument list ("...") would not compile either
+            assert "..." not in block, "an extern block elides arguments"
+    return out
+
+
+def test_rust_binding_text_agrees_with_the_header_by_type():
+    protos = _prototypes(("rscm_gpu.h",))          # a Rust host binds the public boundary only
+    rust = _rust_externs()
+    assert len(rust) >= 25, sorted(rust)
+    for must in ("rscm_ens_create", "rscm_ens_set_params_aos", "rscm_ens_set_forcing", "rscm_ens_set_initial", "rscm_ens_run",
+                 "rscm_ens_get_series", "rscm_ens_status", "rscm_ens_loglik", "rscm_ens_link_input", "rscm_ens_run_lockstep",
+                 "rscm_sampler_create", "rscm_sampler_create_sharded", "rscm_sampler_create_graph", "rscm_ens_create_windowed"):
+        assert must in rust, must
+    for name, decls in rust.items():
+        assert name in protos, f"INTEGRATION.md declares {name}, which include/rscm_gpu.h does not export"
+        want_ret, want_args = protos[name]
+        for ret, args in decls:               # a function may be declared in more than one section: every copy must be right
+            assert ret == want_ret, (name, "return", ret, want_ret)
+            assert len(args) == len(want_args), (name, "arity", len(args), len(want_args))
+            assert args == want_args, (name, args, want_args)
+
+
+def test_the_rust_parser_refuses_what_it_does_not_know(tmp_path):
+    p = tmp_path / "x.md"
+    p.write_text('```rust\nextern "C" {\n    fn rscm_ens_run(h: *mut RscmEns, step_begin: i32, step_end: usize) -> c_int;\n}\n```\n')
+    import pytest
+    with pytest.raises(AssertionError, match="unknown Rust type"):
+        _rust_externs(str(p))
+    p.write_text('```rust\nextern "C" {\n    fn rscm_ens_run(h: *mut RscmEns, step_begin: i64, step_end: i32) -> c_int;\n}\n```\n')
+    got = _rust_externs(str(p))["rscm_ens_run"][0]
+    assert got == ("i4", ["p:void", "i8", "i4"]) and got[1] != _prototypes(("rscm_gpu.h",))["rscm_ens_run"][1]
+
+
+def test_the_shipped_library_reads_only_the_documented_environment():
+    """a Rust host linking librscm_gpu.so must not inherit undocumented environment-dependent launch plans.  The
+    only getenv calls in csrc/ are RSCM_SPLIT_RUNS and RSCM_POISON_ALLOC -- both documented in include/rscm_gpu.h -- and the one
+    inside `#ifdef RSCM_EXPERIMENTS` of experiment_env.hpp (compiled out of the shipped build: rscm_gpu_experiments_build() == 0)."""
+    csrc = os.path.join(ROOT, "rscm_amd", "csrc")
+    found = {}
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cpp", ".hip", ".hpp")):
+            for m in re.finditer(r"getenv\(([^)]*)\)", open(os.path.join(csrc, f)).read()):
+                found.setdefault(f, []).append(m.group(1))
+    assert found == {"ens.hpp": ['"RSCM_POISON_ALLOC"'], "experiment_env.hpp": ["name"], "rscm_gpu.cpp": ['"RSCM_SPLIT_RUNS"']}, found
+    guard = open(os.path.join(csrc, "experiment_env.hpp")).read()
+    assert guard.index("#ifdef RSCM_EXPERIMENTS") < guard.index("getenv(name)") < guard.index("#else")
+    header = open(os.path.join(ROOT, "include", "rscm_gpu.h")).read()
+    assert "RSCM_SPLIT_RUNS=0" in header and "RSCM_POISON_ALLOC=1" in header
