@@ -59,6 +59,13 @@ def mean(v):
 
 
 def main():
+    if len(sys.argv) == 5 and sys.argv[1] == "--from-json" and sys.argv[3] == "--traffic-key":
+        path = os.path.join(ROOT, "profiles", "traffic.json")
+        table = json.load(open(path))
+        table[sys.argv[4]] = json.load(open(sys.argv[2]))
+        json.dump(table, open(path, "w"), indent=1)
+        print(sys.argv[4], table[sys.argv[4]])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--sq", required=True)
     ap.add_argument("--fetch", required=True)
@@ -140,13 +147,17 @@ def main():
     text = "\n".join(lines) + "\n"
     open(os.path.join(ROOT, args.out) if not os.path.isabs(args.out) else args.out, "w").write(text)
     print(text)
+    entry = {"bytes_per_member_step": total / args.members, "read_per_member_step": per_step["fetched"] / args.members,
+             "written_per_member_step": per_step["written"] / args.members, "members": args.members,
+             "valu_issue_utilisation": round(issue_step, 3), "kernel_us_per_step": per_step["us_trace"],
+             "source": args.out.replace("gpurun_out/", "profiles/")}
+    # (the passes' CSVs are too large to travel back from the GPU box: the figures go into a small file beside the summary, and
+    # `--from-json FILE --traffic-key KEY` enters them into profiles/traffic.json here)
+    json.dump(entry, open((os.path.join(ROOT, args.out) if not os.path.isabs(args.out) else args.out) + ".json", "w"), indent=1)
     if args.traffic_key:
         path = os.path.join(ROOT, "profiles", "traffic.json")
         table = json.load(open(path))
-        table[args.traffic_key] = {"bytes_per_member_step": total / args.members, "read_per_member_step": per_step["fetched"] / args.members,
-                                   "written_per_member_step": per_step["written"] / args.members, "members": args.members,
-                                   "valu_issue_utilisation": round(issue_step, 3), "kernel_us_per_step": per_step["us_trace"],
-                                   "source": args.out}
+        table[args.traffic_key] = entry
         json.dump(table, open(path, "w"), indent=1)
         print(f"{args.traffic_key}: {total / args.members:.0f} B per member-step, issue {issue_step:.2f} -> profiles/traffic.json")
 
