@@ -19,6 +19,9 @@ struct LockstepSettings {
     bool cache = true;       // multi-step fused launches keep per-member values in LDS between steps
     bool by_value = true;    // short op lists travel in the kernel arguments
     bool split = true;       // independent ops of a one-step segment on two wavefronts (group_split_kernel)
+    bool merge = true;       // a step's last fused segment and the next step's first one in ONE launch (they are consecutive launches anyway)
+    bool prefetch = true;    // one-step fused launches request every row their ops will read up front (csrc/group.hip, prefetch_op)
+    int64_t merged_launches = 0;                // launches that carried two steps' segments since the last rscm_gpu_lockstep_merged_launches
     int64_t launches = 0, component_steps = 0;  // since the thread's last rscm_gpu_lockstep_stats
     int64_t split_launches = 0;                 // of those, launches of group_split_kernel
 };
@@ -79,11 +82,20 @@ int rscm_gpu_fail_chunk_launch(int32_t k)
 
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
-    if (enabled < 0 || enabled > 4) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..4)", enabled);
+    if (enabled < 0 || enabled > 6) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..6)", enabled);
     t_ls.fuse = enabled != 0;
-    t_ls.cache = enabled == 1 || enabled == 3 || enabled == 4;
+    t_ls.cache = enabled == 1 || enabled >= 3;
     t_ls.by_value = enabled != 3;
     t_ls.split = enabled != 4;
+    t_ls.merge = enabled != 5 && enabled != 6;   // (6: round 5's launch plan -- neither the merge nor the prefetch pass)
+    t_ls.prefetch = enabled != 6;
+    return RSCM_OK;
+}
+
+int rscm_gpu_lockstep_merged_launches(int64_t* out)
+{
+    if (out) *out = t_ls.merged_launches;
+    t_ls.merged_launches = 0;
     return RSCM_OK;
 }
 
@@ -197,23 +209,25 @@ static int32_t op_cost(int32_t kind)
         default: return 1;
     }
 }
-static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, SplitPlan* out)
+// idx[k]: the handle of op k in the plan; off[k]: 0 = the launch's step n, 1 = step n + 1 (a merged launch).  Op k reads row
+// s_k + (1 if it reads at the end of its step, else l.off) of a producer q, which writes row s_q + 1: tied when the two are the same row.
+static bool plan_split(const LockstepPlan* plan, const int32_t* idx, const int32_t* off, int32_t count, SplitPlan* out)
 {
     static const bool enabled = rscm::experiment_env("RSCM_LOCKSTEP_SPLIT", 1) != 0;   // (experiments build only: 0 = A/B runs without it)
     if (!enabled || !t_ls.split || count < 3 || count > rscm::kGroupTableOps) return false;
     bool tie[rscm::kGroupTableOps][rscm::kGroupTableOps] = {};
     int32_t cost[rscm::kGroupTableOps], serial = 0;
     for (int32_t k = 0; k < count; ++k) {
-        const rscm_ens* h = plan->handles[first + k];
+        const rscm_ens* h = plan->handles[idx[k]];
         cost[k] = op_cost(h->kind);
         serial += cost[k];
         for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
             const auto& l = h->links[j];
             if (!l.src) continue;
             const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
-            if (!reads_end) continue;
+            const int32_t reads_row = off[k] + (reads_end ? 1 : 0);
             for (int32_t q = 0; q < count; ++q)
-                if (plan->handles[first + q] == l.src && q != k) tie[k][q] = tie[q][k] = true;
+                if (plan->handles[idx[q]] == l.src && q != k && reads_row == off[q] + 1) tie[k][q] = tie[q][k] = true;
         }
     }
     // (worth it from ~15 % of the serial chain: the cut doubles the wavefronts that must be resident)
@@ -269,13 +283,93 @@ static bool plan_split(const LockstepPlan* plan, int32_t first, int32_t count, S
     return out->n_first > 0 && out->n_second > 0;
 }
 
+// The rows op `op` (handle h) will read at model step `at` that an earlier launch wrote, as addresses of their element 0 (lane i reads
+// [i]): exactly the loads the body makes (csrc/*_body.hpp) -- the linked rows through MemberInputs<2>::at(k, n) =
+// row[k][(off[k] + n) * N + i] (the aggregate: at n + 1), the parameter rows that vary over the members, the member constants, the
+// op's own latest rows.  skip[k]: link k reads a row that THIS launch writes (nothing to fetch yet).  Device addresses are only
+// formed here, never dereferenced.  The kernel requests them up front (csrc/group.hip, touch_rows); a row missing from the list
+// costs its op a trip to memory, a row listed in error would be a wasted read of a resident row -- never a wrong result.
+static void prefetch_rows_of(const rscm_ens* h, const rscm::GroupOp& op, int32_t at, const bool* skip, std::vector<const double*>& out)
+{
+    const int64_t N = h->N;
+    auto params = [&](const double* block, uint64_t uniform, int32_t P) {
+        for (int32_t j = 0; j < P; ++j)
+            if (!(j < 64 && ((uniform >> (j & 63)) & 1ull))) out.push_back(block + (size_t)j * N);
+    };
+    auto links = [&](const rscm::InputLinks& l, int32_t n_inputs, int32_t n) {
+        for (int32_t k = 0; k < n_inputs && k < rscm::kMaxLinks; ++k)
+            if (l.row[k] && !skip[k]) out.push_back(l.row[k] + (size_t)(l.off[k] + n) * N);
+    };
+    switch (op.kind) {
+        case RSCM_KIND_TWO_LAYER: {
+            const rscm::TwoLayerArgs& a = op.u.tl;
+            if (a.row_stride != N) break;
+            params(a.params, a.uniform_rows, h->P);
+            if (a.link && !skip[0]) out.push_back(a.link + (size_t)(a.src_off + at) * N);
+            out.push_back(a.ts + (size_t)at * N);
+            out.push_back(a.td + (size_t)at * N);
+            break;
+        }
+        case RSCM_KIND_GHG_FORCING: {
+            const rscm::GhgArgs& a = op.u.ghg;
+            params(a.params, a.uniform_rows, h->P);
+            if (a.derived && !a.derived_uniform) params(a.derived, 0ull, rscm::kDerivedRows);
+            if (a.linked) links(a.links, 3, at);
+            break;
+        }
+        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: {
+            const rscm::ChemArgs& a = op.u.chem;
+            params(a.params, a.uniform_rows, h->P);
+            if (a.linked) links(a.links, h->kind == RSCM_KIND_CH4_CHEMISTRY ? 5 : 1, at);
+            out.push_back(a.conc + (size_t)at * N);
+            if (at > 0) out.push_back(a.conc + (size_t)(at - 1) * N);
+            break;
+        }
+        case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON: case RSCM_KIND_CARBON_CYCLE: {
+            const rscm::CarbonArgs& a = op.u.carbon;
+            params(a.params, a.uniform_rows, h->P);
+            if (h->kind == RSCM_KIND_TERRESTRIAL_CARBON && a.derived && !a.derived_uniform) params(a.derived, 0ull, rscm::kDerivedRows);
+            const int32_t n_in = h->kind == RSCM_KIND_CO2_BUDGET ? 4 : (h->kind == RSCM_KIND_TERRESTRIAL_CARBON ? 3 : 2);
+            if (a.linked) links(a.links, n_in, at);
+            const int32_t n_state = h->kind == RSCM_KIND_CO2_BUDGET ? 1 : (h->kind == RSCM_KIND_TERRESTRIAL_CARBON ? 4 : 3);
+            const size_t vs = (size_t)a.rows * N;
+            for (int32_t v = 0; v < n_state; ++v) out.push_back(a.series + v * vs + (size_t)at * N);
+            break;
+        }
+        case RSCM_KIND_AGGREGATE: {   // the contributors in use, at the END of the step (links.off is 0 for this kind)
+            const rscm::PointwiseArgs& a = op.u.pw;
+            params(a.params, a.uniform_rows, h->P);
+            if (a.linked) links(a.links, std::min(a.n_inputs_used, 8), at + 1);
+            break;
+        }
+        case RSCM_KIND_OZONE_FORCING: case RSCM_KIND_AEROSOL_DIRECT: case RSCM_KIND_AEROSOL_INDIRECT: case RSCM_KIND_FOURBOX_OHU:
+        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: {
+            const rscm::PointwiseArgs& a = op.u.pw;
+            params(a.params, a.uniform_rows, h->P);
+            if (a.linked) links(a.links, h->n_inputs, at);
+            break;
+        }
+        default: break;
+    }
+}
+
 // Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
 // the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
-static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len)
+// next_count > 0 (len == 1, by-value table only): a MERGED launch -- the handles [next_first, next_first + next_count) ride along at
+// step n + 1.  They are the first segment of the next step, i.e. the launch that would follow this one anyway: same order, same
+// operands, one launch boundary less, and the two segments' independent ops share the two wavefronts of the split kernel.
+static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32_t n, int32_t len, int32_t next_first = 0, int32_t next_count = 0)
 {
     rscm_ens* lead = plan->handles[first];
+    const int32_t total = count + next_count;
+    if (next_count > 0 && (len != 1 || total > rscm::kGroupTableOps || !t_ls.by_value)) return fail(RSCM_ERR_STATE, "a merged launch needs a by-value table");
+    int32_t idx[rscm::kMaxGroupOps + rscm::kGroupTableOps], off[rscm::kMaxGroupOps + rscm::kGroupTableOps];
+    for (int32_t k = 0; k < total; ++k) {
+        idx[k] = k < count ? first + k : next_first + (k - count);
+        off[k] = k < count ? 0 : 1;
+    }
     bool all_small = true;
-    for (int32_t k = first; k < first + count; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[k]->kind);
+    for (int32_t k = 0; k < total; ++k) all_small = all_small && rscm::group_kind_is_small(plan->handles[idx[k]]->kind);
     std::vector<rscm::OpCache> slots;
     int32_t cache_slots = 0;
     // a multi-step launch of a graph whose sequence of kinds has a kernel of its own (csrc/group.hip, group_seq_kernel): that kernel keeps
@@ -288,47 +382,49 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
     }
     if (len > 1 && all_small && t_ls.cache) cache_slots = assign_cache_slots(plan, first, count, slots, !own_kernel);
     if (cache_slots <= 0) own_kernel = false;
-    for (int32_t k = first; k < first + count; ++k) {
-        rscm_ens* h = plan->handles[k];
-        if (int rc = step_check(h, n, n + len)) return rc;
-        if (int rc = step_window_pre(h, n, n + len)) return rc;
+    for (int32_t k = 0; k < total; ++k) {
+        rscm_ens* h = plan->handles[idx[k]];
+        if (int rc = step_check(h, n + off[k], n + off[k] + len)) return rc;
+        if (int rc = step_window_pre(h, n + off[k], n + off[k] + len)) return rc;
     }
     // a short op list travels by value in the kernel arguments (one-step launches: window slides change pointers
     // every few steps); a longer one, and the multi-step launch with LDS slots, through the device table, of which
     // only what changed since the last launch is uploaded
-    const bool by_value = (t_ls.by_value && count <= rscm::kGroupTableOps && cache_slots == 0) || own_kernel;
+    const bool by_value = (t_ls.by_value && total <= rscm::kGroupTableOps && cache_slots == 0) || own_kernel;
     rscm::GroupTable table;
     if (by_value) memset((void*)&table, 0, sizeof table);
-    for (int32_t k = first; k < first + count; ++k) {
-        rscm_ens* h = plan->handles[k];
+    for (int32_t k = 0; k < total; ++k) {
+        rscm_ens* h = plan->handles[idx[k]];
+        const int32_t at = n + off[k];
         rscm::InputLinks links{};
         int32_t linked = 0;
-        if (int rc = step_links(h, n, n + 1, links, linked)) return rc;
+        if (int rc = step_links(h, at, at + 1, links, linked)) return rc;
         rscm::GroupOp op;
         memset((void*)&op, 0, sizeof op);
-        if (int rc = step_launch(h, n, n + 1, links, linked, &op)) return rc;
-        if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", k, h->kind);
+        if (int rc = step_launch(h, at, at + 1, links, linked, &op)) return rc;
+        if (op.kind < 0) return fail(RSCM_ERR_STATE, "handle %d (kind %d) cannot be fused", idx[k], h->kind);
         clear_step_fields(op);
+        op.step_off = off[k];
         if (cache_slots > 0) {
-            op.cache = slots[(size_t)(k - first)];
+            op.cache = slots[(size_t)k];
         } else {
             op.cache.series_slot = op.cache.param_slot = -1;
             for (int32_t& sl : op.cache.link_slot) sl = -1;
         }
         if (by_value) {
-            memcpy((void*)&table.ops[k - first], &op, sizeof op);
-        } else if (!plan->valid[k] || memcmp(&plan->cached[k], &op, sizeof op) != 0) {
+            memcpy((void*)&table.ops[k], &op, sizeof op);
+        } else if (!plan->valid[idx[k]] || memcmp(&plan->cached[idx[k]], &op, sizeof op) != 0) {
             if (plan->ring_pos == LockstepPlan::kRing) {  // every slot may still be the source of a queued copy
                 HIPCHK(hipStreamSynchronize(lead->stream));
                 plan->ring_pos = 0;
             }
             rscm::GroupOp* slot = plan->staging + plan->ring_pos++;
             memcpy((void*)slot, &op, sizeof op);
-            HIPCHK(hipMemcpyAsync(plan->d_ops + k, slot, sizeof op, hipMemcpyHostToDevice, lead->stream));
-            memcpy((void*)&plan->cached[k], &op, sizeof op);
-            plan->valid[k] = 1;
+            HIPCHK(hipMemcpyAsync(plan->d_ops + idx[k], slot, sizeof op, hipMemcpyHostToDevice, lead->stream));
+            memcpy((void*)&plan->cached[idx[k]], &op, sizeof op);
+            plan->valid[idx[k]] = 1;
         }
-        h->time_index = n + 1;  // provisional: later handles of the segment may read this one's row n + 1
+        h->time_index = at + 1;  // provisional: later handles of the launch may read this one's row at + 1
     }
     hipError_t seq_status = hipSuccess;
     if (own_kernel) {
@@ -337,19 +433,52 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         HIPCHK(seq_status);
     } else {
         SplitPlan split;
-        if (by_value && len == 1 && cache_slots == 0 && plan_split(plan, first, count, &split)) {
+        const bool one_step = by_value && len == 1 && cache_slots == 0;
+        const bool cut = one_step && plan_split(plan, idx, off, total, &split);
+        if (!cut && one_step)   // (one_step: total <= kGroupTableOps, the length of split.order)
+            for (int32_t k = 0; k < total; ++k) split.order[k] = k;
+        // the rows the launch's ops read that earlier launches wrote, in the order the wavefronts run the ops
+        rscm::PrefetchList rows;
+        memset((void*)&rows, 0, sizeof rows);
+        if (one_step && t_ls.prefetch) {
+            std::vector<const double*> list;
+            int32_t* counts[3] = {&rows.n_first, &rows.n_second, &rows.n_tail};
+            for (int32_t pos = 0; pos < total; ++pos) {
+                const int32_t k = split.order[pos];
+                const rscm_ens* h = plan->handles[idx[k]];
+                bool skip[rscm::kMaxLinks] = {};
+                for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
+                    const auto& l = h->links[j];
+                    if (!l.src) continue;
+                    const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
+                    for (int32_t q = 0; q < total; ++q)   // written by this very launch: nothing to fetch
+                        if (plan->handles[idx[q]] == l.src && off[k] + (reads_end ? 1 : 0) == off[q] + 1) skip[j] = true;
+                }
+                const size_t before = list.size();
+                prefetch_rows_of(h, table.ops[k], n + off[k], skip, list);
+                if (list.size() > (size_t)rscm::kPrefetchRows) {   // best effort: what does not fit costs its op a trip, as before
+                    list.resize(before);
+                    continue;
+                }
+                const int32_t set = !cut ? 0 : (pos < split.n_first ? 0 : (pos < split.n_first + split.n_second ? 1 : 2));
+                *counts[set] += (int32_t)(list.size() - before);
+            }
+            for (size_t r = 0; r < list.size(); ++r) rows.row[r] = list[r];
+        }
+        if (cut) {
             rscm::GroupTable ordered;
             memset((void*)&ordered, 0, sizeof ordered);
-            for (int32_t k = 0; k < count; ++k) memcpy((void*)&ordered.ops[k], &table.ops[split.order[k]], sizeof(rscm::GroupOp));
-            HIPCHK(rscm::launch_group_split(ordered, split.n_first, split.n_second, count, lead->N, n, all_small, lead->stream));
+            for (int32_t k = 0; k < total; ++k) memcpy((void*)&ordered.ops[k], &table.ops[split.order[k]], sizeof(rscm::GroupOp));
+            HIPCHK(rscm::launch_group_split(ordered, rows, split.n_first, split.n_second, total, lead->N, n, all_small, lead->stream));
             t_ls.split_launches += 1;
         } else {
-            HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, count, lead->N, n, n + len, all_small,
-                                      cache_slots, lead->stream));
+            HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, total, lead->N, n, n + len, all_small,
+                                      cache_slots, lead->stream, one_step ? &rows : nullptr));
         }
     }
-    for (int32_t k = first; k < first + count; ++k)
-        if (int rc = step_finish(plan->handles[k], n, n + len)) return rc;
+    if (next_count > 0) t_ls.merged_launches += 1;
+    for (int32_t k = 0; k < total; ++k)
+        if (int rc = step_finish(plan->handles[idx[k]], n + off[k], n + off[k] + len)) return rc;
     return RSCM_OK;
 }
 
@@ -429,16 +558,58 @@ int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, int32_t s
         }
         return RSCM_OK;
     }
-    for (int32_t n = step_begin; n < step_end; ++n) {
-        for (const auto& sgm : segments) {
-            t_ls.launches += 1;
-            t_ls.component_steps += sgm.second;
-            if (sgm.second > 1) {
-                if (int rc = fused_segment(plan, sgm.first, sgm.second, n, 1)) return rc;
-            } else if (int rc = run_range(handles[sgm.first], n, n + 1, false)) {
-                return rc;
+    auto run_one = [&](const std::pair<int32_t, int32_t>& sgm, int32_t n) -> int {
+        t_ls.launches += 1;
+        t_ls.component_steps += sgm.second;
+        if (sgm.second > 1) return fused_segment(plan, sgm.first, sgm.second, n, 1);
+        return run_range(handles[sgm.first], n, n + 1, false);
+    };
+    // MERGED schedule.  In graph order a step's last segment L(n) and the next step's first segment F(n + 1) are consecutive launches
+    // with nothing but the window upkeep between them.  Where both are fused (light) segments and fit one by-value table, they go
+    // out as ONE launch: the same ops on the same operands in the same order, one launch boundary less per step, and their
+    // independent ops side by side on the two wavefronts of the split kernel.  What moves is the upkeep: it is flushed after the
+    // merged launch (L's handles have finished step n, F's step n + 1) instead of between the two.  Every window keeps at least
+    // two rows behind its handle's time index (keep_rows), so the rows n and n + 1 that the other components read of a handle that
+    // is one step ahead are resident whichever side of the flush they are read on.  Not merged: when an op of F reads a row at the
+    // END of its step from a handle outside F (a read-ahead link: the window of that handle would have to have moved first).
+    bool merged = false;
+    if (t_ls.fuse && t_ls.merge && t_ls.by_value && plan && segments.size() >= 3 && step_end - step_begin >= 2) {
+        const auto& F = segments.front();
+        const auto& L = segments.back();
+        merged = fusable(handles[F.first]) && fusable(handles[L.first]) && F.second + L.second <= rscm::kGroupTableOps &&
+                 handles[F.first]->N == handles[L.first]->N && handles[F.first]->device == handles[L.first]->device;
+        for (int32_t k = F.first; merged && k < F.first + F.second; ++k) {
+            const rscm_ens* h = handles[k];
+            for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
+                const auto& l = h->links[j];
+                if (!l.src || !(h->kind == RSCM_KIND_AGGREGATE || l.off == 1)) continue;
+                bool inside = false;
+                for (int32_t q = F.first; q < F.first + F.second; ++q) inside = inside || handles[q] == l.src;
+                if (!inside) merged = false;
             }
         }
+    }
+    if (merged) {
+        const auto F = segments.front(), L = segments.back();
+        if (int rc = run_one(F, step_begin)) return rc;                         // prologue: F(step_begin)
+        if (int rc = window_flush(&deferral, handles[0]->stream)) return rc;
+        for (int32_t n = step_begin; n < step_end; ++n) {
+            for (size_t q = 1; q + 1 < segments.size(); ++q)
+                if (int rc = run_one(segments[q], n)) return rc;
+            if (n + 1 < step_end) {
+                t_ls.launches += 1;
+                t_ls.component_steps += L.second + F.second;
+                if (int rc = fused_segment(plan, L.first, L.second, n, 1, F.first, F.second)) return rc;   // L(n) + F(n + 1)
+            } else if (int rc = run_one(L, n)) {                                // epilogue: L(step_end - 1) alone
+                return rc;
+            }
+            if (int rc = window_flush(&deferral, handles[0]->stream)) return rc;
+        }
+        return RSCM_OK;
+    }
+    for (int32_t n = step_begin; n < step_end; ++n) {
+        for (const auto& sgm : segments)
+            if (int rc = run_one(sgm, n)) return rc;
         if (int rc = window_flush(&deferral, handles[0]->stream)) return rc;
     }
     return RSCM_OK;

@@ -627,26 +627,40 @@ struct GroupOp {
         Args() : pw() {}
     } u;
     OpCache cache;     // LDS slots of a multi-step launch (all -1 otherwise)
-    GroupOp() : kind(-1), variant(0), u(), cache() {}
+    // One-step launches (csrc/group.hip): the op runs model step `step + step_off` of the launch -- 1 for the ops of the NEXT step's
+    // first segment when the scheduler merges them with this step's last segment (csrc/lockstep.cpp, MERGED schedule).
+    int32_t step_off;
+    GroupOp() : kind(-1), variant(0), u(), cache(), step_off(0) {}
 };
 constexpr int kMaxGroupOps = 16;
-// up to this many ops travel by value in the kernel-argument segment (4 KiB in all) instead of a device table
-constexpr int kGroupTableOps = 8;
+// up to this many ops travel by value in the kernel-argument segment (4 KiB in all) instead of a device table: the eight light
+// components of the MAGICC graph's first segment, or that segment merged with the three of the previous step's last one (eleven)
+constexpr int kGroupTableOps = 12;
 struct GroupTable {
     GroupOp ops[kGroupTableOps];
 };
-static_assert(sizeof(GroupTable) <= 3840, "the by-value op table must fit the kernel-argument segment beside the other arguments");
+// The rows a one-step launch's ops will read that EARLIER launches wrote -- linked rows, the ops' own latest rows, the parameter rows
+// that vary over the members -- as the host resolves them while it builds the table (csrc/lockstep.cpp, prefetch_rows): lane i of the
+// launch reads row[r][i].  The kernel requests them all up front (csrc/group.hip).  With the split kernel: the rows of the first
+// set's ops, then the second set's, then the tail's; the plain kernel: n_first rows.
+constexpr int kPrefetchRows = 48;
+struct PrefetchList {
+    int32_t n_first, n_second, n_tail, reserved;
+    const double* row[kPrefetchRows];
+};
+static_assert(sizeof(GroupOp) == 296, "GroupOp grew: twelve of them must fit the kernel-argument segment");
+static_assert(sizeof(GroupTable) + sizeof(PrefetchList) + 64 <= 4096, "the by-value op table and the prefetch list must fit the kernel-argument segment");
 // all_small: every op is one of the kinds group_kind_is_small accepts (the low-register variant of the kernel)
 bool group_kind_is_small(int32_t kind);
 // cache_slots > 0 (all_small only): the ops carry LDS slots (OpCache), cache_slots doubles per thread in all.
 // Exactly one of d_ops (device table) and table (host, passed by value, n_ops <= kGroupTableOps) is given.
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
-                        bool all_small, int32_t cache_slots, hipStream_t s);
+                        bool all_small, int32_t cache_slots, hipStream_t s, const PrefetchList* rows = nullptr);
 
 // One model step of a by-value table whose first n_first ops and next n_second ops have no edge between them (two wavefronts per 64
 // members run them at the same time), the rest after a workgroup barrier (csrc/group.hip, group_split_kernel).
-hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
-                              hipStream_t s);
+hipError_t launch_group_split(const GroupTable& table, const PrefetchList& rows, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members,
+                              int32_t step, bool all_small, hipStream_t s);
 
 // A multi-step launch of a light graph whose sequence of kinds has a kernel of its own (csrc/group.hip: the op table
 // by value, the kinds compile-time): true if one was launched (*status: its launch status), false if the sequence has none.

@@ -75,8 +75,12 @@ __global__ __launch_bounds__(kUdeb2Block) void udeb2_kernel(UdebArgs a)
 }
 
 // 65 .. kUdebMaxLdsLayers layers: a hemisphere per wavefront as above, the column in registers (it fills them) and the sweep's c' array
-// in LDS (2 x 128 rows x 512 B = 128 KB per workgroup: one workgroup per CU, i.e. two of a CU's four SIMDs busy -- half the on-chip
-// kernels' rate per layer, six times the columns-in-HBM kernel's).  The geometry table comes from device memory (6 KB: past the
+// in LDS (2 x 128 rows x 512 B = 128 KB per workgroup: one workgroup per CU, i.e. two of a CU's four SIMDs busy).  Measured, per
+// 65 536 members x 750 years: 499 ms at 65 layers against 76.7 ms at 64 (profiles/r5_udeb_layer_counts.txt) -- 3.3x (128 layers) to
+// 6.4x (65) the on-chip kernels' cost per layer, not the 2x the occupancy alone would give: col[128] fills the 256 VGPRs and the
+// kernel spills 624-672 bytes per lane to scratch (`make check-udeb-scratch` reports it; profiles/r6_udeb_lds_65.txt: 11.3 GB written
+// per launch against 3.2 GB at 50 layers, issue utilisation 0.25).  Still 1.6x (65 layers) to 2.5x (100) faster than the columns-in-HBM kernel.  No configuration
+// of the reference or of MAGICC7 has more than 50 layers: recorded, not pursued.  The geometry table comes from device memory (6 KB: past the
 // kernel-argument segment), through the scalar cache all the same.
 template <bool FAST>
 __global__ __launch_bounds__(kUdeb2Block) void udeb2_lds_kernel(UdebArgs a)

@@ -119,10 +119,10 @@ def _variant(ra, v):
 def test_udeb_gpu_any_layer_count(ra, orc, n_layers):
     """Every n_layers >= 2 the reference accepts (parameters/climate_udeb.rs:41; from_parameters refuses < 2, mod.rs:162-165) runs on
     the device.  Up to 64 layers a member's columns stay in registers + LDS: counts other than 20 / 30 / 40 / 50 take the next
-    capacity's instance of the unrolled kernels with the count at run time (csrc/udeb_body.hpp, DYN: a scalar branch per row, the
-    statements of a live row unchanged); 65 to 128 layers a hemisphere per wavefront with the column in registers and the sweep's c' array
+    capacity's instance of the unrolled kernels with the count at run time (csrc/udeb_body.hpp, DYN: no branch -- the rows past the
+    count are ZERO ROWS of the geometry table, exact no-ops; the statements of a live row unchanged); 65 to 128 layers a hemisphere per wavefront with the column in registers and the sweep's c' array
     in LDS; beyond 128 the columns-in-HBM kernel (csrc/udeb_any_body.hpp: plain loops over the layers, the same row arithmetic).  Same 1e-9 bar against the oracle (which takes any count; the reference's MAGICC7 files pin 50
-    layers only: parity at other counts is against the restatement); both arithmetic modes; launch boundaries (resume from the
+    layers only: at every other count, and for the LDS kernel, parity is against the in-repo restatement alone -- PARITY UNPINNED); both arithmetic modes; launch boundaries (resume from the
     stored columns and scalars) change nothing; a member the reference refuses to build is flagged and NaN; more than 50 layers
     means the initial profile's last value below layer 50, as in the oracle.  Up to 64 layers the three kernels -- a hemisphere per
     wavefront, one thread per member, columns in HBM -- carry the same bits; from 65 to 128 the LDS kernel and the HBM kernel do."""

@@ -303,7 +303,7 @@ def test_configs3_shape_fits_one_gpu(ra):
 def test_configs3_share_runs_at_full_size(ra):
     """BASELINE.json configs[3], one GPU's share AT FULL SIZE: 125 000 members x 9000 monthly steps (1750-2500)
     of the ten-component MAGICC graph (RSCM_MODE_FAST: OceanCarbon's O(T) recurrence; 16-row window, annual
-    outputs).  Checked: no member fails, four launches per model step, the ensemble ends warm with CO2 above
+    outputs).  Checked: no member fails, THREE launches per model step (round 6: the step's last light segment rides with the next step's first), the ensemble ends warm with CO2 above
     pre-industrial -- and the first 64 members equal a 64-member run given their parameters, bit for bit, on
     every kept row of five variables (nothing depends on the ensemble size, the position in a wavefront or the
     fused launches).  scripts/run_configs3_share.py is the same thing as a program (profiles/r2_configs3_share_*)."""
@@ -328,7 +328,7 @@ def test_configs3_share_runs_at_full_size(ra):
     out = json.loads(buf.getvalue().strip().splitlines()[-1])
     print(f"configs[3] share: {out['run_s']:.2f} s, {out['hbm_allocated_gib']:.0f} GiB, {out['launches_per_step']:.0f} launches per step, "
           f"{out['member_years_per_s']:.3g} member-years/s")
-    assert out["failed_members"] == 0 and out["launches_per_step"] == 4.0 and out["hbm_allocated_gib"] < 250e9 / 2**30
+    assert out["failed_members"] == 0 and 3.0 <= out["launches_per_step"] <= 3.001 and out["hbm_allocated_gib"] < 250e9 / 2**30
     assert all(out["first_64_members_equal_a_64_member_run"].values())
     assert out["warming_end_K"]["count"] == 125_000 and 1.0 < out["warming_end_K"]["mean"] < 12.0
     assert out["co2_end_ppm"]["min"] > 278.0
