@@ -44,7 +44,44 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ void touch_rows(const PrefetchList& rows, int32_t begin, int32_t end, int64_t i, uint32_t* sink)
 {
-    for (int32_t r = begin; r < end; ++r) __builtin_amdgcn_global_load_lds((gptr_t)(rows.row[r] + i), (lptr_t)sink, 4, 0, 0);
+    // eight addresses per trip through the scalar cache (the list lies in the kernel-argument segment), not one
+    for (int32_t r = begin; r < end; r += 8) {
+        const double* p[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p[q] = rows.row[r + q < kPrefetchRows ? r + q : kPrefetchRows - 1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (r + q < end) __builtin_amdgcn_global_load_lds((gptr_t)(p[q] + i), (lptr_t)sink, 4, 0, 0);
+    }
+}
+
+// The ops' compact uniform-parameter blocks (rscm_device.hpp, param_at: 256 bytes = 4 lines each) into the L2, all of them requested
+// by ONE vector instruction that nothing waits for: lane l asks for line l & 3 of block l >> 2 (48 lanes for the table's twelve
+// slots).  The bodies' parameter loads -- scalar loads through the scalar cache, or same-address vector loads -- then find their lines
+// on chip instead of each op making its own trip to HBM for lines the L2 lost since the last step.  Every slot of the table holds a
+// valid block address (the host repeats op 0's in the unused ones).  (Scalar loads straight into the scalar cache were tried first:
+// SMEM returns out of order, so the compiler drains lgkmcnt after every block -- twelve trips in a row, worse than none.)
+__device__ __forceinline__ void touch_uniform_blocks(const GroupTable& table, uint32_t* sink)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    // (the twelve addresses as SCALAR loads from the table -- said so with readfirstlane: left to itself the compiler selects the
+    // table OFFSET per lane and fetches the address with a vector load from the kernel-argument segment, a trip of its own)
+    uint32_t lo[kGroupTableOps], hi[kGroupTableOps];
+#pragma unroll
+    for (int k = 0; k < kGroupTableOps; ++k) {
+        const uintptr_t q = (uintptr_t)table.ops[k].uparams();
+        lo[k] = __builtin_amdgcn_readfirstlane((uint32_t)q);
+        hi[k] = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+    }
+    uint32_t alo = lo[0], ahi = hi[0];
+#pragma unroll
+    for (int k = 1; k < kGroupTableOps; ++k) {
+        const bool mine = (lane >> 2) == (uint32_t)k;
+        alo = mine ? lo[k] : alo;
+        ahi = mine ? hi[k] : ahi;
+    }
+    const uintptr_t addr = (((uintptr_t)ahi << 32) | alo) + (uintptr_t)(lane & 3u) * 64u;
+    if (lane < 4u * kGroupTableOps) __builtin_amdgcn_global_load_lds((gptr_t)addr, (lptr_t)sink, 4, 0, 0);
 }
 
 // CACHED (a graph of light components only, stepped many model steps in one launch): between the steps every op
@@ -108,6 +145,7 @@ __global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable tab
         for (int32_t l = 0; l < n_lines; ++l) touched |= words[(size_t)l * 16];
         asm volatile("" ::"s"(touched));
     }
+    if (rows.uniform_blocks) touch_uniform_blocks(table, sink + (threadIdx.x & ~63));   // (one-step launches: the host says so)
     {
         const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (i < n_members) touch_rows(rows, 0, rows.n_first, i, sink + (threadIdx.x & ~63));
@@ -151,6 +189,7 @@ __global__ __launch_bounds__(128) void group_split_kernel(const GroupTable table
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));   // wave-uniform, and said so: the op index stays scalar
     const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const bool live = i < n_members;
+    if (rows.uniform_blocks) touch_uniform_blocks(table, sink + wave * 64);
     if (live) {   // this wavefront's own set, and for wavefront 0 the tail: the rows of what it will run, nothing else
         const int32_t b0 = wave == 0 ? 0 : rows.n_first, e0 = wave == 0 ? rows.n_first : rows.n_first + rows.n_second;
         touch_rows(rows, b0, e0, i, sink + wave * 64);
@@ -219,7 +258,7 @@ struct OpRegs {
         else if constexpr (KIND == kKindCarbonCycle || KIND == kKindCo2Budget) { params = op.u.carbon.params; uniform = op.u.carbon.uniform_rows; N = op.u.carbon.n_members; }
         else { params = op.u.pw.params; uniform = op.u.pw.uniform_rows; N = op.u.pw.n_members; }
 #pragma unroll
-        for (int j = 0; j < SeqShape<KIND>::P; ++j) prm[j] = param_at(params, uniform, j, N, i);
+        for (int j = 0; j < SeqShape<KIND>::P; ++j) prm[j] = param_at(params, uniform, j, N, i, op.uparams());
         // the state rows the bodies ask their cache for (the pointwise kinds have outputs only: nothing is read back)
         const size_t r0 = (size_t)step_begin * N + i;
         if constexpr (KIND == 0) {

@@ -441,6 +441,14 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         rscm::PrefetchList rows;
         memset((void*)&rows, 0, sizeof rows);
         if (one_step && t_ls.prefetch) {
+            // every slot of the table names a compact uniform-parameter block (the unused ones repeat op 0's): the kernel asks for all
+            // of them before anything waits (csrc/group.hip, touch_uniform_blocks)
+            bool all = true;
+            for (int32_t k = 0; k < total; ++k) all = all && table.ops[k].uparams() != nullptr;
+            if (all) {
+                for (int32_t k = total; k < rscm::kGroupTableOps; ++k) table.ops[k].u.pw.uparams = table.ops[0].uparams();
+                rows.uniform_blocks = 1;
+            }
             std::vector<const double*> list;
             int32_t* counts[3] = {&rows.n_first, &rows.n_second, &rows.n_tail};
             for (int32_t pos = 0; pos < total; ++pos) {
@@ -469,6 +477,8 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
             rscm::GroupTable ordered;
             memset((void*)&ordered, 0, sizeof ordered);
             for (int32_t k = 0; k < total; ++k) memcpy((void*)&ordered.ops[k], &table.ops[split.order[k]], sizeof(rscm::GroupOp));
+            if (rows.uniform_blocks)   // (the unused slots must name a valid block here too)
+                for (int32_t k = total; k < rscm::kGroupTableOps; ++k) ordered.ops[k].u.pw.uparams = ordered.ops[0].uparams();
             HIPCHK(rscm::launch_group_split(ordered, rows, split.n_first, split.n_second, total, lead->N, n, all_small, lead->stream));
             t_ls.split_launches += 1;
         } else {
