@@ -23,9 +23,8 @@ extern "C" {
  *   2  as 1 without the LDS slots;
  *   3  as 1 with every op table sent through device memory instead of the kernel arguments;
  *   4  as 1 without cutting a one-step segment's independent ops over two wavefronts (csrc/group.hip, group_split_kernel): A/B.
- *   5  as 1 without MERGED launches: a step's last fused segment and the next step's first one stay two launches (A/B, and the
- *      yardstick of tests/test_gpu_group.py: merged == unmerged bit for bit);
- *   6  as 5 and without the prefetch pass of the one-step fused launches (csrc/group.hip, prefetch_op): round 5's launch plan.
+ *   5  as 1 without MERGED launches: a step's last fused segment and the next step's first one stay two launches (round 5's launch
+ *      plan; A/B, and the yardstick of tests/test_gpu_group.py: merged == unmerged bit for bit).
  *      (Round 3's mode 4 -- ClimateUDEB and OceanCarbon inside the fused launch too, one launch per window chunk with the ocean columns
  *      resident on chip -- existed in round 3: bit-identical to mode 1 and 17 % slower on an MI355X, removed in round 4;
  *      DESIGN.md section 8g, profiles/r3_graph_stamps.json, commit f22e743.)

@@ -95,8 +95,8 @@ __device__ __forceinline__ void carbon_cycle_body(const CarbonArgs& a, int64_t i
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    const double tau = cache.param(a.params, a.uniform_rows, 0, N, i, a.uparams), conc_pi = cache.param(a.params, a.uniform_rows, 1, N, i, a.uparams),
-                 alpha = cache.param(a.params, a.uniform_rows, 2, N, i, a.uparams);
+    const double tau = cache.param(a.params, a.uniform_rows, 0, N, i), conc_pi = cache.param(a.params, a.uniform_rows, 1, N, i),
+                 alpha = cache.param(a.params, a.uniform_rows, 2, N, i);
     const MemberInputs<SRC, 2> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
     const size_t r0 = (size_t)step_begin * N + i;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void co2_budget_body(const CarbonArgs& a, int64_t i, 
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    const double gtc_per_ppm = cache.param(a.params, a.uniform_rows, 0, N, i, a.uparams);
+    const double gtc_per_ppm = cache.param(a.params, a.uniform_rows, 0, N, i);
     const MemberInputs<SRC, 4> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;
     double co2 = cache.state(0, a.series + (size_t)step_begin * N + i);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void terrestrial_body(const CarbonArgs& a, int64_t i,
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i, a.uparams); };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     // state and the first step's rows first: in flight together with the parameters (rscm_device.hpp, StepRows)
     const MemberInputs<SRC, 3> in(a.inputs, a.scen, a.links, T, N, i);
     const size_t vs = (size_t)a.rows * N;

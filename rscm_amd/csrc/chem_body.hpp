@@ -20,7 +20,7 @@ __device__ __forceinline__ void ch4_body(const ChemArgs& a, int64_t i, int32_t s
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i, a.uparams); };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     // state and the first step's rows first: in flight together with the parameters (rscm_device.hpp, StepRows)
     const MemberInputs<SRC, 5> in(a.inputs, a.scen, a.links, T, N, i);
     double cur = a.conc[(size_t)step_begin * N + i];
@@ -81,7 +81,7 @@ __device__ __forceinline__ void n2o_body(const ChemArgs& a, int64_t i, int32_t s
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i, a.uparams); };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     // state and the first step's row first: in flight together with the parameters (the delayed rows cannot be: their
     // address is a parameter)
     const MemberInputs<SRC, 1> in(a.inputs, a.scen, a.links, T, N, i);

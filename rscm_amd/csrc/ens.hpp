@@ -93,7 +93,6 @@ struct rscm_ens {
     int32_t* d_nsub_cc = nullptr;
 
     double* d_params = nullptr;  // [P][N]
-    double* d_uparams = nullptr; // [kUniformBlock] the uniform rows' values side by side (element j = element 0 of row j), written with the parameters
     int32_t ag_rows_set = 0;     // aggregate kind: 1 + the highest contributor row rscm_ens_set_forcing has ever been given data for
     uint64_t uniform_rows = 0;   // bit j: parameter row j (< 64) holds one value for every member (the kernels then read element 0: param_at)
     // member constants of the kinds that have them (GhgForcing, TerrestrialCarbon; rscm_device.hpp, launch_*_derive): [kDerivedRows][N],

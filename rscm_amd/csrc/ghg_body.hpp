@@ -56,7 +56,7 @@ __device__ __forceinline__ void ghg_body(const GhgArgs& a, const double* __restr
 {
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
-    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i, a.uparams); };
+    auto P = [&](int j) -> double { return param_at(a.params, a.uniform_rows, j, N, i); };
     // LINKED: the first step's concentrations first, in flight together with the parameters (rscm_device.hpp, StepRows)
     const MemberInputs<LINKED ? 2 : 0, 3> conc(a.conc, a.scen, a.links, T, N, i);
     StepRows<3> ahead = {};

@@ -20,7 +20,6 @@
 // scalar cache.  Heavy components -- ClimateUDEB (two 50-layer columns in registers and LDS),
 // OceanCarbon (history convolution), HalocarbonChemistry (species-parallel grid) -- keep their own
 // launches; rscm_gpu.cpp cuts the step's component list into segments accordingly.
-#include <cstring>
 #include <utility>
 
 #include "group_body.hpp"
@@ -28,61 +27,6 @@
 namespace rscm {
 
 namespace {
-
-// ---- one trip instead of one per op: the prefetch pass of the one-step launches -------------------------------------
-// A one-step launch of light components is a chain of dependent memory trips: op k's loads are issued after op k - 1's arithmetic
-// (in-order issue), and a trip costs ~2.5 us at 125 000 members (every wavefront of the launch asks at once).  Measured
-// (profiles/r6_configs3_share_pmc.txt): 0.13-0.24 FP64 issue utilisation, two thirds of the wave cycles in s_waitcnt, 35 MB moved in
-// 29 us.  Every row the ops of this wavefront will read that an EARLIER launch wrote -- linked rows, the ops' own latest rows, the
-// parameter rows that vary over the members; the host lists them while it builds the table (PrefetchList) -- is therefore requested
-// up front, all together, as LDS-DMA loads (global_load_lds_dword: no destination register, nothing waits for them) into a sink
-// nobody reads: one dword of every 8-byte element, i.e. every cache line of the row.  The bodies then run unchanged -- same
-// statements, same bits -- and find their lines in the L2 (mostly in this CU's L1): a few hundred cycles instead of a trip to HBM
-// behind the previous op.  Live lanes only: row[r][i] is an address the body itself will read.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ void touch_rows(const PrefetchList& rows, int32_t begin, int32_t end, int64_t i, uint32_t* sink)
-{
-    // eight addresses per trip through the scalar cache (the list lies in the kernel-argument segment), not one
-    for (int32_t r = begin; r < end; r += 8) {
-        const double* p[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = rows.row[r + q < kPrefetchRows ? r + q : kPrefetchRows - 1];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (r + q < end) __builtin_amdgcn_global_load_lds((gptr_t)(p[q] + i), (lptr_t)sink, 4, 0, 0);
-    }
-}
-
-// The ops' compact uniform-parameter blocks (rscm_device.hpp, param_at: 256 bytes = 4 lines each) into the L2, all of them requested
-// by ONE vector instruction that nothing waits for: lane l asks for line l & 3 of block l >> 2 (48 lanes for the table's twelve
-// slots).  The bodies' parameter loads -- scalar loads through the scalar cache, or same-address vector loads -- then find their lines
-// on chip instead of each op making its own trip to HBM for lines the L2 lost since the last step.  Every slot of the table holds a
-// valid block address (the host repeats op 0's in the unused ones).  (Scalar loads straight into the scalar cache were tried first:
-// SMEM returns out of order, so the compiler drains lgkmcnt after every block -- twelve trips in a row, worse than none.)
-__device__ __forceinline__ void touch_uniform_blocks(const GroupTable& table, uint32_t* sink)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    // (the twelve addresses as SCALAR loads from the table -- said so with readfirstlane: left to itself the compiler selects the
-    // table OFFSET per lane and fetches the address with a vector load from the kernel-argument segment, a trip of its own)
-    uint32_t lo[kGroupTableOps], hi[kGroupTableOps];
-#pragma unroll
-    for (int k = 0; k < kGroupTableOps; ++k) {
-        const uintptr_t q = (uintptr_t)table.ops[k].uparams();
-        lo[k] = __builtin_amdgcn_readfirstlane((uint32_t)q);
-        hi[k] = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
-    }
-    uint32_t alo = lo[0], ahi = hi[0];
-#pragma unroll
-    for (int k = 1; k < kGroupTableOps; ++k) {
-        const bool mine = (lane >> 2) == (uint32_t)k;
-        alo = mine ? lo[k] : alo;
-        ahi = mine ? hi[k] : ahi;
-    }
-    const uintptr_t addr = (((uintptr_t)ahi << 32) | alo) + (uintptr_t)(lane & 3u) * 64u;
-    if (lane < 4u * kGroupTableOps) __builtin_amdgcn_global_load_lds((gptr_t)addr, (lptr_t)sink, 4, 0, 0);
-}
 
 // CACHED (a graph of light components only, stepped many model steps in one launch): between the steps every op
 // keeps its varying parameter rows, the latest row of its series and thereby what its consumers read in
@@ -130,11 +74,10 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const GroupOp* __restrict
 // or a new link changes an op's pointers (the windowed MAGICC graph re-sent 2.7 ops per model step), and the
 // fields still arrive through scalar loads.
 template <bool FULL, bool CACHED>
-__global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable table, const PrefetchList rows, int32_t n_ops, int64_t n_members,
-                                                            int32_t step_begin, int32_t step_end)
+__global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable table, int32_t n_ops, int64_t n_members, int32_t step_begin,
+                                                            int32_t step_end)
 {
     extern __shared__ double lds_slots[];
-    __shared__ uint32_t sink[kBlock];   // the prefetch pass's landing strip, 256 bytes per wavefront; never read
     // Every op starts by reading its fields out of this table through the scalar cache, and a step's ops run one after the other:
     // n_ops first-touch trips to L2 in a row, each exposed (all wavefronts of a one-step launch start together).  One dword of every
     // 64-byte line the ops in use cover, requested here together and awaited once, leaves the lines in the scalar cache for them.
@@ -144,11 +87,6 @@ __global__ __launch_bounds__(kBlock) void group_kernel_args(const GroupTable tab
         uint32_t touched = 0;
         for (int32_t l = 0; l < n_lines; ++l) touched |= words[(size_t)l * 16];
         asm volatile("" ::"s"(touched));
-    }
-    if (rows.uniform_blocks) touch_uniform_blocks(table, sink + (threadIdx.x & ~63));   // (one-step launches: the host says so)
-    {
-        const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-        if (i < n_members) touch_rows(rows, 0, rows.n_first, i, sink + (threadIdx.x & ~63));
     }
     run_graph<FULL, CACHED>(table.ops, n_ops, n_members, step_begin, step_end, lds_slots);
 }
@@ -175,10 +113,9 @@ __device__ __forceinline__ void split_range(const Ops& ops, int32_t begin, int32
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(128) void group_split_kernel(const GroupTable table, const PrefetchList rows, int32_t n_first, int32_t n_second, int32_t n_ops,
-                                                          int64_t n_members, int32_t step)
+__global__ __launch_bounds__(128) void group_split_kernel(const GroupTable table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members,
+                                                          int32_t step)
 {
-    __shared__ uint32_t sink[128];   // the prefetch pass's landing strip, 256 bytes per wavefront; never read
     {   // the table's lines up front, as in group_kernel_args
         const uint32_t* words = reinterpret_cast<const uint32_t*>(&table);
         const int32_t n_lines = (int32_t)(((size_t)n_ops * sizeof(GroupOp) + 63) / 64);
@@ -189,12 +126,6 @@ __global__ __launch_bounds__(128) void group_split_kernel(const GroupTable table
     const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));   // wave-uniform, and said so: the op index stays scalar
     const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const bool live = i < n_members;
-    if (rows.uniform_blocks) touch_uniform_blocks(table, sink + wave * 64);
-    if (live) {   // this wavefront's own set, and for wavefront 0 the tail: the rows of what it will run, nothing else
-        const int32_t b0 = wave == 0 ? 0 : rows.n_first, e0 = wave == 0 ? rows.n_first : rows.n_first + rows.n_second;
-        touch_rows(rows, b0, e0, i, sink + wave * 64);
-        if (wave == 0) touch_rows(rows, rows.n_first + rows.n_second, rows.n_first + rows.n_second + rows.n_tail, i, sink);
-    }
     // ONE call site of the bodies (a second one takes the uses of the by-value table past the point where the compiler stops treating its
     // stack copy as read-only and keeps the copy: 2.4 KB of scratch per lane): phase 0 = this wavefront's set, phase 1 = the tail.
     for (int32_t phase = 0; phase < 2; ++phase) {
@@ -258,7 +189,7 @@ struct OpRegs {
         else if constexpr (KIND == kKindCarbonCycle || KIND == kKindCo2Budget) { params = op.u.carbon.params; uniform = op.u.carbon.uniform_rows; N = op.u.carbon.n_members; }
         else { params = op.u.pw.params; uniform = op.u.pw.uniform_rows; N = op.u.pw.n_members; }
 #pragma unroll
-        for (int j = 0; j < SeqShape<KIND>::P; ++j) prm[j] = param_at(params, uniform, j, N, i, op.uparams());
+        for (int j = 0; j < SeqShape<KIND>::P; ++j) prm[j] = param_at(params, uniform, j, N, i);
         // the state rows the bodies ask their cache for (the pointwise kinds have outputs only: nothing is read back)
         const size_t r0 = (size_t)step_begin * N + i;
         if constexpr (KIND == 0) {
@@ -356,11 +287,11 @@ bool group_kind_is_small(int32_t kind)
 
 template <class... Args>
 static void launch_variant(bool by_value, bool all_small, int32_t cache_slots, dim3 grid, size_t lds, hipStream_t s, const GroupOp* d_ops,
-                           const GroupTable* table, const PrefetchList& rows, Args... rest)
+                           const GroupTable* table, Args... rest)
 {
     if (by_value) {  // (never with LDS slots: indexing the by-value table for the slot records sends it to scratch)
-        if (all_small) hipLaunchKernelGGL((group_kernel_args<false, false>), grid, dim3(kBlock), 0, s, *table, rows, rest...);
-        else hipLaunchKernelGGL((group_kernel_args<true, false>), grid, dim3(kBlock), 0, s, *table, rows, rest...);
+        if (all_small) hipLaunchKernelGGL((group_kernel_args<false, false>), grid, dim3(kBlock), 0, s, *table, rest...);
+        else hipLaunchKernelGGL((group_kernel_args<true, false>), grid, dim3(kBlock), 0, s, *table, rest...);
     } else {
         if (cache_slots > 0) hipLaunchKernelGGL((group_kernel<false, true>), grid, dim3(kBlock), lds, s, d_ops, rest...);
         else if (all_small) hipLaunchKernelGGL((group_kernel<false, false>), grid, dim3(kBlock), 0, s, d_ops, rest...);
@@ -388,30 +319,25 @@ bool launch_group_seq(const GroupTable& table, int32_t n_ops, int64_t n_members,
     return true;
 }
 
-hipError_t launch_group_split(const GroupTable& table, const PrefetchList& rows, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members,
-                              int32_t step, bool all_small, hipStream_t s)
+hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
+                              hipStream_t s)
 {
     if (n_first < 1 || n_second < 1 || n_first + n_second > n_ops || n_ops > kGroupTableOps || n_members <= 0) return hipErrorInvalidValue;
-    if (rows.n_first < 0 || rows.n_second < 0 || rows.n_tail < 0 || rows.n_first + rows.n_second + rows.n_tail > kPrefetchRows) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_members + 63) / 64));
-    if (all_small) hipLaunchKernelGGL(group_split_kernel<false>, grid, dim3(128), 0, s, table, rows, n_first, n_second, n_ops, n_members, step);
-    else hipLaunchKernelGGL(group_split_kernel<true>, grid, dim3(128), 0, s, table, rows, n_first, n_second, n_ops, n_members, step);
+    if (all_small) hipLaunchKernelGGL(group_split_kernel<false>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
+    else hipLaunchKernelGGL(group_split_kernel<true>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
     return hipGetLastError();
 }
 
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
-                        bool all_small, int32_t cache_slots, hipStream_t s, const PrefetchList* rows)
+                        bool all_small, int32_t cache_slots, hipStream_t s)
 {
     if (n_ops <= 0 || n_members <= 0 || step_end <= step_begin) return hipSuccess;
     if (cache_slots > 0 && !all_small) return hipErrorInvalidValue;
     if ((table != nullptr) == (d_ops != nullptr) || (table && (n_ops > kGroupTableOps || cache_slots > 0))) return hipErrorInvalidValue;
-    PrefetchList none;
-    memset((void*)&none, 0, sizeof none);
-    // (the prefetch pass belongs to the one-step launches of a by-value table: a multi-step launch keeps its values in LDS slots instead)
-    const bool use = rows && table && step_end == step_begin + 1 && rows->n_first >= 0 && rows->n_first <= kPrefetchRows;
     const dim3 grid((unsigned)((n_members + kBlock - 1) / kBlock));
     const size_t lds = (size_t)cache_slots * kBlock * sizeof(double);
-    launch_variant(table != nullptr, all_small, cache_slots, grid, lds, s, d_ops, table, use ? *rows : none, n_ops, n_members, step_begin, step_end);
+    launch_variant(table != nullptr, all_small, cache_slots, grid, lds, s, d_ops, table, n_ops, n_members, step_begin, step_end);
     return hipGetLastError();
 }
 

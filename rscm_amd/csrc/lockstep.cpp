@@ -20,7 +20,6 @@ struct LockstepSettings {
     bool by_value = true;    // short op lists travel in the kernel arguments
     bool split = true;       // independent ops of a one-step segment on two wavefronts (group_split_kernel)
     bool merge = true;       // a step's last fused segment and the next step's first one in ONE launch (they are consecutive launches anyway)
-    bool prefetch = true;    // one-step fused launches request every row their ops will read up front (csrc/group.hip, prefetch_op)
     int64_t merged_launches = 0;                // launches that carried two steps' segments since the last rscm_gpu_lockstep_merged_launches
     int64_t launches = 0, component_steps = 0;  // since the thread's last rscm_gpu_lockstep_stats
     int64_t split_launches = 0;                 // of those, launches of group_split_kernel
@@ -82,13 +81,12 @@ int rscm_gpu_fail_chunk_launch(int32_t k)
 
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
-    if (enabled < 0 || enabled > 6) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..6)", enabled);
+    if (enabled < 0 || enabled > 5) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..5)", enabled);
     t_ls.fuse = enabled != 0;
     t_ls.cache = enabled == 1 || enabled >= 3;
     t_ls.by_value = enabled != 3;
     t_ls.split = enabled != 4;
-    t_ls.merge = enabled != 5 && enabled != 6;   // (6: round 5's launch plan -- neither the merge nor the prefetch pass)
-    t_ls.prefetch = enabled != 6;
+    t_ls.merge = enabled != 5;   // (5: round 5's launch plan)
     return RSCM_OK;
 }
 
@@ -283,76 +281,6 @@ static bool plan_split(const LockstepPlan* plan, const int32_t* idx, const int32
     return out->n_first > 0 && out->n_second > 0;
 }
 
-// The rows op `op` (handle h) will read at model step `at` that an earlier launch wrote, as addresses of their element 0 (lane i reads
-// [i]): exactly the loads the body makes (csrc/*_body.hpp) -- the linked rows through MemberInputs<2>::at(k, n) =
-// row[k][(off[k] + n) * N + i] (the aggregate: at n + 1), the parameter rows that vary over the members, the member constants, the
-// op's own latest rows.  skip[k]: link k reads a row that THIS launch writes (nothing to fetch yet).  Device addresses are only
-// formed here, never dereferenced.  The kernel requests them up front (csrc/group.hip, touch_rows); a row missing from the list
-// costs its op a trip to memory, a row listed in error would be a wasted read of a resident row -- never a wrong result.
-static void prefetch_rows_of(const rscm_ens* h, const rscm::GroupOp& op, int32_t at, const bool* skip, std::vector<const double*>& out)
-{
-    const int64_t N = h->N;
-    auto params = [&](const double* block, uint64_t uniform, int32_t P) {
-        for (int32_t j = 0; j < P; ++j)
-            if (!(j < 64 && ((uniform >> (j & 63)) & 1ull))) out.push_back(block + (size_t)j * N);
-    };
-    auto links = [&](const rscm::InputLinks& l, int32_t n_inputs, int32_t n) {
-        for (int32_t k = 0; k < n_inputs && k < rscm::kMaxLinks; ++k)
-            if (l.row[k] && !skip[k]) out.push_back(l.row[k] + (size_t)(l.off[k] + n) * N);
-    };
-    switch (op.kind) {
-        case RSCM_KIND_TWO_LAYER: {
-            const rscm::TwoLayerArgs& a = op.u.tl;
-            if (a.row_stride != N) break;
-            params(a.params, a.uniform_rows, h->P);
-            if (a.link && !skip[0]) out.push_back(a.link + (size_t)(a.src_off + at) * N);
-            out.push_back(a.ts + (size_t)at * N);
-            out.push_back(a.td + (size_t)at * N);
-            break;
-        }
-        case RSCM_KIND_GHG_FORCING: {
-            const rscm::GhgArgs& a = op.u.ghg;
-            params(a.params, a.uniform_rows, h->P);
-            if (a.derived && !a.derived_uniform) params(a.derived, 0ull, rscm::kDerivedRows);
-            if (a.linked) links(a.links, 3, at);
-            break;
-        }
-        case RSCM_KIND_CH4_CHEMISTRY: case RSCM_KIND_N2O_CHEMISTRY: {
-            const rscm::ChemArgs& a = op.u.chem;
-            params(a.params, a.uniform_rows, h->P);
-            if (a.linked) links(a.links, h->kind == RSCM_KIND_CH4_CHEMISTRY ? 5 : 1, at);
-            out.push_back(a.conc + (size_t)at * N);
-            if (at > 0) out.push_back(a.conc + (size_t)(at - 1) * N);
-            break;
-        }
-        case RSCM_KIND_CO2_BUDGET: case RSCM_KIND_TERRESTRIAL_CARBON: case RSCM_KIND_CARBON_CYCLE: {
-            const rscm::CarbonArgs& a = op.u.carbon;
-            params(a.params, a.uniform_rows, h->P);
-            if (h->kind == RSCM_KIND_TERRESTRIAL_CARBON && a.derived && !a.derived_uniform) params(a.derived, 0ull, rscm::kDerivedRows);
-            const int32_t n_in = h->kind == RSCM_KIND_CO2_BUDGET ? 4 : (h->kind == RSCM_KIND_TERRESTRIAL_CARBON ? 3 : 2);
-            if (a.linked) links(a.links, n_in, at);
-            const int32_t n_state = h->kind == RSCM_KIND_CO2_BUDGET ? 1 : (h->kind == RSCM_KIND_TERRESTRIAL_CARBON ? 4 : 3);
-            const size_t vs = (size_t)a.rows * N;
-            for (int32_t v = 0; v < n_state; ++v) out.push_back(a.series + v * vs + (size_t)at * N);
-            break;
-        }
-        case RSCM_KIND_AGGREGATE: {   // the contributors in use, at the END of the step (links.off is 0 for this kind)
-            const rscm::PointwiseArgs& a = op.u.pw;
-            params(a.params, a.uniform_rows, h->P);
-            if (a.linked) links(a.links, std::min(a.n_inputs_used, 8), at + 1);
-            break;
-        }
-        case RSCM_KIND_OZONE_FORCING: case RSCM_KIND_AEROSOL_DIRECT: case RSCM_KIND_AEROSOL_INDIRECT: case RSCM_KIND_FOURBOX_OHU:
-        case RSCM_KIND_OSPP: case RSCM_KIND_CO2_ERF: {
-            const rscm::PointwiseArgs& a = op.u.pw;
-            params(a.params, a.uniform_rows, h->P);
-            if (a.linked) links(a.links, h->n_inputs, at);
-            break;
-        }
-        default: break;
-    }
-}
-
 // Model steps [n, n + len) of handles [first, first + count) of the plan as ONE launch.  len > 1 only when
 // the segment is the whole graph: then nothing outside the launch reads or writes between its steps.
 // next_count > 0 (len == 1, by-value table only): a MERGED launch -- the handles [next_first, next_first + next_count) ride along at
@@ -433,57 +361,15 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
         HIPCHK(seq_status);
     } else {
         SplitPlan split;
-        const bool one_step = by_value && len == 1 && cache_slots == 0;
-        const bool cut = one_step && plan_split(plan, idx, off, total, &split);
-        if (!cut && one_step)   // (one_step: total <= kGroupTableOps, the length of split.order)
-            for (int32_t k = 0; k < total; ++k) split.order[k] = k;
-        // the rows the launch's ops read that earlier launches wrote, in the order the wavefronts run the ops
-        rscm::PrefetchList rows;
-        memset((void*)&rows, 0, sizeof rows);
-        if (one_step && t_ls.prefetch) {
-            // every slot of the table names a compact uniform-parameter block (the unused ones repeat op 0's): the kernel asks for all
-            // of them before anything waits (csrc/group.hip, touch_uniform_blocks)
-            bool all = true;
-            for (int32_t k = 0; k < total; ++k) all = all && table.ops[k].uparams() != nullptr;
-            if (all) {
-                for (int32_t k = total; k < rscm::kGroupTableOps; ++k) table.ops[k].u.pw.uparams = table.ops[0].uparams();
-                rows.uniform_blocks = 1;
-            }
-            std::vector<const double*> list;
-            int32_t* counts[3] = {&rows.n_first, &rows.n_second, &rows.n_tail};
-            for (int32_t pos = 0; pos < total; ++pos) {
-                const int32_t k = split.order[pos];
-                const rscm_ens* h = plan->handles[idx[k]];
-                bool skip[rscm::kMaxLinks] = {};
-                for (int32_t j = 0; j < rscm::kMaxLinks && j < h->n_inputs; ++j) {
-                    const auto& l = h->links[j];
-                    if (!l.src) continue;
-                    const bool reads_end = h->kind == RSCM_KIND_AGGREGATE || l.off == 1;
-                    for (int32_t q = 0; q < total; ++q)   // written by this very launch: nothing to fetch
-                        if (plan->handles[idx[q]] == l.src && off[k] + (reads_end ? 1 : 0) == off[q] + 1) skip[j] = true;
-                }
-                const size_t before = list.size();
-                prefetch_rows_of(h, table.ops[k], n + off[k], skip, list);
-                if (list.size() > (size_t)rscm::kPrefetchRows) {   // best effort: what does not fit costs its op a trip, as before
-                    list.resize(before);
-                    continue;
-                }
-                const int32_t set = !cut ? 0 : (pos < split.n_first ? 0 : (pos < split.n_first + split.n_second ? 1 : 2));
-                *counts[set] += (int32_t)(list.size() - before);
-            }
-            for (size_t r = 0; r < list.size(); ++r) rows.row[r] = list[r];
-        }
-        if (cut) {
+        if (by_value && len == 1 && cache_slots == 0 && plan_split(plan, idx, off, total, &split)) {
             rscm::GroupTable ordered;
             memset((void*)&ordered, 0, sizeof ordered);
             for (int32_t k = 0; k < total; ++k) memcpy((void*)&ordered.ops[k], &table.ops[split.order[k]], sizeof(rscm::GroupOp));
-            if (rows.uniform_blocks)   // (the unused slots must name a valid block here too)
-                for (int32_t k = total; k < rscm::kGroupTableOps; ++k) ordered.ops[k].u.pw.uparams = ordered.ops[0].uparams();
-            HIPCHK(rscm::launch_group_split(ordered, rows, split.n_first, split.n_second, total, lead->N, n, all_small, lead->stream));
+            HIPCHK(rscm::launch_group_split(ordered, split.n_first, split.n_second, total, lead->N, n, all_small, lead->stream));
             t_ls.split_launches += 1;
         } else {
             HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, total, lead->N, n, n + len, all_small,
-                                      cache_slots, lead->stream, one_step ? &rows : nullptr));
+                                      cache_slots, lead->stream));
         }
     }
     if (next_count > 0) t_ls.merged_launches += 1;

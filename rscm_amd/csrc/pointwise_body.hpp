@@ -123,7 +123,7 @@ __device__ __forceinline__ void aggregate_body(const PointwiseArgs& a, int64_t i
     };
     if (step_begin < step_end) fetch(step_begin);
     double prm[9];   // the operation and the eight weights, together
-    cache.params(a.params, a.uniform_rows, N, i, prm, a.uparams);
+    cache.params(a.params, a.uniform_rows, N, i, prm);
     const int op = (int)prm[0];
     if (used == 1 && op < 2) {
         // One contributor, Sum or Mean (the total of a single forcing, say): 0.0 + v, and v / 1 is v.
@@ -185,7 +185,7 @@ __device__ __forceinline__ void pointwise_body(const PointwiseArgs& a, int64_t i
     const int64_t N = a.n_members;
     const int32_t T = a.n_times;
     double p[S::P];
-    cache.params(a.params, a.uniform_rows, N, i, p, a.uparams);
+    cache.params(a.params, a.uniform_rows, N, i, p);
     const MemberInputs<SRC, S::NI> inputs(a.inputs, a.scen, a.links, T, N, i);
     const size_t var_stride = (size_t)a.rows * N;
     for (int32_t n = step_begin; n < step_end; ++n) {

@@ -48,19 +48,9 @@ struct InputLinks {
 // wavefront from a line that stays hot in L1/L2 instead of 512 coalesced bytes from HBM -- in a graph
 // of linked ensembles most rows are uniform (a calibration varies a handful), and the light
 // components' launches are bound by exactly this traffic.  The value read is the same either way.
-//
-// uparams (optional): the handle's COMPACT copy of its uniform rows -- [P] doubles side by side (kUniformBlock of them, 256-byte
-// aligned; rscm_gpu.cpp writes it with the parameters: element j = element 0 of row j, the very double).  In the [P][N] block the
-// rows lie N * 8 bytes apart: a component's P uniform parameters are P cache lines, which the L2 has lost by the next model step
-// (ClimateUDEB and OceanCarbon stream 370 MB through it in between) -- a trip to HBM per op of a fused launch, in a chain
-// (profiles/r6_configs3_share_pmc.txt).  The compact block is 1-4 lines per component, and the fused launches request the lines of
-// ALL their ops up front (csrc/group.hip).  Same doubles: same bits.
-constexpr int kUniformBlock = 32;
-__device__ __forceinline__ double param_at(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i,
-                                           const double* __restrict__ uparams = nullptr)
+__device__ __forceinline__ double param_at(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i)
 {
     const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;
-    if (u && uparams && j < kUniformBlock) return uparams[j];
     return params[(size_t)j * N + (u ? (int64_t)0 : i)];
 }
 
@@ -69,8 +59,7 @@ __device__ __forceinline__ double param_at(const double* __restrict__ params, ui
 // value (the aggregate's operation) branches uniformly.  For the light bodies only: in the register-bound
 // kernels (ClimateUDEB, OceanCarbon) dozens of parameters in scalar registers spill.  The block is not
 // written while a kernel that reads it runs.
-__device__ __forceinline__ double param_at_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i,
-                                                  const double* __restrict__ uparams = nullptr)
+__device__ __forceinline__ double param_at_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i)
 {
     const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;  // wave-uniform: a scalar branch
     if (u) {
@@ -78,7 +67,7 @@ __device__ __forceinline__ double param_at_scalar(const double* __restrict__ par
         // (the row address is wave-uniform; saying so keeps the scalar load legal where register pressure has moved the
         // pointer into vector registers -- without it hipcc 7.2 emits an s_load with a VGPR address there and stops with
         // "Illegal instruction detected: Operand has incorrect register class"; a no-op when the address is scalar already)
-        const uintptr_t p = (uparams && j < kUniformBlock) ? (uintptr_t)(uparams + j) : (uintptr_t)(params + (size_t)j * N);
+        const uintptr_t p = (uintptr_t)(params + (size_t)j * N);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
         return *(scalar_row)(((uintptr_t)hi << 32) | lo);
     }
@@ -92,26 +81,19 @@ __device__ __forceinline__ double param_at_scalar(const double* __restrict__ par
 // launches of the light components spend two thirds of their time in s_waitcnt (gpurun_out/r3e).
 // Mixed blocks take the vector loads of param_at: no branches either, one wait.
 template <int P>
-__device__ __forceinline__ void params_block(const double* __restrict__ params, uint64_t uniform, int64_t N, int64_t i, double (&p)[P],
-                                             const double* __restrict__ uparams = nullptr)
+__device__ __forceinline__ void params_block(const double* __restrict__ params, uint64_t uniform, int64_t N, int64_t i, double (&p)[P])
 {
     constexpr uint64_t mask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
     if ((uniform & mask) == mask) {
         typedef const __attribute__((address_space(4))) double* scalar_row;
-        const bool compact = uparams != nullptr && P <= kUniformBlock;   // the P values side by side: a few s_load_dwordx16 from 1-4 lines
-        const uintptr_t q = compact ? (uintptr_t)uparams : (uintptr_t)params;   // (wave-uniform; said so for the reason given in param_at_scalar)
+        const uintptr_t q = (uintptr_t)params;   // (wave-uniform; said so for the reason given in param_at_scalar)
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
         const scalar_row row0 = (scalar_row)(((uintptr_t)hi << 32) | lo);
-        if (compact) {
 #pragma unroll
-            for (int j = 0; j < P; ++j) p[j] = row0[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < P; ++j) p[j] = row0[(size_t)j * N];
-        }
+        for (int j = 0; j < P; ++j) p[j] = row0[(size_t)j * N];
     } else {
 #pragma unroll
-        for (int j = 0; j < P; ++j) p[j] = param_at(params, uniform, j, N, i, uparams);
+        for (int j = 0; j < P; ++j) p[j] = param_at(params, uniform, j, N, i);
     }
 }
 
@@ -120,21 +102,18 @@ __device__ __forceinline__ void params_block(const double* __restrict__ params, 
 // the fused multi-step launch passes an LdsCache.
 struct NoCache {
     static constexpr bool kOn = false;
-    __device__ __forceinline__ double param(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i,
-                                            const double* __restrict__ uparams = nullptr) const
+    __device__ __forceinline__ double param(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
     {
-        return param_at(params, uniform, j, N, i, uparams);
+        return param_at(params, uniform, j, N, i);
     }
-    __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i,
-                                                   const double* __restrict__ uparams = nullptr) const
+    __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
     {
-        return param_at_scalar(params, uniform, j, N, i, uparams);
+        return param_at_scalar(params, uniform, j, N, i);
     }
     template <int P>
-    __device__ __forceinline__ void params(const double* __restrict__ block, uint64_t uniform, int64_t N, int64_t i, double (&p)[P],
-                                           const double* __restrict__ uparams = nullptr) const
+    __device__ __forceinline__ void params(const double* __restrict__ block, uint64_t uniform, int64_t N, int64_t i, double (&p)[P]) const
     {
-        params_block<P>(block, uniform, N, i, p, uparams);
+        params_block<P>(block, uniform, N, i, p);
     }
     __device__ __forceinline__ double state(int, const double* p) const { return *p; }
     __device__ __forceinline__ void put(int, double) const {}
@@ -155,11 +134,10 @@ struct LdsCache {
     double* col;
     OpCache c;
     bool last;
-    __device__ __forceinline__ double param(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i,
-                                            const double* __restrict__ uparams = nullptr) const
+    __device__ __forceinline__ double param(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
     {
         const bool u = j < 64 && ((uniform >> (j & 63)) & 1ull) != 0;
-        if (u || c.param_slot < 0) return param_at_scalar(params, uniform, j, N, i, uparams);  // a uniform row is one scalar load
+        if (u || c.param_slot < 0) return param_at_scalar(params, uniform, j, N, i);  // a uniform row is one scalar load
         double* slot = col + (size_t)(c.param_slot + j) * kCacheStride;
         if constexpr (WARM) {
             return *slot;
@@ -169,22 +147,20 @@ struct LdsCache {
             return v;
         }
     }
-    __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i,
-                                                   const double* __restrict__ uparams = nullptr) const
+    __device__ __forceinline__ double param_scalar(const double* __restrict__ params, uint64_t uniform, int j, int64_t N, int64_t i) const
     {
-        return param(params, uniform, j, N, i, uparams);
+        return param(params, uniform, j, N, i);
     }
     template <int P>
-    __device__ __forceinline__ void params(const double* __restrict__ block, uint64_t uniform, int64_t N, int64_t i, double (&p)[P],
-                                           const double* __restrict__ uparams = nullptr) const
+    __device__ __forceinline__ void params(const double* __restrict__ block, uint64_t uniform, int64_t N, int64_t i, double (&p)[P]) const
     {
         constexpr uint64_t mask = P >= 64 ? ~0ull : ((1ull << P) - 1ull);
         if ((uniform & mask) == mask) {   // nothing of this block lives in a slot
-            params_block<P>(block, uniform, N, i, p, uparams);
+            params_block<P>(block, uniform, N, i, p);
             return;
         }
 #pragma unroll
-        for (int j = 0; j < P; ++j) p[j] = param(block, uniform, j, N, i, uparams);
+        for (int j = 0; j < P; ++j) p[j] = param(block, uniform, j, N, i);
     }
     __device__ __forceinline__ double state(int v, const double* p) const
     {
@@ -220,10 +196,10 @@ struct RegCache {
     double* col;         // this thread's column of LDS slots
     OpCache c;
     bool last;
-    __device__ __forceinline__ double param(const double* __restrict__, uint64_t, int j, int64_t, int64_t, const double* = nullptr) const { return prm[j]; }
-    __device__ __forceinline__ double param_scalar(const double* __restrict__, uint64_t, int j, int64_t, int64_t, const double* = nullptr) const { return prm[j]; }
+    __device__ __forceinline__ double param(const double* __restrict__, uint64_t, int j, int64_t, int64_t) const { return prm[j]; }
+    __device__ __forceinline__ double param_scalar(const double* __restrict__, uint64_t, int j, int64_t, int64_t) const { return prm[j]; }
     template <int P>
-    __device__ __forceinline__ void params(const double* __restrict__, uint64_t, int64_t, int64_t, double (&p)[P], const double* = nullptr) const
+    __device__ __forceinline__ void params(const double* __restrict__, uint64_t, int64_t, int64_t, double (&p)[P]) const
     {
 #pragma unroll
         for (int j = 0; j < P; ++j) p[j] = prm[j];
@@ -345,8 +321,6 @@ struct MemberInputsEager {
 
 // Stand-alone two-layer run over steps [step_begin, step_end).
 struct TwoLayerArgs {
-    const double* uparams;   // FIRST in all five light-component argument structs (GroupOp::uparams reads it whatever the kind): the
-                             // compact copy of the uniform parameter rows (param_at), or nullptr
     int64_t n_members;       // members this launch covers ...
     int64_t row_stride;      // ... of an ensemble of this many: the stride of the [rows][N] series and [P][N] parameter rows.  Equal
                              // unless the host launches a BLOCK of members (pointers moved to its first member; rscm_gpu.cpp, split runs)
@@ -455,8 +429,6 @@ enum GhgRow {
 };
 
 struct GhgArgs {
-    const double* uparams;   // FIRST in all five light-component argument structs (GroupOp::uparams reads it whatever the kind): the
-                             // compact copy of the uniform parameter rows (param_at), or nullptr
     int64_t n_members;
     int32_t n_times;
     int32_t step_begin, step_end;
@@ -477,8 +449,6 @@ struct GhgArgs {
 
 // OzoneForcing / AerosolDirect / AerosolIndirect (csrc/pointwise.hip)
 struct PointwiseArgs {
-    const double* uparams;   // FIRST in all five light-component argument structs (GroupOp::uparams reads it whatever the kind): the
-                             // compact copy of the uniform parameter rows (param_at), or nullptr
     int64_t n_members;
     int32_t n_times;
     int32_t step_begin, step_end;
@@ -497,8 +467,6 @@ struct PointwiseArgs {
 
 // CH4Chemistry / N2OChemistry (csrc/chem.hip)
 struct ChemArgs {
-    const double* uparams;   // FIRST in all five light-component argument structs (GroupOp::uparams reads it whatever the kind): the
-                             // compact copy of the uniform parameter rows (param_at), or nullptr
     int64_t n_members;
     int32_t n_times;
     int32_t step_begin, step_end;
@@ -517,8 +485,6 @@ struct ChemArgs {
 
 // CO2Budget / TerrestrialCarbon (csrc/carbon.hip)
 struct CarbonArgs {
-    const double* uparams;   // FIRST in all five light-component argument structs (GroupOp::uparams reads it whatever the kind): the
-                             // compact copy of the uniform parameter rows (param_at), or nullptr
     int64_t n_members;
     int32_t n_times;
     int32_t step_begin, step_end;
@@ -665,8 +631,6 @@ struct GroupOp {
     // first segment when the scheduler merges them with this step's last segment (csrc/lockstep.cpp, MERGED schedule).
     int32_t step_off;
     GroupOp() : kind(-1), variant(0), u(), cache(), step_off(0) {}
-    // (the five argument structs share their first member: reading it through any of them is reading the common initial sequence)
-    __host__ __device__ const double* uparams() const { return u.pw.uparams; }
 };
 constexpr int kMaxGroupOps = 16;
 // up to this many ops travel by value in the kernel-argument segment (4 KiB in all) instead of a device table: the eight light
@@ -675,29 +639,19 @@ constexpr int kGroupTableOps = 12;
 struct GroupTable {
     GroupOp ops[kGroupTableOps];
 };
-// The rows a one-step launch's ops will read that EARLIER launches wrote -- linked rows, the ops' own latest rows, the parameter rows
-// that vary over the members -- as the host resolves them while it builds the table (csrc/lockstep.cpp, prefetch_rows): lane i of the
-// launch reads row[r][i].  The kernel requests them all up front (csrc/group.hip).  With the split kernel: the rows of the first
-// set's ops, then the second set's, then the tail's; the plain kernel: n_first rows.
-constexpr int kPrefetchRows = 40;
-struct PrefetchList {
-    int32_t n_first, n_second, n_tail;
-    int32_t uniform_blocks;   // != 0: every slot of the op table carries a compact uniform-parameter block: request them all up front
-    const double* row[kPrefetchRows];
-};
-static_assert(sizeof(GroupOp) == 304, "GroupOp grew: twelve of them must fit the kernel-argument segment");
-static_assert(sizeof(GroupTable) + sizeof(PrefetchList) + 64 <= 4096, "the by-value op table and the prefetch list must fit the kernel-argument segment");
+static_assert(sizeof(GroupOp) == 296, "GroupOp grew: twelve of them must fit the kernel-argument segment");
+static_assert(sizeof(GroupTable) <= 3840, "the by-value op table must fit the kernel-argument segment beside the other arguments");
 // all_small: every op is one of the kinds group_kind_is_small accepts (the low-register variant of the kernel)
 bool group_kind_is_small(int32_t kind);
 // cache_slots > 0 (all_small only): the ops carry LDS slots (OpCache), cache_slots doubles per thread in all.
 // Exactly one of d_ops (device table) and table (host, passed by value, n_ops <= kGroupTableOps) is given.
 hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n_ops, int64_t n_members, int32_t step_begin, int32_t step_end,
-                        bool all_small, int32_t cache_slots, hipStream_t s, const PrefetchList* rows = nullptr);
+                        bool all_small, int32_t cache_slots, hipStream_t s);
 
 // One model step of a by-value table whose first n_first ops and next n_second ops have no edge between them (two wavefronts per 64
 // members run them at the same time), the rest after a workgroup barrier (csrc/group.hip, group_split_kernel).
-hipError_t launch_group_split(const GroupTable& table, const PrefetchList& rows, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members,
-                              int32_t step, bool all_small, hipStream_t s);
+hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
+                              hipStream_t s);
 
 // A multi-step launch of a light graph whose sequence of kinds has a kernel of its own (csrc/group.hip: the op table
 // by value, the kinds compile-time): true if one was launched (*status: its launch status), false if the sequence has none.

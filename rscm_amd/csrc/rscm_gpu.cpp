@@ -681,8 +681,6 @@ int rscm_ens_create_windowed(int32_t kind, int64_t n_members, int32_t n_times, c
     CK(hipEventCreate(&h->ev1));
     const size_t series_elems = (size_t)(h->V - 1) * (size_t)h->rows * (size_t)h->N;
     CK(rscm::dev_malloc(&h->d_params, (size_t)h->P * h->N * sizeof(double)));
-    CK(rscm::dev_malloc(&h->d_uparams, (size_t)rscm::kUniformBlock * sizeof(double)));   // the compact copy of the uniform rows (rscm_device.hpp, param_at)
-    CK(hipMemset(h->d_uparams, 0, (size_t)rscm::kUniformBlock * sizeof(double)));
     CK(rscm::dev_malloc(&h->d_series, series_elems * sizeof(double)));
     CK(rscm::dev_malloc(&h->d_status, (size_t)h->N));
     if (h->windowed) {
@@ -739,7 +737,6 @@ int rscm_ens_destroy(rscm_ens* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_params);
-    (void)hipFree(h->d_uparams);
     (void)hipFree(h->d_series);
     (void)hipFree(h->d_forcing);
     (void)hipFree(h->d_scen);
@@ -903,11 +900,6 @@ int rscm_ens_set_params(rscm_ens* h, const double* soa)
         }
         h->uniform_rows = h->params_exposed ? 0 : uni;  // a caller holding the device pointer may rewrite any row
         h->derived_dirty = true;
-        // the uniform rows' values side by side (element j = element 0 of row j, the very double): what the light components' kernels read
-        // for a row whose bit is set (rscm_device.hpp, param_at).  Rows that vary are never read from here.
-        double compact[rscm::kUniformBlock] = {};
-        for (int32_t j = 0; j < h->P && j < rscm::kUniformBlock; ++j) compact[j] = soa[(size_t)j * h->N];
-        HIPCHK(hipMemcpyAsync(h->d_uparams, compact, sizeof compact, hipMemcpyHostToDevice, h->stream));   // (synchronised below: `compact` is on the stack)
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->params_set = true;
@@ -1446,7 +1438,6 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
     if (!op_out) h->last_blocks = h->last_chunks = 1;
     if (h->kind == RSCM_KIND_TWO_LAYER) {
         rscm::TwoLayerArgs a{};
-        a.uparams = h->d_uparams;
         a.n_members = h->N;
         a.row_stride = h->N;
         a.n_times = h->T;
@@ -1501,7 +1492,6 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         }
     } else if (h->kind == RSCM_KIND_GHG_FORCING) {
         rscm::GhgArgs a{};
-        a.uparams = h->d_uparams;
         a.n_members = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
@@ -1611,7 +1601,6 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         HIPCHK(rscm::launch_ocean(a, h->stream));
     } else if (h->kind == RSCM_KIND_CO2_BUDGET || h->kind == RSCM_KIND_TERRESTRIAL_CARBON || h->kind == RSCM_KIND_CARBON_CYCLE) {
         rscm::CarbonArgs a{};
-        a.uparams = h->d_uparams;
         a.n_members = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
@@ -1642,7 +1631,6 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
         HIPCHK(rscm::launch_carbon(a, h->mode, h->stream));
     } else if (h->kind == RSCM_KIND_CH4_CHEMISTRY || h->kind == RSCM_KIND_N2O_CHEMISTRY) {
         rscm::ChemArgs a{};
-        a.uparams = h->d_uparams;
         a.n_members = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
@@ -1669,7 +1657,6 @@ int step_launch(rscm_ens* h, int32_t step_begin, int32_t step_end, const rscm::I
                h->kind == RSCM_KIND_FOURBOX_OHU || h->kind == RSCM_KIND_OSPP || h->kind == RSCM_KIND_CO2_ERF ||
                h->kind == RSCM_KIND_AGGREGATE) {
         rscm::PointwiseArgs a{};
-        a.uparams = h->d_uparams;
         a.n_members = h->N;
         a.n_times = h->T;
         a.step_begin = step_begin;
@@ -2191,7 +2178,6 @@ hipError_t launch_loglik(rscm_ens* h)
     const int32_t len = h->loglik_stop_at_last_obs ? std::max(1, std::min(h->T - 1, h->obs_last_tidx)) : h->T - 1;
     const size_t lds_bytes = (size_t)h->n_scen * (size_t)len * sizeof(double);
     rscm::TwoLayerArgs a{};
-    a.uparams = h->d_uparams;
     a.n_members = h->N;
     a.row_stride = h->N;
     a.n_times = h->T;

@@ -148,12 +148,12 @@ __device__ __forceinline__ void two_layer_body(const TwoLayerArgs& a, const doub
     const int32_t len = step_end - step_begin;
     const int64_t N = a.row_stride;   // the rows' stride (the caller has checked i against a.n_members)
 
-    const double lambda0 = cache.param(a.params, a.uniform_rows, 0, N, i, a.uparams);
-    const double pa = cache.param(a.params, a.uniform_rows, 1, N, i, a.uparams);
-    const double efficacy = cache.param(a.params, a.uniform_rows, 2, N, i, a.uparams);
-    const double eta = cache.param(a.params, a.uniform_rows, 3, N, i, a.uparams);
-    const double cs = cache.param(a.params, a.uniform_rows, 4, N, i, a.uparams);
-    const double cd = cache.param(a.params, a.uniform_rows, 5, N, i, a.uparams);
+    const double lambda0 = cache.param(a.params, a.uniform_rows, 0, N, i);
+    const double pa = cache.param(a.params, a.uniform_rows, 1, N, i);
+    const double efficacy = cache.param(a.params, a.uniform_rows, 2, N, i);
+    const double eta = cache.param(a.params, a.uniform_rows, 3, N, i);
+    const double cs = cache.param(a.params, a.uniform_rows, 4, N, i);
+    const double cd = cache.param(a.params, a.uniform_rows, 5, N, i);
     const int32_t scen = a.scen ? a.scen[i] : 0;
     // a linked forcing (rscm_ens_link_input, always the non-LDS variant) is another ensemble's
     // [T][N] series: coalesced, one stride of N per year
