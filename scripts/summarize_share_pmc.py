@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--members", type=int, default=125000)
     ap.add_argument("--step-kernels", default="udeb_kernel,ocean_recur_kernel,group_split_kernel,group_kernel_args",
                     help="the kernels launched once per model step (substrings); everything else is set-up / summary work")
+    ap.add_argument("--min-dispatches", type=int, default=1,
+                    help="a step kernel with fewer dispatches than this in the SQ pass is left out of the per-step sums (the prologue / epilogue "
+                         "launches of the merged schedule)")
     ap.add_argument("--series", type=int, default=36, help="stored variables of the graph: algorithmic bytes per member-step = 8 x this")
     ap.add_argument("--out", required=True)
     ap.add_argument("--traffic-key")
@@ -125,7 +128,7 @@ def main():
                      f"{salu / waves if waves else float('nan'):10.1f} {issue:6.2f} {wait:8.2f} {fetched / 1e6:11.2f} {written / 1e6:11.2f} "
                      f"{(fetched + written) / (base_us * 1e-6) / 1e9:7.0f} {(fetched + written) / args.members:9.1f} "
                      f"{m['VGPR_Count']:>5s} {m['Accum_VGPR_Count']:>5s} {m['LDS_Block_Size']:>6s} {m['Scratch_Size']:>7s}")
-        if any(s in name for s in step):
+        if any(s in name for s in step) and len(sq_us[name]) >= args.min_dispatches:
             per_step["us"] += us
             per_step["us_trace"] += base_us
             per_step["valu"] += valu
@@ -136,7 +139,7 @@ def main():
     alg = 8.0 * args.series * args.members
     total = per_step["fetched"] + per_step["written"]
     issue_step = 4 * per_step["valu"] / 1024 / per_step["cycles"] if per_step["cycles"] else float("nan")
-    lines += ["## one model step = " + " -> ".join(n for n in rows if any(s in n for s in step)) + " (one launch each, one stream, in a dependency chain)",
+    lines += ["## one model step = " + " -> ".join(n for n in rows if any(s in n for s in step) and rows[n]["dispatches"] >= args.min_dispatches) + " (one launch each, one stream, in a dependency chain)",
               f"kernel time per step under counters = {per_step['us']:.1f} us; un-profiled (kernel trace) = {per_step['us_trace']:.1f} us",
               f"HBM traffic per step = {per_step['fetched'] / 1e6:.1f} MB read + {per_step['written'] / 1e6:.1f} MB written = "
               f"{total / 1e6:.1f} MB = {total / args.members:.0f} B per member-step",
