@@ -123,7 +123,7 @@ def configs3_roofline(members, steps, run_s, ranks=1, mode="fast"):
     gbs = alg / run_s / 1e9
     prof = profile_entry("configs3_share", 125000, mode)
     per = prof.get("bytes_per_member_step")
-    out = {"bound": "hbm", "binding": "fp64_valu (ClimateUDEB, ~2/3 of a step) + the dependency chain of 4 launches per step",
+    out = {"bound": "hbm", "binding": "fp64_valu (ClimateUDEB, ~2/3 of a step) + the dependency chain of 3 launches per step",
            "achieved": gbs, "peak": HBM_PEAK_GBS * ranks, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * ranks),
            "traffic": per * members * steps * ranks if per else None,
            "traffic_from": "profiles/traffic.json" if per else None,
@@ -132,7 +132,7 @@ def configs3_roofline(members, steps, run_s, ranks=1, mode="fast"):
            "traffic_over_algorithmic": per / (CONFIGS3_SERIES * 8.0) if per else None,
            "hbm_frac_of_measured_traffic": (per * members * steps * ranks / run_s / 1e9) / (HBM_PEAK_GBS * ranks) if per else None,
            "algorithmic_bytes": alg, "algorithmic_bytes_per_member_step": CONFIGS3_SERIES * 8.0,
-           "kernel": "udeb_kernel + ocean kernel + group_split_kernel + group_kernel_args (one of each per step)",
+           "kernel": "udeb_kernel + ocean kernel + group_split_kernel (3 launches per step; round 5: 4)",
            "kernel_us_per_step_profiled": prof.get("kernel_us_per_step"),
            "note": "36 series x 8 B x members x monthly steps / run wall time"}
     valu = None
