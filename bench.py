@@ -117,7 +117,7 @@ def configs3_roofline(members, steps, run_s, ranks=1, mode="fast"):
     (what the reference's stepper writes into its collection, runtime.rs:480), over the run's wall time.  `traffic` = the HBM bytes
     the step's four kernels move per member-step (separate FETCH_SIZE / WRITE_SIZE passes of scripts/run_configs3_share.py at 125 000
     members, profiles/traffic.json -> profiles/r6_configs3_share_pmc*.txt) x members x steps: ClimateUDEB's two 50-layer columns in and
-    out every step and OceanCarbon's recurrence state are what it moves beyond the 288 algorithmic bytes.  The run is 4 launches per
+    out every step and OceanCarbon's recurrence state are what it moves beyond the 288 algorithmic bytes.  The run is 3 launches per
     step in a dependency chain, two thirds of it ClimateUDEB's 12 column solves: FP64 issue and the chain's latency bind, not HBM."""
     alg = CONFIGS3_SERIES * 8.0 * members * steps * ranks
     gbs = alg / run_s / 1e9
@@ -1066,7 +1066,7 @@ def magicc_chain_extra(members, years, fast=False):
     return {"member_years_per_s": members * years / dt, "ms": dt * 1e3, "launches": int(nl.value), "ensembles": n,
             "finite_members": warm["count"], "mean_warming_K": warm["mean"],
             "note": "10 components + aggregate + 2 grid transforms, lock-step in topological order; runs of light "
-                    "components share a launch (4 launches per model step)"}
+                    "components share a launch (3 launches per model step: a step's last light launch rides with the next step's first)"}
 
 
 def end_to_end_extra(members, device, mode, stream, years):

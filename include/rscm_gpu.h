@@ -525,6 +525,11 @@ RSCM_API int rscm_ens_run_lockstep(rscm_ens* const* handles, int32_t n_handles, 
  * launches.  A graph made of light components only runs ALL its steps in one launch, and between the steps
  * every component keeps its varying parameters, its state and what its consumers read in thread-private LDS
  * slots instead of reading them back from HBM (the series are still written every step).
+ * Where the graph order ends a step with light components and begins the next with light components (the MAGICC graph:
+ * [8 light] ClimateUDEB OceanCarbon [3 light]), the two runs are consecutive launches and go out as ONE when they fit a
+ * table of twelve ops: three launches per model step.  Inside a call of two steps or more the handles of the first run
+ * therefore stand one step ahead of the others between the launches -- exactly where they would stand after their own
+ * launch of the next step; at the end of the call every handle stands at step_end.
  * (A/B switches and launch counters for tests: include/rscm_gpu_internal.h.) */
 RSCM_API int rscm_ens_sync(rscm_ens* h);
 RSCM_API int rscm_ens_time_index(const rscm_ens* h, int32_t* out);
