@@ -34,7 +34,7 @@ def main():
     table = json.load(open(path))
     if sys.argv[1] == "--refresh":
         for key, old in table.items():
-            if isinstance(old, dict) and "source" in old:
+            if isinstance(old, dict) and "source" in old and "bytes_per_member_step" not in old:   # (per-step entries: scripts/summarize_share_pmc.py)
                 summary = old["source"].split(" ")[0]
                 if os.path.exists(os.path.join(ROOT, summary)):
                     table[key] = entry(summary, old["source"])
