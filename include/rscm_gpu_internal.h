@@ -24,7 +24,9 @@ extern "C" {
  *   3  as 1 with every op table sent through device memory instead of the kernel arguments;
  *   4  as 1 without cutting a one-step segment's independent ops over two wavefronts (csrc/group.hip, group_split_kernel): A/B.
  *   5  as 1 without MERGED launches: a step's last fused segment and the next step's first one stay two launches (round 5's launch
- *      plan; A/B, and the yardstick of tests/test_gpu_group.py: merged == unmerged bit for bit).
+ *      plan; A/B, and the yardstick of tests/test_gpu_group.py: merged == unmerged bit for bit);
+ *   6  as 1 with every cut launch through the op interpreter (group_split_kernel), also where its sequence of kinds has a kernel of its
+ *      own (group_split_seq_kernel: the MAGICC graph's merged launch): A/B.
  *      (Round 3's mode 4 -- ClimateUDEB and OceanCarbon inside the fused launch too, one launch per window chunk with the ocean columns
  *      resident on chip -- existed in round 3: bit-identical to mode 1 and 17 % slower on an MI355X, removed in round 4;
  *      DESIGN.md section 8g, profiles/r3_graph_stamps.json, commit f22e743.)
@@ -41,6 +43,14 @@ RSCM_API int rscm_gpu_lockstep_split_launches(int64_t* out);
 /* How many of the calling thread's fused launches since its last call of this function carried the segments of TWO model steps (the
  * last segment of step n with the first segment of step n + 1; csrc/lockstep.cpp, MERGED schedule); resets the counter. */
 RSCM_API int rscm_gpu_lockstep_merged_launches(int64_t* out);
+
+/* The layout of the calling thread's last one-step fused launch that was cut over two wavefronts: out[0] = ops, out[1] / out[2] = ops
+ * of the first / second set (the rest is the tail), then per op in launch order its kind and (step offset | variant << 8).
+ * out must hold 3 + 2 * 12 int32. */
+RSCM_API int rscm_gpu_lockstep_last_layout(int32_t* out);
+/* How many of the calling thread's cut launches went through a kernel compiled for their sequence of kinds (csrc/group.hip,
+ * group_split_seq_kernel) since its last call of this function; resets the counter. */
+RSCM_API int rscm_gpu_lockstep_own_cut_launches(int64_t* out);
 
 /* Which ClimateUDEB kernel the calling thread's launches take (csrc/udeb.hip): 0 one thread per member, 2 a hemisphere per
  * wavefront; -1 (default): chosen by ensemble size.  The two carry the same bits, at every layer count up to 64 (20 / 30 / 40 / 50

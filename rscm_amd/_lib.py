@@ -272,6 +272,8 @@ SIGNATURES = {
     "rscm_gpu_lockstep_stats": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rscm_gpu_lockstep_split_launches": (C.c_int, [C.POINTER(C.c_int64)]),
     "rscm_gpu_lockstep_merged_launches": (C.c_int, [C.POINTER(C.c_int64)]),
+    "rscm_gpu_lockstep_last_layout": (C.c_int, [C.POINTER(C.c_int32)]),
+    "rscm_gpu_lockstep_own_cut_launches": (C.c_int, [C.POINTER(C.c_int64)]),
     "rscm_ens_sync": (C.c_int, [_h]),
     "rscm_ens_time_index": (C.c_int, [_h, _ip]),
     "rscm_ens_clear_series": (C.c_int, [_h]),

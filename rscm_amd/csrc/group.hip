@@ -142,6 +142,84 @@ __global__ __launch_bounds__(128) void group_split_kernel(const GroupTable table
     }
 }
 
+// ---- the cut launch with the op KINDS fixed at compile time ------------------------------------------------------------
+// The interpreter above reaches an op's fields through a dynamic index into the by-value table and a switch on its kind: every field is
+// a scalar load of its own in some basic block of the body, awaited where it is used -- 122 scalar-memory instructions per wavefront in
+// the MAGICC graph's first segment, two thirds of the wave cycles in s_waitcnt at 0.2 issue utilisation
+// (profiles/r6_configs3_share_pmc.txt, profiles/r6_group_latency_counters.txt).  For the op sequences the front end emits most often --
+// the MAGICC graph's merged launch -- the kinds and the cut are template arguments: the bodies are called directly, every field of
+// every op sits at a constant offset of the kernel-argument segment (invariant loads the compiler batches and hoists), there is no
+// switch.  Same bodies, same template arguments, same operands as group_split_kernel: the same bits (tests/test_gpu_group.py).
+template <int KIND>
+__device__ __forceinline__ void run_kind_once(const GroupOp& op, int64_t i, int32_t at)
+{
+    if constexpr (KIND == 0) {
+        if (op.variant == 0) tl::two_layer_body<0, false, true>(op.u.tl, nullptr, i, at, at + 1, NoCache());
+        else tl::two_layer_body<1, false, true>(op.u.tl, nullptr, i, at, at + 1, NoCache());
+    } else if constexpr (KIND == 3) {
+        if (op.variant == 0) ghg::ghg_body<0, false, true>(op.u.ghg, nullptr, i, at, at + 1);
+        else ghg::ghg_body<1, false, true>(op.u.ghg, nullptr, i, at, at + 1);
+    }
+    else if constexpr (KIND == kKindCh4Chemistry) chem::ch4_body<2>(op.u.chem, i, at, at + 1);
+    else if constexpr (KIND == kKindN2oChemistry) chem::n2o_body<2>(op.u.chem, i, at, at + 1);
+    else if constexpr (KIND == kKindTerrestrialCarbon) carbon::terrestrial_body<2>(op.u.carbon, i, at, at + 1);
+    else if constexpr (KIND == kKindCo2Budget) carbon::co2_budget_body<2>(op.u.carbon, i, at, at + 1, NoCache());
+    else if constexpr (KIND == kKindCarbonCycle) {
+        if (op.variant == 0) carbon::carbon_cycle_body<0, 2>(op.u.carbon, i, at, at + 1, NoCache());
+        else carbon::carbon_cycle_body<1, 2>(op.u.carbon, i, at, at + 1, NoCache());
+    }
+    else if constexpr (KIND == kKindOzoneForcing || KIND == kKindAerosolDirect) pw::pointwise_body<KIND, 2>(op.u.pw, i, at, at + 1);
+    else pw::pointwise_body<KIND, 2>(op.u.pw, i, at, at + 1, NoCache());   // AerosolIndirect, FourBoxOHU, OSPP, CO2ERF, the aggregate
+}
+
+template <int... KINDS>
+struct OpKinds {
+    static constexpr int n = sizeof...(KINDS);
+    static constexpr int kinds[sizeof...(KINDS) > 0 ? sizeof...(KINDS) : 1] = {KINDS...};
+};
+
+template <class Seq, int BASE, int... IDX>
+__device__ __forceinline__ void run_kinds(const GroupTable& table, int64_t i, int32_t step, std::integer_sequence<int, IDX...>)
+{
+    (run_kind_once<Seq::kinds[IDX]>(table.ops[BASE + IDX], i, step + table.ops[BASE + IDX].step_off), ...);
+}
+
+// wavefront 0: the ops of A, wavefront 1: the ops of B, at the same time; a workgroup barrier; wavefront 0: the tail T.
+template <class A, class B, class T>
+__global__ __launch_bounds__(128) void group_split_seq_kernel(const GroupTable table, int64_t n_members, int32_t step)
+{
+    const int32_t wave = __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6));
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool live = i < n_members;
+    if (wave == 0) {
+        if (live) run_kinds<A, 0>(table, i, step, std::make_integer_sequence<int, A::n>());
+    } else {
+        if (live) run_kinds<B, A::n>(table, i, step, std::make_integer_sequence<int, B::n>());
+    }
+    __syncthreads();
+    if (wave == 0 && live) run_kinds<T, A::n + B::n>(table, i, step, std::make_integer_sequence<int, T::n>());
+}
+
+// The MAGICC graph in topological order, a step's last segment merged with the next step's first (csrc/lockstep.cpp; the cut as
+// plan_split makes it): wavefront 0 the temperature's grid transform, TerrestrialCarbon, CO2Budget and CH4; wavefront 1 the aerosol
+// forcings, their grid transform and N2O; the tail GhgForcing, OzoneForcing and the Sum of the forcings.
+using MagiccA = OpKinds<kKindAggregate, kKindTerrestrialCarbon, kKindCo2Budget, kKindCh4Chemistry>;
+using MagiccB = OpKinds<kKindAerosolIndirect, kKindAerosolDirect, kKindAggregate, kKindN2oChemistry>;
+using MagiccT = OpKinds<3, kKindOzoneForcing, kKindAggregate>;
+
+template <class A, class B, class T>
+static bool split_seq_matches(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops)
+{
+    if (n_first != A::n || n_second != B::n || n_ops != A::n + B::n + T::n) return false;
+    for (int k = 0; k < A::n; ++k)
+        if (table.ops[k].kind != A::kinds[k]) return false;
+    for (int k = 0; k < B::n; ++k)
+        if (table.ops[A::n + k].kind != B::kinds[k]) return false;
+    for (int k = 0; k < T::n; ++k)
+        if (table.ops[A::n + B::n + k].kind != T::kinds[k]) return false;
+    return true;
+}
+
 // ---- a kernel per graph: the op KINDS fixed at compile time -------------------------------------------------
 // The interpreter above pays, per op and model step, for what it cannot know: the switch on the kind, the op's
 // fields re-read through the scalar cache (a dynamic index into the table), the slot records of its LDS cache --
@@ -319,11 +397,20 @@ bool launch_group_seq(const GroupTable& table, int32_t n_ops, int64_t n_members,
     return true;
 }
 
+bool group_split_seq_available(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops)
+{
+    return split_seq_matches<MagiccA, MagiccB, MagiccT>(table, n_first, n_second, n_ops);
+}
+
 hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
-                              hipStream_t s)
+                              hipStream_t s, bool own_kernel)
 {
     if (n_first < 1 || n_second < 1 || n_first + n_second > n_ops || n_ops > kGroupTableOps || n_members <= 0) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_members + 63) / 64));
+    if (own_kernel && split_seq_matches<MagiccA, MagiccB, MagiccT>(table, n_first, n_second, n_ops)) {
+        hipLaunchKernelGGL((group_split_seq_kernel<MagiccA, MagiccB, MagiccT>), grid, dim3(128), 0, s, table, n_members, step);
+        return hipGetLastError();
+    }
     if (all_small) hipLaunchKernelGGL(group_split_kernel<false>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
     else hipLaunchKernelGGL(group_split_kernel<true>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
     return hipGetLastError();

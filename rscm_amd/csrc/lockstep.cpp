@@ -20,7 +20,10 @@ struct LockstepSettings {
     bool by_value = true;    // short op lists travel in the kernel arguments
     bool split = true;       // independent ops of a one-step segment on two wavefronts (group_split_kernel)
     bool merge = true;       // a step's last fused segment and the next step's first one in ONE launch (they are consecutive launches anyway)
+    bool own_cut = true;     // the cut launch through the kernel compiled for its sequence of kinds where one exists (csrc/group.hip)
     int64_t merged_launches = 0;                // launches that carried two steps' segments since the last rscm_gpu_lockstep_merged_launches
+    int64_t own_cut_launches = 0;               // cut launches that went through a kernel of their own since the last rscm_gpu_lockstep_own_cut_launches
+    int32_t last_layout[3 + 2 * rscm::kGroupTableOps] = {};   // the last one-step by-value launch: n_ops, n_first, n_second, then kind and step offset per op
     int64_t launches = 0, component_steps = 0;  // since the thread's last rscm_gpu_lockstep_stats
     int64_t split_launches = 0;                 // of those, launches of group_split_kernel
 };
@@ -81,12 +84,27 @@ int rscm_gpu_fail_chunk_launch(int32_t k)
 
 int rscm_gpu_set_lockstep_fusion(int32_t enabled)
 {
-    if (enabled < 0 || enabled > 5) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..5)", enabled);
+    if (enabled < 0 || enabled > 6) return fail(RSCM_ERR_INVALID, "lock-step fusion mode %d (0..6)", enabled);
     t_ls.fuse = enabled != 0;
     t_ls.cache = enabled == 1 || enabled >= 3;
     t_ls.by_value = enabled != 3;
     t_ls.split = enabled != 4;
     t_ls.merge = enabled != 5;   // (5: round 5's launch plan)
+    t_ls.own_cut = enabled != 5 && enabled != 6;   // (6: merged launches through the op interpreter)
+    return RSCM_OK;
+}
+
+int rscm_gpu_lockstep_own_cut_launches(int64_t* out)
+{
+    if (out) *out = t_ls.own_cut_launches;
+    t_ls.own_cut_launches = 0;
+    return RSCM_OK;
+}
+
+int rscm_gpu_lockstep_last_layout(int32_t* out)
+{
+    if (!out) return fail(RSCM_ERR_INVALID, "out is NULL");
+    memcpy(out, t_ls.last_layout, sizeof t_ls.last_layout);
     return RSCM_OK;
 }
 
@@ -365,7 +383,13 @@ static int fused_segment(LockstepPlan* plan, int32_t first, int32_t count, int32
             rscm::GroupTable ordered;
             memset((void*)&ordered, 0, sizeof ordered);
             for (int32_t k = 0; k < total; ++k) memcpy((void*)&ordered.ops[k], &table.ops[split.order[k]], sizeof(rscm::GroupOp));
-            HIPCHK(rscm::launch_group_split(ordered, split.n_first, split.n_second, total, lead->N, n, all_small, lead->stream));
+            t_ls.last_layout[0] = total; t_ls.last_layout[1] = split.n_first; t_ls.last_layout[2] = split.n_second;
+            for (int32_t k = 0; k < total; ++k) {
+                t_ls.last_layout[3 + 2 * k] = ordered.ops[k].kind;
+                t_ls.last_layout[4 + 2 * k] = ordered.ops[k].step_off | (ordered.ops[k].variant << 8);
+            }
+            HIPCHK(rscm::launch_group_split(ordered, split.n_first, split.n_second, total, lead->N, n, all_small, lead->stream, t_ls.own_cut));
+            if (t_ls.own_cut && rscm::group_split_seq_available(ordered, split.n_first, split.n_second, total)) t_ls.own_cut_launches += 1;
             t_ls.split_launches += 1;
         } else {
             HIPCHK(rscm::launch_group(by_value ? nullptr : plan->d_ops + first, by_value ? &table : nullptr, total, lead->N, n, n + len, all_small,

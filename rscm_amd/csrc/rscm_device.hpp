@@ -650,8 +650,10 @@ hipError_t launch_group(const GroupOp* d_ops, const GroupTable* table, int32_t n
 
 // One model step of a by-value table whose first n_first ops and next n_second ops have no edge between them (two wavefronts per 64
 // members run them at the same time), the rest after a workgroup barrier (csrc/group.hip, group_split_kernel).
+// own_kernel: use the kernel compiled for this sequence of kinds and this cut where one exists (group_split_seq_available), else the interpreter
 hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
-                              hipStream_t s);
+                              hipStream_t s, bool own_kernel = true);
+bool group_split_seq_available(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops);
 
 // A multi-step launch of a light graph whose sequence of kinds has a kernel of its own (csrc/group.hip: the op table
 // by value, the kinds compile-time): true if one was launched (*status: its launch status), false if the sequence has none.

@@ -317,7 +317,9 @@ def test_independent_ops_of_a_step_on_two_wavefronts(ra, execution_order):
 def test_merged_launches_keep_the_bits(ra, execution_order):
     """Round 6: in graph order a step's LAST fused segment and the next step's FIRST one are consecutive launches; where both fit one
     by-value table (twelve ops) they go out as ONE launch -- the three light components behind OceanCarbon with the eight in front
-    of ClimateUDEB: three launches per model step instead of four.  Same ops on the same operands in the same order:
+    of ClimateUDEB: three launches per model step instead of four; in topological order that launch's sequence of kinds and its cut
+    over two wavefronts have a kernel of their own (csrc/group.hip, group_split_seq_kernel; fusion mode 6 sends it through the op
+    interpreter instead).  Same ops on the same operands in the same order:
     every series equals the unmerged run (fusion mode 5: round 5's launch plan) and the unfused run (mode 0), bit
     for bit; with windowed series (the window upkeep moves from between the two segments to behind the merged launch), a ragged last
     workgroup, and a run made in two calls (the prologue / epilogue of the merged schedule at a call boundary)."""
@@ -330,6 +332,7 @@ def test_merged_launches_keep_the_bits(ra, execution_order):
     def run(mode, halves=False, **kw):
         L.check(lib.rscm_gpu_set_lockstep_fusion(mode))
         L.check(lib.rscm_gpu_lockstep_merged_launches(None))
+        L.check(lib.rscm_gpu_lockstep_own_cut_launches(None))
         m = mod.build_chain(N, years, execution_order, **kw)
         m.set_mode(L.MODE_FAST)
         _stats()
@@ -353,6 +356,16 @@ def test_merged_launches_keep_the_bits(ra, execution_order):
     try:
         for kw in (dict(), dict(series_window=12, output_stride=4), dict(steps_per_year=12, series_window=16, output_stride=12)):
             merged, launches, n_merged, steps = run(1, **kw)
+            own = C.c_int64()
+            L.check(lib.rscm_gpu_lockstep_own_cut_launches(C.byref(own)))
+            interpreted, launches6, n6, _ = run(6, **kw)   # the same launches through the op interpreter
+            own6 = C.c_int64()
+            L.check(lib.rscm_gpu_lockstep_own_cut_launches(C.byref(own6)))
+            assert own6.value == 0 and launches6 == launches and n6 == n_merged
+            if execution_order == "topological":   # the merged launch's sequence of kinds and its cut have a kernel of their own
+                assert own.value == steps - 1, (own.value, steps)
+            for name in merged:
+                assert_bit_equal(merged[name], interpreted[name], f"{execution_order} {kw}: the sequence's own kernel vs the interpreter: {name}")
             unmerged, launches5, n5, _ = run(5, **kw)
             unfused, _, _, _ = run(0, **kw)
             assert n5 == 0
