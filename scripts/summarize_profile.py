@@ -19,8 +19,10 @@ HOT = ("two_layer_kernel", "coupled_kernel", "coupled_fast_kernel", "udeb_kernel
 
 
 def short(name):
-    """'void rscm::(anonymous namespace)::coupled_kernel<true>(rscm::CoupledArgs)' -> 'coupled_kernel<true>'"""
-    head = name.split("(anonymous namespace)::")[-1]
+    """'void rscm::(anonymous namespace)::coupled_kernel<true>(rscm::CoupledArgs)' -> 'coupled_kernel<true>'; template arguments that are
+    themselves types of the anonymous namespace keep their names ('group_split_seq_kernel<OpKinds<17, 10, 9, 7>, ...>')"""
+    head = name[5:] if name.startswith("void ") else name
+    head = head.replace("rscm::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
     depth, out = 0, []
     for ch in head:
         if ch == "<":

@@ -10,7 +10,10 @@ import sys
 
 
 def short(name):
-    return name.split("(anonymous namespace)::")[-1].split("(rscm::")[0][:60]
+    # (nested template arguments of the anonymous namespace keep their names: group_split_seq_kernel<OpKinds<...>, ...>)
+    head = name[5:] if name.startswith("void ") else name
+    head = head.replace("rscm::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    return head.split("(rscm::")[0][:60]
 
 
 def main():
