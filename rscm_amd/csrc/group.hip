@@ -206,6 +206,13 @@ __global__ __launch_bounds__(128) void group_split_seq_kernel(const GroupTable t
 using MagiccA = OpKinds<kKindAggregate, kKindTerrestrialCarbon, kKindCo2Budget, kKindCh4Chemistry>;
 using MagiccB = OpKinds<kKindAerosolIndirect, kKindAerosolDirect, kKindAggregate, kKindN2oChemistry>;
 using MagiccT = OpKinds<3, kKindOzoneForcing, kKindAggregate>;
+// ... and in the reference's breadth-first order (what ModelBuilder.build() steps a graph in; the temperature's grid transform is a
+// launch of its own there, in front of OceanCarbon): wavefront 0 the aerosol forcings, their transform and CH4; wavefront 1
+// TerrestrialCarbon, CO2Budget and N2O; the tail the Sum of the forcings (which that order places BEFORE GhgForcing: it reads the
+// forcing of the step before), GhgForcing and OzoneForcing.
+using MagiccRefA = OpKinds<kKindAerosolIndirect, kKindAerosolDirect, kKindAggregate, kKindCh4Chemistry>;
+using MagiccRefB = OpKinds<kKindTerrestrialCarbon, kKindCo2Budget, kKindN2oChemistry>;
+using MagiccRefT = OpKinds<kKindAggregate, 3, kKindOzoneForcing>;
 
 template <class A, class B, class T>
 static bool split_seq_matches(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops)
@@ -397,9 +404,19 @@ bool launch_group_seq(const GroupTable& table, int32_t n_ops, int64_t n_members,
     return true;
 }
 
+template <class A, class B, class T>
+static bool launch_split_seq(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, dim3 grid,
+                             hipStream_t s)
+{
+    if (!split_seq_matches<A, B, T>(table, n_first, n_second, n_ops)) return false;
+    hipLaunchKernelGGL((group_split_seq_kernel<A, B, T>), grid, dim3(128), 0, s, table, n_members, step);
+    return true;
+}
+
 bool group_split_seq_available(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops)
 {
-    return split_seq_matches<MagiccA, MagiccB, MagiccT>(table, n_first, n_second, n_ops);
+    return split_seq_matches<MagiccA, MagiccB, MagiccT>(table, n_first, n_second, n_ops) ||
+           split_seq_matches<MagiccRefA, MagiccRefB, MagiccRefT>(table, n_first, n_second, n_ops);
 }
 
 hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t n_second, int32_t n_ops, int64_t n_members, int32_t step, bool all_small,
@@ -407,10 +424,9 @@ hipError_t launch_group_split(const GroupTable& table, int32_t n_first, int32_t 
 {
     if (n_first < 1 || n_second < 1 || n_first + n_second > n_ops || n_ops > kGroupTableOps || n_members <= 0) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n_members + 63) / 64));
-    if (own_kernel && split_seq_matches<MagiccA, MagiccB, MagiccT>(table, n_first, n_second, n_ops)) {
-        hipLaunchKernelGGL((group_split_seq_kernel<MagiccA, MagiccB, MagiccT>), grid, dim3(128), 0, s, table, n_members, step);
+    if (own_kernel && (launch_split_seq<MagiccA, MagiccB, MagiccT>(table, n_first, n_second, n_ops, n_members, step, grid, s) ||
+                       launch_split_seq<MagiccRefA, MagiccRefB, MagiccRefT>(table, n_first, n_second, n_ops, n_members, step, grid, s)))
         return hipGetLastError();
-    }
     if (all_small) hipLaunchKernelGGL(group_split_kernel<false>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
     else hipLaunchKernelGGL(group_split_kernel<true>, grid, dim3(128), 0, s, table, n_first, n_second, n_ops, n_members, step);
     return hipGetLastError();

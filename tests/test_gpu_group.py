@@ -362,8 +362,8 @@ def test_merged_launches_keep_the_bits(ra, execution_order):
             own6 = C.c_int64()
             L.check(lib.rscm_gpu_lockstep_own_cut_launches(C.byref(own6)))
             assert own6.value == 0 and launches6 == launches and n6 == n_merged
-            if execution_order == "topological":   # the merged launch's sequence of kinds and its cut have a kernel of their own
-                assert own.value == steps - 1, (own.value, steps)
+            # in both orders the merged launch's sequence of kinds and its cut have a kernel of their own
+            assert own.value == n_merged == steps - 1, (own.value, n_merged, steps)
             for name in merged:
                 assert_bit_equal(merged[name], interpreted[name], f"{execution_order} {kw}: the sequence's own kernel vs the interpreter: {name}")
             unmerged, launches5, n5, _ = run(5, **kw)
