@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS the experiments build (make -C rscm_amd/csrc EXPERIMENTS=1; plain `make` afterwards): the shipped library does not read these knobs (csrc/experiment_env.hpp)
 # the member split's two knobs (rscm_gpu.cpp, plan_member_split) against the headline: RSCM_SPLIT_CHUNK (model steps per launch) and
 # RSCM_SPLIT_FIRST (members of the first block); MODE=fast for the FAST arithmetic
 MODE="${MODE:-exact}"
